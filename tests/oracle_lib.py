@@ -1,0 +1,165 @@
+"""ctypes binding of oracle/liboracle.so — test infrastructure only (never imported by the product)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+TYPE_F32, TYPE_F16, TYPE_Q4_K, TYPE_Q6_K = 0, 1, 12, 14
+BLOCK_BYTES = {TYPE_F32: 4, TYPE_F16: 2, TYPE_Q4_K: 144, TYPE_Q6_K: 210}
+BLOCK_ELEMS = {TYPE_F32: 1, TYPE_F16: 1, TYPE_Q4_K: 256, TYPE_Q6_K: 256}
+
+T_TOKEN_EMBD, T_OUT_NORM, T_OUTPUT = 0, 1, 2
+L_ATTN_NORM, L_Q, L_K, L_V, L_O, L_FFN_NORM, L_GATE, L_UP, L_DOWN = range(9)
+
+
+class LlmConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_layer", "d_model", "n_head", "n_kv_head", "head_dim", "d_ff", "vocab", "max_ctx", "max_seq")] + \
+               [("rms_eps", C.c_float), ("rope_theta", C.c_float)] + \
+               [(n, C.c_int32) for n in ("ks_qkv", "ks_o", "ks_gateup", "ks_down", "ks_out")]
+
+
+def tiny_config(**kw):
+    cfg = dict(n_layer=2, d_model=256, n_head=4, n_kv_head=2, head_dim=64, d_ff=512, vocab=512, max_ctx=64,
+               max_seq=4, rms_eps=1e-5, rope_theta=10000.0, ks_qkv=1, ks_o=1, ks_gateup=1, ks_down=1, ks_out=1)
+    cfg.update(kw)
+    return LlmConfig(**cfg)
+
+
+def mistral7b_config(**kw):
+    cfg = dict(n_layer=32, d_model=4096, n_head=32, n_kv_head=8, head_dim=128, d_ff=14336, vocab=32000,
+               max_ctx=256, max_seq=16, rms_eps=1e-5, rope_theta=10000.0,
+               ks_qkv=4, ks_o=4, ks_gateup=1, ks_down=7, ks_out=1)
+    cfg.update(kw)
+    return LlmConfig(**cfg)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle.so missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(path)
+        L.orc_llm_create.restype = C.c_void_p
+        L.orc_llm_create.argtypes = [C.POINTER(LlmConfig)]
+        L.orc_llm_destroy.argtypes = [C.c_void_p]
+        L.orc_llm_synth.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_llm_reset.argtypes = [C.c_void_p]
+        L.orc_llm_set_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        L.orc_llm_get_tensor.restype = C.c_int64
+        L.orc_llm_get_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int64]
+        L.orc_llm_tensor_type.argtypes = [C.POINTER(LlmConfig), C.c_int, C.c_int]
+        L.orc_llm_forward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.orc_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.orc_q8k_quantize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_gemv_q8.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 4
+        L.orc_dequant_row.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.orc_quantize_rows.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        for f in ("orc_expf", "orc_logf", "orc_tanhf", "orc_geluf", "orc_siluf"):
+            getattr(L, f).restype = C.c_float
+            getattr(L, f).argtypes = [C.c_float]
+        L.orc_f32_to_f16.restype = C.c_uint16
+        L.orc_f32_to_f16.argtypes = [C.c_float]
+        L.orc_f16_to_f32.restype = C.c_float
+        L.orc_f16_to_f32.argtypes = [C.c_uint16]
+        _LIB = L
+    return _LIB
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleLlm:
+    def __init__(self, cfg, seed=None):
+        self.cfg = cfg
+        self.h = lib().orc_llm_create(C.byref(cfg))
+        if seed is not None:
+            lib().orc_llm_synth(self.h, seed)
+
+    def close(self):
+        if self.h:
+            lib().orc_llm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def reset(self):
+        lib().orc_llm_reset(self.h)
+
+    def get_tensor(self, layer, which):
+        t = C.c_int(0)
+        n = lib().orc_llm_get_tensor(self.h, layer, which, C.byref(t), None, 0)
+        buf = np.empty(n, dtype=np.uint8)
+        lib().orc_llm_get_tensor(self.h, layer, which, C.byref(t), ptr(buf), n)
+        return t.value, buf
+
+    def set_tensor(self, layer, which, ttype, data):
+        data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        rc = lib().orc_llm_set_tensor(self.h, layer, which, ttype, ptr(data), data.size)
+        assert rc == 0, "tensor size mismatch"
+
+    def dequant(self, layer, which, rows, cols):
+        t, buf = self.get_tensor(layer, which)
+        out = np.empty((rows, cols), dtype=np.float32)
+        row = np.empty(cols, dtype=np.float32)
+        for r in range(rows):
+            lib().orc_dequant_row(t, ptr(buf), cols, r, ptr(row))
+            out[r] = row
+        return out
+
+    def forward(self, seq, pos, tok, want_logits=True):
+        seq = np.ascontiguousarray(seq, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        tok = np.ascontiguousarray(tok, dtype=np.int32)
+        n = len(seq)
+        logits = np.empty((n, self.cfg.vocab), dtype=np.float32) if want_logits else None
+        am = np.empty(n, dtype=np.int32)
+        lib().orc_llm_forward(self.h, n, ptr(seq), ptr(pos), ptr(tok), ptr(logits) if want_logits else None, ptr(am))
+        return logits, am
+
+
+def q8k_quantize(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.size
+    q = np.empty(n, dtype=np.int8)
+    d = np.empty(n // 256, dtype=np.float32)
+    bs = np.empty(n // 32, dtype=np.int32)
+    lib().orc_q8k_quantize(ptr(x), n, ptr(q), ptr(d), ptr(bs))
+    return q, d, bs
+
+
+def quantize_rows(ttype, x):
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    out = np.empty(x.size // 256 * BLOCK_BYTES[ttype], dtype=np.uint8)
+    lib().orc_quantize_rows(ttype, ptr(x), x.size, ptr(out))
+    return out
+
+
+def dequant_rows(ttype, blocks, rows, cols):
+    out = np.empty((rows, cols), dtype=np.float32)
+    row = np.empty(cols, dtype=np.float32)
+    for r in range(rows):
+        lib().orc_dequant_row(ttype, ptr(blocks), cols, r, ptr(row))
+        out[r] = row
+    return out
+
+
+def gemv_q8(ttype, blocks, rows, K, ks, x):
+    q, d, bs = q8k_quantize(x)
+    y = np.empty(rows, dtype=np.float32)
+    lib().orc_gemv_q8(ttype, ptr(blocks), rows, K, ks, ptr(q), ptr(d), ptr(bs), ptr(y))
+    return y
+
+
+def rmsnorm(x, w, eps):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().orc_rmsnorm(ptr(x), ptr(w), x.size, eps, ptr(out))
+    return out
