@@ -1,0 +1,64 @@
+/*
+ * tk_mi355x_ext.h — extensions of the drop-in library that have no reference counterpart.
+ *
+ * The reference runs ONE sequence per runner on one thread (src/cortex/tk_cortex_main.c:957-994).
+ * SURVEY.md §0 F9 shows the headline target needs >= 6 cortex cycles decoded concurrently so the
+ * 4.3 GB weight stream is shared; these entry points expose that batched path (and the pieces the
+ * parity tests drive directly) with plain pointers and sizes only.
+ */
+#ifndef TK_MI355X_EXT_H
+#define TK_MI355X_EXT_H
+
+#include "tk_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t n_layer, d_model, n_head, n_kv_head, head_dim, d_ff, vocab;
+    float rms_eps, rope_theta;
+    int32_t ks_qkv, ks_o, ks_gateup, ks_down, ks_out; /* K-split plan (canonical summation order) */
+} tk_mi355x_llm_hparams_t;
+
+typedef struct tk_mi355x_llm_model_s tk_mi355x_llm_model_t;
+typedef struct tk_mi355x_llm_session_s tk_mi355x_llm_session_t;
+
+TK_API const char* tk_mi355x_version(void);
+TK_API int tk_mi355x_device_count(void);
+
+/* models ----------------------------------------------------------------------------------- */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_create(tk_mi355x_llm_model_t** out, const tk_mi355x_llm_hparams_t* hp, int device);
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_fill_synthetic(tk_mi355x_llm_model_t* m, uint64_t seed);
+/* tensor in GGUF block layout; layer = -1 for {0 token_embd, 1 output_norm, 2 output}, else
+ * {0 attn_norm,1 q,2 k,3 v,4 o,5 ffn_norm,6 gate,7 up,8 down}; type = ggml type id (0 F32, 12 Q4_K, 14 Q6_K) */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_set_tensor(tk_mi355x_llm_model_t* m, int layer, int which, int type, const void* data,
+                                                                   size_t nbytes);
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_load_gguf(tk_mi355x_llm_model_t** out, const char* path, int device);
+/* parses GGUF metadata only (runs without a GPU); n_vocab_tokens optional */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_gguf_probe(const char* path, tk_mi355x_llm_hparams_t* out, int32_t* n_vocab_tokens);
+TK_API void tk_mi355x_llm_model_get_hparams(const tk_mi355x_llm_model_t* m, tk_mi355x_llm_hparams_t* out);
+TK_API uint64_t tk_mi355x_llm_model_weight_bytes(const tk_mi355x_llm_model_t* m);
+TK_API void tk_mi355x_llm_model_destroy(tk_mi355x_llm_model_t** m);
+
+/* sessions --------------------------------------------------------------------------------- */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_session_create(tk_mi355x_llm_session_t** out, tk_mi355x_llm_model_t* m, int max_seq,
+                                                                 int max_ctx);
+TK_API void tk_mi355x_llm_session_destroy(tk_mi355x_llm_session_t** s);
+/* one pass over nrows <= 16 (sequence, position, token) rows; logits [nrows][vocab] and argmax [nrows] optional */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_forward(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos,
+                                                          const int32_t* tok, float* logits, int32_t* argmax);
+/* equal-length prompts for sequences 0..nseq-1; first_tokens[nseq] optional */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_prefill(tk_mi355x_llm_session_t* s, int nseq, int n_prompt, const int32_t* tokens,
+                                                          int32_t* first_tokens);
+/* greedy decode of n_steps tokens for rows 0..nrows-1, hipGraph replay; out_tokens[n_steps][16] */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t* s, int nrows, int n_steps, int32_t* out_tokens,
+                                                         float* ms_per_step);
+/* HIP-event timing of one GEMV launch on the session stream: which = 0 gate+up, 1 down, 2 qkv, 3 lm_head */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int which, int nrows, int iters, float* avg_ms,
+                                                            double* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

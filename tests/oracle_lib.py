@@ -23,7 +23,7 @@ class LlmConfig(C.Structure):
 
 
 def tiny_config(**kw):
-    cfg = dict(n_layer=2, d_model=256, n_head=4, n_kv_head=2, head_dim=64, d_ff=512, vocab=512, max_ctx=64,
+    cfg = dict(n_layer=2, d_model=256, n_head=8, n_kv_head=2, head_dim=64, d_ff=512, vocab=512, max_ctx=64,
                max_seq=4, rms_eps=1e-5, rope_theta=10000.0, ks_qkv=1, ks_o=1, ks_gateup=1, ks_down=1, ks_out=1)
     cfg.update(kw)
     return LlmConfig(**cfg)

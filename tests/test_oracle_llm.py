@@ -1,0 +1,119 @@
+"""CPU: the LLM oracle against its pins (HF-transformers golden fixture, codecs, exact math)."""
+import math
+import os
+
+import numpy as np
+
+import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_oracle_matches_hf_fixture():
+    g = np.load(os.path.join(GOLD, "llm_tiny.npz"))
+    orc = O.OracleLlm(O.tiny_config(), seed=int(g["seed"]))
+    n = len(g["tokens"])
+    logits, am = orc.forward(np.zeros(n, np.int32), np.arange(n, dtype=np.int32), g["tokens"])
+    # the oracle is deterministic: today's build reproduces the committed oracle logits bit for bit
+    assert np.array_equal(logits, g["oracle_logits"])
+    assert np.array_equal(am, g["oracle_argmax"])
+    # and stays within activation-quantisation noise of the independent HF fp32 implementation
+    hf = g["hf_logits"].astype(np.float32)
+    assert np.abs(logits - hf).max() < 0.05 * np.abs(hf).max()
+    assert float(g["fp32_mode_err"]) < 2e-3
+
+
+def test_prefill_equals_incremental_decode():
+    orc = O.OracleLlm(O.tiny_config(), seed=7)
+    toks = np.array([5, 17, 300, 42, 9, 260], dtype=np.int32)
+    full, _ = orc.forward(np.zeros(6, np.int32), np.arange(6, dtype=np.int32), toks)
+    orc.reset()
+    for i, t in enumerate(toks):
+        step, _ = orc.forward([0], [i], [t])
+        assert np.array_equal(step[0], full[i])
+
+
+def test_ksplit_changes_only_rounding():
+    a = O.OracleLlm(O.tiny_config(), seed=4)
+    b = O.OracleLlm(O.tiny_config(ks_down=2, ks_o=2), seed=4)
+    la, _ = a.forward([0, 0], [0, 1], [11, 12])
+    lb, _ = b.forward([0, 0], [0, 1], [11, 12])
+    assert np.allclose(la, lb, atol=1e-5) and not np.array_equal(la, lb)
+
+
+def test_codec_roundtrip_q4k_q6k():
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(256 * 64) * 0.02).astype(np.float32)
+    for t, tol in ((O.TYPE_Q4_K, 0.08), (O.TYPE_Q6_K, 0.02)):
+        blocks = O.quantize_rows(t, x)
+        assert blocks.size == 64 * O.BLOCK_BYTES[t]
+        y = O.dequant_rows(t, blocks, 1, x.size)[0]
+        rel = np.abs(y - x).max() / np.abs(x).max()
+        assert rel < tol, (t, rel)
+    # all-zero and constant rows survive (edge cases)
+    z = np.zeros(256, np.float32)
+    assert np.array_equal(O.dequant_rows(O.TYPE_Q4_K, O.quantize_rows(O.TYPE_Q4_K, z), 1, 256)[0], z)
+    assert np.array_equal(O.dequant_rows(O.TYPE_Q6_K, O.quantize_rows(O.TYPE_Q6_K, z), 1, 256)[0], z)
+    c = np.full(256, 0.5, np.float32)
+    assert np.abs(O.dequant_rows(O.TYPE_Q4_K, O.quantize_rows(O.TYPE_Q4_K, c), 1, 256)[0] - c).max() < 0.02
+
+
+def test_q4k_known_answer_block():
+    """Hand-built block in the published ggml layout: d=1, dmin=1, sc_j=j+1, m_j=j, q = i & 15."""
+    blk = np.zeros(144, np.uint8)
+    blk[0:2] = np.frombuffer(np.float16(1.0).tobytes(), np.uint8)
+    blk[2:4] = np.frombuffer(np.float16(1.0).tobytes(), np.uint8)
+    sc = [j + 1 for j in range(8)]
+    mn = [j for j in range(8)]
+    s = np.zeros(12, np.uint8)
+    for j in range(4):
+        s[j] = sc[j] | ((sc[j + 4] >> 4) << 6)
+        s[j + 4] = mn[j] | ((mn[j + 4] >> 4) << 6)
+        s[j + 8] = (sc[j + 4] & 0xF) | ((mn[j + 4] & 0xF) << 4)
+    blk[4:16] = s
+    for c in range(4):
+        for l in range(32):
+            lo = (64 * c + l) & 15
+            hi = (64 * c + 32 + l) & 15
+            blk[16 + 32 * c + l] = lo | (hi << 4)
+    y = O.dequant_rows(O.TYPE_Q4_K, blk, 1, 256)[0]
+    want = np.array([sc[i // 32] * (i & 15) - mn[i // 32] for i in range(256)], np.float32)
+    assert np.array_equal(y, want)
+
+
+def test_q8k_quantize_properties():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(512).astype(np.float32)
+    q, d, bs = O.q8k_quantize(x)
+    assert np.abs(q).max() == 127
+    assert np.array_equal(bs, q.reshape(-1, 32).sum(1))
+    assert np.abs(q.reshape(2, 256) * d[:, None] - x.reshape(2, 256)).max() <= d.max() * 0.5 + 1e-7
+
+
+def test_exact_math_accuracy():
+    L = O.lib()
+    xs = np.concatenate([np.linspace(-87, 88, 4001), np.linspace(-2, 2, 2001)]).astype(np.float32)
+    for x in xs:
+        want = math.exp(float(x))
+        got = L.orc_expf(float(x))
+        assert abs(got - want) <= 4e-7 * want, (x, got, want)
+    for x in np.geomspace(1e-30, 1e30, 3001).astype(np.float32):
+        assert abs(L.orc_logf(float(x)) - math.log(float(x))) <= 3e-7 * max(1.0, abs(math.log(float(x))))
+    for x in np.linspace(-12, 12, 2001).astype(np.float32):
+        assert abs(L.orc_tanhf(float(x)) - math.tanh(float(x))) < 3e-7
+        silu = float(x) / (1 + math.exp(-float(x)))
+        assert abs(L.orc_siluf(float(x)) - silu) <= 3e-7 * max(1.0, abs(silu))
+    assert L.orc_expf(-200.0) == 0.0 and L.orc_expf(1000.0) == L.orc_expf(88.0)
+
+
+def test_f16_conversion_matches_numpy():
+    rng = np.random.default_rng(2)
+    vals = np.concatenate([rng.standard_normal(4000) * 10.0 ** rng.integers(-9, 6, 4000),
+                           [0.0, -0.0, 65504.0, 65520.0, 1e-8, 5.96e-8, 2.98e-8, 6.1e-5, -7e4]]).astype(np.float32)
+    L = O.lib()
+    for v in vals:
+        want = np.float16(v)
+        got = L.orc_f32_to_f16(float(v))
+        assert got == int(want.view(np.uint16)), (v, got, int(want.view(np.uint16)))
+    for h in range(0, 0x7c00, 7):
+        assert L.orc_f16_to_f32(h) == float(np.uint16(h).view(np.float16))

@@ -1,0 +1,11 @@
+"""trackiellm_amd — Python host-side mirror of the tk_* C-ABI of libtrackie_mi355x.so.
+
+The product is the shared library (hand-written gfx950 HIP kernels behind TrackieLLM's own
+C operator surface).  This package only binds it with ctypes so that tests, bench.py and
+Python callers can drive exactly the entry points a C/Rust host would link against.
+There is no Python or CPU fallback: importing works without a GPU (symbols can be inspected),
+calling a compute entry without a gfx950 device returns a TK_ERROR_GPU_* code, and a missing
+.so raises immediately.
+"""
+from ._lib import lib, TkError, check, LIB_PATH  # noqa: F401
+from .llm import LlmHParams, LlmModel, LlmSession, ModelLoader, LlmRunner, MISTRAL_7B, TINY  # noqa: F401

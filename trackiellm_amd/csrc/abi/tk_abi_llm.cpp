@@ -1,0 +1,414 @@
+/*
+ * tk_abi_llm.cpp — tk_model_loader_* / tk_llm_runner_* (reference surface) and the
+ * tk_mi355x_llm_* extension entry points on top of the HIP engine.
+ *
+ * Behaviour mirrored from the reference:
+ *   loader: find-or-load by path, handle is an opaque pointer (src/ai_models/tk_model_loader.c:918-1083,
+ *           tk_model_loader_private.h:43-51)
+ *   runner: prepare = tokenise(add_bos) -> clear KV -> prefill whole prompt (tk_runner_streaming.c:20-34);
+ *           next_token = sample -> EOS? NULL -> decode one token -> piece valid until next call (:57-85);
+ *           add_tool_response formats "[TOOL_RESULT] name: \"%s\", output: %s [/TOOL_RESULT]" and decodes it
+ *           at n_past (tk_runner_helpers.c:78-126); reset_context clears the KV state (:128-138).
+ * There is no CPU fallback: every entry fails with a GPU error when no gfx950 device is usable.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../llm/tk_gguf.h"
+#include "../llm/tk_llm_engine.h"
+#include "../llm/tk_tokenizer.h"
+#include "../common/tk_ggml_blocks.h"
+#include "tk/tk_mi355x_ext.h"
+#include "tk/tk_model_runner.h"
+
+struct tk_mi355x_llm_model_s {
+    TkLlmModel model;
+    TkTokenizer tok;
+    int context_length = 4096;
+    std::string path;
+    int refcount = 1;
+};
+
+struct tk_mi355x_llm_session_s {
+    TkLlmSession session;
+};
+
+static tk_error_code_t fail(tk_error_code_t code, const std::string& why) {
+    tk_error_set_detail("%s", why.c_str());
+    return code;
+}
+
+static TkLlmHParams to_hp(const tk_mi355x_llm_hparams_t& h) {
+    TkLlmHParams o{};
+    o.n_layer = h.n_layer; o.d_model = h.d_model; o.n_head = h.n_head; o.n_kv_head = h.n_kv_head; o.head_dim = h.head_dim;
+    o.d_ff = h.d_ff; o.vocab = h.vocab; o.rms_eps = h.rms_eps; o.rope_theta = h.rope_theta;
+    o.ks_qkv = h.ks_qkv; o.ks_o = h.ks_o; o.ks_gateup = h.ks_gateup; o.ks_down = h.ks_down; o.ks_out = h.ks_out;
+    return o;
+}
+
+/* K-split plan: at least one 64-row workgroup per CU (256) where the matrix allows it */
+static void default_plan(tk_mi355x_llm_hparams_t* h) {
+    auto pick = [](int64_t rows, int64_t K) {
+        int nb = (int)(K / 256);
+        int want = (int)((256 + rows / 64 - 1) / (rows / 64));
+        int ks = 1;
+        for (int c = 1; c <= nb; ++c)
+            if (nb % c == 0) { ks = c; if (c >= want) break; }
+        if (K / ks > 4096) { /* LDS image of the K-range must fit: 16 B per k */
+            for (int c = ks; c <= nb; ++c) if (nb % c == 0 && K / c <= 4096) { ks = c; break; }
+        }
+        return ks;
+    };
+    const int64_t qd = (int64_t)h->n_head * h->head_dim, kvd = (int64_t)h->n_kv_head * h->head_dim;
+    h->ks_qkv = pick(qd + 2 * kvd, h->d_model);
+    h->ks_o = pick(h->d_model, qd);
+    h->ks_gateup = pick(2 * (int64_t)h->d_ff, h->d_model);
+    h->ks_down = pick(h->d_model, h->d_ff);
+    h->ks_out = 1;
+}
+
+extern "C" {
+
+tk_error_code_t tk_mi355x_llm_model_create(tk_mi355x_llm_model_t** out, const tk_mi355x_llm_hparams_t* hp, int device) {
+    if (!out || !hp) return TK_ERROR_INVALID_ARGUMENT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TK_ERROR_GPU_DEVICE_NOT_FOUND, "no HIP device visible (the MI355X path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(TK_ERROR_INVALID_ARGUMENT, "device ordinal out of range");
+    tk_mi355x_llm_hparams_t h = *hp;
+    if (h.ks_qkv <= 0 || h.ks_o <= 0 || h.ks_gateup <= 0 || h.ks_down <= 0) default_plan(&h);
+    std::unique_ptr<tk_mi355x_llm_model_s> m(new tk_mi355x_llm_model_s());
+    if (!m->model.init(to_hp(h), device)) return fail(TK_ERROR_MODEL_LOAD_FAILED, m->model.error);
+    m->tok.init_bytes(h.vocab);
+    *out = m.release();
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_model_fill_synthetic(tk_mi355x_llm_model_t* m, uint64_t seed) {
+    if (!m) return TK_ERROR_INVALID_ARGUMENT;
+    if (!m->model.fill_synthetic(seed)) return fail(TK_ERROR_GPU_ROCM_ERROR, m->model.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_model_set_tensor(tk_mi355x_llm_model_t* m, int layer, int which, int type, const void* data, size_t nbytes) {
+    if (!m || !data) return TK_ERROR_INVALID_ARGUMENT;
+    if (!m->model.set_tensor(layer, which, type, data, nbytes)) return fail(TK_ERROR_INVALID_INPUT_TENSOR, m->model.error);
+    return TK_SUCCESS;
+}
+
+void tk_mi355x_llm_model_get_hparams(const tk_mi355x_llm_model_t* m, tk_mi355x_llm_hparams_t* out) {
+    if (!m || !out) return;
+    const TkLlmHParams& h = m->model.hp;
+    *out = tk_mi355x_llm_hparams_t{h.n_layer, h.d_model, h.n_head, h.n_kv_head, h.head_dim, h.d_ff, h.vocab, h.rms_eps, h.rope_theta,
+                                   h.ks_qkv, h.ks_o, h.ks_gateup, h.ks_down, h.ks_out};
+}
+
+uint64_t tk_mi355x_llm_model_weight_bytes(const tk_mi355x_llm_model_t* m) {
+    if (!m) return 0;
+    uint64_t b = m->model.output.bytes;
+    for (const auto& L : m->model.layers) b += L.q.bytes + L.k.bytes + L.v.bytes + L.o.bytes + L.gate.bytes + L.up.bytes + L.down.bytes;
+    return b;
+}
+
+void tk_mi355x_llm_model_destroy(tk_mi355x_llm_model_t** m) {
+    if (!m || !*m) return;
+    delete *m;
+    *m = nullptr;
+}
+
+/* GGUF metadata only (no GPU): lets the loader report geometry errors before touching the device */
+tk_error_code_t tk_mi355x_gguf_probe(const char* path, tk_mi355x_llm_hparams_t* out, int32_t* n_vocab_tokens) {
+    if (!path || !out) return TK_ERROR_INVALID_ARGUMENT;
+    TkGgufFile f;
+    if (!f.open(path)) return fail(access(path, 0) == 0 ? TK_ERROR_FILE_CORRUPT : TK_ERROR_FILE_NOT_FOUND, f.error);
+    auto it = f.str.find("general.architecture");
+    std::string arch = it == f.str.end() ? "llama" : it->second;
+    tk_mi355x_llm_hparams_t h{};
+    h.n_layer = (int)f.get(arch + ".block_count", 0);
+    h.d_model = (int)f.get(arch + ".embedding_length", 0);
+    h.d_ff = (int)f.get(arch + ".feed_forward_length", 0);
+    h.n_head = (int)f.get(arch + ".attention.head_count", 0);
+    h.n_kv_head = (int)f.get(arch + ".attention.head_count_kv", h.n_head);
+    h.head_dim = (int)f.get(arch + ".rope.dimension_count", h.n_head ? h.d_model / h.n_head : 0);
+    h.rms_eps = (float)f.get(arch + ".attention.layer_norm_rms_epsilon", 1e-5);
+    h.rope_theta = (float)f.get(arch + ".rope.freq_base", 10000.0);
+    const TkGgufTensor* te = f.find("token_embd.weight");
+    h.vocab = te && te->dims.size() == 2 ? (int)te->dims[1] : (int)f.tokens.size();
+    if (h.n_layer <= 0 || h.d_model <= 0 || h.n_head <= 0 || h.vocab <= 0) return fail(TK_ERROR_MODEL_LOAD_FAILED, "GGUF lacks llama hyper-parameters");
+    default_plan(&h);
+    *out = h;
+    if (n_vocab_tokens) *n_vocab_tokens = (int32_t)f.tokens.size();
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_model_load_gguf(tk_mi355x_llm_model_t** out, const char* path, int device) {
+    if (!out || !path) return TK_ERROR_INVALID_ARGUMENT;
+    tk_mi355x_llm_hparams_t h{};
+    tk_error_code_t rc = tk_mi355x_gguf_probe(path, &h, nullptr);
+    if (rc != TK_SUCCESS) return rc;
+    TkGgufFile f;
+    if (!f.open(path)) return fail(TK_ERROR_FILE_CORRUPT, f.error);
+    tk_mi355x_llm_model_t* m = nullptr;
+    rc = tk_mi355x_llm_model_create(&m, &h, device);
+    if (rc != TK_SUCCESS) return rc;
+    auto put = [&](int layer, int which, const std::string& name, const char* alt) -> bool {
+        const TkGgufTensor* t = f.find(name);
+        if (!t && alt) t = f.find(alt);
+        if (!t) { tk_error_set_detail("GGUF tensor missing: %s", name.c_str()); return false; }
+        if (!t->data) { tk_error_set_detail("GGUF tensor %s has unsupported type %u (supported: F32, Q4_K, Q6_K)", name.c_str(), t->type); return false; }
+        if (!m->model.set_tensor(layer, which, (int)t->type, t->data, t->nbytes)) { tk_error_set_detail("%s: %s", name.c_str(), m->model.error.c_str()); return false; }
+        return true;
+    };
+    bool ok = put(-1, TK_T_TOKEN_EMBD, "token_embd.weight", nullptr) && put(-1, TK_T_OUT_NORM, "output_norm.weight", nullptr) &&
+              put(-1, TK_T_OUTPUT, "output.weight", "token_embd.weight");
+    static const char* names[TK_L_COUNT] = {"attn_norm", "attn_q", "attn_k", "attn_v", "attn_output", "ffn_norm", "ffn_gate", "ffn_up", "ffn_down"};
+    for (int l = 0; l < h.n_layer && ok; ++l)
+        for (int w = 0; w < TK_L_COUNT && ok; ++w) {
+            char nm[96];
+            snprintf(nm, sizeof nm, "blk.%d.%s.weight", l, names[w]);
+            ok = put(l, w, nm, nullptr);
+        }
+    if (!ok) { tk_mi355x_llm_model_destroy(&m); return TK_ERROR_MODEL_LOAD_FAILED; }
+    if (!f.tokens.empty()) m->tok.init_spm(f.tokens, f.scores, f.token_type, (int)f.get("tokenizer.ggml.bos_token_id", 1), (int)f.get("tokenizer.ggml.eos_token_id", 2));
+    auto it = f.str.find("general.architecture");
+    m->context_length = (int)f.get((it == f.str.end() ? std::string("llama") : it->second) + ".context_length", 4096);
+    m->path = path;
+    *out = m;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_session_create(tk_mi355x_llm_session_t** out, tk_mi355x_llm_model_t* m, int max_seq, int max_ctx) {
+    if (!out || !m) return TK_ERROR_INVALID_ARGUMENT;
+    std::unique_ptr<tk_mi355x_llm_session_s> s(new tk_mi355x_llm_session_s());
+    if (!s->session.init(&m->model, max_seq, max_ctx)) return fail(TK_ERROR_GPU_MEMORY, s->session.error);
+    *out = s.release();
+    return TK_SUCCESS;
+}
+
+void tk_mi355x_llm_session_destroy(tk_mi355x_llm_session_t** s) {
+    if (!s || !*s) return;
+    delete *s;
+    *s = nullptr;
+}
+
+tk_error_code_t tk_mi355x_llm_forward(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok,
+                                      float* logits, int32_t* argmax) {
+    if (!s || !seq || !pos || !tok) return TK_ERROR_INVALID_ARGUMENT;
+    if (!s->session.forward(nrows, seq, pos, tok, logits, argmax, true)) return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_prefill(tk_mi355x_llm_session_t* s, int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens) {
+    if (!s || !tokens) return TK_ERROR_INVALID_ARGUMENT;
+    if (!s->session.prefill(nseq, n_prompt, tokens, first_tokens)) return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t* s, int nrows, int n_steps, int32_t* out_tokens, float* ms_per_step) {
+    if (!s) return TK_ERROR_INVALID_ARGUMENT;
+    if (!s->session.decode(nrows, n_steps, out_tokens)) return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);
+    if (ms_per_step) *ms_per_step = s->session.last_step_ms;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int which, int nrows, int iters, float* avg_ms, double* algorithmic_bytes) {
+    if (!s || !avg_ms || !algorithmic_bytes || iters <= 0) return TK_ERROR_INVALID_ARGUMENT;
+    if (!s->session.time_gemv(which, nrows, iters, avg_ms, algorithmic_bytes)) return fail(TK_ERROR_GPU_ROCM_ERROR, s->session.error);
+    return TK_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ reference surface ------ */
+
+struct tk_model_loader_s {
+    std::mutex mu;
+    std::vector<tk_mi355x_llm_model_t*> models;
+    uint32_t max_models = 4;
+};
+
+tk_error_code_t tk_model_loader_create(tk_model_loader_t** out_loader, const tk_model_loader_config_t* config) {
+    if (!out_loader || !config) return TK_ERROR_INVALID_ARGUMENT;
+    tk_model_loader_s* l = new tk_model_loader_s();
+    l->max_models = config->max_models ? config->max_models : 4;
+    *out_loader = l;
+    return TK_SUCCESS;
+}
+
+void tk_model_loader_destroy(tk_model_loader_t** loader) {
+    if (!loader || !*loader) return;
+    for (auto* m : (*loader)->models) tk_mi355x_llm_model_destroy(&m);
+    delete *loader;
+    *loader = nullptr;
+}
+
+static bool parse_synthetic(const std::string& p, std::string* name, uint64_t* seed) {
+    const std::string pre = "synthetic://";
+    if (p.compare(0, pre.size(), pre) != 0) return false;
+    std::string rest = p.substr(pre.size());
+    *seed = 4;
+    size_t q = rest.find('?');
+    *name = rest.substr(0, q);
+    if (q != std::string::npos) {
+        size_t s = rest.find("seed=", q);
+        if (s != std::string::npos) *seed = strtoull(rest.c_str() + s + 5, nullptr, 10);
+    }
+    return true;
+}
+
+tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_model_load_params_t* params, void** out_model_handle) {
+    if (!loader || !params || !out_model_handle || !params->model_path || !params->model_path->path_str) return TK_ERROR_INVALID_ARGUMENT;
+    if (params->lora_adapter) return fail(TK_ERROR_NOT_IMPLEMENTED, "LoRA adapters are out of scope of the MI355X path");
+    if (params->model_type == TK_MODEL_FORMAT_ONNX) return fail(TK_ERROR_NOT_IMPLEMENTED, "ONNX graphs are not interpreted: the detector/ASR/VAD streams have dedicated entry points");
+    std::lock_guard<std::mutex> lk(loader->mu);
+    const std::string path = params->model_path->path_str;
+    if (!params->force_reload)
+        for (auto* m : loader->models)
+            if (m->path == path) { m->refcount++; *out_model_handle = m; return TK_SUCCESS; }
+    if (loader->models.size() >= loader->max_models) return fail(TK_ERROR_OUT_OF_MEMORY, "model cache full (max_models)");
+    tk_mi355x_llm_model_t* m = nullptr;
+    std::string name;
+    uint64_t seed;
+    tk_error_code_t rc;
+    if (parse_synthetic(path, &name, &seed)) {
+        tk_mi355x_llm_hparams_t h{};
+        if (name == "mistral-7b") h = tk_mi355x_llm_hparams_t{32, 4096, 32, 8, 128, 14336, 32000, 1e-5f, 10000.0f, 0, 0, 0, 0, 1};
+        else if (name == "tiny") h = tk_mi355x_llm_hparams_t{2, 256, 8, 2, 64, 512, 512, 1e-5f, 10000.0f, 0, 0, 0, 0, 1};
+        else return fail(TK_ERROR_FILE_NOT_FOUND, "unknown synthetic model: " + name);
+        rc = tk_mi355x_llm_model_create(&m, &h, 0);
+        if (rc == TK_SUCCESS) rc = tk_mi355x_llm_model_fill_synthetic(m, seed);
+        if (rc != TK_SUCCESS) { tk_mi355x_llm_model_destroy(&m); return rc; }
+        m->path = path;
+    } else {
+        rc = tk_mi355x_llm_model_load_gguf(&m, path.c_str(), 0);
+        if (rc != TK_SUCCESS) return rc;
+    }
+    loader->models.push_back(m);
+    *out_model_handle = m;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_model_loader_unload_model(tk_model_loader_t* loader, void** model_handle) {
+    if (!loader || !model_handle || !*model_handle) return TK_ERROR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(loader->mu);
+    for (size_t i = 0; i < loader->models.size(); ++i)
+        if (loader->models[i] == *model_handle) {
+            if (--loader->models[i]->refcount <= 0) {
+                tk_mi355x_llm_model_destroy(&loader->models[i]);
+                loader->models.erase(loader->models.begin() + i);
+            }
+            *model_handle = nullptr;
+            return TK_SUCCESS;
+        }
+    return fail(TK_ERROR_INVALID_ARGUMENT, "handle was not produced by this loader");
+}
+
+struct tk_llm_runner_s {
+    tk_mi355x_llm_model_t* model = nullptr;
+    tk_mi355x_llm_session_t* session = nullptr;
+    int n_ctx = 0;
+    int n_past = 0;
+    int32_t pending = -1; /* token sampled from the last logits, not yet decoded */
+    bool is_processing = false;
+    std::string piece;
+    std::string system_prompt;
+};
+
+tk_error_code_t tk_llm_runner_create(tk_llm_runner_t** out_runner, void* model_handle, const tk_llm_config_t* config) {
+    if (!out_runner || !model_handle || !config) return TK_ERROR_INVALID_ARGUMENT;
+    std::unique_ptr<tk_llm_runner_s> r(new tk_llm_runner_s());
+    r->model = (tk_mi355x_llm_model_t*)model_handle;
+    r->n_ctx = config->context_size ? (int)config->context_size : 4096;
+    if (config->system_prompt) r->system_prompt = config->system_prompt;
+    tk_error_code_t rc = tk_mi355x_llm_session_create(&r->session, r->model, 1, r->n_ctx);
+    if (rc != TK_SUCCESS) return rc;
+    *out_runner = r.release();
+    return TK_SUCCESS;
+}
+
+void tk_llm_runner_destroy(tk_llm_runner_t** runner) {
+    if (!runner || !*runner) return;
+    tk_mi355x_llm_session_destroy(&(*runner)->session);
+    delete *runner;
+    *runner = nullptr;
+}
+
+/* feed `toks` at positions n_past.. ; the last one is sampled */
+static tk_error_code_t feed(tk_llm_runner_s* r, const std::vector<int32_t>& toks) {
+    if (toks.empty()) return TK_SUCCESS;
+    if (r->n_past + (int)toks.size() >= r->n_ctx) return fail(TK_ERROR_INFERENCE_FAILED, "prompt exceeds the context window");
+    TkLlmSession& s = r->session->session;
+    std::vector<int32_t> sq, ps, tk;
+    size_t i = 0;
+    while (i + 1 < toks.size()) {
+        sq.clear(); ps.clear(); tk.clear();
+        while (i + 1 < toks.size() && sq.size() < TK_ROW_SLOTS) { sq.push_back(0); ps.push_back(r->n_past++); tk.push_back(toks[i++]); }
+        if (!s.forward((int)sq.size(), sq.data(), ps.data(), tk.data(), nullptr, nullptr, false)) return fail(TK_ERROR_INFERENCE_FAILED, s.error);
+    }
+    int32_t z = 0, p = r->n_past++, t = toks.back(), am = -1;
+    if (!s.forward(1, &z, &p, &t, nullptr, &am, true)) return fail(TK_ERROR_INFERENCE_FAILED, s.error);
+    r->pending = am;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_llm_runner_prepare_generation(tk_llm_runner_t* runner, const char* prompt, bool use_tool_grammar) {
+    if (!runner || !prompt) return TK_ERROR_INVALID_ARGUMENT;
+    (void)use_tool_grammar; /* GBNF-constrained sampling is SURVEY.md §8(f) rank 1, not part of this path yet */
+    std::vector<int32_t> toks = runner->model->tok.encode(prompt, true);
+    runner->n_past = 0; /* llama_kv_cache_clear: positions restart, stale cache rows are never attended */
+    runner->pending = -1;
+    tk_error_code_t rc = feed(runner, toks);
+    if (rc != TK_SUCCESS) return rc;
+    runner->is_processing = true;
+    return TK_SUCCESS;
+}
+
+const char* tk_llm_runner_generate_next_token(tk_llm_runner_t* runner) {
+    if (!runner || !runner->is_processing) return NULL;
+    const int32_t id = runner->pending;
+    if (id < 0 || id == runner->model->tok.eos) { runner->is_processing = false; return NULL; }
+    if (runner->n_past + 1 >= runner->n_ctx) { runner->is_processing = false; return NULL; }
+    int32_t z = 0, p = runner->n_past, t = id, am = -1;
+    if (!runner->session->session.forward(1, &z, &p, &t, nullptr, &am, true)) {
+        tk_error_set_detail("%s", runner->session->session.error.c_str());
+        runner->is_processing = false;
+        return NULL;
+    }
+    runner->n_past++;
+    runner->pending = am;
+    runner->piece = runner->model->tok.piece(id);
+    return runner->piece.c_str();
+}
+
+tk_error_code_t tk_llm_runner_add_tool_response(tk_llm_runner_t* runner, const char* tool_name, const char* tool_output) {
+    if (!runner || !tool_name || !tool_output) return TK_ERROR_INVALID_ARGUMENT;
+    std::string text = std::string("[TOOL_RESULT] name: \"") + tool_name + "\", output: " + tool_output + " [/TOOL_RESULT]";
+    std::vector<int32_t> toks = runner->model->tok.encode(text, false);
+    tk_error_code_t rc = feed(runner, toks);
+    if (rc != TK_SUCCESS) return rc;
+    runner->is_processing = true;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_llm_runner_reset_context(tk_llm_runner_t* runner) {
+    if (!runner) return TK_ERROR_INVALID_ARGUMENT;
+    runner->n_past = 0;
+    runner->pending = -1;
+    runner->is_processing = false;
+    return TK_SUCCESS;
+}
+
+void tk_llm_result_destroy(tk_llm_result_t** result) {
+    if (!result || !*result) return;
+    tk_llm_result_t* r = *result;
+    if (r->type == TK_LLM_RESULT_TYPE_TEXT_RESPONSE) free(r->data.text_response);
+    else if (r->type == TK_LLM_RESULT_TYPE_TOOL_CALL) { free(r->data.tool_call.name); free(r->data.tool_call.arguments_json); }
+    free(r);
+    *result = NULL;
+}
+
+} /* extern "C" */

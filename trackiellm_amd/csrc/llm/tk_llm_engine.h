@@ -1,0 +1,102 @@
+/*
+ * tk_llm_engine.h — device-resident Mistral-class model + batched decode session.
+ *
+ * Replaces what the reference obtains from llama.cpp:
+ *   model  <-> llama_load_model_from_file            (src/ai_models/tk_model_loader.c:245-251)
+ *   session<-> llama_new_context_with_model + KV     (src/ai_models/tk_runner_lifecycle.c:47-51)
+ *   forward<-> llama_decode(batch)                   (src/ai_models/tk_runner_streaming.c:34,77)
+ * One model is shared by any number of sessions; a session owns a KV cache for `max_seq`
+ * sequences and runs up to 16 (sequence, position) rows per pass so that B concurrent
+ * cortex cycles read the 4.3 GB of weights once per step.
+ */
+#ifndef TK_LLM_ENGINE_H
+#define TK_LLM_ENGINE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "tk_llm_kernels.h"
+
+struct TkLlmHParams {
+    int32_t n_layer, d_model, n_head, n_kv_head, head_dim, d_ff, vocab;
+    float rms_eps, rope_theta;
+    /* K-split plan: part of the canonical summation order shared with the oracle */
+    int32_t ks_qkv, ks_o, ks_gateup, ks_down, ks_out;
+};
+
+struct TkDevTensor {
+    uint8_t* data = nullptr; /* tiles (matrices) or raw f32 / GGUF blocks */
+    int type = 0;
+    int64_t rows = 0, cols = 0;
+    size_t bytes = 0;
+};
+
+struct TkLlmLayer {
+    TkDevTensor attn_norm, ffn_norm, q, k, v, o, gate, up, down;
+};
+
+enum TkLlmTensorId { TK_T_TOKEN_EMBD = 0, TK_T_OUT_NORM = 1, TK_T_OUTPUT = 2 };
+enum TkLlmLayerTensorId { TK_L_ATTN_NORM = 0, TK_L_Q, TK_L_K, TK_L_V, TK_L_O, TK_L_FFN_NORM, TK_L_GATE, TK_L_UP, TK_L_DOWN, TK_L_COUNT };
+
+class TkLlmModel {
+public:
+    TkLlmHParams hp{};
+    int device = 0;
+    TkDevTensor token_embd, out_norm, output;
+    std::vector<TkLlmLayer> layers;
+    std::string error;
+    size_t weight_bytes = 0; /* bytes a decode step streams (matrices only) */
+
+    ~TkLlmModel();
+    /* returns false and sets `error` on failure */
+    bool init(const TkLlmHParams& hp, int device);
+    bool fill_synthetic(uint64_t seed);
+    /* `host_blocks` is the tensor in GGUF layout (F32 for norms) */
+    bool set_tensor(int layer, int which, int type, const void* host_blocks, size_t nbytes);
+    bool ready() const;
+    static int recipe_type(const TkLlmHParams& hp, int layer, int which);
+    void shape(int layer, int which, int64_t* rows, int64_t* cols) const;
+
+private:
+    TkDevTensor* slot(int layer, int which);
+    bool install(TkDevTensor* t, int type, int64_t rows, int64_t cols, const void* dev_blocks, hipStream_t s);
+};
+
+class TkLlmSession {
+public:
+    TkLlmModel* model = nullptr;
+    int max_seq = 0, max_ctx = 0;
+    std::string error;
+    hipStream_t stream = nullptr;
+
+    ~TkLlmSession();
+    bool init(TkLlmModel* m, int max_seq, int max_ctx);
+    /* one pass over nrows <= 16 rows; host arrays */
+    bool forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
+                 bool lm_head = true);
+    /* prompts of equal length for sequences 0..nseq-1 (tokens[nseq][n_prompt]); leaves row r = sequence r
+     * holding the first sampled token so decode() can follow; first_tokens_host[nseq] optional */
+    bool prefill(int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens_host);
+    /* greedy decode loop, on-device feedback, hipGraph replay.  Starts from the rows' current
+     * (tok, pos) state left by the previous forward()/decode(); out_tokens[n_steps][nrows]. */
+    bool decode(int nrows, int n_steps, int32_t* out_tokens_host);
+    bool reset();
+    /* per-launch timing of the last decode(): average ms of one step measured with HIP events */
+    float last_step_ms = 0.0f;
+    /* stand-alone timing of the dominant GEMV (gate/up of layer 0) for bench.py's roofline leg */
+    bool time_gemv(int which, int nrows, int iters, float* avg_ms, double* algo_bytes);
+
+private:
+    void enqueue_pass(int nrows, bool lm_head);
+    uint16_t *kcache = nullptr, *vcache = nullptr;
+    float *x = nullptr, *qbuf = nullptr, *partial = nullptr, *logits = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    TkActQ8 act_d{}, act_qd{}, act_ff{};
+    int32_t *d_seq = nullptr, *d_pos = nullptr, *d_tok = nullptr, *d_nsteps = nullptr, *d_hist = nullptr;
+    int hist_cap = 0;
+    hipGraphExec_t graph_exec[TK_ROW_SLOTS + 1] = {};
+};
+
+#endif

@@ -1,0 +1,413 @@
+/*
+ * tk_llm_engine.hip — host side of the LLM stream: weight residency, KV cache, pass
+ * scheduling and hipGraph capture.  See tk_llm_engine.h for the reference call sites replaced.
+ */
+#include "tk_llm_engine.h"
+
+#include <math.h>
+#include <algorithm>
+#include <stdio.h>
+#include <string.h>
+
+#include "../common/tk_ggml_blocks.h"
+
+#define HIPQ(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            char b__[256];                                                                      \
+            snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            error = b__;                                                                        \
+            return false;                                                                       \
+        }                                                                                       \
+    } while (0)
+
+/* ------------------------------------------------------------------ model ------------------ */
+
+static int use_more_bits(int i, int n) { return i < n / 8 || i >= 7 * n / 8 || (i - n / 8) % 3 == 2; }
+
+int TkLlmModel::recipe_type(const TkLlmHParams& hp, int layer, int which) {
+    if (layer < 0) return which == TK_T_OUTPUT ? TK_TYPE_Q6_K : (which == TK_T_TOKEN_EMBD ? TK_TYPE_Q4_K : TK_TYPE_F32);
+    if (which == TK_L_ATTN_NORM || which == TK_L_FFN_NORM) return TK_TYPE_F32;
+    if ((which == TK_L_V || which == TK_L_DOWN) && use_more_bits(layer, hp.n_layer)) return TK_TYPE_Q6_K;
+    return TK_TYPE_Q4_K;
+}
+
+void TkLlmModel::shape(int layer, int which, int64_t* rows, int64_t* cols) const {
+    const int64_t d = hp.d_model, kv = (int64_t)hp.n_kv_head * hp.head_dim, qd = (int64_t)hp.n_head * hp.head_dim;
+    if (layer < 0) {
+        if (which == TK_T_OUT_NORM) { *rows = 1; *cols = d; }
+        else { *rows = hp.vocab; *cols = d; }
+        return;
+    }
+    switch (which) {
+        case TK_L_ATTN_NORM: case TK_L_FFN_NORM: *rows = 1; *cols = d; break;
+        case TK_L_Q: *rows = qd; *cols = d; break;
+        case TK_L_K: case TK_L_V: *rows = kv; *cols = d; break;
+        case TK_L_O: *rows = d; *cols = qd; break;
+        case TK_L_GATE: case TK_L_UP: *rows = hp.d_ff; *cols = d; break;
+        default: *rows = d; *cols = hp.d_ff; break;
+    }
+}
+
+TkDevTensor* TkLlmModel::slot(int layer, int which) {
+    if (layer < 0) return which == TK_T_TOKEN_EMBD ? &token_embd : which == TK_T_OUT_NORM ? &out_norm : which == TK_T_OUTPUT ? &output : nullptr;
+    if (layer >= (int)layers.size() || which < 0 || which >= TK_L_COUNT) return nullptr;
+    TkLlmLayer& L = layers[layer];
+    TkDevTensor* t[TK_L_COUNT] = {&L.attn_norm, &L.q, &L.k, &L.v, &L.o, &L.ffn_norm, &L.gate, &L.up, &L.down};
+    return t[which];
+}
+
+bool TkLlmModel::init(const TkLlmHParams& h, int dev) {
+    hp = h;
+    device = dev;
+    const int grp = h.n_kv_head > 0 ? h.n_head / h.n_kv_head : 0;
+    const int64_t qd = (int64_t)h.n_head * h.head_dim, kvd = (int64_t)h.n_kv_head * h.head_dim;
+    auto bad = [&](const char* why) { error = std::string("unsupported model geometry: ") + why; return false; };
+    if (h.n_layer <= 0 || h.d_model % 256 || h.d_ff % 256 || qd % 256) return bad("d_model, d_ff and n_head*head_dim must be multiples of 256");
+    if (h.n_kv_head <= 0 || h.n_head % h.n_kv_head || (grp != 1 && grp != 2 && grp != 4)) return bad("n_head / n_kv_head must be 1, 2 or 4");
+    if ((grp * h.head_dim) % 256 || h.head_dim % 8) return bad("(n_head/n_kv_head)*head_dim must be a multiple of 256");
+    if (qd % 64 || kvd % 64 || h.d_ff % 64 || h.vocab % 64 || h.d_model % 64) return bad("row counts must be multiples of 64");
+    if (h.ks_out != 1) return bad("ks_out must be 1");
+    const int ksv[4] = {h.ks_qkv, h.ks_o, h.ks_gateup, h.ks_down};
+    const int64_t kk[4] = {h.d_model, qd, h.d_model, h.d_ff};
+    for (int i = 0; i < 4; ++i)
+        if (ksv[i] <= 0 || (kk[i] / 256) % ksv[i]) return bad("K-split must divide K/256");
+    HIPQ(hipSetDevice(device));
+    layers.assign(h.n_layer, TkLlmLayer());
+    return true;
+}
+
+TkLlmModel::~TkLlmModel() {
+    (void)hipSetDevice(device);
+    auto fr = [](TkDevTensor& t) { if (t.data) (void)hipFree(t.data); t.data = nullptr; };
+    fr(token_embd); fr(out_norm); fr(output);
+    for (auto& L : layers) { fr(L.attn_norm); fr(L.ffn_norm); fr(L.q); fr(L.k); fr(L.v); fr(L.o); fr(L.gate); fr(L.up); fr(L.down); }
+}
+
+/* dev_blocks: tensor in GGUF layout already in device memory */
+bool TkLlmModel::install(TkDevTensor* t, int type, int64_t rows, int64_t cols, const void* dev_blocks, hipStream_t s) {
+    if (t->data) { (void)hipFree(t->data); t->data = nullptr; }
+    t->type = type; t->rows = rows; t->cols = cols;
+    const bool is_matrix = rows > 1 && t != &token_embd;
+    if (type == TK_TYPE_F32) {
+        t->bytes = (size_t)rows * cols * 4;
+        HIPQ(hipMalloc((void**)&t->data, t->bytes));
+        HIPQ(hipMemcpyAsync(t->data, dev_blocks, t->bytes, hipMemcpyDeviceToDevice, s));
+        return true;
+    }
+    if (type != TK_TYPE_Q4_K && type != TK_TYPE_Q6_K) { error = "unsupported tensor type (want F32, Q4_K or Q6_K)"; return false; }
+    t->bytes = (size_t)rows * cols / 256 * tk_type_block_bytes(type);
+    HIPQ(hipMalloc((void**)&t->data, t->bytes));
+    if (!is_matrix) { /* token_embd stays in GGUF layout: one row is gathered per token */
+        if (type != TK_TYPE_Q4_K) { error = "token_embd must be Q4_K"; return false; }
+        HIPQ(hipMemcpyAsync(t->data, dev_blocks, t->bytes, hipMemcpyDeviceToDevice, s));
+        return true;
+    }
+    tk_launch_repack(type, dev_blocks, rows, cols, t->data, s);
+    HIPQ(hipGetLastError());
+    return true;
+}
+
+bool TkLlmModel::set_tensor(int layer, int which, int type, const void* host_blocks, size_t nbytes) {
+    HIPQ(hipSetDevice(device));
+    TkDevTensor* t = slot(layer, which);
+    if (!t) { error = "no such tensor"; return false; }
+    int64_t rows, cols;
+    shape(layer, which, &rows, &cols);
+    size_t expect = (size_t)rows * cols / tk_type_block_elems(type) * tk_type_block_bytes(type);
+    if (expect != nbytes) { error = "tensor byte size does not match the model geometry"; return false; }
+    void* tmp = nullptr;
+    HIPQ(hipMalloc(&tmp, nbytes));
+    HIPQ(hipMemcpy(tmp, host_blocks, nbytes, hipMemcpyHostToDevice));
+    bool ok = install(t, type, rows, cols, tmp, nullptr);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(tmp);
+    return ok;
+}
+
+bool TkLlmModel::fill_synthetic(uint64_t seed) {
+    HIPQ(hipSetDevice(device));
+    /* scratch big enough for the largest tensor in GGUF layout */
+    size_t maxb = 0;
+    for (int l = -1; l < hp.n_layer; ++l)
+        for (int w = 0; w < (l < 0 ? 3 : (int)TK_L_COUNT); ++w) {
+            int64_t r, c;
+            shape(l, w, &r, &c);
+            int type = recipe_type(hp, l, w);
+            size_t b = (size_t)r * c / tk_type_block_elems(type) * tk_type_block_bytes(type);
+            maxb = b > maxb ? b : maxb;
+        }
+    void* tmp = nullptr;
+    HIPQ(hipMalloc(&tmp, maxb));
+    bool ok = true;
+    for (int l = -1; l < hp.n_layer && ok; ++l)
+        for (int w = 0; w < (l < 0 ? 3 : (int)TK_L_COUNT) && ok; ++w) {
+            int64_t r, c;
+            shape(l, w, &r, &c);
+            int type = recipe_type(hp, l, w);
+            uint64_t tid = l < 0 ? (uint64_t)w : (uint64_t)(16 + l * 16 + w);
+            if (type == TK_TYPE_F32) tk_launch_synth_f32(seed, tid, r * c, (float*)tmp, nullptr);
+            else tk_launch_synth_blocks(type, seed, tid, r * c / 256, 0.02f, tmp, nullptr);
+            ok = install(slot(l, w), type, r, c, tmp, nullptr);
+            if (ok && hipStreamSynchronize(nullptr) != hipSuccess) { error = "synthetic weight generation failed"; ok = false; }
+        }
+    (void)hipFree(tmp);
+    return ok;
+}
+
+bool TkLlmModel::ready() const {
+    if (!token_embd.data || !out_norm.data || !output.data) return false;
+    for (const auto& L : layers)
+        if (!L.attn_norm.data || !L.ffn_norm.data || !L.q.data || !L.k.data || !L.v.data || !L.o.data || !L.gate.data || !L.up.data || !L.down.data)
+            return false;
+    return true;
+}
+
+/* ------------------------------------------------------------------ session ---------------- */
+
+static bool alloc_act(TkActQ8* a, int K, std::string& error) {
+    if (hipMalloc((void**)&a->aq, TK_AQ_BYTES(K)) != hipSuccess || hipMalloc((void**)&a->ad, TK_AD_FLOATS(K) * 4) != hipSuccess ||
+        hipMalloc((void**)&a->abs, TK_ABS_INTS(K) * 4) != hipSuccess) {
+        error = "out of device memory (activation buffers)";
+        return false;
+    }
+    (void)hipMemset(a->aq, 0, TK_AQ_BYTES(K));
+    (void)hipMemset(a->ad, 0, TK_AD_FLOATS(K) * 4);
+    (void)hipMemset(a->abs, 0, TK_ABS_INTS(K) * 4);
+    return true;
+}
+static void free_act(TkActQ8* a) {
+    if (a->aq) (void)hipFree(a->aq);
+    if (a->ad) (void)hipFree(a->ad);
+    if (a->abs) (void)hipFree(a->abs);
+    *a = TkActQ8{};
+}
+
+bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
+    model = m;
+    max_seq = mseq;
+    max_ctx = mctx;
+    if (!m || !m->ready()) { error = "model has missing tensors"; return false; }
+    if (mseq <= 0 || mctx <= 0) { error = "max_seq and max_ctx must be positive"; return false; }
+    const TkLlmHParams& h = m->hp;
+    HIPQ(hipSetDevice(m->device));
+    HIPQ(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const int QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim, half = h.head_dim / 2;
+    size_t kv = (size_t)h.n_layer * mseq * mctx * KVD;
+    HIPQ(hipMalloc((void**)&kcache, kv * 2));
+    HIPQ(hipMalloc((void**)&vcache, kv * 2));
+    HIPQ(hipMemset(kcache, 0, kv * 2));
+    HIPQ(hipMemset(vcache, 0, kv * 2));
+    HIPQ(hipMalloc((void**)&x, (size_t)TK_ROW_SLOTS * h.d_model * 4));
+    HIPQ(hipMalloc((void**)&qbuf, (size_t)TK_ROW_SLOTS * QD * 4));
+    size_t pmax = (size_t)h.ks_qkv * (QD + 2 * KVD);
+    pmax = std::max(pmax, (size_t)h.ks_o * h.d_model);
+    pmax = std::max(pmax, (size_t)h.ks_gateup * 2 * h.d_ff);
+    pmax = std::max(pmax, (size_t)h.ks_down * h.d_model);
+    HIPQ(hipMalloc((void**)&partial, pmax * TK_ROW_SLOTS * 4));
+    HIPQ(hipMalloc((void**)&logits, (size_t)TK_ROW_SLOTS * h.vocab * 4));
+    if (!alloc_act(&act_d, h.d_model, error) || !alloc_act(&act_qd, QD, error) || !alloc_act(&act_ff, h.d_ff, error)) return false;
+    HIPQ(hipMalloc((void**)&d_seq, TK_ROW_SLOTS * 4));
+    HIPQ(hipMalloc((void**)&d_pos, TK_ROW_SLOTS * 4));
+    HIPQ(hipMalloc((void**)&d_tok, TK_ROW_SLOTS * 4));
+    HIPQ(hipMalloc((void**)&d_nsteps, TK_ROW_SLOTS * 4));
+    HIPQ(hipMemset(d_nsteps, 0, TK_ROW_SLOTS * 4));
+    hist_cap = mctx;
+    HIPQ(hipMalloc((void**)&d_hist, (size_t)hist_cap * TK_ROW_SLOTS * 4));
+    /* RoPE table, double precision on the host (same formula as the oracle) */
+    std::vector<float> cs((size_t)mctx * half), sn((size_t)mctx * half);
+    for (int p = 0; p < mctx; ++p)
+        for (int i = 0; i < half; ++i) {
+            double theta = pow((double)h.rope_theta, -2.0 * i / (double)h.head_dim);
+            double a = (double)p * theta;
+            cs[(size_t)p * half + i] = (float)cos(a);
+            sn[(size_t)p * half + i] = (float)sin(a);
+        }
+    HIPQ(hipMalloc((void**)&rope_cos, cs.size() * 4));
+    HIPQ(hipMalloc((void**)&rope_sin, sn.size() * 4));
+    HIPQ(hipMemcpy(rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+    HIPQ(hipMemcpy(rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    /* kernels that want more than the default 64 KiB of dynamic LDS */
+    HIPQ(hipDeviceSynchronize());
+    return true;
+}
+
+TkLlmSession::~TkLlmSession() {
+    if (model) (void)hipSetDevice(model->device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto& g : graph_exec) if (g) (void)hipGraphExecDestroy(g);
+    void* ptrs[] = {kcache, vcache, x, qbuf, partial, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    free_act(&act_d); free_act(&act_qd); free_act(&act_ff);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+bool TkLlmSession::reset() {
+    HIPQ(hipSetDevice(model->device));
+    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_ROW_SLOTS * 4, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    return true;
+}
+
+static TkGemvSeg seg_of(const TkDevTensor& t) { return TkGemvSeg{t.data, t.type, (int)(t.rows / TK_TILE_ROWS)}; }
+
+void TkLlmSession::enqueue_pass(int nrows, bool lm_head) {
+    const TkLlmHParams& h = model->hp;
+    const int D = h.d_model, QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim, FF = h.d_ff;
+    hipStream_t s = stream;
+    tk_launch_embed(model->token_embd.data, D, d_tok, nrows, x, s);
+    for (int l = 0; l < h.n_layer; ++l) {
+        const TkLlmLayer& L = model->layers[l];
+        tk_launch_rmsnorm_q8(x, l == 0 ? nullptr : partial, h.ks_down, D, (const float*)L.attn_norm.data, h.rms_eps, D, nrows, act_d, s);
+        TkGemvArgs a{};
+        a.seg[0] = seg_of(L.q); a.seg[1] = seg_of(L.k); a.seg[2] = seg_of(L.v);
+        a.nseg = 3; a.K = D; a.ks = h.ks_qkv; a.n_total = QD + 2 * KVD; a.nrows = nrows;
+        a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
+        tk_launch_gemv(a, s);
+        tk_launch_qkv_rope_append(partial, h.ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
+                                  qbuf, kcache, vcache, l, max_seq, max_ctx, s);
+        tk_launch_attention(qbuf, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
+        TkGemvArgs o{};
+        o.seg[0] = seg_of(L.o); o.nseg = 1; o.K = QD; o.ks = h.ks_o; o.n_total = D; o.nrows = nrows;
+        o.aq = act_qd.aq; o.ad = act_qd.ad; o.abs = act_qd.abs; o.out = partial;
+        tk_launch_gemv(o, s);
+        tk_launch_rmsnorm_q8(x, partial, h.ks_o, D, (const float*)L.ffn_norm.data, h.rms_eps, D, nrows, act_d, s);
+        TkGemvArgs gu{};
+        gu.seg[0] = seg_of(L.gate); gu.seg[1] = seg_of(L.up); gu.nseg = 2; gu.K = D; gu.ks = h.ks_gateup; gu.n_total = 2 * FF; gu.nrows = nrows;
+        gu.aq = act_d.aq; gu.ad = act_d.ad; gu.abs = act_d.abs; gu.out = partial;
+        tk_launch_gemv(gu, s);
+        tk_launch_swiglu_q8(partial, h.ks_gateup, FF, nrows, act_ff, s);
+        TkGemvArgs dn{};
+        dn.seg[0] = seg_of(L.down); dn.nseg = 1; dn.K = FF; dn.ks = h.ks_down; dn.n_total = D; dn.nrows = nrows;
+        dn.aq = act_ff.aq; dn.ad = act_ff.ad; dn.abs = act_ff.abs; dn.out = partial;
+        tk_launch_gemv(dn, s);
+    }
+    if (!lm_head) return; /* prompt rows whose logits nobody reads: K/V are already appended */
+    tk_launch_rmsnorm_q8(x, partial, h.ks_down, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
+    TkGemvArgs lm{};
+    lm.seg[0] = seg_of(model->output); lm.nseg = 1; lm.K = D; lm.ks = 1; lm.n_total = h.vocab; lm.nrows = nrows;
+    lm.aq = act_d.aq; lm.ad = act_d.ad; lm.abs = act_d.abs; lm.out = logits;
+    tk_launch_gemv(lm, s);
+    tk_launch_argmax(logits, h.vocab, nrows, d_tok, d_pos, d_nsteps, d_hist, TK_ROW_SLOTS, s);
+}
+
+bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
+                           bool lm_head) {
+    if (nrows <= 0 || nrows > TK_ROW_SLOTS) { error = "nrows must be in [1,16]"; return false; }
+    for (int r = 0; r < nrows; ++r) {
+        if (seq[r] < 0 || seq[r] >= max_seq || pos[r] < 0 || pos[r] >= max_ctx || tok[r] < 0 || tok[r] >= model->hp.vocab) {
+            error = "row out of range (sequence id, position or token id)";
+            return false;
+        }
+    }
+    HIPQ(hipSetDevice(model->device));
+    HIPQ(hipMemcpyAsync(d_seq, seq, nrows * 4, hipMemcpyHostToDevice, stream));
+    HIPQ(hipMemcpyAsync(d_pos, pos, nrows * 4, hipMemcpyHostToDevice, stream));
+    HIPQ(hipMemcpyAsync(d_tok, tok, nrows * 4, hipMemcpyHostToDevice, stream));
+    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_ROW_SLOTS * 4, stream));
+    enqueue_pass(nrows, lm_head);
+    HIPQ(hipGetLastError());
+    if (!lm_head) { HIPQ(hipStreamSynchronize(stream)); return true; }
+    if (logits_host) HIPQ(hipMemcpyAsync(logits_host, logits, (size_t)nrows * model->hp.vocab * 4, hipMemcpyDeviceToHost, stream));
+    if (argmax_host) HIPQ(hipMemcpyAsync(argmax_host, d_tok, nrows * 4, hipMemcpyDeviceToHost, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    return true;
+}
+
+bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens_host) {
+    if (nseq <= 0 || nseq > TK_ROW_SLOTS || nseq > max_seq) { error = "nseq must be in [1, min(16, max_seq)]"; return false; }
+    if (n_prompt <= 0 || n_prompt >= max_ctx) { error = "prompt does not fit the context"; return false; }
+    /* all but the last prompt token: 16 rows per pass, positions ascending so causality holds inside a pass */
+    std::vector<int32_t> sq, ps, tk;
+    auto flush = [&]() -> bool {
+        if (sq.empty()) return true;
+        bool ok = forward((int)sq.size(), sq.data(), ps.data(), tk.data(), nullptr, nullptr, false);
+        sq.clear(); ps.clear(); tk.clear();
+        return ok;
+    };
+    for (int s = 0; s < nseq; ++s)
+        for (int p = 0; p + 1 < n_prompt; ++p) {
+            sq.push_back(s); ps.push_back(p); tk.push_back(tokens[(size_t)s * n_prompt + p]);
+            if ((int)sq.size() == TK_ROW_SLOTS && !flush()) return false;
+        }
+    if (!flush()) return false;
+    /* last prompt token of every sequence: row r == sequence r, sampled -> decode() continues from here */
+    for (int s = 0; s < nseq; ++s) { sq.push_back(s); ps.push_back(n_prompt - 1); tk.push_back(tokens[(size_t)s * n_prompt + n_prompt - 1]); }
+    return forward(nseq, sq.data(), ps.data(), tk.data(), nullptr, first_tokens_host, true);
+}
+
+bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
+    if (nrows <= 0 || nrows > TK_ROW_SLOTS) { error = "nrows must be in [1,16]"; return false; }
+    if (n_steps <= 0 || n_steps > hist_cap) { error = "n_steps exceeds the session context"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    /* positions must stay inside the cache for the whole loop */
+    int32_t hpos[TK_ROW_SLOTS];
+    HIPQ(hipMemcpyAsync(hpos, d_pos, nrows * 4, hipMemcpyDeviceToHost, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    for (int r = 0; r < nrows; ++r)
+        if (hpos[r] + n_steps > max_ctx) { error = "decode would run past max_ctx"; return false; }
+    if (!graph_exec[nrows]) {
+        hipGraph_t g = nullptr;
+        HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        enqueue_pass(nrows, true);
+        HIPQ(hipStreamEndCapture(stream, &g));
+        HIPQ(hipGraphInstantiate(&graph_exec[nrows], g, nullptr, nullptr, 0));
+        HIPQ(hipGraphDestroy(g));
+    }
+    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_ROW_SLOTS * 4, stream));
+    hipEvent_t e0, e1;
+    HIPQ(hipEventCreate(&e0));
+    HIPQ(hipEventCreate(&e1));
+    HIPQ(hipEventRecord(e0, stream));
+    for (int i = 0; i < n_steps; ++i) HIPQ(hipGraphLaunch(graph_exec[nrows], stream));
+    HIPQ(hipEventRecord(e1, stream));
+    if (out_tokens_host) HIPQ(hipMemcpyAsync(out_tokens_host, d_hist, (size_t)n_steps * TK_ROW_SLOTS * 4, hipMemcpyDeviceToHost, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    float ms = 0.0f;
+    HIPQ(hipEventElapsedTime(&ms, e0, e1));
+    last_step_ms = ms / n_steps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return true;
+}
+
+bool TkLlmSession::time_gemv(int which, int nrows, int iters, float* avg_ms, double* algo_bytes) {
+    const TkLlmHParams& h = model->hp;
+    const TkLlmLayer& L = model->layers[0];
+    HIPQ(hipSetDevice(model->device));
+    TkGemvArgs a{};
+    a.nrows = nrows;
+    if (which == 0) { /* gate+up of layer 0 */
+        a.seg[0] = seg_of(L.gate); a.seg[1] = seg_of(L.up); a.nseg = 2; a.K = h.d_model; a.ks = h.ks_gateup; a.n_total = 2 * h.d_ff;
+        a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
+        *algo_bytes = (double)L.gate.bytes + (double)L.up.bytes;
+    } else if (which == 1) { /* down */
+        a.seg[0] = seg_of(L.down); a.nseg = 1; a.K = h.d_ff; a.ks = h.ks_down; a.n_total = h.d_model;
+        a.aq = act_ff.aq; a.ad = act_ff.ad; a.abs = act_ff.abs; a.out = partial;
+        *algo_bytes = (double)L.down.bytes;
+    } else if (which == 2) { /* qkv */
+        a.seg[0] = seg_of(L.q); a.seg[1] = seg_of(L.k); a.seg[2] = seg_of(L.v); a.nseg = 3; a.K = h.d_model; a.ks = h.ks_qkv;
+        a.n_total = (h.n_head + 2 * h.n_kv_head) * h.head_dim;
+        a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
+        *algo_bytes = (double)L.q.bytes + (double)L.k.bytes + (double)L.v.bytes;
+    } else { /* lm head */
+        a.seg[0] = seg_of(model->output); a.nseg = 1; a.K = h.d_model; a.ks = 1; a.n_total = h.vocab;
+        a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = logits;
+        *algo_bytes = (double)model->output.bytes;
+    }
+    hipEvent_t e0, e1;
+    HIPQ(hipEventCreate(&e0));
+    HIPQ(hipEventCreate(&e1));
+    tk_launch_gemv(a, stream);
+    HIPQ(hipEventRecord(e0, stream));
+    for (int i = 0; i < iters; ++i) tk_launch_gemv(a, stream);
+    HIPQ(hipEventRecord(e1, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    float ms = 0.0f;
+    HIPQ(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return true;
+}

@@ -1,0 +1,60 @@
+/*
+ * tk_llm_kernels.h — launch wrappers of the hand-written gfx950 kernels of the LLM stream.
+ * Every wrapper only enqueues on `stream` (no allocation, no sync) so a whole decode step
+ * can be captured in a hipGraph.
+ */
+#ifndef TK_LLM_KERNELS_H
+#define TK_LLM_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tk_llm_layout.h"
+
+struct TkGemvSeg {
+    const uint8_t* tiles; /* device tiles [row_tile][K/256][tile bytes] */
+    int type;             /* TK_TYPE_Q4_K / TK_TYPE_Q6_K */
+    int row_tiles;        /* rows / 16; must be a multiple of 4 */
+};
+
+struct TkGemvArgs {
+    TkGemvSeg seg[3];
+    int nseg;
+    int K;        /* reduction length, multiple of 256*ks */
+    int ks;       /* K-split count: partial sums land in out[ks][16][n_total] */
+    int n_total;  /* sum of rows over segments */
+    int nrows;    /* live row slots (<= 16) */
+    const int8_t* aq;
+    const float* ad;
+    const int32_t* abs;
+    float* out;
+};
+
+struct TkActQ8 { /* quantised-activation buffers for one K */
+    int8_t* aq;
+    float* ad;
+    int32_t* abs;
+};
+
+/* weights */
+void tk_launch_synth_blocks(int type, uint64_t seed, uint64_t tensor_id, int64_t nblocks, float scale, void* out, hipStream_t s);
+void tk_launch_synth_f32(uint64_t seed, uint64_t tensor_id, int64_t n, float* out, hipStream_t s);
+void tk_launch_repack(int type, const void* blocks, int64_t rows, int64_t K, uint8_t* tiles, hipStream_t s);
+
+/* step kernels */
+void tk_launch_embed(const void* embd_q4k, int D, const int32_t* tok, int nrows, float* x, hipStream_t s);
+void tk_launch_rmsnorm_q8(float* x, const float* partial, int ks, int n_total_partial, const float* w, float eps, int D, int nrows,
+                          TkActQ8 out, hipStream_t s);
+void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s);
+void tk_launch_qkv_rope_append(const float* partial, int ks, int n_total, int n_head, int n_kv_head, int head_dim, const float* rope_cos,
+                               const float* rope_sin, const int32_t* seq, const int32_t* pos, int nrows, float* qbuf, uint16_t* kcache,
+                               uint16_t* vcache, int layer, int max_seq, int max_ctx, hipStream_t s);
+void tk_launch_attention(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows,
+                         int n_head, int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, hipStream_t s);
+void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ8 out, hipStream_t s);
+void tk_launch_argmax(const float* logits, int vocab, int nrows, int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride,
+                      hipStream_t s);
+
+size_t tk_gemv_lds_bytes(int K, int ks);
+
+#endif

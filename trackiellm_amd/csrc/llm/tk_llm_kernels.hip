@@ -1,0 +1,645 @@
+/*
+ * tk_llm_kernels.hip — hand-written gfx950 (CDNA4) kernels of the Mistral-7B GGUF decode path
+ * that the reference hands to llama.cpp (src/ai_models/tk_runner_streaming.c:34,77 `llama_decode`).
+ *
+ * Numerics contract = oracle/tk_oracle_llm.cpp: int8 (Q8_K-style) activations, integer dot
+ * inside a 256-block, float accumulation across blocks in ascending order, canonical
+ * reduction trees elsewhere.  Results are bit-identical to the oracle.
+ *
+ * Roofline: every kernel here is HBM-bound.  The dominant one is tk_gemv_w4a8 (weights
+ * streamed once per pass, 0.5625 / 0.8203 B per weight); MFMA is used for the int8
+ * contraction [16 row slots x 32 k] x [32 k x 16 weight rows] so the same instruction stream
+ * serves 1..16 concurrent sequences without touching the VALU budget.
+ */
+#include "tk_llm_kernels.h"
+
+#include "../common/tk_exact_math.h"
+#include "../common/tk_ggml_blocks.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define TK_WAVE 64
+
+/* ------------------------------------------------------------------------------------------
+ * synthetic checkpoints (no real weights offline) — generated directly in HBM
+ * ------------------------------------------------------------------------------------------ */
+__global__ void k_synth_blocks(int type, uint64_t seed, uint64_t tid, int64_t nblocks, float scale, uint8_t* out) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    float x[256];
+    for (int i = 0; i < 256; ++i) x[i] = scale * tk_synth_normal(seed, tid, (uint64_t)(256 * b + i));
+    if (type == TK_TYPE_Q4_K) {
+        tk_block_q4_K blk;
+        tk_quantize_q4_K(x, &blk);
+        ((tk_block_q4_K*)out)[b] = blk;
+    } else {
+        tk_block_q6_K blk;
+        tk_quantize_q6_K(x, &blk);
+        ((tk_block_q6_K*)out)[b] = blk;
+    }
+}
+
+__global__ void k_synth_f32(uint64_t seed, uint64_t tid, int64_t n, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 1.0f + 0.1f * tk_synth_normal(seed, tid, (uint64_t)i);
+}
+
+void tk_launch_synth_blocks(int type, uint64_t seed, uint64_t tensor_id, int64_t nblocks, float scale, void* out, hipStream_t s) {
+    int64_t grid = (nblocks + 63) / 64;
+    hipLaunchKernelGGL(k_synth_blocks, dim3((unsigned)grid), dim3(64), 0, s, type, seed, tensor_id, nblocks, scale, (uint8_t*)out);
+}
+void tk_launch_synth_f32(uint64_t seed, uint64_t tensor_id, int64_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_synth_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, tensor_id, n, out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * GGUF blocks -> MFMA-fragment tiles (tk_llm_layout.h).  One wave per tile.
+ * ------------------------------------------------------------------------------------------ */
+__global__ void k_repack_q4k(const tk_block_q4_K* src, int64_t nblk, uint8_t* tiles) {
+    const int lane = threadIdx.x;
+    const int n = lane & 15, g = lane >> 4;
+    const int64_t rt = blockIdx.y, blk = blockIdx.x;
+    const tk_block_q4_K* b = src + (rt * 16 + n) * nblk + blk;
+    uint8_t* tile = tiles + (rt * nblk + blk) * TK_Q4K_TILE_BYTES;
+    for (int i = 0; i < 2; ++i) {
+        uint32_t dw[4];
+        for (int s = 0; s < 4; ++s) {
+            int k0 = 32 * (4 * i + s) + 8 * g;
+            uint32_t v = 0;
+            for (int t = 0; t < 4; ++t) v |= (uint32_t)(tk_q4k_quant(b, k0 + t) | (tk_q4k_quant(b, k0 + 4 + t) << 4)) << (8 * t);
+            dw[s] = v;
+        }
+        *(uint4*)(tile + 1024 * i + lane * 16) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+    }
+    if (g == 0) {
+        uint32_t h[4];
+        h[0] = (uint32_t)b->d | ((uint32_t)b->dmin << 16);
+        for (int k = 0; k < 3; ++k)
+            h[1 + k] = (uint32_t)b->scales[4 * k] | ((uint32_t)b->scales[4 * k + 1] << 8) | ((uint32_t)b->scales[4 * k + 2] << 16) |
+                       ((uint32_t)b->scales[4 * k + 3] << 24);
+        *(uint4*)(tile + 2048 + n * 16) = make_uint4(h[0], h[1], h[2], h[3]);
+    }
+}
+
+__global__ void k_repack_q6k(const tk_block_q6_K* src, int64_t nblk, uint8_t* tiles) {
+    const int lane = threadIdx.x;
+    const int n = lane & 15, g = lane >> 4;
+    const int64_t rt = blockIdx.y, blk = blockIdx.x;
+    const tk_block_q6_K* b = src + (rt * 16 + n) * nblk + blk;
+    uint8_t* tile = tiles + (rt * nblk + blk) * TK_Q6K_TILE_BYTES;
+    uint32_t hi[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 2; ++i) {
+        uint32_t dw[4];
+        for (int s = 0; s < 4; ++s) {
+            int j = 4 * i + s;
+            int k0 = 32 * j + 8 * g;
+            uint32_t v = 0;
+            for (int t = 0; t < 4; ++t) {
+                int qa = (tk_q6k_quant(b, k0 + t) ^ 32);     /* 6-bit two's complement of q-32 */
+                int qb = (tk_q6k_quant(b, k0 + 4 + t) ^ 32);
+                v |= (uint32_t)((qa & 15) | ((qb & 15) << 4)) << (8 * t);
+                int u = j >> 1, e = j & 1;
+                hi[u] |= (uint32_t)(qa >> 4) << (8 * t + 2 * (2 * e));
+                hi[u] |= (uint32_t)(qb >> 4) << (8 * t + 2 * (2 * e + 1));
+            }
+            dw[s] = v;
+        }
+        *(uint4*)(tile + 1024 * i + lane * 16) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+    }
+    *(uint4*)(tile + 2048 + lane * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    if (g == 0) {
+        uint32_t sc[4];
+        for (int k = 0; k < 4; ++k)
+            sc[k] = (uint32_t)(uint8_t)b->scales[4 * k] | ((uint32_t)(uint8_t)b->scales[4 * k + 1] << 8) |
+                    ((uint32_t)(uint8_t)b->scales[4 * k + 2] << 16) | ((uint32_t)(uint8_t)b->scales[4 * k + 3] << 24);
+        *(uint4*)(tile + 3072 + n * 16) = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+        *(uint16_t*)(tile + 3328 + n * 2) = b->d;
+    }
+}
+
+void tk_launch_repack(int type, const void* blocks, int64_t rows, int64_t K, uint8_t* tiles, hipStream_t s) {
+    dim3 grid((unsigned)(K / 256), (unsigned)(rows / 16));
+    if (type == TK_TYPE_Q4_K) hipLaunchKernelGGL(k_repack_q4k, grid, dim3(64), 0, s, (const tk_block_q4_K*)blocks, K / 256, tiles);
+    else hipLaunchKernelGGL(k_repack_q6k, grid, dim3(64), 0, s, (const tk_block_q6_K*)blocks, K / 256, tiles);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * token embedding: one Q4_K row (GGUF layout) de-quantised per row slot
+ * ------------------------------------------------------------------------------------------ */
+__global__ void k_embed(const tk_block_q4_K* embd, int D, const int32_t* tok, float* x) {
+    const int r = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const tk_block_q4_K* row = embd + (int64_t)tok[r] * (D / 256);
+    x[(int64_t)r * D + i] = tk_q4k_dequant(row + i / 256, i % 256);
+}
+
+void tk_launch_embed(const void* embd_q4k, int D, const int32_t* tok, int nrows, float* x, hipStream_t s) {
+    hipLaunchKernelGGL(k_embed, dim3((D + 255) / 256, nrows), dim3(256), 0, s, (const tk_block_q4_K*)embd_q4k, D, tok, x);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * shared device helpers
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ float wave_xor_f(float v, int mask) { return __shfl_xor(v, mask, TK_WAVE); }
+
+/* canonical sum of 256 per-thread partials (oracle: orc_sum256) */
+__device__ __forceinline__ float block_sum256(float v, float* red /* >= 4 floats LDS */) {
+    for (int s = 32; s >= 1; s >>= 1) v = v + wave_xor_f(v, s);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float r = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    return r;
+}
+
+/*
+ * Quantise one 8-element chunk (chunk index c of the row) to the aq/ad/abs images.
+ * Must be called by all 32 lanes of a half-wave that together hold one 256-block
+ * (lane order == chunk order), so the block amax / sub-block sums come from shuffles.
+ */
+__device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot, TkActQ8 out) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = tk_fmaxf(amax, tk_fabsf(v[i]));
+#pragma unroll
+    for (int s = 1; s <= 16; s <<= 1) amax = tk_fmaxf(amax, wave_xor_f(amax, s));
+    const float id = amax > 0.0f ? tk_divf(127.0f, amax) : 0.0f;
+    int q[8];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int t = (int)tk_rintf(v[i] * id);
+        t = t > 127 ? 127 : (t < -127 ? -127 : t);
+        q[i] = t;
+        sum += t;
+    }
+    uint32_t lo = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) | ((uint32_t)(q[3] & 255) << 24);
+    uint32_t hi = (uint32_t)(q[4] & 255) | ((uint32_t)(q[5] & 255) << 8) | ((uint32_t)(q[6] & 255) << 16) | ((uint32_t)(q[7] & 255) << 24);
+    *(uint2*)(out.aq + ((size_t)c * TK_ROW_SLOTS + slot) * 8) = make_uint2(lo, hi);
+    sum += __shfl_xor(sum, 1, TK_WAVE);
+    sum += __shfl_xor(sum, 2, TK_WAVE);
+    if ((c & 3) == 0) out.abs[(size_t)(c >> 2) * TK_ROW_SLOTS + slot] = sum;
+    if ((c & 31) == 0) out.ad[(size_t)(c >> 5) * TK_ROW_SLOTS + slot] = amax > 0.0f ? tk_divf(amax, 127.0f) : 0.0f;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * residual add (sum of K-split partials, ascending) + RMSNorm + Q8 quantise.  One WG per row.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_rmsnorm_q8(float* x, const float* partial, int ks, int n_total, const float* w, float eps, int D,
+                                                     TkActQ8 out) {
+    extern __shared__ float sh[]; /* D floats + 4 */
+    float* hbuf = sh;
+    float* red = sh + D;
+    const int r = blockIdx.x, t = threadIdx.x;
+    float* xr = x + (int64_t)r * D;
+    float ss = 0.0f;
+    for (int i = t; i < D; i += 256) {
+        float v = xr[i];
+        if (partial) {
+            float o = partial[(int64_t)r * n_total + i];
+            for (int s = 1; s < ks; ++s) o = o + partial[((int64_t)s * TK_ROW_SLOTS + r) * n_total + i];
+            v = v + o;
+            xr[i] = v;
+        }
+        hbuf[i] = v;
+        ss = tk_fmaf(v, v, ss);
+    }
+    float tot = block_sum256(ss, red);
+    float mean = tk_divf(tot, (float)D);
+    float scale = tk_divf(1.0f, tk_sqrtf(mean + eps));
+    __syncthreads();
+    for (int c = t; c < D / 8; c += 256) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (hbuf[8 * c + i] * scale) * w[8 * c + i];
+        quantize_chunk8(v, c, r, out);
+    }
+}
+
+void tk_launch_rmsnorm_q8(float* x, const float* partial, int ks, int n_total_partial, const float* w, float eps, int D, int nrows,
+                          TkActQ8 out, hipStream_t s) {
+    hipLaunchKernelGGL(k_rmsnorm_q8, dim3(nrows), dim3(256), (D + 4) * sizeof(float), s, x, partial, ks, n_total_partial, w, eps, D, out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * W4A8 / W6A8 GEMV on MFMA:   out[ks][slot][n] = sum_{k in K-range ks} W[n][k] * a[slot][k]
+ *
+ * WG = 4 waves, wave w owns the 16-row tile 4*blockIdx.x + w and walks the K-range
+ * blockIdx.y block by block; its weight stream is one contiguous run of tiles.  The int8
+ * activations of the K-range (shared by the 4 waves) are staged once in LDS in MFMA
+ * A-operand order.  Per 256-block and wave: 3 x 1 KiB coalesced non-temporal loads (Q4_K),
+ * 8 MFMA 16x16x32 i8, scales applied in integer, two fp32 FMAs per (row, slot).
+ * Algorithmic bytes per launch = rows * K * (144 | 210) / 256.
+ * ------------------------------------------------------------------------------------------ */
+struct FragQ4 { uint4 q0, q1, h; };
+struct FragQ6 { uint4 q0, q1, qh, sc; uint32_t d; };
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ldg_nt(const uint8_t* p) {
+    const v4u v = __builtin_nontemporal_load((const v4u*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ FragQ4 load_q4(const uint8_t* tile, int lane) {
+    FragQ4 f;
+    f.q0 = ldg_nt(tile + lane * 16);
+    f.q1 = ldg_nt(tile + 1024 + lane * 16);
+    f.h = ldg_nt(tile + 2048 + (lane & 15) * 16);
+    return f;
+}
+
+__device__ __forceinline__ FragQ6 load_q6(const uint8_t* tile, int lane) {
+    FragQ6 f;
+    f.q0 = ldg_nt(tile + lane * 16);
+    f.q1 = ldg_nt(tile + 1024 + lane * 16);
+    f.qh = ldg_nt(tile + 2048 + lane * 16);
+    f.sc = ldg_nt(tile + 3072 + (lane & 15) * 16);
+    f.d = *(const uint16_t*)(tile + 3328 + (lane & 15) * 2);
+    return f;
+}
+
+__device__ __forceinline__ float f16bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+
+__device__ __forceinline__ void block_q4(const FragQ4& f, const uint8_t* lds_act, const int* lds_abs, const float* lds_ad, int blk, int lane,
+                                         float* acc) {
+    const int g = lane >> 4;
+    const v4i zero = {0, 0, 0, 0};
+    int P[4] = {0, 0, 0, 0}, M[4] = {0, 0, 0, 0};
+    const uint32_t qs[8] = {f.q0.x, f.q0.y, f.q0.z, f.q0.w, f.q1.x, f.q1.y, f.q1.z, f.q1.w};
+    const uint32_t s0 = f.h.y, s1 = f.h.z, s2 = f.h.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t x = qs[j];
+        const uint32_t lo = x & 0x0F0F0F0Fu;
+        const uint32_t hi = (x >> 4) & 0x0F0F0F0Fu;
+        const long b = (long)(((unsigned long)hi << 32) | lo);
+        const long a = *(const long*)(lds_act + (size_t)(blk * 8 + j) * 512 + lane * 8);
+        const v4i c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, zero, 0, 0, 0);
+        int sc, m;
+        if (j < 4) {
+            sc = (s0 >> (8 * j)) & 63;
+            m = (s1 >> (8 * j)) & 63;
+        } else {
+            const int jj = j - 4;
+            sc = ((s2 >> (8 * jj)) & 0xF) | (((s0 >> (8 * jj + 6)) & 3) << 4);
+            m = ((s2 >> (8 * jj + 4)) & 0xF) | (((s1 >> (8 * jj + 6)) & 3) << 4);
+        }
+        const v4i bs = *(const v4i*)(lds_abs + (blk * 8 + j) * TK_ROW_SLOTS + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            P[r] += sc * c[r];
+            M[r] += m * bs[r];
+        }
+    }
+    const float dw = f16bits_to_f32(f.h.x & 0xffffu);
+    const float dmin = f16bits_to_f32(f.h.x >> 16);
+    const v4f da = *(const v4f*)(lds_ad + blk * TK_ROW_SLOTS + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float s1f = dw * da[r];
+        const float s2f = dmin * da[r];
+        acc[r] = tk_fmaf(s1f, (float)P[r], acc[r]);
+        acc[r] = tk_fmaf(-s2f, (float)M[r], acc[r]);
+    }
+}
+
+__device__ __forceinline__ void block_q6(const FragQ6& f, const uint8_t* lds_act, const float* lds_ad, int blk, int lane, float* acc) {
+    const int g = lane >> 4;
+    const v4i zero = {0, 0, 0, 0};
+    const long mask_a = (g < 2) ? -1L : 0L;
+    int P[4] = {0, 0, 0, 0};
+    const uint32_t qs[8] = {f.q0.x, f.q0.y, f.q0.z, f.q0.w, f.q1.x, f.q1.y, f.q1.z, f.q1.w};
+    const uint32_t qh[4] = {f.qh.x, f.qh.y, f.qh.z, f.qh.w};
+    const uint32_t scw[4] = {f.sc.x, f.sc.y, f.sc.z, f.sc.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t x = qs[j];
+        const uint32_t H = qh[j >> 1];
+        const int e = j & 1;
+        const uint32_t lo = ((x << 2) & 0x3C3C3C3Cu) | ((H << (6 - 4 * e)) & 0xC0C0C0C0u);
+        const uint32_t hi = ((x >> 2) & 0x3C3C3C3Cu) | ((H << (4 - 4 * e)) & 0xC0C0C0C0u);
+        const long b = (long)(((unsigned long)hi << 32) | lo);
+        const long a = *(const long*)(lds_act + (size_t)(blk * 8 + j) * 512 + lane * 8);
+        const v4i ca = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b & mask_a, zero, 0, 0, 0);
+        const v4i cb = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b & ~mask_a, zero, 0, 0, 0);
+        const uint32_t w = scw[j >> 1];
+        const int sca = (int)(int8_t)(w >> (16 * e));
+        const int scb = (int)(int8_t)(w >> (16 * e + 8));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[r] += sca * ca[r] + scb * cb[r];
+    }
+    const float dw = f16bits_to_f32(f.d);
+    const v4f da = *(const v4f*)(lds_ad + blk * TK_ROW_SLOTS + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float s1f = (dw * da[r]) * 0.25f; /* operand bytes are 4*(q-32): exact power-of-two fold */
+        acc[r] = tk_fmaf(s1f, (float)P[r], acc[r]);
+    }
+}
+
+size_t tk_gemv_lds_bytes(int K, int ks) {
+    size_t Kr = (size_t)K / ks;
+    return Kr * TK_ROW_SLOTS + (Kr / 256) * TK_ROW_SLOTS * 4 + (Kr / 32) * TK_ROW_SLOTS * 4;
+}
+
+__global__ __launch_bounds__(256) void k_gemv_w4a8(TkGemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Kr = a.K / a.ks;
+    const int nb = Kr / 256;
+    const int nblk_total = a.K / 256;
+    const int blk0 = blockIdx.y * nb;
+
+    /* which segment / tile does this wave own */
+    int rt = blockIdx.x * 4 + wave;
+    int seg = 0, row_base = 0;
+    while (seg < a.nseg - 1 && rt >= a.seg[seg].row_tiles) {
+        rt -= a.seg[seg].row_tiles;
+        row_base += a.seg[seg].row_tiles * TK_TILE_ROWS;
+        ++seg;
+    }
+    const int type = a.seg[seg].type;
+    const size_t tile_bytes = type == TK_TYPE_Q4_K ? TK_Q4K_TILE_BYTES : TK_Q6K_TILE_BYTES;
+    const uint8_t* tile = a.seg[seg].tiles + ((size_t)rt * nblk_total + blk0) * tile_bytes;
+
+    uint8_t* lds_act = lds;
+    float* lds_ad = (float*)(lds + (size_t)Kr * TK_ROW_SLOTS);
+    int* lds_abs = (int*)(lds_ad + nb * TK_ROW_SLOTS);
+
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (type == TK_TYPE_Q4_K) {
+        /* issue the first weight loads before staging activations so HBM latency overlaps the LDS fill */
+        FragQ4 cur = load_q4(tile, lane);
+        FragQ4 nxt = cur;
+        if (nb > 1) nxt = load_q4(tile + tile_bytes, lane);
+        {
+            const uint4* src = (const uint4*)(a.aq + (size_t)blk0 * 256 * TK_ROW_SLOTS);
+            for (int i = tid; i < Kr; i += 256) ((uint4*)lds_act)[i] = src[i];
+            const uint4* sd = (const uint4*)(a.ad + (size_t)blk0 * TK_ROW_SLOTS);
+            for (int i = tid; i < nb * 4; i += 256) ((uint4*)lds_ad)[i] = sd[i];
+            const uint4* sb = (const uint4*)(a.abs + (size_t)blk0 * 8 * TK_ROW_SLOTS);
+            for (int i = tid; i < nb * 32; i += 256) ((uint4*)lds_abs)[i] = sb[i];
+        }
+        __syncthreads();
+        for (int blk = 0; blk < nb; ++blk) {
+            FragQ4 nn = nxt;
+            if (blk + 2 < nb) nn = load_q4(tile + (size_t)(blk + 2) * tile_bytes, lane);
+            block_q4(cur, lds_act, lds_abs, lds_ad, blk, lane, acc);
+            cur = nxt;
+            nxt = nn;
+        }
+    } else {
+        FragQ6 cur = load_q6(tile, lane);
+        FragQ6 nxt = cur;
+        if (nb > 1) nxt = load_q6(tile + tile_bytes, lane);
+        {
+            const uint4* src = (const uint4*)(a.aq + (size_t)blk0 * 256 * TK_ROW_SLOTS);
+            for (int i = tid; i < Kr; i += 256) ((uint4*)lds_act)[i] = src[i];
+            const uint4* sd = (const uint4*)(a.ad + (size_t)blk0 * TK_ROW_SLOTS);
+            for (int i = tid; i < nb * 4; i += 256) ((uint4*)lds_ad)[i] = sd[i];
+        }
+        __syncthreads();
+        for (int blk = 0; blk < nb; ++blk) {
+            FragQ6 nn = nxt;
+            if (blk + 2 < nb) nn = load_q6(tile + (size_t)(blk + 2) * tile_bytes, lane);
+            block_q6(cur, lds_act, lds_ad, blk, lane, acc);
+            cur = nxt;
+            nxt = nn;
+        }
+    }
+
+    const int n = row_base + rt * TK_TILE_ROWS + (lane & 15);
+    const int g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int slot = 4 * g + r;
+        if (slot < a.nrows) a.out[((size_t)blockIdx.y * TK_ROW_SLOTS + slot) * a.n_total + n] = acc[r];
+    }
+}
+
+void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
+    int row_tiles = 0;
+    for (int i = 0; i < a.nseg; ++i) row_tiles += a.seg[i].row_tiles;
+    size_t lds = tk_gemv_lds_bytes(a.K, a.ks);
+    static size_t lds_cap = 0; /* >64 KiB of dynamic LDS must be opted into once per process */
+    if (lds > lds_cap) {
+        (void)hipFuncSetAttribute((const void*)k_gemv_w4a8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_cap = lds;
+    }
+    hipLaunchKernelGGL(k_gemv_w4a8, dim3(row_tiles / 4, a.ks), dim3(256), lds, s, a);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * q/k/v: sum K-split partials, RoPE (adjacent pairs), append K/V (f16) to the cache.
+ * grid (n_kv_head, nrows); 256 threads = one q pair each (4 q heads x 64 pairs per kv head).
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ float sum_partials(const float* partial, int ks, int n_total, int row, int col) {
+    float o = partial[(int64_t)row * n_total + col];
+    for (int s = 1; s < ks; ++s) o = o + partial[((int64_t)s * TK_ROW_SLOTS + row) * n_total + col];
+    return o;
+}
+
+__global__ void k_qkv_rope_append(const float* partial, int ks, int n_total, int n_head, int n_kv_head, int head_dim, const float* rope_cos,
+                                  const float* rope_sin, const int32_t* seq, const int32_t* pos, float* qbuf, uint16_t* kcache,
+                                  uint16_t* vcache, int layer, int max_seq, int max_ctx) {
+    const int kvh = blockIdx.x, r = blockIdx.y;
+    const int half = head_dim / 2, grp = n_head / n_kv_head;
+    const int QD = n_head * head_dim, KVD = n_kv_head * head_dim;
+    const int p = pos[r], sq = seq[r];
+    const float* cs = rope_cos + (int64_t)p * half;
+    const float* sn = rope_sin + (int64_t)p * half;
+    const int64_t cbase = ((((int64_t)layer * max_seq + sq) * max_ctx + p) * n_kv_head + kvh) * head_dim;
+    for (int idx = threadIdx.x; idx < (grp + 1) * half; idx += blockDim.x) {
+        const int hsel = idx / half, i = idx % half;
+        if (hsel < grp) {
+            const int col = (kvh * grp + hsel) * head_dim + 2 * i;
+            const float a = sum_partials(partial, ks, n_total, r, col);
+            const float b = sum_partials(partial, ks, n_total, r, col + 1);
+            qbuf[(int64_t)r * QD + col] = tk_fmaf(-b, sn[i], a * cs[i]);
+            qbuf[(int64_t)r * QD + col + 1] = tk_fmaf(a, sn[i], b * cs[i]);
+        } else {
+            const int col = QD + kvh * head_dim + 2 * i;
+            const float a = sum_partials(partial, ks, n_total, r, col);
+            const float b = sum_partials(partial, ks, n_total, r, col + 1);
+            kcache[cbase + 2 * i] = tk_f32_to_f16(tk_fmaf(-b, sn[i], a * cs[i]));
+            kcache[cbase + 2 * i + 1] = tk_f32_to_f16(tk_fmaf(a, sn[i], b * cs[i]));
+            const int vcol = QD + KVD + kvh * head_dim + 2 * i;
+            vcache[cbase + 2 * i] = tk_f32_to_f16(sum_partials(partial, ks, n_total, r, vcol));
+            vcache[cbase + 2 * i + 1] = tk_f32_to_f16(sum_partials(partial, ks, n_total, r, vcol + 1));
+        }
+    }
+}
+
+void tk_launch_qkv_rope_append(const float* partial, int ks, int n_total, int n_head, int n_kv_head, int head_dim, const float* rope_cos,
+                               const float* rope_sin, const int32_t* seq, const int32_t* pos, int nrows, float* qbuf, uint16_t* kcache,
+                               uint16_t* vcache, int layer, int max_seq, int max_ctx, hipStream_t s) {
+    hipLaunchKernelGGL(k_qkv_rope_append, dim3(n_kv_head, nrows), dim3(256), 0, s, partial, ks, n_total, n_head, n_kv_head, head_dim, rope_cos,
+                       rope_sin, seq, pos, qbuf, kcache, vcache, layer, max_seq, max_ctx);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * causal GQA attention for one (row, kv head): scores (sequential fma over head_dim),
+ * max, exp, PV and the softmax denominator accumulated in ascending position order —
+ * the oracle's order — then the Q8 quantisation the o-projection consumes.
+ * Requires head_dim * (n_head / n_kv_head) == 512 or less and a multiple of 256.
+ * ------------------------------------------------------------------------------------------ */
+#define TK_ATT_MAX_GRP 4
+template <int GRP>
+__global__ __launch_bounds__(256) void k_attention(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq,
+                                                    const int32_t* pos, int n_head, int n_kv_head, int head_dim, int layer, int max_seq,
+                                                    int max_ctx, TkActQ8 out) {
+    extern __shared__ float sh[];
+    const int kvh = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
+    constexpr int grp = GRP;
+    const int T = pos[r] + 1, sq = seq[r];
+    const int W = grp * head_dim;              /* outputs of this WG */
+    float* qs = sh;                            /* [grp][head_dim] */
+    float* sc = qs + W;                        /* [grp][T] */
+    float* red = sc + (size_t)grp * max_ctx;   /* [4 waves][grp] */
+    float* obuf = red + 4 * TK_ATT_MAX_GRP;    /* [W] */
+    const int QD = n_head * head_dim;
+    for (int i = t; i < W; i += 256) qs[i] = qbuf[(int64_t)r * QD + kvh * W + i];
+    __syncthreads();
+    const float att_scale = tk_divf(1.0f, tk_sqrtf((float)head_dim));
+    const int64_t sbase = (((int64_t)layer * max_seq + sq) * max_ctx) * n_kv_head * head_dim;
+    float mx[GRP];
+#pragma unroll
+    for (int h = 0; h < grp; ++h) mx[h] = -INFINITY;
+    for (int tt = t; tt < T; tt += 256) {
+        const uint16_t* kr = kcache + sbase + ((int64_t)tt * n_kv_head + kvh) * head_dim;
+        float a[GRP];
+#pragma unroll
+        for (int h = 0; h < grp; ++h) a[h] = 0.0f;
+        for (int i = 0; i < head_dim; i += 8) {
+            const uint4 kv = *(const uint4*)(kr + i);
+            const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float kf = f16bits_to_f32((kw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+#pragma unroll
+                for (int h = 0; h < grp; ++h) a[h] = tk_fmaf(qs[h * head_dim + i + e], kf, a[h]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < grp; ++h) {
+            const float s = a[h] * att_scale;
+            sc[(size_t)h * max_ctx + tt] = s;
+            mx[h] = tk_fmaxf(mx[h], s);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < grp; ++h) {
+        float m = mx[h];
+        for (int s = 32; s >= 1; s >>= 1) m = tk_fmaxf(m, wave_xor_f(m, s));
+        if ((t & 63) == 0) red[(t >> 6) * TK_ATT_MAX_GRP + h] = m;
+    }
+    __syncthreads();
+    for (int h = 0; h < grp; ++h) {
+        const float m = tk_fmaxf(tk_fmaxf(red[h], red[TK_ATT_MAX_GRP + h]), tk_fmaxf(red[2 * TK_ATT_MAX_GRP + h], red[3 * TK_ATT_MAX_GRP + h]));
+        for (int tt = t; tt < T; tt += 256) sc[(size_t)h * max_ctx + tt] = tk_expf(sc[(size_t)h * max_ctx + tt] - m);
+    }
+    __syncthreads();
+    /* PV: thread owns output column i of the W = grp*head_dim outputs (2 per thread at W = 512) */
+    for (int i = t; i < W; i += 256) {
+        const int h = i / head_dim, d = i % head_dim;
+        const float* pr = sc + (size_t)h * max_ctx;
+        const uint16_t* vc = vcache + sbase + (int64_t)kvh * head_dim + d;
+        float acc = 0.0f, l = 0.0f;
+        for (int tt = 0; tt < T; ++tt) {
+            const float p = pr[tt];
+            acc = tk_fmaf(p, f16bits_to_f32(vc[(int64_t)tt * n_kv_head * head_dim]), acc);
+            l = l + p;
+        }
+        obuf[i] = tk_divf(acc, l);
+    }
+    __syncthreads();
+    for (int c = t; c < W / 8; c += 256) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = obuf[8 * c + i];
+        quantize_chunk8(v, kvh * (W / 8) + c, r, out);
+    }
+}
+
+void tk_launch_attention(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows,
+                         int n_head, int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, hipStream_t s) {
+    const int grp = n_head / n_kv_head;
+    const int W = grp * head_dim;
+    size_t lds = ((size_t)W + (size_t)grp * max_ctx + 4 * TK_ATT_MAX_GRP + W) * sizeof(float);
+#define TK_ATT_LAUNCH(G)                                                                                                             \
+    do {                                                                                                                             \
+        (void)hipFuncSetAttribute((const void*)k_attention<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        hipLaunchKernelGGL(k_attention<G>, dim3(n_kv_head, nrows), dim3(256), lds, s, qbuf, kcache, vcache, seq, pos, n_head,           \
+                           n_kv_head, head_dim, layer, max_seq, max_ctx, out);                                                          \
+    } while (0)
+    if (grp == 4) TK_ATT_LAUNCH(4);
+    else if (grp == 2) TK_ATT_LAUNCH(2);
+    else TK_ATT_LAUNCH(1);
+#undef TK_ATT_LAUNCH
+}
+
+/* ------------------------------------------------------------------------------------------
+ * SwiGLU + Q8 quantise:  act = silu(gate) * up ; gate = cols [0,FF), up = cols [FF,2FF)
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_swiglu_q8(const float* partial, int ks, int FF, TkActQ8 out) {
+    const int r = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= FF / 8) return; /* FF/8 is a multiple of 32: whole half-waves drop out together */
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float g = sum_partials(partial, ks, 2 * FF, r, 8 * c + i);
+        const float u = sum_partials(partial, ks, 2 * FF, r, FF + 8 * c + i);
+        v[i] = tk_siluf(g) * u;
+    }
+    quantize_chunk8(v, c, r, out);
+}
+
+void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ8 out, hipStream_t s) {
+    hipLaunchKernelGGL(k_swiglu_q8, dim3((FF / 8 + 255) / 256, nrows), dim3(256), 0, s, partial, ks, FF, out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * greedy sampling: first index of the maximum; feeds the next step entirely on-device
+ * (tok <- argmax, pos <- pos + 1, history append) so a decode loop is a pure graph replay.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab, int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist,
+                                                  int hist_stride) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const float* lg = logits + (int64_t)r * vocab;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = t; i < vocab; i += 1024) {
+        const float v = lg[i];
+        if (v > best) { best = v; idx = i; }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const float ov = __shfl_xor(best, s, TK_WAVE);
+        const int oi = __shfl_xor(idx, s, TK_WAVE);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((t & 63) == 0) { bv[t >> 6] = best; bi[t >> 6] = idx; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        if (tok) tok[r] = idx;
+        if (pos) pos[r] = pos[r] + 1;
+        if (hist) {
+            const int n = nsteps[r];
+            hist[(int64_t)n * hist_stride + r] = idx;
+            nsteps[r] = n + 1;
+        }
+    }
+}
+
+void tk_launch_argmax(const float* logits, int vocab, int nrows, int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_argmax, dim3(nrows), dim3(1024), 0, s, logits, vocab, tok, pos, nsteps, hist, hist_stride);
+}

@@ -1,0 +1,189 @@
+"""LLM stream: tk_model_loader_* / tk_llm_runner_* and the batched tk_mi355x_llm_* extension."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+class LlmHParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_layer", "d_model", "n_head", "n_kv_head", "head_dim", "d_ff", "vocab")] + \
+               [("rms_eps", C.c_float), ("rope_theta", C.c_float)] + \
+               [(n, C.c_int32) for n in ("ks_qkv", "ks_o", "ks_gateup", "ks_down", "ks_out")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def MISTRAL_7B():
+    return LlmHParams(32, 4096, 32, 8, 128, 14336, 32000, 1e-5, 10000.0, 0, 0, 0, 0, 1)
+
+
+def TINY():
+    return LlmHParams(2, 256, 8, 2, 64, 512, 512, 1e-5, 10000.0, 0, 0, 0, 0, 1)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class LlmModel:
+    def __init__(self, hparams=None, device=0, gguf=None):
+        self.h = C.c_void_p()
+        if gguf is not None:
+            check(lib().tk_mi355x_llm_model_load_gguf(C.byref(self.h), gguf.encode(), device))
+        else:
+            check(lib().tk_mi355x_llm_model_create(C.byref(self.h), C.byref(hparams), device))
+
+    @property
+    def hparams(self):
+        hp = LlmHParams()
+        lib().tk_mi355x_llm_model_get_hparams(self.h, C.byref(hp))
+        return hp
+
+    @property
+    def weight_bytes(self):
+        lib().tk_mi355x_llm_model_weight_bytes.restype = C.c_uint64
+        return lib().tk_mi355x_llm_model_weight_bytes(self.h)
+
+    def fill_synthetic(self, seed):
+        check(lib().tk_mi355x_llm_model_fill_synthetic(self.h, C.c_uint64(seed)))
+        return self
+
+    def set_tensor(self, layer, which, ttype, data):
+        data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        check(lib().tk_mi355x_llm_model_set_tensor(self.h, layer, which, ttype, _p(data), C.c_size_t(data.size)))
+
+    def close(self):
+        if self.h:
+            lib().tk_mi355x_llm_model_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LlmSession:
+    def __init__(self, model, max_seq, max_ctx):
+        self.model = model
+        self.vocab = model.hparams.vocab
+        self.h = C.c_void_p()
+        check(lib().tk_mi355x_llm_session_create(C.byref(self.h), model.h, max_seq, max_ctx))
+
+    def forward(self, seq, pos, tok, want_logits=True):
+        seq = np.ascontiguousarray(seq, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        tok = np.ascontiguousarray(tok, dtype=np.int32)
+        n = len(seq)
+        logits = np.empty((n, self.vocab), dtype=np.float32) if want_logits else None
+        am = np.empty(n, dtype=np.int32)
+        check(lib().tk_mi355x_llm_forward(self.h, n, _p(seq), _p(pos), _p(tok), _p(logits), _p(am)))
+        return logits, am
+
+    def prefill(self, tokens):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        nseq, n_prompt = tokens.shape
+        first = np.empty(nseq, dtype=np.int32)
+        check(lib().tk_mi355x_llm_prefill(self.h, nseq, n_prompt, _p(tokens), _p(first)))
+        return first
+
+    def decode(self, nrows, n_steps):
+        out = np.empty((n_steps, 16), dtype=np.int32)
+        ms = C.c_float(0)
+        check(lib().tk_mi355x_llm_decode(self.h, nrows, n_steps, _p(out), C.byref(ms)))
+        return out[:, :nrows].copy(), ms.value
+
+    def time_gemv(self, which, nrows, iters):
+        ms = C.c_float(0)
+        nbytes = C.c_double(0)
+        check(lib().tk_mi355x_llm_time_gemv(self.h, which, nrows, iters, C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value
+
+    def close(self):
+        if self.h:
+            lib().tk_mi355x_llm_session_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- reference surface (what trackie-core links against) ------------------------------------
+
+class _Path(C.Structure):
+    _fields_ = [("path_str", C.c_char_p), ("length", C.c_size_t), ("capacity", C.c_size_t)]
+
+
+class _LoaderConfig(C.Structure):
+    _fields_ = [("max_models", C.c_uint32), ("num_threads", C.c_uint32)]
+
+
+class _LoadParams(C.Structure):
+    _fields_ = [("model_path", C.POINTER(_Path)), ("model_type", C.c_uint32), ("force_reload", C.c_bool),
+                ("gpu_layers", C.c_uint32), ("cpu_threads", C.c_uint32), ("use_mmap", C.c_bool), ("use_mlock", C.c_bool),
+                ("numa", C.c_bool), ("seed", C.c_uint32), ("lora_adapter", C.c_char_p)]
+
+
+class _LlmConfig(C.Structure):
+    _fields_ = [("context_size", C.c_uint32), ("system_prompt", C.c_char_p), ("random_seed", C.c_uint32)]
+
+
+class ModelLoader:
+    def __init__(self, max_models=4):
+        self.h = C.c_void_p()
+        cfg = _LoaderConfig(max_models, 1)
+        check(lib().tk_model_loader_create(C.byref(self.h), C.byref(cfg)))
+
+    def load(self, path):
+        lib().tk_path_create.restype = C.POINTER(_Path)
+        p = lib().tk_path_create(path.encode())
+        params = _LoadParams(p, 1, False, 99, 1, True, False, False, 0, None)
+        handle = C.c_void_p()
+        try:
+            check(lib().tk_model_loader_load_model(self.h, C.byref(params), C.byref(handle)))
+        finally:
+            lib().tk_path_destroy(C.byref(p))
+        return handle
+
+    def unload(self, handle):
+        check(lib().tk_model_loader_unload_model(self.h, C.byref(handle)))
+
+    def close(self):
+        if self.h:
+            lib().tk_model_loader_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+
+class LlmRunner:
+    """tk_llm_runner_* exactly as the reference's Rust GgufRunner drives it."""
+
+    def __init__(self, model_handle, context_size=4096):
+        self.h = C.c_void_p()
+        cfg = _LlmConfig(context_size, None, 0)
+        check(lib().tk_llm_runner_create(C.byref(self.h), model_handle, C.byref(cfg)))
+        lib().tk_llm_runner_generate_next_token.restype = C.c_void_p
+
+    def prepare(self, prompt, use_tool_grammar=False):
+        check(lib().tk_llm_runner_prepare_generation(self.h, prompt.encode(), use_tool_grammar))
+
+    def next_token(self):
+        p = lib().tk_llm_runner_generate_next_token(self.h)
+        if not p:
+            return None
+        if p == 1:
+            return "<tool_call>"
+        return C.string_at(p)
+
+    def reset(self):
+        check(lib().tk_llm_runner_reset_context(self.h))
+
+    def close(self):
+        if self.h:
+            lib().tk_llm_runner_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
