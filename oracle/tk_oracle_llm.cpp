@@ -445,3 +445,5 @@ void orc_llm_reset(orc_llm* m) {
 }
 
 } /* extern "C" */
+
+extern "C" float orc_sqrtf(float x) { return tk_sqrtf(x); }

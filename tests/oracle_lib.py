@@ -59,7 +59,7 @@ def lib():
         L.orc_gemv_q8.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 4
         L.orc_dequant_row.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.orc_quantize_rows.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
-        for f in ("orc_expf", "orc_logf", "orc_tanhf", "orc_geluf", "orc_siluf"):
+        for f in ("orc_expf", "orc_logf", "orc_tanhf", "orc_geluf", "orc_siluf", "orc_sqrtf"):
             getattr(L, f).restype = C.c_float
             getattr(L, f).argtypes = [C.c_float]
         L.orc_f32_to_f16.restype = C.c_uint16

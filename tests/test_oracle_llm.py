@@ -103,6 +103,11 @@ def test_exact_math_accuracy():
         assert abs(L.orc_tanhf(float(x)) - math.tanh(float(x))) < 3e-7
         silu = float(x) / (1 + math.exp(-float(x)))
         assert abs(L.orc_siluf(float(x)) - silu) <= 3e-7 * max(1.0, abs(silu))
+    for x in np.geomspace(1e-30, 1e30, 4001).astype(np.float32):
+        want = np.float32(math.sqrt(float(x)))
+        got = np.float32(L.orc_sqrtf(float(x)))
+        assert abs(int(got.view(np.uint32)) - int(want.view(np.uint32))) <= 1, (x, got, want)
+    assert L.orc_sqrtf(0.0) == 0.0 and L.orc_sqrtf(64.0) == 8.0 and L.orc_sqrtf(128.0) == np.float32(math.sqrt(128.0))
     assert L.orc_expf(-200.0) == 0.0 and L.orc_expf(1000.0) == L.orc_expf(88.0)
 
 

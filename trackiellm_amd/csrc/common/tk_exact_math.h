@@ -35,12 +35,25 @@ TK_HD float tk_divf(float a, float b) {
 #endif
 }
 
+TK_HD uint32_t tk_f32_bits(float f);
+TK_HD float tk_bits_f32(uint32_t u);
+
+/*
+ * sqrt(a), a >= 0 (normal range): NOT the hardware instruction (gfx950's v_sqrt_f32 is a 1-ulp
+ * approximation and __fsqrt_rn lowers to it), but a fixed Newton sequence of IEEE mul/fma from an
+ * integer seed, so host and device agree bit for bit.  <= 1 ulp of the true root (tests pin it).
+ */
 TK_HD float tk_sqrtf(float a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(a);
-#else
-    return __builtin_sqrtf(a);
-#endif
+    if (!(a > 0.0f)) return 0.0f;
+    float y = tk_bits_f32(0x5f3759dfu - (tk_f32_bits(a) >> 1)); /* ~1/sqrt(a), 3.4 % */
+    const float h = 0.5f * a;
+    y = y * tk_fmaf(-h * y, y, 1.5f);
+    y = y * tk_fmaf(-h * y, y, 1.5f);
+    y = y * tk_fmaf(-h * y, y, 1.5f);
+    y = y * tk_fmaf(-h * y, y, 1.5f);
+    float s = a * y;
+    float r = tk_fmaf(-s, s, a);
+    return tk_fmaf(r, 0.5f * y, s);
 }
 
 TK_HD uint32_t tk_f32_bits(float f) {
