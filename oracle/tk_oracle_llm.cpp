@@ -403,12 +403,15 @@ void orc_llm_forward(orc_llm* m, int n_rows, const int32_t* seq, const int32_t* 
                     sc[t] = a * att_scale;
                     mx = tk_fmaxf(mx, sc[t]);
                 }
-                float lsum = 0.0f;
-                for (int t = 0; t < T; ++t) { sc[t] = tk_expf(sc[t] - mx); lsum = lsum + sc[t]; }
+                /* canonical order: 4 interleaved partial sums over positions (t mod 4), combined in order */
+                float lp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int t = 0; t < T; ++t) { sc[t] = tk_expf(sc[t] - mx); lp[t & 3] = lp[t & 3] + sc[t]; }
+                const float lsum = ((lp[0] + lp[1]) + lp[2]) + lp[3];
                 for (int i = 0; i < HD; ++i) {
-                    float a = 0.0f;
-                    for (int t = 0; t < T; ++t) a = tk_fmaf(sc[t], tk_f16_to_f32(m->vcache[sbase + ((size_t)t * NKV + kvh) * HD + i]), a);
-                    ar[hh * HD + i] = tk_divf(a, lsum);
+                    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int t = 0; t < T; ++t)
+                        a[t & 3] = tk_fmaf(sc[t], tk_f16_to_f32(m->vcache[sbase + ((size_t)t * NKV + kvh) * HD + i]), a[t & 3]);
+                    ar[hh * HD + i] = tk_divf(((a[0] + a[1]) + a[2]) + a[3], lsum);
                 }
             }
             matvec(L[ORC_L_O], c.ks_o, ar, o.data(), q8, qd, qb);

@@ -98,7 +98,7 @@ def test_mistral_shaped_layer_bit_exact(gpu):
     hp.n_layer = 1
     model = gpu.LlmModel(hp).fill_synthetic(4)
     hp = model.hparams
-    assert (hp.ks_qkv, hp.ks_o, hp.ks_gateup, hp.ks_down) == (4, 4, 1, 4)
+    assert (hp.ks_qkv, hp.ks_o, hp.ks_gateup, hp.ks_down) == (4, 4, 1, 7)
     sess = gpu.LlmSession(model, 16, 32)
     orc = O.OracleLlm(oracle_cfg_from(hp, 32, 16), seed=4)
     rng = np.random.default_rng(1)

@@ -59,8 +59,9 @@ static void default_plan(tk_mi355x_llm_hparams_t* h) {
         int nb = (int)(K / 256);
         int want = (int)((256 + rows / 64 - 1) / (rows / 64));
         int ks = 1;
+        /* prefer K-ranges of a multiple of 4 blocks: the GEMV keeps 4 weight tiles in flight per wave */
         for (int c = 1; c <= nb; ++c)
-            if (nb % c == 0) { ks = c; if (c >= want) break; }
+            if (nb % c == 0 && ((nb / c) % 4 == 0 || nb < 4 * want)) { ks = c; if (c >= want) break; }
         if (K / ks > 4096) { /* LDS image of the K-range must fit: 16 B per k */
             for (int c = ks; c <= nb; ++c) if (nb % c == 0 && K / c <= 4096) { ks = c; break; }
         }
@@ -217,9 +218,10 @@ tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t* s, int nrows, int 
     return TK_SUCCESS;
 }
 
-tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int which, int nrows, int iters, float* avg_ms, double* algorithmic_bytes) {
+tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int layer, int which, int nrows, int iters, float* avg_ms,
+                                        double* algorithmic_bytes) {
     if (!s || !avg_ms || !algorithmic_bytes || iters <= 0) return TK_ERROR_INVALID_ARGUMENT;
-    if (!s->session.time_gemv(which, nrows, iters, avg_ms, algorithmic_bytes)) return fail(TK_ERROR_GPU_ROCM_ERROR, s->session.error);
+    if (!s->session.time_gemv(layer, which, nrows, iters, avg_ms, algorithmic_bytes)) return fail(TK_ERROR_GPU_ROCM_ERROR, s->session.error);
     return TK_SUCCESS;
 }
 

@@ -87,7 +87,7 @@ public:
     /* per-launch timing of the last decode(): average ms of one step measured with HIP events */
     float last_step_ms = 0.0f;
     /* stand-alone timing of the dominant GEMV (gate/up of layer 0) for bench.py's roofline leg */
-    bool time_gemv(int which, int nrows, int iters, float* avg_ms, double* algo_bytes);
+    bool time_gemv(int layer, int which, int nrows, int iters, float* avg_ms, double* algo_bytes);
 
 private:
     void enqueue_pass(int nrows, bool lm_head);

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <algorithm>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../common/tk_ggml_blocks.h"
@@ -66,7 +67,7 @@ bool TkLlmModel::init(const TkLlmHParams& h, int dev) {
     auto bad = [&](const char* why) { error = std::string("unsupported model geometry: ") + why; return false; };
     if (h.n_layer <= 0 || h.d_model % 256 || h.d_ff % 256 || qd % 256) return bad("d_model, d_ff and n_head*head_dim must be multiples of 256");
     if (h.n_kv_head <= 0 || h.n_head % h.n_kv_head || (grp != 1 && grp != 2 && grp != 4)) return bad("n_head / n_kv_head must be 1, 2 or 4");
-    if ((grp * h.head_dim) % 256 || h.head_dim % 8) return bad("(n_head/n_kv_head)*head_dim must be a multiple of 256");
+    if ((grp * h.head_dim) % 256 || h.head_dim % 64) return bad("head_dim must be a multiple of 64 and (n_head/n_kv_head)*head_dim a multiple of 256");
     if (qd % 64 || kvd % 64 || h.d_ff % 64 || h.vocab % 64 || h.d_model % 64) return bad("row counts must be multiples of 64");
     if (h.ks_out != 1) return bad("ks_out must be 1");
     const int ksv[4] = {h.ks_qkv, h.ks_o, h.ks_gateup, h.ks_down};
@@ -347,7 +348,10 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     HIPQ(hipStreamSynchronize(stream));
     for (int r = 0; r < nrows; ++r)
         if (hpos[r] + n_steps > max_ctx) { error = "decode would run past max_ctx"; return false; }
-    if (!graph_exec[nrows]) {
+    /* TK_MI355X_NO_GRAPH=1: eager launches (rocprofv3's kernel trace crashes inside hipGraphLaunch on ROCm 7.2) */
+    const char* ng = getenv("TK_MI355X_NO_GRAPH");
+    const bool use_graph = !(ng && ng[0] == '1');
+    if (use_graph && !graph_exec[nrows]) {
         hipGraph_t g = nullptr;
         HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         enqueue_pass(nrows, true);
@@ -360,7 +364,11 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     HIPQ(hipEventCreate(&e0));
     HIPQ(hipEventCreate(&e1));
     HIPQ(hipEventRecord(e0, stream));
-    for (int i = 0; i < n_steps; ++i) HIPQ(hipGraphLaunch(graph_exec[nrows], stream));
+    for (int i = 0; i < n_steps; ++i) {
+        if (use_graph) HIPQ(hipGraphLaunch(graph_exec[nrows], stream));
+        else enqueue_pass(nrows, true);
+    }
+    HIPQ(hipGetLastError());
     HIPQ(hipEventRecord(e1, stream));
     if (out_tokens_host) HIPQ(hipMemcpyAsync(out_tokens_host, d_hist, (size_t)n_steps * TK_ROW_SLOTS * 4, hipMemcpyDeviceToHost, stream));
     HIPQ(hipStreamSynchronize(stream));
@@ -372,36 +380,56 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     return true;
 }
 
-bool TkLlmSession::time_gemv(int which, int nrows, int iters, float* avg_ms, double* algo_bytes) {
+bool TkLlmSession::time_gemv(int layer, int which, int nrows, int iters, float* avg_ms, double* algo_bytes) {
     const TkLlmHParams& h = model->hp;
-    const TkLlmLayer& L = model->layers[0];
+    if (layer < 0 || layer >= h.n_layer || nrows < 1 || nrows > TK_ROW_SLOTS) { error = "bad layer / nrows"; return false; }
     HIPQ(hipSetDevice(model->device));
-    TkGemvArgs a{};
-    a.nrows = nrows;
-    if (which == 0) { /* gate+up of layer 0 */
-        a.seg[0] = seg_of(L.gate); a.seg[1] = seg_of(L.up); a.nseg = 2; a.K = h.d_model; a.ks = h.ks_gateup; a.n_total = 2 * h.d_ff;
-        a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
-        *algo_bytes = (double)L.gate.bytes + (double)L.up.bytes;
-    } else if (which == 1) { /* down */
-        a.seg[0] = seg_of(L.down); a.nseg = 1; a.K = h.d_ff; a.ks = h.ks_down; a.n_total = h.d_model;
-        a.aq = act_ff.aq; a.ad = act_ff.ad; a.abs = act_ff.abs; a.out = partial;
-        *algo_bytes = (double)L.down.bytes;
-    } else if (which == 2) { /* qkv */
-        a.seg[0] = seg_of(L.q); a.seg[1] = seg_of(L.k); a.seg[2] = seg_of(L.v); a.nseg = 3; a.K = h.d_model; a.ks = h.ks_qkv;
-        a.n_total = (h.n_head + 2 * h.n_kv_head) * h.head_dim;
-        a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
-        *algo_bytes = (double)L.q.bytes + (double)L.k.bytes + (double)L.v.bytes;
-    } else { /* lm head */
-        a.seg[0] = seg_of(model->output); a.nseg = 1; a.K = h.d_model; a.ks = 1; a.n_total = h.vocab;
-        a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = logits;
-        *algo_bytes = (double)model->output.bytes;
+    auto args_for = [&](int l, double* bytes) {
+        const TkLlmLayer& L = model->layers[l];
+        TkGemvArgs a{};
+        a.nrows = nrows;
+        if (which == 0) { /* gate+up */
+            a.seg[0] = seg_of(L.gate); a.seg[1] = seg_of(L.up); a.nseg = 2; a.K = h.d_model; a.ks = h.ks_gateup; a.n_total = 2 * h.d_ff;
+            a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
+            *bytes = (double)L.gate.bytes + (double)L.up.bytes;
+        } else if (which == 1) { /* down */
+            a.seg[0] = seg_of(L.down); a.nseg = 1; a.K = h.d_ff; a.ks = h.ks_down; a.n_total = h.d_model;
+            a.aq = act_ff.aq; a.ad = act_ff.ad; a.abs = act_ff.abs; a.out = partial;
+            *bytes = (double)L.down.bytes;
+        } else if (which == 4) { /* o */
+            a.seg[0] = seg_of(L.o); a.nseg = 1; a.K = h.n_head * h.head_dim; a.ks = h.ks_o; a.n_total = h.d_model;
+            a.aq = act_qd.aq; a.ad = act_qd.ad; a.abs = act_qd.abs; a.out = partial;
+            *bytes = (double)L.o.bytes;
+        } else if (which == 2) { /* qkv */
+            a.seg[0] = seg_of(L.q); a.seg[1] = seg_of(L.k); a.seg[2] = seg_of(L.v); a.nseg = 3; a.K = h.d_model; a.ks = h.ks_qkv;
+            a.n_total = (h.n_head + 2 * h.n_kv_head) * h.head_dim;
+            a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
+            *bytes = (double)L.q.bytes + (double)L.k.bytes + (double)L.v.bytes;
+        } else { /* lm head */
+            a.seg[0] = seg_of(model->output); a.nseg = 1; a.K = h.d_model; a.ks = 1; a.n_total = h.vocab;
+            a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = logits;
+            *bytes = (double)model->output.bytes;
+        }
+        return a;
+    };
+    /* every layer whose tensors have the same types as `layer`: cycling through them keeps each launch on
+     * cold HBM lines (32 layers x 66 MB >> the 256 MiB Infinity Cache), as in a real decode step */
+    std::vector<TkGemvArgs> set;
+    double bytes = 0.0;
+    for (int l = 0; l < h.n_layer; ++l) {
+        if (which == 3 && l != layer) continue;
+        if (model->layers[l].v.type != model->layers[layer].v.type || model->layers[l].down.type != model->layers[layer].down.type) continue;
+        double b;
+        set.push_back(args_for(l, &b));
+        bytes = b;
     }
+    *algo_bytes = bytes;
     hipEvent_t e0, e1;
     HIPQ(hipEventCreate(&e0));
     HIPQ(hipEventCreate(&e1));
-    tk_launch_gemv(a, stream);
+    for (size_t i = 0; i < set.size(); ++i) tk_launch_gemv(set[i], stream);
     HIPQ(hipEventRecord(e0, stream));
-    for (int i = 0; i < iters; ++i) tk_launch_gemv(a, stream);
+    for (int i = 0; i < iters; ++i) tk_launch_gemv(set[(size_t)i % set.size()], stream);
     HIPQ(hipEventRecord(e1, stream));
     HIPQ(hipStreamSynchronize(stream));
     float ms = 0.0f;

@@ -188,33 +188,64 @@ __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot,
 /* ------------------------------------------------------------------------------------------
  * residual add (sum of K-split partials, ascending) + RMSNorm + Q8 quantise.  One WG per row.
  * ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(256) void k_rmsnorm_q8(float* x, const float* partial, int ks, int n_total, const float* w, float eps, int D,
-                                                     TkActQ8 out) {
+__global__ __launch_bounds__(256) void k_rmsnorm_q8(float* __restrict__ x, const float* __restrict__ partial, int ks, int n_total,
+                                                     const float* __restrict__ w, float eps, int D, TkActQ8 out) {
     extern __shared__ float sh[]; /* D floats + 4 */
     float* hbuf = sh;
     float* red = sh + D;
     const int r = blockIdx.x, t = threadIdx.x;
     float* xr = x + (int64_t)r * D;
     float ss = 0.0f;
-    for (int i = t; i < D; i += 256) {
-        float v = xr[i];
-        if (partial) {
-            float o = partial[(int64_t)r * n_total + i];
-            for (int s = 1; s < ks; ++s) o = o + partial[((int64_t)s * TK_ROW_SLOTS + r) * n_total + i];
-            v = v + o;
-            xr[i] = v;
+    /* 16 elements per thread and pass: every load of the pass is issued before the first use so the
+     * row costs ~one memory round trip instead of one per element (the residual add is latency-bound) */
+    for (int base = 0; base < D; base += 256 * 16) {
+        float v[16], o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = base + t + 256 * e;
+            v[e] = i < D ? xr[i] : 0.0f;
         }
-        hbuf[i] = v;
-        ss = tk_fmaf(v, v, ss);
+        if (partial) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = base + t + 256 * e;
+                o[e] = i < D ? partial[(int64_t)r * n_total + i] : 0.0f;
+            }
+            for (int s = 1; s < ks; ++s) {
+                float p[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = base + t + 256 * e;
+                    p[e] = i < D ? partial[((int64_t)s * TK_ROW_SLOTS + r) * n_total + i] : 0.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] = o[e] + p[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = v[e] + o[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = base + t + 256 * e;
+            if (i < D) {
+                if (partial) xr[i] = v[e];
+                hbuf[i] = v[e];
+                ss = tk_fmaf(v[e], v[e], ss);
+            }
+        }
     }
     float tot = block_sum256(ss, red);
     float mean = tk_divf(tot, (float)D);
     float scale = tk_divf(1.0f, tk_sqrtf(mean + eps));
-    __syncthreads();
     for (int c = t; c < D / 8; c += 256) {
+        const v4f h0 = *(const v4f*)(hbuf + 8 * c), h1 = *(const v4f*)(hbuf + 8 * c + 4);
+        const v4f w0 = *(const v4f*)(w + 8 * c), w1 = *(const v4f*)(w + 8 * c + 4);
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (hbuf[8 * c + i] * scale) * w[8 * c + i];
+        for (int i = 0; i < 4; ++i) {
+            v[i] = (h0[i] * scale) * w0[i];
+            v[4 + i] = (h1[i] * scale) * w1[i];
+        }
         quantize_chunk8(v, c, r, out);
     }
 }
@@ -345,16 +376,28 @@ size_t tk_gemv_lds_bytes(int K, int ks) {
     return Kr * TK_ROW_SLOTS + (Kr / 256) * TK_ROW_SLOTS * 4 + (Kr / 32) * TK_ROW_SLOTS * 4;
 }
 
-__global__ __launch_bounds__(256) void k_gemv_w4a8(TkGemvArgs a) {
+/*
+ * Work mapping (XCD/CU-aware, persistent-style): the launch has one workgroup per CU (256, rounded to a
+ * multiple of ks).  Workgroup b owns K-range b % ks and the row tiles {b / ks + w * groups}, one per wave,
+ * so (a) every CU streams the same number of 16-row tiles (+-1), (b) the K-range's int8 activations are
+ * staged once per CU, (c) all waves of a CU walk disjoint contiguous tile runs.
+ */
+template <int PF>
+__global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int total_row_tiles) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* scalar: tile/segment/type selection stays on the SALU */
     const int Kr = a.K / a.ks;
-    const int nb = Kr / 256;
+    const int nb = Kr / 256;           /* host guarantees nb % PF == 0 */
+    const int ngrp = nb / PF;
     const int nblk_total = a.K / 256;
-    const int blk0 = blockIdx.y * nb;
+    const int ksi = blockIdx.x % a.ks;
+    const int blk0 = ksi * nb;
 
     /* which segment / tile does this wave own */
-    int rt = blockIdx.x * 4 + wave;
+    int rt = blockIdx.x / a.ks + wave * groups;
+    const bool active = rt < total_row_tiles;
+    if (!active) rt = 0;
     int seg = 0, row_base = 0;
     while (seg < a.nseg - 1 && rt >= a.seg[seg].row_tiles) {
         rt -= a.seg[seg].row_tiles;
@@ -371,45 +414,63 @@ __global__ __launch_bounds__(256) void k_gemv_w4a8(TkGemvArgs a) {
 
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
+    /* The first PF weight tiles are requested before the activations are staged so HBM latency overlaps the LDS
+     * fill.  Loop bodies below contain NO conditional loads: hipcc then keeps counted vmcnt waits and the next
+     * group's tiles stay in flight under the current group's MFMAs (a branch around a load costs a vmcnt(0)). */
+    FragQ4 f4[PF];
+    FragQ6 f6[PF];
     if (type == TK_TYPE_Q4_K) {
-        /* issue the first weight loads before staging activations so HBM latency overlaps the LDS fill */
-        FragQ4 cur = load_q4(tile, lane);
-        FragQ4 nxt = cur;
-        if (nb > 1) nxt = load_q4(tile + tile_bytes, lane);
-        {
-            const uint4* src = (const uint4*)(a.aq + (size_t)blk0 * 256 * TK_ROW_SLOTS);
-            for (int i = tid; i < Kr; i += 256) ((uint4*)lds_act)[i] = src[i];
-            const uint4* sd = (const uint4*)(a.ad + (size_t)blk0 * TK_ROW_SLOTS);
-            for (int i = tid; i < nb * 4; i += 256) ((uint4*)lds_ad)[i] = sd[i];
-            const uint4* sb = (const uint4*)(a.abs + (size_t)blk0 * 8 * TK_ROW_SLOTS);
-            for (int i = tid; i < nb * 32; i += 256) ((uint4*)lds_abs)[i] = sb[i];
-        }
-        __syncthreads();
-        for (int blk = 0; blk < nb; ++blk) {
-            FragQ4 nn = nxt;
-            if (blk + 2 < nb) nn = load_q4(tile + (size_t)(blk + 2) * tile_bytes, lane);
-            block_q4(cur, lds_act, lds_abs, lds_ad, blk, lane, acc);
-            cur = nxt;
-            nxt = nn;
-        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) f4[u] = load_q4(tile + (size_t)u * tile_bytes, lane);
     } else {
-        FragQ6 cur = load_q6(tile, lane);
-        FragQ6 nxt = cur;
-        if (nb > 1) nxt = load_q6(tile + tile_bytes, lane);
-        {
-            const uint4* src = (const uint4*)(a.aq + (size_t)blk0 * 256 * TK_ROW_SLOTS);
-            for (int i = tid; i < Kr; i += 256) ((uint4*)lds_act)[i] = src[i];
-            const uint4* sd = (const uint4*)(a.ad + (size_t)blk0 * TK_ROW_SLOTS);
-            for (int i = tid; i < nb * 4; i += 256) ((uint4*)lds_ad)[i] = sd[i];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) f6[u] = load_q6(tile + (size_t)u * tile_bytes, lane);
+    }
+    {
+        /* activations: LDS-DMA (global_load_lds_dwordx4), one contiguous 1 KiB piece per wave-instruction, no VGPR
+         * round trip and no per-piece wait: the whole K-range image is in flight at once. */
+        const uint8_t* src = (const uint8_t*)a.aq + (size_t)blk0 * 256 * TK_ROW_SLOTS;
+        const int nw = nthr >> 6, npiece = Kr * TK_ROW_SLOTS / 1024;
+        for (int c = wave; c < npiece; c += nw)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(lds_act + c * 1024), 16, 0, 0);
+        /* block scales and sub-block sums: <= 2 x 16 B per thread, loaded together, stored together */
+        const uint4* sd = (const uint4*)(a.ad + (size_t)blk0 * TK_ROW_SLOTS);
+        const uint4* sb = (const uint4*)(a.abs + (size_t)blk0 * 8 * TK_ROW_SLOTS);
+        const int nd = nb * 4, ns = nb * 32;
+        uint4 t0 = make_uint4(0, 0, 0, 0), t1[4];
+        if (tid < nd) t0 = sd[tid];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t1[k] = (tid + k * nthr < ns) ? sb[tid + k * nthr] : make_uint4(0, 0, 0, 0);
+        if (tid < nd) ((uint4*)lds_ad)[tid] = t0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + k * nthr < ns) ((uint4*)lds_abs)[tid + k * nthr] = t1[k];
+        __builtin_amdgcn_s_waitcnt(0); /* vmcnt(0): the LDS-DMA pieces have landed (the first weight tiles too) */
+    }
+    __syncthreads();
+    if (!active) return;
+
+    if (type == TK_TYPE_Q4_K) {
+        for (int g = 0; g < ngrp - 1; ++g) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                block_q4(f4[u], lds_act, lds_abs, lds_ad, g * PF + u, lane, acc);
+                f4[u] = load_q4(tile + (size_t)((g + 1) * PF + u) * tile_bytes, lane);
+            }
         }
-        __syncthreads();
-        for (int blk = 0; blk < nb; ++blk) {
-            FragQ6 nn = nxt;
-            if (blk + 2 < nb) nn = load_q6(tile + (size_t)(blk + 2) * tile_bytes, lane);
-            block_q6(cur, lds_act, lds_ad, blk, lane, acc);
-            cur = nxt;
-            nxt = nn;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) block_q4(f4[u], lds_act, lds_abs, lds_ad, (ngrp - 1) * PF + u, lane, acc);
+    } else {
+        for (int g = 0; g < ngrp - 1; ++g) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                block_q6(f6[u], lds_act, lds_ad, g * PF + u, lane, acc);
+                f6[u] = load_q6(tile + (size_t)((g + 1) * PF + u) * tile_bytes, lane);
+            }
         }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) block_q6(f6[u], lds_act, lds_ad, (ngrp - 1) * PF + u, lane, acc);
     }
 
     const int n = row_base + rt * TK_TILE_ROWS + (lane & 15);
@@ -417,20 +478,31 @@ __global__ __launch_bounds__(256) void k_gemv_w4a8(TkGemvArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int slot = 4 * g + r;
-        if (slot < a.nrows) a.out[((size_t)blockIdx.y * TK_ROW_SLOTS + slot) * a.n_total + n] = acc[r];
+        if (slot < a.nrows) a.out[((size_t)ksi * TK_ROW_SLOTS + slot) * a.n_total + n] = acc[r];
     }
 }
 
+#define TK_NUM_CU 256
 void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     int row_tiles = 0;
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.seg[i].row_tiles;
     size_t lds = tk_gemv_lds_bytes(a.K, a.ks);
     static size_t lds_cap = 0; /* >64 KiB of dynamic LDS must be opted into once per process */
     if (lds > lds_cap) {
-        (void)hipFuncSetAttribute((const void*)k_gemv_w4a8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemv_w4a8<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemv_w4a8<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemv_w4a8<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_cap = lds;
     }
-    hipLaunchKernelGGL(k_gemv_w4a8, dim3(row_tiles / 4, a.ks), dim3(256), lds, s, a);
+    int groups = TK_NUM_CU / a.ks;            /* workgroups per K-range */
+    if (groups < 1) groups = 1;
+    if (groups > row_tiles) groups = row_tiles;
+    int waves = (row_tiles + groups - 1) / groups;
+    while (waves > 8) { groups *= 2; waves = (row_tiles + groups - 1) / groups; } /* tall matrices: more than one WG per CU */
+    const int nb = a.K / a.ks / 256;
+    if (nb % 4 == 0) hipLaunchKernelGGL(k_gemv_w4a8<4>, dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles);
+    else if (nb % 2 == 0) hipLaunchKernelGGL(k_gemv_w4a8<2>, dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles);
+    else hipLaunchKernelGGL(k_gemv_w4a8<1>, dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -488,40 +560,50 @@ void tk_launch_qkv_rope_append(const float* partial, int ks, int n_total, int n_
  * Requires head_dim * (n_head / n_kv_head) == 512 or less and a multiple of 256.
  * ------------------------------------------------------------------------------------------ */
 #define TK_ATT_MAX_GRP 4
+#define TK_ATT_TSPLIT 4 /* canonical: 4 interleaved partial sums over positions (t mod 4), added in order */
 template <int GRP>
-__global__ __launch_bounds__(256) void k_attention(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq,
-                                                    const int32_t* pos, int n_head, int n_kv_head, int head_dim, int layer, int max_seq,
-                                                    int max_ctx, TkActQ8 out) {
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbuf, const uint16_t* __restrict__ kcache,
+                                                    const uint16_t* __restrict__ vcache, const int32_t* __restrict__ seq,
+                                                    const int32_t* __restrict__ pos, int n_head, int n_kv_head, int head_dim, int layer,
+                                                    int max_seq, int max_ctx, TkActQ8 out) {
     extern __shared__ float sh[];
     const int kvh = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
     constexpr int grp = GRP;
     const int T = pos[r] + 1, sq = seq[r];
     const int W = grp * head_dim;              /* outputs of this WG */
     float* qs = sh;                            /* [grp][head_dim] */
-    float* sc = qs + W;                        /* [grp][T] */
+    float* sc = qs + W;                        /* [grp][max_ctx] */
     float* red = sc + (size_t)grp * max_ctx;   /* [4 waves][grp] */
-    float* obuf = red + 4 * TK_ATT_MAX_GRP;    /* [W] */
+    float* part = red + 4 * TK_ATT_MAX_GRP;    /* [TSPLIT][W] partial outputs, then [TSPLIT][grp] partial denominators */
+    float* lpart = part + TK_ATT_TSPLIT * W;
+    float* obuf = lpart + TK_ATT_TSPLIT * TK_ATT_MAX_GRP; /* [W] */
     const int QD = n_head * head_dim;
     for (int i = t; i < W; i += 256) qs[i] = qbuf[(int64_t)r * QD + kvh * W + i];
     __syncthreads();
     const float att_scale = tk_divf(1.0f, tk_sqrtf((float)head_dim));
-    const int64_t sbase = (((int64_t)layer * max_seq + sq) * max_ctx) * n_kv_head * head_dim;
+    const int64_t rowstride = (int64_t)n_kv_head * head_dim;
+    const int64_t sbase = (((int64_t)layer * max_seq + sq) * max_ctx) * rowstride + (int64_t)kvh * head_dim;
     float mx[GRP];
 #pragma unroll
     for (int h = 0; h < grp; ++h) mx[h] = -INFINITY;
     for (int tt = t; tt < T; tt += 256) {
-        const uint16_t* kr = kcache + sbase + ((int64_t)tt * n_kv_head + kvh) * head_dim;
+        const uint16_t* kr = kcache + sbase + (int64_t)tt * rowstride;
         float a[GRP];
 #pragma unroll
         for (int h = 0; h < grp; ++h) a[h] = 0.0f;
-        for (int i = 0; i < head_dim; i += 8) {
-            const uint4 kv = *(const uint4*)(kr + i);
-            const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+        for (int i0 = 0; i0 < head_dim; i0 += 64) { /* 8 x 16 B of the key row in flight per pass */
+            uint4 kv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float kf = f16bits_to_f32((kw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+            for (int u = 0; u < 8; ++u) kv[u] = *(const uint4*)(kr + i0 + 8 * u);
 #pragma unroll
-                for (int h = 0; h < grp; ++h) a[h] = tk_fmaf(qs[h * head_dim + i + e], kf, a[h]);
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float kf = f16bits_to_f32((kw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+#pragma unroll
+                    for (int h = 0; h < grp; ++h) a[h] = tk_fmaf(qs[h * head_dim + i0 + 8 * u + e], kf, a[h]);
+                }
             }
         }
 #pragma unroll
@@ -538,23 +620,63 @@ __global__ __launch_bounds__(256) void k_attention(const float* qbuf, const uint
         if ((t & 63) == 0) red[(t >> 6) * TK_ATT_MAX_GRP + h] = m;
     }
     __syncthreads();
+#pragma unroll
     for (int h = 0; h < grp; ++h) {
         const float m = tk_fmaxf(tk_fmaxf(red[h], red[TK_ATT_MAX_GRP + h]), tk_fmaxf(red[2 * TK_ATT_MAX_GRP + h], red[3 * TK_ATT_MAX_GRP + h]));
         for (int tt = t; tt < T; tt += 256) sc[(size_t)h * max_ctx + tt] = tk_expf(sc[(size_t)h * max_ctx + tt] - m);
     }
     __syncthreads();
-    /* PV: thread owns output column i of the W = grp*head_dim outputs (2 per thread at W = 512) */
-    for (int i = t; i < W; i += 256) {
-        const int h = i / head_dim, d = i % head_dim;
-        const float* pr = sc + (size_t)h * max_ctx;
-        const uint16_t* vc = vcache + sbase + (int64_t)kvh * head_dim + d;
-        float acc = 0.0f, l = 0.0f;
-        for (int tt = 0; tt < T; ++tt) {
-            const float p = pr[tt];
-            acc = tk_fmaf(p, f16bits_to_f32(vc[(int64_t)tt * n_kv_head * head_dim]), acc);
-            l = l + p;
+    /* PV: wave j takes positions t = j (mod 4); lane owns dims (2*lane, 2*lane+1) [+128k] of every head, so one
+     * 4-byte V load feeds GRP heads.  Partials are combined in j order afterwards. */
+    {
+        const int j = t >> 6, lane = t & 63;
+        for (int d0 = 2 * lane; d0 < head_dim; d0 += 128) {
+            float acc[GRP][2], l[GRP];
+#pragma unroll
+            for (int h = 0; h < grp; ++h) { acc[h][0] = 0.0f; acc[h][1] = 0.0f; l[h] = 0.0f; }
+            const uint16_t* vc = vcache + sbase + d0;
+            int tt = j;
+            for (; tt + 7 * TK_ATT_TSPLIT < T; tt += 8 * TK_ATT_TSPLIT) {
+                uint32_t vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vv[u] = *(const uint32_t*)(vc + (int64_t)(tt + u * TK_ATT_TSPLIT) * rowstride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float v0 = f16bits_to_f32(vv[u] & 0xffffu), v1 = f16bits_to_f32(vv[u] >> 16);
+#pragma unroll
+                    for (int h = 0; h < grp; ++h) {
+                        const float p = sc[(size_t)h * max_ctx + tt + u * TK_ATT_TSPLIT];
+                        acc[h][0] = tk_fmaf(p, v0, acc[h][0]);
+                        acc[h][1] = tk_fmaf(p, v1, acc[h][1]);
+                        l[h] = l[h] + p;
+                    }
+                }
+            }
+            for (; tt < T; tt += TK_ATT_TSPLIT) {
+                const uint32_t vv = *(const uint32_t*)(vc + (int64_t)tt * rowstride);
+                const float v0 = f16bits_to_f32(vv & 0xffffu), v1 = f16bits_to_f32(vv >> 16);
+#pragma unroll
+                for (int h = 0; h < grp; ++h) {
+                    const float p = sc[(size_t)h * max_ctx + tt];
+                    acc[h][0] = tk_fmaf(p, v0, acc[h][0]);
+                    acc[h][1] = tk_fmaf(p, v1, acc[h][1]);
+                    l[h] = l[h] + p;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < grp; ++h) {
+                part[j * W + h * head_dim + d0] = acc[h][0];
+                part[j * W + h * head_dim + d0 + 1] = acc[h][1];
+                if (lane == 0 && d0 == 0) lpart[j * TK_ATT_MAX_GRP + h] = l[h];
+            }
         }
-        obuf[i] = tk_divf(acc, l);
+    }
+    __syncthreads();
+    for (int i = t; i < W; i += 256) {
+        const int h = i / head_dim;
+        const float a = ((part[i] + part[W + i]) + part[2 * W + i]) + part[3 * W + i];
+        const float l = ((lpart[h] + lpart[TK_ATT_MAX_GRP + h]) + lpart[2 * TK_ATT_MAX_GRP + h]) + lpart[3 * TK_ATT_MAX_GRP + h];
+        obuf[i] = tk_divf(a, l);
     }
     __syncthreads();
     for (int c = t; c < W / 8; c += 256) {
@@ -569,7 +691,7 @@ void tk_launch_attention(const float* qbuf, const uint16_t* kcache, const uint16
                          int n_head, int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, hipStream_t s) {
     const int grp = n_head / n_kv_head;
     const int W = grp * head_dim;
-    size_t lds = ((size_t)W + (size_t)grp * max_ctx + 4 * TK_ATT_MAX_GRP + W) * sizeof(float);
+    size_t lds = ((size_t)W + (size_t)grp * max_ctx + 4 * TK_ATT_MAX_GRP + (size_t)TK_ATT_TSPLIT * W + TK_ATT_TSPLIT * TK_ATT_MAX_GRP + W) * sizeof(float);
 #define TK_ATT_LAUNCH(G)                                                                                                             \
     do {                                                                                                                             \
         (void)hipFuncSetAttribute((const void*)k_attention<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \

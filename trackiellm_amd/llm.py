@@ -96,10 +96,10 @@ class LlmSession:
         check(lib().tk_mi355x_llm_decode(self.h, nrows, n_steps, _p(out), C.byref(ms)))
         return out[:, :nrows].copy(), ms.value
 
-    def time_gemv(self, which, nrows, iters):
+    def time_gemv(self, layer, which, nrows, iters):
         ms = C.c_float(0)
         nbytes = C.c_double(0)
-        check(lib().tk_mi355x_llm_time_gemv(self.h, which, nrows, iters, C.byref(ms), C.byref(nbytes)))
+        check(lib().tk_mi355x_llm_time_gemv(self.h, layer, which, nrows, iters, C.byref(ms), C.byref(nbytes)))
         return ms.value, nbytes.value
 
     def close(self):
