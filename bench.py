@@ -34,8 +34,9 @@ def cpu_baseline(hp, max_tokens=3):
     """oracle ('port') on the host cores: bounded sample of the same Mistral-7B workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("TK_BENCH_CPU_CORES", "16")))  # the GPU box grants a 16-core share per GPU
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     cfg = O.LlmConfig(n_layer=hp.n_layer, d_model=hp.d_model, n_head=hp.n_head, n_kv_head=hp.n_kv_head, head_dim=hp.head_dim,
                       d_ff=hp.d_ff, vocab=hp.vocab, max_ctx=16, max_seq=1, rms_eps=hp.rms_eps, rope_theta=hp.rope_theta,
                       ks_qkv=hp.ks_qkv, ks_o=hp.ks_o, ks_gateup=hp.ks_gateup, ks_down=hp.ks_down, ks_out=hp.ks_out)

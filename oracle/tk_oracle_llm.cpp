@@ -108,25 +108,28 @@ void orc_q8k_quantize(const float* x, int n, int8_t* q, float* d, int32_t* bsum3
     }
 }
 
-/* one (row, K-range) partial of a Q4_K x Q8_K dot: blocks ascending, two fmas per block */
+/* one (row, K-range) partial of a Q4_K x Q8_K dot: blocks ascending, two fmas per block.
+ * The nibbles are unpacked to a byte array first so the integer dot auto-vectorises (AVX2). */
 static float dot_q4k_range(const tk_block_q4_K* w, const int8_t* q, const float* d, const int32_t* bsum, int b0, int b1) {
     float acc = 0.0f;
     for (int b = b0; b < b1; ++b) {
         const tk_block_q4_K* blk = w + b;
         const int8_t* qb = q + 256 * b;
-        int32_t P = 0, M = 0;
-        for (int c = 0; c < 4; ++c) {
-            uint8_t sc0, m0, sc1, m1;
-            tk_q4k_get_scale_min(2 * c, blk->scales, &sc0, &m0);
-            tk_q4k_get_scale_min(2 * c + 1, blk->scales, &sc1, &m1);
-            int32_t s0 = 0, s1 = 0;
+        int8_t u[256];
+        for (int c = 0; c < 4; ++c)
             for (int l = 0; l < 32; ++l) {
                 uint8_t byte = blk->qs[32 * c + l];
-                s0 += (int32_t)(byte & 0x0F) * qb[64 * c + l];
-                s1 += (int32_t)(byte >> 4) * qb[64 * c + 32 + l];
+                u[64 * c + l] = (int8_t)(byte & 0x0F);
+                u[64 * c + 32 + l] = (int8_t)(byte >> 4);
             }
-            P += (int32_t)sc0 * s0 + (int32_t)sc1 * s1;
-            M += (int32_t)m0 * bsum[8 * b + 2 * c] + (int32_t)m1 * bsum[8 * b + 2 * c + 1];
+        int32_t P = 0, M = 0;
+        for (int j = 0; j < 8; ++j) {
+            uint8_t sc, mn;
+            tk_q4k_get_scale_min(j, blk->scales, &sc, &mn);
+            int32_t s = 0;
+            for (int l = 0; l < 32; ++l) s += (int32_t)u[32 * j + l] * (int32_t)qb[32 * j + l];
+            P += (int32_t)sc * s;
+            M += (int32_t)mn * bsum[8 * b + j];
         }
         float dw = tk_f16_to_f32(blk->d), dmin = tk_f16_to_f32(blk->dmin);
         float s1f = dw * d[b];
@@ -142,10 +145,19 @@ static float dot_q6k_range(const tk_block_q6_K* w, const int8_t* q, const float*
     for (int b = b0; b < b1; ++b) {
         const tk_block_q6_K* blk = w + b;
         const int8_t* qb = q + 256 * b;
+        int8_t u[256];
+        for (int n = 0; n < 2; ++n)
+            for (int l = 0; l < 32; ++l) {
+                const uint8_t la = blk->ql[64 * n + l], lb = blk->ql[64 * n + 32 + l], h = blk->qh[32 * n + l];
+                u[128 * n + l] = (int8_t)((la & 0x0F) | ((h & 3) << 4)) - 32;
+                u[128 * n + 32 + l] = (int8_t)((lb & 0x0F) | (((h >> 2) & 3) << 4)) - 32;
+                u[128 * n + 64 + l] = (int8_t)((la >> 4) | (((h >> 4) & 3) << 4)) - 32;
+                u[128 * n + 96 + l] = (int8_t)((lb >> 4) | (((h >> 6) & 3) << 4)) - 32;
+            }
         int32_t P = 0;
         for (int g = 0; g < 16; ++g) {
             int32_t s = 0;
-            for (int i = 0; i < 16; ++i) s += (tk_q6k_quant(blk, 16 * g + i) - 32) * (int32_t)qb[16 * g + i];
+            for (int i = 0; i < 16; ++i) s += (int32_t)u[16 * g + i] * (int32_t)qb[16 * g + i];
             P += (int32_t)blk->scales[g] * s;
         }
         float dw = tk_f16_to_f32(blk->d);
