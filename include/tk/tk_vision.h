@@ -1,0 +1,70 @@
+/*
+ * tk_vision.h — detector stream of the tk_* C-ABI.
+ *   tk_object_detector_*                         src/vision/tk_object_detector.h:42-57 (config), :66-71 (result), :99-166 (API)
+ *   tk_preprocessor_resize_and_normalize_to_chw  src/vision/tk_image_preprocessor.h:49-56
+ * model_path forms: "synthetic://yolov8n?seed=5&cls_bias=-4" or a TKYOLO1 weight container
+ * (ONNX graphs are not parsed — the network topology is fixed: YOLOv8n, nc = class_count).
+ * Results: score-descending, at most 500, class-aware NMS applied, bbox in ORIGINAL frame pixels.
+ * `label` is borrowed from config.class_labels (never freed by the library; the reference's
+ * tk_vision_result_destroy frees it wrongly, src/vision/tk_vision_pipeline.c:297-299 — not replicated).
+ */
+#ifndef TK_MI355X_VISION_H
+#define TK_MI355X_VISION_H
+
+#include "tk_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tk_object_detector_s tk_object_detector_t;
+
+typedef struct {
+    tk_vision_backend_e backend; /* anything but CPU selects the GPU; CPU is refused: no fallback exists */
+    int gpu_device_id;
+    tk_path_t* model_path;
+    uint32_t input_width;
+    uint32_t input_height;
+    const char** class_labels;
+    size_t class_count;
+    float confidence_threshold;
+    float iou_threshold;
+} tk_object_detector_config_t;
+
+typedef struct {
+    uint32_t class_id;
+    const char* label;
+    float confidence;
+    tk_rect_t bbox;
+} tk_detection_result_t;
+
+TK_API TK_NODISCARD tk_error_code_t tk_object_detector_create(tk_object_detector_t** out_detector, const tk_object_detector_config_t* config);
+TK_API void tk_object_detector_destroy(tk_object_detector_t** detector);
+TK_API TK_NODISCARD tk_error_code_t tk_object_detector_detect(tk_object_detector_t* detector, const tk_video_frame_t* video_frame,
+                                                              tk_detection_result_t** out_results, size_t* out_result_count);
+TK_API void tk_object_detector_free_results(tk_detection_result_t** results);
+TK_API void tk_object_detector_update_thresholds(tk_object_detector_t* detector, float confidence_threshold, float iou_threshold);
+
+/* host buffers in, host buffer out; the arithmetic runs on the GPU and is bit-identical to the
+ * reference's scalar CPU loop (frame->stride is honoured; the reference assumes width*3) */
+TK_API TK_NODISCARD tk_error_code_t tk_preprocessor_resize_and_normalize_to_chw(const tk_video_frame_t* frame, float* out_tensor,
+                                                                                uint32_t target_width, uint32_t target_height,
+                                                                                const float mean[3], const float std_dev[3]);
+
+/* ---- extensions (no reference counterpart) ---- */
+/* B frames of identical geometry in one pass (one per concurrent cortex cycle); results[i] / counts[i] per frame */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_set_max_batch(tk_object_detector_t* detector, int max_batch);
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_detect_batch(tk_object_detector_t* detector, int n_frames, const tk_video_frame_t* frames,
+                                                                    tk_detection_result_t** out_results, size_t* out_counts);
+/* test hook: run the network on a pre-processed NHWC fp32 tensor [B][H][W][3]; raw head maps [B][anchors][64+nc] */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_forward_raw(tk_object_detector_t* detector, int batch, const float* nhwc, float* raw_out,
+                                                                   size_t raw_floats);
+/* detections of the last forward_raw / detect in input-tensor coordinates: [x1,y1,x2,y2,score] + class + anchor */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_last_boxes(tk_object_detector_t* detector, int frame, float* boxes5, int32_t* cls,
+                                                                  int32_t* anchors, int cap, int* count);
+TK_API int tk_mi355x_detector_anchor_count(const tk_object_detector_t* detector);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -163,3 +163,113 @@ def rmsnorm(x, w, eps):
     out = np.empty_like(x)
     lib().orc_rmsnorm(ptr(x), ptr(w), x.size, eps, ptr(out))
     return out
+
+
+# ---------------------------------------------------------------- vision oracle bindings
+class _Frame(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("stride", C.c_uint32), ("format", C.c_int), ("data", C.c_void_p)]
+
+
+IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], np.float32)
+IMAGENET_STD = np.array([0.229, 0.224, 0.225], np.float32)
+
+
+def preprocess(frame, tw, th, mean=IMAGENET_MEAN, std=IMAGENET_STD, nhwc=False, stride=None, bpp=3):
+    """oracle restatement of the reference pre-processor; frame: uint8 [H][W][bpp] (or a padded buffer with stride)"""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w = frame.shape[0], frame.shape[1]
+    stride = stride or frame.strides[0]
+    out = np.empty((th, tw, 3) if nhwc else (3, th, tw), np.float32)
+    L = lib()
+    L.orc_preprocess.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                 C.c_void_p, C.c_void_p, C.c_int]
+    rc = L.orc_preprocess(ptr(frame), w, h, stride, bpp, ptr(out), tw, th, ptr(np.ascontiguousarray(mean, np.float32)),
+                          ptr(np.ascontiguousarray(std, np.float32)), int(nhwc))
+    assert rc == 0
+    return out
+
+
+def ref_preprocess(frame, tw, th, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """the COMPILED reference function (oracle/_ref/libtkref_preprocess.so); frame uint8 [H][W][3] contiguous"""
+    path = os.path.join(ROOT, "oracle", "_ref", "libtkref_preprocess.so")
+    R = C.CDLL(path)
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w = frame.shape[:2]
+    f = _Frame(w, h, w * 3, 0, frame.ctypes.data)
+    out = np.empty((3, th, tw), np.float32)
+    R.tk_preprocessor_resize_and_normalize_to_chw.argtypes = [C.POINTER(_Frame), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    rc = R.tk_preprocessor_resize_and_normalize_to_chw(C.byref(f), ptr(out), tw, th, ptr(np.ascontiguousarray(mean, np.float32)),
+                                                       ptr(np.ascontiguousarray(std, np.float32)))
+    assert rc == 0
+    return out
+
+
+def have_ref():
+    return os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libtkref_preprocess.so"))
+
+
+class OracleYolo:
+    def __init__(self, nc=80, seed=5, cls_bias=-4.0):
+        L = lib()
+        L.orc_yolo_create.restype = C.c_void_p
+        L.orc_yolo_create.argtypes = [C.c_int, C.c_uint64, C.c_float]
+        L.orc_yolo_destroy.argtypes = [C.c_void_p]
+        L.orc_yolo_layer_count.argtypes = [C.c_void_p]
+        L.orc_yolo_layer_spec.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_yolo_get_layer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_yolo_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_yolo_post.restype = C.c_int
+        L.orc_yolo_post.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.nc = nc
+        self.h = L.orc_yolo_create(nc, seed, cls_bias)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_yolo_destroy(self.h)
+            self.h = None
+
+    def layers(self):
+        out = []
+        for i in range(lib().orc_yolo_layer_count(self.h)):
+            sp = np.zeros(5, np.int32)
+            lib().orc_yolo_layer_spec(self.h, i, ptr(sp))
+            cin, cout, k, s, act = [int(v) for v in sp]
+            w = np.empty((cout, k, k, cin), np.float32)
+            b = np.empty(cout, np.float32)
+            lib().orc_yolo_get_layer(self.h, i, ptr(w), ptr(b))
+            out.append(dict(cin=cin, cout=cout, k=k, s=s, act=act, w=w, b=b))
+        return out
+
+    @staticmethod
+    def anchors(H, W):
+        return (H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32)
+
+    def forward(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        B, H, W, _ = x.shape
+        raw = np.empty((B, self.anchors(H, W), 64 + self.nc), np.float32)
+        lib().orc_yolo_forward(self.h, B, H, W, ptr(x), ptr(raw))
+        return raw
+
+    def post(self, raw1, H, W, conf, iou, cap=500):
+        raw1 = np.ascontiguousarray(raw1, np.float32)
+        boxes = np.zeros((cap, 5), np.float32)
+        cls = np.zeros(cap, np.int32)
+        anc = np.zeros(cap, np.int32)
+        n = lib().orc_yolo_post(ptr(raw1), H, W, self.nc, conf, iou, ptr(boxes), ptr(cls), ptr(anc), cap)
+        return boxes[:n], cls[:n], anc[:n]
+
+
+def gemm(A, B, bias=None, residual=None, b_kn=False, act=0, alpha=1.0):
+    A = np.ascontiguousarray(A, np.float32)
+    B = np.ascontiguousarray(B, np.float32)
+    M, K = A.shape
+    N = B.shape[1] if b_kn else B.shape[0]
+    Cm = np.empty((M, N), np.float32)
+    L = lib()
+    L.orc_gemm.argtypes = [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float]
+    bias = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    residual = None if residual is None else np.ascontiguousarray(residual, np.float32)
+    L.orc_gemm(ptr(A), ptr(B), ptr(Cm), ptr(bias) if bias is not None else None, ptr(residual) if residual is not None else None,
+               M, N, K, K, B.shape[1], N, N, int(b_kn), act, alpha)
+    return Cm

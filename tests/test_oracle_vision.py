@@ -1,0 +1,77 @@
+"""CPU: detector-stream oracle against its pins (compiled reference pre-processor, torch YOLOv8n fixture)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLD)
+from make_vision_golden import frames  # noqa: E402  (seeded frame generator only; no reference code)
+
+
+def test_preprocess_restatement_matches_compiled_reference_fixture():
+    g = np.load(os.path.join(GOLD, "preprocess_small.npz"))
+    fr = frames()
+    assert np.array_equal(O.preprocess(fr["rand_96x64"], 64, 64).view(np.uint32), g["small_a"].view(np.uint32))
+    assert np.array_equal(O.preprocess(fr["rand_37x23"], 32, 32).view(np.uint32), g["small_b"].view(np.uint32))
+    for name in ("rand_640x480", "rand_640x640", "gray128_640x480"):
+        y = O.preprocess(fr[name], 640, 640)
+        assert hashlib.sha256(y.tobytes()).digest() == g["sha_" + name].tobytes(), name
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_preprocess_against_live_compiled_reference():
+    rng = np.random.default_rng(9)
+    for (w, h, tw, th) in ((50, 40, 32, 32), (640, 480, 640, 640), (33, 17, 64, 96)):
+        f = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(O.preprocess(f, tw, th).view(np.uint32), O.ref_preprocess(f, tw, th).view(np.uint32))
+
+
+def test_preprocess_is_not_identity_and_honours_stride():
+    f = np.arange(8 * 8 * 3, dtype=np.uint8).reshape(8, 8, 3)
+    y = O.preprocess(f, 8, 8, mean=np.zeros(3), std=np.ones(3))
+    assert not np.allclose(y[0, 1, 1] * 255.0, f[1, 1, 0])          # ratio 7/8 resamples every pixel
+    pad = np.zeros((8, 40), np.uint8)
+    pad[:, :24] = f.reshape(8, 24)
+    out = np.empty((3, 8, 8), np.float32)
+    O.lib().orc_preprocess(O.ptr(pad), 8, 8, 40, 3, O.ptr(out), 8, 8, O.ptr(np.zeros(3, np.float32)), O.ptr(np.ones(3, np.float32)), 0)
+    assert np.array_equal(out, y)
+
+
+def test_yolo_oracle_matches_torch_fixture():
+    g = np.load(os.path.join(GOLD, "yolo_tiny.npz"))
+    orc = O.OracleYolo(nc=80, seed=5, cls_bias=-4.0)
+    raw = orc.forward(g["x"])
+    assert np.array_equal(raw, g["oracle_raw"])
+    assert np.abs(raw - g["torch_raw"]).max() < 2e-4 * max(1.0, np.abs(g["torch_raw"]).max())
+    assert len(orc.layers()) == 63 and sum(l["w"].size + l["b"].size for l in orc.layers()) > 3_000_000
+
+
+def test_nms_properties():
+    orc = O.OracleYolo(nc=80, seed=5, cls_bias=-2.0)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 64, 64, 3)).astype(np.float32)
+    raw = orc.forward(x)[0]
+    boxes, cls, anc = orc.post(raw, 64, 64, 0.05, 0.5)
+    assert len(boxes) > 3
+    assert np.all(np.diff(boxes[:, 4]) <= 0)                              # score-descending
+    assert len(set(anc.tolist())) == len(anc)                             # no duplicates
+    # idempotence: survivors never suppress each other
+    for i in range(len(boxes)):
+        for j in range(i + 1, len(boxes)):
+            if cls[i] == cls[j]:
+                iw = min(boxes[i, 2], boxes[j, 2]) - max(boxes[i, 0], boxes[j, 0])
+                ih = min(boxes[i, 3], boxes[j, 3]) - max(boxes[i, 1], boxes[j, 1])
+                if iw > 0 and ih > 0:
+                    inter = iw * ih
+                    u = (boxes[i, 2] - boxes[i, 0]) * (boxes[i, 3] - boxes[i, 1]) + (boxes[j, 2] - boxes[j, 0]) * (boxes[j, 3] - boxes[j, 1]) - inter
+                    assert inter / u <= 0.5 + 1e-6
+    # IoU threshold 1.0 keeps every candidate; threshold 0 keeps at most one per overlapping class cluster
+    allb, _, _ = orc.post(raw, 64, 64, 0.05, 1.0)
+    assert len(allb) >= len(boxes)
+    none, _, _ = orc.post(raw, 64, 64, 0.999999, 0.5)
+    assert len(none) == 0                                                  # empty result is legal

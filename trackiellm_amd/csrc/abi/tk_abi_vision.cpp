@@ -1,0 +1,200 @@
+/*
+ * tk_abi_vision.cpp — tk_object_detector_* / tk_preprocessor_* on the HIP vision engine.
+ * Call sequence mirrored from src/vision/tk_object_detector.c:182-219 (detect = preprocess ->
+ * inference -> postprocess -> caller-freed malloc'd array) and :83-178 (create/destroy).
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../vision/tk_vision_engine.h"
+#include "tk/tk_vision.h"
+
+struct tk_object_detector_s {
+    TkYoloModel model;
+    std::unique_ptr<TkDetector> det;
+    std::vector<const char*> labels;
+    size_t class_count = 0;
+    int in_w = 640, in_h = 640;
+    std::vector<std::vector<TkDetection>> last;
+};
+
+static tk_error_code_t vfail(tk_error_code_t code, const std::string& why) {
+    tk_error_set_detail("%s", why.c_str());
+    return code;
+}
+
+static double query_param(const std::string& p, const char* key, double dflt) {
+    size_t k = p.find(std::string(key) + "=");
+    if (k == std::string::npos) return dflt;
+    return strtod(p.c_str() + k + strlen(key) + 1, nullptr);
+}
+
+extern "C" {
+
+tk_error_code_t tk_object_detector_create(tk_object_detector_t** out_detector, const tk_object_detector_config_t* config) {
+    if (!out_detector || !config || !config->model_path || !config->model_path->path_str) return TK_ERROR_INVALID_ARGUMENT;
+    if (config->class_count == 0 || !config->class_labels) return vfail(TK_ERROR_INVALID_ARGUMENT, "class_labels / class_count missing");
+    if (config->backend == TK_VISION_BACKEND_CPU) return vfail(TK_ERROR_BACKEND_NOT_SUPPORTED, "this library is the MI355X path: there is no CPU backend");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return vfail(TK_ERROR_GPU_DEVICE_NOT_FOUND, "no HIP device visible");
+    const int dev = config->gpu_device_id >= 0 ? config->gpu_device_id : 0;
+    if (dev >= ndev) return vfail(TK_ERROR_INVALID_ARGUMENT, "gpu_device_id out of range");
+    std::unique_ptr<tk_object_detector_s> d(new tk_object_detector_s());
+    d->class_count = config->class_count;
+    d->labels.assign(config->class_labels, config->class_labels + config->class_count);
+    d->in_w = config->input_width ? (int)config->input_width : 640;
+    d->in_h = config->input_height ? (int)config->input_height : 640;
+    if (!d->model.init(dev, (int)config->class_count)) return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
+    const std::string path = config->model_path->path_str;
+    if (path.compare(0, 12, "synthetic://") == 0) {
+        if (!d->model.fill_synthetic((uint64_t)query_param(path, "seed", 5), (float)query_param(path, "cls_bias", -4.0)))
+            return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
+    } else if (!d->model.load_file(path.c_str())) {
+        return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
+    }
+    d->det.reset(new TkDetector());
+    if (!d->det->init(&d->model, d->in_w, d->in_h, 1)) return vfail(TK_ERROR_GPU_MEMORY, d->det->error);
+    d->det->conf = config->confidence_threshold;
+    d->det->iou = config->iou_threshold;
+    *out_detector = d.release();
+    return TK_SUCCESS;
+}
+
+void tk_object_detector_destroy(tk_object_detector_t** detector) {
+    if (!detector || !*detector) return;
+    delete *detector;
+    *detector = nullptr;
+}
+
+tk_error_code_t tk_mi355x_detector_set_max_batch(tk_object_detector_t* d, int max_batch) {
+    if (!d) return TK_ERROR_INVALID_ARGUMENT;
+    std::unique_ptr<TkDetector> nd(new TkDetector());
+    if (!nd->init(&d->model, d->in_w, d->in_h, max_batch)) return vfail(TK_ERROR_GPU_MEMORY, nd->error);
+    nd->conf = d->det->conf;
+    nd->iou = d->det->iou;
+    d->det.swap(nd);
+    return TK_SUCCESS;
+}
+
+static tk_error_code_t to_results(tk_object_detector_s* d, const std::vector<TkDetection>& v, const tk_video_frame_t* f,
+                                  tk_detection_result_t** out, size_t* count) {
+    *count = v.size();
+    *out = (tk_detection_result_t*)malloc((v.size() ? v.size() : 1) * sizeof(tk_detection_result_t));
+    if (!*out) return TK_ERROR_OUT_OF_MEMORY;
+    const float sx = (float)f->width / (float)d->in_w, sy = (float)f->height / (float)d->in_h;
+    for (size_t i = 0; i < v.size(); ++i) {
+        tk_detection_result_t& r = (*out)[i];
+        r.class_id = (uint32_t)v[i].cls;
+        r.label = v[i].cls >= 0 && (size_t)v[i].cls < d->class_count ? d->labels[v[i].cls] : NULL;
+        r.confidence = v[i].score;
+        r.bbox.x = (int)(v[i].x1 * sx);
+        r.bbox.y = (int)(v[i].y1 * sy);
+        r.bbox.w = (int)((v[i].x2 - v[i].x1) * sx);
+        r.bbox.h = (int)((v[i].y2 - v[i].y1) * sy);
+    }
+    return TK_SUCCESS;
+}
+
+static int bytes_per_pixel(const tk_video_frame_t* f) { return f->format == TK_PIXEL_FORMAT_RGBA8 ? 4 : 3; }
+
+tk_error_code_t tk_mi355x_detector_detect_batch(tk_object_detector_t* d, int n, const tk_video_frame_t* frames, tk_detection_result_t** out_results,
+                                                size_t* out_counts) {
+    if (!d || !frames || !out_results || !out_counts || n <= 0) return TK_ERROR_INVALID_ARGUMENT;
+    std::vector<const uint8_t*> ptrs(n);
+    for (int i = 0; i < n; ++i) {
+        if (!frames[i].data) return TK_ERROR_INVALID_ARGUMENT;
+        if (frames[i].width != frames[0].width || frames[i].height != frames[0].height || frames[i].stride != frames[0].stride ||
+            frames[i].format != frames[0].format)
+            return vfail(TK_ERROR_INVALID_ARGUMENT, "frames of one batch must share geometry");
+        ptrs[i] = frames[i].data;
+    }
+    if (!d->det->detect(n, ptrs.data(), frames[0].width, frames[0].height, frames[0].stride, (uint32_t)bytes_per_pixel(&frames[0]), &d->last))
+        return vfail(TK_ERROR_INFERENCE_FAILED, d->det->error);
+    for (int i = 0; i < n; ++i) {
+        tk_error_code_t rc = to_results(d, d->last[i], &frames[i], &out_results[i], &out_counts[i]);
+        if (rc != TK_SUCCESS) return rc;
+    }
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_object_detector_detect(tk_object_detector_t* detector, const tk_video_frame_t* video_frame, tk_detection_result_t** out_results,
+                                          size_t* out_result_count) {
+    if (!detector || !video_frame || !video_frame->data || !out_results || !out_result_count) return TK_ERROR_INVALID_ARGUMENT;
+    return tk_mi355x_detector_detect_batch(detector, 1, video_frame, out_results, out_result_count);
+}
+
+void tk_object_detector_free_results(tk_detection_result_t** results) {
+    if (!results || !*results) return;
+    free(*results);
+    *results = NULL;
+}
+
+void tk_object_detector_update_thresholds(tk_object_detector_t* detector, float confidence_threshold, float iou_threshold) {
+    if (!detector) return;
+    detector->det->conf = confidence_threshold;
+    detector->det->iou = iou_threshold;
+}
+
+tk_error_code_t tk_mi355x_detector_forward_raw(tk_object_detector_t* d, int batch, const float* nhwc, float* raw_out, size_t raw_floats) {
+    if (!d || !nhwc || !raw_out) return TK_ERROR_INVALID_ARGUMENT;
+    std::vector<float> raw;
+    if (!d->det->forward_tensor(batch, nhwc, &raw)) return vfail(TK_ERROR_INFERENCE_FAILED, d->det->error);
+    if (raw.size() > raw_floats) return vfail(TK_ERROR_BUFFER_TOO_SMALL, "raw_out too small");
+    memcpy(raw_out, raw.data(), raw.size() * 4);
+    if (!d->det->fetch(batch, &d->last)) return vfail(TK_ERROR_INFERENCE_FAILED, d->det->error); /* for last_boxes */
+    return TK_SUCCESS;
+}
+
+int tk_mi355x_detector_anchor_count(const tk_object_detector_t* d) { return d ? d->det->n_anchors : 0; }
+
+tk_error_code_t tk_mi355x_detector_last_boxes(tk_object_detector_t* d, int frame, float* boxes5, int32_t* cls, int32_t* anchors, int cap, int* count) {
+    if (!d || !count || frame < 0 || frame >= (int)d->last.size()) return TK_ERROR_INVALID_ARGUMENT;
+    const auto& v = d->last[frame];
+    *count = (int)v.size();
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) {
+        if (boxes5) { boxes5[5 * i] = v[i].x1; boxes5[5 * i + 1] = v[i].y1; boxes5[5 * i + 2] = v[i].x2; boxes5[5 * i + 3] = v[i].y2; boxes5[5 * i + 4] = v[i].score; }
+        if (cls) cls[i] = v[i].cls;
+        if (anchors) anchors[i] = v[i].anchor;
+    }
+    return TK_SUCCESS;
+}
+
+/* ---- stand-alone pre-processor entry (reference: tk_image_preprocessor.c:21) ---- */
+tk_error_code_t tk_preprocessor_resize_and_normalize_to_chw(const tk_video_frame_t* frame, float* out_tensor, uint32_t target_width,
+                                                            uint32_t target_height, const float mean[3], const float std_dev[3]) {
+    if (!frame || !frame->data || !out_tensor || target_width == 0 || target_height == 0 || !mean || !std_dev) return TK_ERROR_INVALID_ARGUMENT;
+    if (frame->width < 2 || frame->height < 2) return vfail(TK_ERROR_INVALID_ARGUMENT, "frame must be at least 2x2");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return vfail(TK_ERROR_GPU_DEVICE_NOT_FOUND, "no HIP device visible");
+    const uint32_t bpp = (uint32_t)bytes_per_pixel(frame);
+    const uint32_t stride = frame->stride ? frame->stride : frame->width * bpp;
+    if (stride < frame->width * bpp) return vfail(TK_ERROR_INVALID_ARGUMENT, "stride smaller than a row");
+    const size_t fb = (size_t)stride * frame->height, ob = (size_t)target_width * target_height * 3 * sizeof(float);
+    uint8_t* dsrc = nullptr;
+    float* ddst = nullptr;
+    if (hipMalloc((void**)&dsrc, fb) != hipSuccess || hipMalloc((void**)&ddst, ob) != hipSuccess) {
+        if (dsrc) (void)hipFree(dsrc);
+        return vfail(TK_ERROR_GPU_MEMORY, "device allocation failed");
+    }
+    tk_error_code_t rc = TK_SUCCESS;
+    TkPreprocessArgs a{};
+    a.src = dsrc; a.in_w = frame->width; a.in_h = frame->height; a.in_stride = stride; a.bpp = bpp;
+    a.dst = ddst; a.out_w = target_width; a.out_h = target_height; a.nhwc = 0;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std_dev[c] = std_dev[c]; }
+    if (hipMemcpy(dsrc, frame->data, fb, hipMemcpyHostToDevice) != hipSuccess) rc = TK_ERROR_GPU_MEMORY;
+    if (rc == TK_SUCCESS) {
+        tk_launch_preprocess(a, nullptr);
+        if (hipGetLastError() != hipSuccess) rc = TK_ERROR_GPU_KERNEL_LAUNCH;
+        else if (hipMemcpy(out_tensor, ddst, ob, hipMemcpyDeviceToHost) != hipSuccess) rc = TK_ERROR_GPU_MEMORY;
+    }
+    (void)hipFree(dsrc);
+    (void)hipFree(ddst);
+    return rc;
+}
+
+} /* extern "C" */

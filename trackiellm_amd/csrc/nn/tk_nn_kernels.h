@@ -1,0 +1,48 @@
+/*
+ * tk_nn_kernels.h — fp32 building blocks shared by the detector and ASR streams.
+ *
+ * The reference runs these networks inside ONNX Runtime / whisper.cpp (absent: SURVEY.md §0 F1).
+ * Here every dense contraction (conv as implicit GEMM, linear layers, QK^T, PV, the DFT and
+ * mel filterbank) goes through ONE kernel, tk_gemm_f32, built on v_mfma_f32_32x32x2_f32.
+ * That instruction is bit-for-bit a k-ordered fp32 fma chain, so with the accumulator started at
+ * zero and k walked in ascending order the result equals the oracle's
+ *     acc = 0; for k: acc = fmaf(a[k], b[k], acc);  out = act(acc + bias) (+ residual)
+ * exactly — the detector and ASR parity tests are 0-ulp, like the LLM ones.
+ * fp32 (not bf16) is deliberate: YOLOv8n is 8.7 GFLOP and the Whisper-tiny encoder 37 GFLOP per
+ * call, ~1 ms of fp32 MFMA against a >= 70 ms LLM decode; exactness is worth more than speed here.
+ */
+#ifndef TK_NN_KERNELS_H
+#define TK_NN_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum TkAct { TK_ACT_NONE = 0, TK_ACT_SILU = 1, TK_ACT_GELU = 2, TK_ACT_SIGMOID = 3 };
+
+struct TkGemm {
+    const float* A; /* [M][lda]  (k contiguous) */
+    const float* B; /* b_kn == 0: [N][ldb] (k contiguous);  b_kn == 1: [K][ldb] (n contiguous) */
+    float* C;       /* [M][ldc] */
+    const float* bias;     /* [N] or null */
+    const float* residual; /* [M][ldr] or null; added after the activation */
+    int M, N, K, lda, ldb, ldc, ldr;
+    int b_kn;
+    int act;
+    float alpha; /* out = act(alpha * acc + bias); alpha == 1 is skipped exactly */
+    int batch;
+    int64_t sA, sB, sC, sR; /* batch strides in floats */
+};
+
+void tk_launch_gemm(const TkGemm& g, hipStream_t s);
+
+/* NHWC im2col: col[b*Ho*Wo + oy*Wo + ox][(ky*kw + kx)*C + c]; input row stride ldx floats per pixel */
+void tk_launch_im2col(const float* x, int B, int H, int W, int C, int ldx, int kh, int kw, int stride, int pad, float* col, hipStream_t s);
+/* 1-D variant for conv1d over [T][C] rows */
+void tk_launch_maxpool5(const float* x, int B, int H, int W, int C, int ldx, float* y, int ldy, hipStream_t s);
+void tk_launch_upsample2x(const float* x, int B, int H, int W, int C, int ldx, float* y, int ldy, hipStream_t s);
+void tk_launch_copy_cols(const float* x, int rows, int C, int ldx, float* y, int ldy, hipStream_t s);
+void tk_launch_layernorm(const float* x, int rows, int D, const float* w, const float* b, float eps, float* y, hipStream_t s);
+void tk_launch_softmax_rows(float* x, int rows, int cols, int ld, int causal_offset, hipStream_t s);
+void tk_launch_add_rows(float* x, const float* add, int rows, int D, int add_rows, hipStream_t s);
+
+#endif

@@ -1,0 +1,260 @@
+#include "tk_nn_kernels.h"
+
+#include "../common/tk_exact_math.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define BM 64
+#define BN 64
+#define BK 32
+#define LDS_LD (BK + 1)
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case TK_ACT_SILU: return tk_siluf(v);
+        case TK_ACT_GELU: return tk_geluf(v);
+        case TK_ACT_SIGMOID: return tk_sigmoidf(v);
+        default: return v;
+    }
+}
+
+/*
+ * 64x64 output tile per workgroup, 4 waves in 2x2, one 32x32 fp32 MFMA accumulator per wave.
+ * A/B k-slabs of 32 are staged through LDS with 16 B coalesced loads (row pitch 33 floats:
+ * the 32 lanes of an MFMA operand read hit 32 different banks).
+ */
+__global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
+    __shared__ float As[BM * LDS_LD];
+    __shared__ float Bs[BN * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const float* A = g.A + (int64_t)blockIdx.z * g.sA;
+    const float* B = g.B + (int64_t)blockIdx.z * g.sB;
+    float* C = g.C + (int64_t)blockIdx.z * g.sC;
+    v16f acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
+    const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & 15) == 0;
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        /* stage A: 64 rows x 32 k; thread -> (row = e / 8, 4 consecutive k) for e = tid, tid + 256 */
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = tid + 256 * h;
+            const int row = e >> 3, kc = (e & 7) * 4;
+            const int m = m0 + row, k = k0 + kc;
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (m < g.M) {
+                const float* p = A + (int64_t)m * g.lda + k;
+                if (a_vec && k + 3 < g.K) {
+                    const float4 t = *(const float4*)p;
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (k + i < g.K) v[i] = p[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[row * LDS_LD + kc + i] = v[i];
+        }
+        if (!g.b_kn) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = tid + 256 * h;
+                const int row = e >> 3, kc = (e & 7) * 4;
+                const int n = n0 + row, k = k0 + kc;
+                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (n < g.N) {
+                    const float* p = B + (int64_t)n * g.ldb + k;
+                    if (b_vec && k + 3 < g.K) {
+                        const float4 t = *(const float4*)p;
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (k + i < g.K) v[i] = p[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Bs[row * LDS_LD + kc + i] = v[i];
+            }
+        } else { /* B is [K][N]: read 4 consecutive n of one k, scatter transposed */
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = tid + 256 * h;
+                const int kk = e >> 4, nc = (e & 15) * 4;
+                const int k = k0 + kk, n = n0 + nc;
+                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (k < g.K) {
+                    const float* p = B + (int64_t)k * g.ldb + n;
+                    if (b_vec && n + 3 < g.N) {
+                        const float4 t = *(const float4*)p;
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (n + i < g.N) v[i] = p[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Bs[(nc + i) * LDS_LD + kk] = v[i];
+            }
+        }
+        __syncthreads();
+        const float* ap = As + (wm * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
+        const float* bp = Bs + (wn * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n >= g.N) return;
+    const float bias = g.bias ? g.bias[n] : 0.0f;
+    const float* R = g.residual ? g.residual + (int64_t)blockIdx.z * g.sR : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M) {
+            float v = acc[r];
+            if (g.alpha != 1.0f) v = v * g.alpha;
+            v = v + bias;
+            v = apply_act(v, g.act);
+            if (R) v = v + R[(int64_t)m * g.ldr + n];
+            C[(int64_t)m * g.ldc + n] = v;
+        }
+    }
+}
+
+void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch > 0 ? g.batch : 1);
+    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, s, g);
+}
+
+__global__ void k_im2col(const float* x, int B, int H, int W, int C, int ldx, int kh, int kw, int stride, int pad, int Ho, int Wo, float* col) {
+    const int64_t K = (int64_t)kh * kw * C;
+    const int64_t total = (int64_t)B * Ho * Wo * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / K;
+        const int k = (int)(i % K);
+        const int c = k % C, kx = (k / C) % kw, ky = k / (C * kw);
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+        const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+        float v = 0.0f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((int64_t)b * H + iy) * W + ix) * ldx + c];
+        col[i] = v;
+    }
+}
+
+void tk_launch_im2col(const float* x, int B, int H, int W, int C, int ldx, int kh, int kw, int stride, int pad, float* col, hipStream_t s) {
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    const int64_t total = (int64_t)B * Ho * Wo * kh * kw * C;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_im2col, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, C, ldx, kh, kw, stride, pad, Ho, Wo, col);
+}
+
+/* 5x5 max pool, stride 1, pad 2 (SPPF); padding never wins (-inf) */
+__global__ void k_maxpool5(const float* x, int B, int H, int W, int C, int ldx, float* y, int ldy) {
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        float m = -INFINITY;
+        for (int dy = -2; dy <= 2; ++dy)
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int iy = oy + dy, ix = ox + dx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) m = tk_fmaxf(m, x[(((int64_t)b * H + iy) * W + ix) * ldx + c]);
+            }
+        y[pix * ldy + c] = m;
+    }
+}
+void tk_launch_maxpool5(const float* x, int B, int H, int W, int C, int ldx, float* y, int ldy, hipStream_t s) {
+    const int64_t total = (int64_t)B * H * W * C;
+    hipLaunchKernelGGL(k_maxpool5, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, B, H, W, C, ldx, y, ldy);
+}
+
+__global__ void k_upsample2x(const float* x, int B, int H, int W, int C, int ldx, float* y, int ldy) {
+    const int64_t total = (int64_t)B * 2 * H * 2 * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int ox = (int)(pix % (2 * W)), oy = (int)((pix / (2 * W)) % (2 * H)), b = (int)(pix / ((int64_t)4 * W * H));
+        y[pix * ldy + c] = x[(((int64_t)b * H + oy / 2) * W + ox / 2) * ldx + c];
+    }
+}
+void tk_launch_upsample2x(const float* x, int B, int H, int W, int C, int ldx, float* y, int ldy, hipStream_t s) {
+    const int64_t total = (int64_t)B * 4 * H * W * C;
+    hipLaunchKernelGGL(k_upsample2x, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, B, H, W, C, ldx, y, ldy);
+}
+
+__global__ void k_copy_cols(const float* x, int64_t rows, int C, int ldx, float* y, int ldy) {
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        y[(i / C) * ldy + (i % C)] = x[(i / C) * ldx + (i % C)];
+}
+void tk_launch_copy_cols(const float* x, int rows, int C, int ldx, float* y, int ldy, hipStream_t s) {
+    const int64_t total = (int64_t)rows * C;
+    hipLaunchKernelGGL(k_copy_cols, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, (int64_t)rows, C, ldx, y, ldy);
+}
+
+__device__ __forceinline__ float nn_block_sum256(float v, float* red) {
+    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    return r;
+}
+
+/* y = ((x - mean) * rstd) * w + b ; sums in the canonical 256-partial order */
+__global__ __launch_bounds__(256) void k_layernorm(const float* x, int D, const float* w, const float* b, float eps, float* y) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const float* xr = x + r * D;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < D; i += 256) s = s + xr[i];
+    const float mean = tk_divf(nn_block_sum256(s, red), (float)D);
+    float q = 0.0f;
+    for (int i = threadIdx.x; i < D; i += 256) { const float d = xr[i] - mean; q = tk_fmaf(d, d, q); }
+    const float var = tk_divf(nn_block_sum256(q, red), (float)D);
+    const float rstd = tk_divf(1.0f, tk_sqrtf(var + eps));
+    for (int i = threadIdx.x; i < D; i += 256) y[r * D + i] = ((xr[i] - mean) * rstd) * w[i] + b[i];
+}
+void tk_launch_layernorm(const float* x, int rows, int D, const float* w, const float* b, float eps, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(k_layernorm, dim3(rows), dim3(256), 0, s, x, D, w, b, eps, y);
+}
+
+/* in-place row softmax; causal_offset >= 0: row r of a [rows][cols] block attends to columns <= r + causal_offset */
+__global__ __launch_bounds__(256) void k_softmax_rows(float* x, int cols, int ld, int causal_offset, int rows_per_batch) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    float* xr = x + r * ld;
+    int n = cols;
+    if (causal_offset >= 0) { const int lim = (int)(r % rows_per_batch) + causal_offset + 1; n = lim < cols ? lim : cols; }
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) m = tk_fmaxf(m, xr[i]);
+    for (int s = 32; s >= 1; s >>= 1) m = tk_fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = tk_fmaxf(tk_fmaxf(red[0], red[1]), tk_fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float e = tk_expf(xr[i] - m); xr[i] = e; s = s + e; }
+    const float tot = nn_block_sum256(s, red);
+    for (int i = threadIdx.x; i < cols; i += 256) xr[i] = i < n ? tk_divf(xr[i], tot) : 0.0f;
+}
+void tk_launch_softmax_rows(float* x, int rows, int cols, int ld, int causal_offset, hipStream_t s) {
+    hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, s, x, cols, ld, causal_offset, rows);
+}
+
+__global__ void k_add_rows(float* x, const float* add, int64_t rows, int D, int add_rows) {
+    const int64_t total = rows * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        x[i] = x[i] + add[(r % add_rows) * D + (i % D)];
+    }
+}
+void tk_launch_add_rows(float* x, const float* add, int rows, int D, int add_rows, hipStream_t s) {
+    const int64_t total = (int64_t)rows * D;
+    hipLaunchKernelGGL(k_add_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, add, (int64_t)rows, D, add_rows);
+}

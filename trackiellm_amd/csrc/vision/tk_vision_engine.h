@@ -1,0 +1,85 @@
+/*
+ * tk_vision_engine.h — detector stream on the GPU: frame upload, the reference pre-processor's
+ * arithmetic (src/vision/tk_image_preprocessor.c:43-69,156-160) as a HIP kernel, YOLOv8n on the
+ * fp32 MFMA GEMM, DFL decode + on-device NMS.  Batched over B frames (one per concurrent cycle).
+ */
+#ifndef TK_VISION_ENGINE_H
+#define TK_VISION_ENGINE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../common/tk_ggml_blocks.h"
+#include "../common/tk_yolo_post.h"
+#include "../common/tk_yolov8n_graph.h"
+
+struct TkPreprocessArgs {
+    const uint8_t* src;  /* device, interleaved */
+    uint32_t in_w, in_h, in_stride, bpp;
+    float* dst;          /* device */
+    uint32_t out_w, out_h;
+    float mean[3], std_dev[3];
+    int nhwc;            /* 0: planar CHW (reference layout), 1: NHWC (detector input) */
+};
+void tk_launch_preprocess(const TkPreprocessArgs& a, hipStream_t s);
+
+struct TkDetection {
+    float x1, y1, x2, y2, score;
+    int32_t cls, anchor;
+};
+
+class TkYoloModel {
+public:
+    int device = 0, nc = TK_YOLO_NC;
+    std::vector<TkConvSpec> specs;
+    std::vector<float*> w, b; /* device: [cout][k*k*cin], [cout] */
+    std::string error;
+    ~TkYoloModel();
+    bool init(int device, int nc);
+    bool fill_synthetic(uint64_t seed, float cls_bias);
+    bool set_layer(int idx, const float* w_host, const float* b_host);
+    bool load_file(const char* path); /* "TKYOLO1\0" flat container: see INTEGRATION.md */
+    size_t param_count() const;
+};
+
+class TkDetector {
+public:
+    TkYoloModel* model = nullptr;
+    int in_w = 640, in_h = 640, max_batch = 1;
+    float conf = 0.5f, iou = 0.5f;
+    float mean[3] = {0.485f, 0.456f, 0.406f}, std_dev[3] = {0.229f, 0.224f, 0.225f};
+    std::string error;
+    hipStream_t stream = nullptr;
+
+    ~TkDetector();
+    bool init(TkYoloModel* m, int in_w, int in_h, int max_batch);
+    /* frames: B host frames of identical geometry; results per frame, score-descending */
+    bool detect(int B, const uint8_t* const* frames, uint32_t w, uint32_t h, uint32_t stride, uint32_t bpp, std::vector<std::vector<TkDetection>>* out);
+    /* test hooks: run the network on an already pre-processed NHWC tensor / fetch the raw head maps */
+    bool forward_tensor(int B, const float* nhwc_host, std::vector<float>* raw_out /* [B][8400][64+nc] */);
+    bool fetch(int B, std::vector<std::vector<TkDetection>>* out); /* download the NMS survivors of the last enqueue */
+    bool enqueue(int B); /* pre-processed input already in `input`; network + decode + NMS on `stream` */
+    float* input = nullptr;        /* [B][H][W][3] */
+    int n_anchors = 0;
+
+private:
+    friend struct TkGpuOps;
+    uint8_t* frame_dev = nullptr;
+    size_t frame_cap = 0;
+    float* arena = nullptr;
+    size_t arena_floats = 0, arena_used = 0;
+    float* col = nullptr;
+    size_t col_floats = 0;
+    TkT heads[3];
+    tk_yolo_cand_t* cand = nullptr;     /* [B][n_anchors] decoded */
+    int32_t* order = nullptr;           /* [B][MAX_CAND] anchor ids, sorted */
+    int32_t* n_cand = nullptr;          /* [B] */
+    uint64_t* mask = nullptr;           /* [B][MAX_CAND][MAX_CAND/64] */
+    TkDetection* kept = nullptr;        /* [B][MAX_DET] */
+    int32_t* n_kept = nullptr;          /* [B] */
+};
+
+#endif

@@ -1,0 +1,390 @@
+#include "tk_vision_engine.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include "../nn/tk_nn_kernels.h"
+
+#define HIPQ(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            char b__[256];                                                                      \
+            snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            error = b__;                                                                        \
+            return false;                                                                       \
+        }                                                                                       \
+    } while (0)
+
+/* ------------------------------------------------------------------------------------------
+ * pre-processing: the reference CPU formula, op for op (scalar branch):
+ *   ratio = (orig - 1) / target ; g = ratio * o ; i = (int)g ; d = g - i
+ *   v = p1*(1-dx)*(1-dy) + p2*dx*(1-dy) + p3*(1-dx)*dy + p4*dx*dy      (left to right)
+ *   out = (v / 255 - mean) / std
+ * compiled with -ffp-contract=off; bit-identical to the compiled reference object (tests).
+ * One thread per output pixel, all three channels; u8 reads are served by L2 (the 4 taps of
+ * neighbouring pixels overlap), fp32 writes are coalesced per plane.  HBM-bound: 1.23 MB in, 4.92 MB out.
+ * ------------------------------------------------------------------------------------------ */
+__global__ void k_preprocess(TkPreprocessArgs a) {
+    const uint32_t ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ox >= a.out_w || oy >= a.out_h) return;
+    const float x_ratio = tk_divf((float)a.in_w - 1.0f, (float)a.out_w);
+    const float y_ratio = tk_divf((float)a.in_h - 1.0f, (float)a.out_h);
+    const float gx = x_ratio * (float)ox, gy = y_ratio * (float)oy;
+    const int x = (int)gx, y = (int)gy;
+    const float xd = gx - (float)x, yd = gy - (float)y;
+    const int x1 = x + 1 < (int)a.in_w ? x + 1 : x, y1 = y + 1 < (int)a.in_h ? y + 1 : y; /* reference reads x+1/y+1 (always in range for w,h >= 2) */
+    const uint8_t* r0 = a.src + (size_t)y * a.in_stride;
+    const uint8_t* r1 = a.src + (size_t)y1 * a.in_stride;
+    const size_t np = (size_t)a.out_w * a.out_h, pix = (size_t)oy * a.out_w + ox;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float p1 = (float)r0[x * a.bpp + c], p2 = (float)r0[x1 * a.bpp + c];
+        const float p3 = (float)r1[x * a.bpp + c], p4 = (float)r1[x1 * a.bpp + c];
+        float v = (p1 * (1.0f - xd)) * (1.0f - yd);
+        v = v + (p2 * xd) * (1.0f - yd);
+        v = v + (p3 * (1.0f - xd)) * yd;
+        v = v + (p4 * xd) * yd;
+        const float o = tk_divf(tk_divf(v, 255.0f) - a.mean[c], a.std_dev[c]);
+        if (a.nhwc) a.dst[pix * 3 + c] = o;
+        else a.dst[c * np + pix] = o;
+    }
+}
+
+void tk_launch_preprocess(const TkPreprocessArgs& a, hipStream_t s) {
+    dim3 block(64, 4);
+    dim3 grid((a.out_w + 63) / 64, (a.out_h + 3) / 4);
+    hipLaunchKernelGGL(k_preprocess, grid, block, 0, s, a);
+}
+
+/* ------------------------------------------------------------------------------------------ model */
+
+TkYoloModel::~TkYoloModel() {
+    (void)hipSetDevice(device);
+    for (auto p : w) if (p) (void)hipFree(p);
+    for (auto p : b) if (p) (void)hipFree(p);
+}
+
+bool TkYoloModel::init(int dev, int n_classes) {
+    device = dev;
+    nc = n_classes;
+    if (nc < 1 || nc > 1024) { error = "class count out of range"; return false; }
+    struct Dummy {};
+    specs = TkYoloV8n<Dummy>::specs(nc);
+    HIPQ(hipSetDevice(device));
+    w.assign(specs.size(), nullptr);
+    b.assign(specs.size(), nullptr);
+    for (size_t i = 0; i < specs.size(); ++i) {
+        const TkConvSpec& s = specs[i];
+        HIPQ(hipMalloc((void**)&w[i], (size_t)s.cout * s.k * s.k * s.cin * 4));
+        HIPQ(hipMalloc((void**)&b[i], (size_t)s.cout * 4));
+    }
+    return true;
+}
+
+size_t TkYoloModel::param_count() const {
+    size_t n = 0;
+    for (const auto& s : specs) n += (size_t)s.cout * s.k * s.k * s.cin + s.cout;
+    return n;
+}
+
+bool TkYoloModel::set_layer(int idx, const float* w_host, const float* b_host) {
+    if (idx < 0 || idx >= (int)specs.size()) { error = "layer index out of range"; return false; }
+    const TkConvSpec& s = specs[idx];
+    HIPQ(hipSetDevice(device));
+    HIPQ(hipMemcpy(w[idx], w_host, (size_t)s.cout * s.k * s.k * s.cin * 4, hipMemcpyHostToDevice));
+    HIPQ(hipMemcpy(b[idx], b_host, (size_t)s.cout * 4, hipMemcpyHostToDevice));
+    return true;
+}
+
+bool TkYoloModel::fill_synthetic(uint64_t seed, float cls_bias) {
+    std::vector<float> hw, hb;
+    const int n = (int)specs.size();
+    for (int i = 0; i < n; ++i) {
+        const TkConvSpec& s = specs[i];
+        const int fan = s.k * s.k * s.cin;
+        hw.resize((size_t)s.cout * fan);
+        hb.resize(s.cout);
+        /* the last class conv of each scale: layers n-13, n-7, n-1 (6 convs per scale, class 1x1 last) */
+        const bool cls_out = (i == n - 1 || i == n - 7 || i == n - 13);
+        for (size_t j = 0; j < hw.size(); ++j) hw[j] = tk_yolo_synth_w(seed, i, (int64_t)j, fan);
+        for (int j = 0; j < s.cout; ++j) hb[j] = tk_yolo_synth_b(seed, i, j, cls_out, cls_bias);
+        if (!set_layer(i, hw.data(), hb.data())) return false;
+    }
+    return true;
+}
+
+bool TkYoloModel::load_file(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { error = std::string("cannot open ") + path; return false; }
+    char magic[8];
+    int32_t hdr[2];
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "TKYOLO1", 8) == 0 && fread(hdr, 4, 2, f) == 2 && hdr[0] == (int)specs.size() && hdr[1] == nc;
+    std::vector<float> hw, hb;
+    for (size_t i = 0; ok && i < specs.size(); ++i) {
+        const TkConvSpec& s = specs[i];
+        int32_t d[4];
+        ok = fread(d, 4, 4, f) == 4 && d[0] == s.cin && d[1] == s.cout && d[2] == s.k && d[3] == s.s;
+        hw.resize((size_t)s.cout * s.k * s.k * s.cin);
+        hb.resize(s.cout);
+        ok = ok && fread(hw.data(), 4, hw.size(), f) == hw.size() && fread(hb.data(), 4, hb.size(), f) == hb.size();
+        ok = ok && set_layer((int)i, hw.data(), hb.data());
+    }
+    fclose(f);
+    if (!ok && error.empty()) error = "not a TKYOLO1 container for this geometry";
+    return ok;
+}
+
+/* ------------------------------------------------------------------------------------------ graph ops on the GPU */
+
+struct TkGpuOps {
+    TkDetector* d;
+    hipStream_t s;
+    TkT alloc(int B, int H, int W, int C) {
+        TkT t;
+        t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
+        size_t n = ((size_t)B * H * W * C + 63) & ~(size_t)63;
+        t.p = d->arena + d->arena_used;
+        d->arena_used += n;
+        return t;
+    }
+    void conv(const TkT& x, int idx, const TkT& y, const TkT* res) {
+        const TkConvSpec& sp = d->model->specs[idx];
+        TkGemm g{};
+        g.M = y.B * y.H * y.W; g.N = sp.cout; g.K = sp.k * sp.k * sp.cin;
+        if (sp.k == 1 && sp.s == 1) { g.A = x.p; g.lda = x.ld; }
+        else {
+            tk_launch_im2col(x.p, x.B, x.H, x.W, x.C, x.ld, sp.k, sp.k, sp.s, sp.k / 2, d->col, s);
+            g.A = d->col; g.lda = g.K;
+        }
+        g.B = d->model->w[idx]; g.ldb = g.K; g.b_kn = 0;
+        g.C = y.p; g.ldc = y.ld;
+        g.bias = d->model->b[idx];
+        g.residual = res ? res->p : nullptr; g.ldr = res ? res->ld : 0;
+        g.act = sp.act ? TK_ACT_SILU : TK_ACT_NONE;
+        g.alpha = 1.0f; g.batch = 1;
+        tk_launch_gemm(g, s);
+    }
+    void maxpool5(const TkT& x, const TkT& y) { tk_launch_maxpool5(x.p, x.B, x.H, x.W, x.C, x.ld, y.p, y.ld, s); }
+    void upsample2x(const TkT& x, const TkT& y) { tk_launch_upsample2x(x.p, x.B, x.H, x.W, x.C, x.ld, y.p, y.ld, s); }
+    void copy(const TkT& x, const TkT& y) { tk_launch_copy_cols(x.p, x.B * x.H * x.W, x.C, x.ld, y.p, y.ld, s); }
+};
+
+/* sizing pass: same graph, counts arena floats and the largest im2col matrix */
+struct TkSizeOps {
+    const std::vector<TkConvSpec>* specs;
+    size_t used = 0, col = 0;
+    TkT alloc(int B, int H, int W, int C) {
+        TkT t;
+        t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
+        used += ((size_t)B * H * W * C + 63) & ~(size_t)63;
+        return t;
+    }
+    void conv(const TkT&, int idx, const TkT& y, const TkT*) {
+        const TkConvSpec& sp = (*specs)[idx];
+        if (!(sp.k == 1 && sp.s == 1)) { size_t n = (size_t)y.B * y.H * y.W * sp.k * sp.k * sp.cin; col = n > col ? n : col; }
+    }
+    void maxpool5(const TkT&, const TkT&) {}
+    void upsample2x(const TkT&, const TkT&) {}
+    void copy(const TkT&, const TkT&) {}
+};
+
+/* ------------------------------------------------------------------------------------------ decode + NMS kernels */
+
+__global__ void k_yolo_decode(TkT h0, TkT h1, TkT h2, int nc, int n_anchors, float conf, tk_yolo_cand_t* cand) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (a >= n_anchors) return;
+    const int n0 = h0.H * h0.W, n1 = h1.H * h1.W;
+    const TkT* h;
+    int local;
+    float stride;
+    if (a < n0) { h = &h0; local = a; stride = 8.0f; }
+    else if (a < n0 + n1) { h = &h1; local = a - n0; stride = 16.0f; }
+    else { h = &h2; local = a - n0 - n1; stride = 32.0f; }
+    const float ax = (float)(local % h->W) + 0.5f, ay = (float)(local / h->W) + 0.5f;
+    tk_yolo_cand_t c;
+    tk_yolo_decode_anchor(h->p + ((size_t)b * h->H * h->W + local) * h->ld, nc, ax, ay, stride, &c);
+    c.anchor = a;
+    if (!(c.score > conf)) c.cls = -1; /* not a candidate */
+    cand[(size_t)b * n_anchors + a] = c;
+}
+
+/* rank of every candidate among the candidates: (score desc, anchor asc); the best MAX_CAND are kept */
+__global__ void k_yolo_rank(const tk_yolo_cand_t* cand, int n_anchors, int32_t* order, int32_t* n_cand) {
+    const int b = blockIdx.y;
+    const tk_yolo_cand_t* cb = cand + (size_t)b * n_anchors;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float ss[256];
+    __shared__ int sc[256];
+    const bool valid = a < n_anchors && cb[a].cls >= 0;
+    const float mys = valid ? cb[a].score : 0.0f;
+    int rank = 0, total = 0;
+    for (int base = 0; base < n_anchors; base += 256) {
+        const int j = base + threadIdx.x;
+        ss[threadIdx.x] = j < n_anchors ? cb[j].score : 0.0f;
+        sc[threadIdx.x] = j < n_anchors ? cb[j].cls : -1;
+        __syncthreads();
+        const int lim = n_anchors - base < 256 ? n_anchors - base : 256;
+        for (int k = 0; k < lim; ++k) {
+            if (sc[k] < 0) continue;
+            ++total;
+            const int j2 = base + k;
+            if (ss[k] > mys || (ss[k] == mys && j2 < a)) ++rank;
+        }
+        __syncthreads();
+    }
+    if (valid && rank < TK_YOLO_MAX_CAND) order[(size_t)b * TK_YOLO_MAX_CAND + rank] = a;
+    if (a == 0) n_cand[b] = total < TK_YOLO_MAX_CAND ? total : TK_YOLO_MAX_CAND;
+}
+
+/* suppression bit matrix: bit j of mask[i] set iff j > i, same class, IoU > thr */
+__global__ void k_yolo_mask(const tk_yolo_cand_t* cand, int n_anchors, const int32_t* order, const int32_t* n_cand, float iou_thr, uint64_t* mask) {
+    const int b = blockIdx.z;
+    const int n = n_cand[b];
+    const int i = blockIdx.y * blockDim.y + threadIdx.y;
+    const int wj = blockIdx.x * blockDim.x + threadIdx.x; /* 64-candidate word */
+    if (i >= n || wj * 64 >= n) return;
+    const tk_yolo_cand_t* cb = cand + (size_t)b * n_anchors;
+    const int32_t* ob = order + (size_t)b * TK_YOLO_MAX_CAND;
+    const tk_yolo_cand_t ci = cb[ob[i]];
+    uint64_t bits = 0;
+    for (int k = 0; k < 64; ++k) {
+        const int j = wj * 64 + k;
+        if (j <= i || j >= n) continue;
+        const tk_yolo_cand_t cj = cb[ob[j]];
+        if (cj.cls == ci.cls && tk_yolo_iou(&ci, &cj) > iou_thr) bits |= 1ull << k;
+    }
+    mask[((size_t)b * TK_YOLO_MAX_CAND + i) * (TK_YOLO_MAX_CAND / 64) + wj] = bits;
+}
+
+/* greedy scan, one wave per frame */
+__global__ void k_yolo_scan(const tk_yolo_cand_t* cand, int n_anchors, const int32_t* order, const int32_t* n_cand, const uint64_t* mask,
+                            TkDetection* kept, int32_t* n_kept) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ uint64_t removed[TK_YOLO_MAX_CAND / 64];
+    const int n = n_cand[b];
+    const int words = (n + 63) / 64;
+    for (int w = lane; w < TK_YOLO_MAX_CAND / 64; w += 64) removed[w] = 0;
+    __syncthreads();
+    const tk_yolo_cand_t* cb = cand + (size_t)b * n_anchors;
+    const int32_t* ob = order + (size_t)b * TK_YOLO_MAX_CAND;
+    int nk = 0;
+    for (int i = 0; i < n && nk < TK_OBJECT_DETECTOR_MAX_DETECTIONS; ++i) {
+        const bool dead = (removed[i >> 6] >> (i & 63)) & 1;
+        if (!dead) {
+            const uint64_t* mrow = mask + ((size_t)b * TK_YOLO_MAX_CAND + i) * (TK_YOLO_MAX_CAND / 64);
+            for (int w = lane; w < words; w += 64) removed[w] |= mrow[w];
+            if (lane == 0) {
+                const tk_yolo_cand_t c = cb[ob[i]];
+                TkDetection dt{c.x1, c.y1, c.x2, c.y2, c.score, c.cls, c.anchor};
+                kept[(size_t)b * TK_OBJECT_DETECTOR_MAX_DETECTIONS + nk] = dt;
+            }
+            ++nk;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) n_kept[b] = nk;
+}
+
+/* ------------------------------------------------------------------------------------------ detector */
+
+TkDetector::~TkDetector() {
+    if (model) (void)hipSetDevice(model->device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    void* ptrs[] = {frame_dev, arena, col, input, cand, order, n_cand, mask, kept, n_kept};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+bool TkDetector::init(TkYoloModel* m, int w, int h, int mb) {
+    model = m; in_w = w; in_h = h; max_batch = mb;
+    if (!m || w <= 0 || h <= 0 || (w % 32) || (h % 32)) { error = "detector input must be a positive multiple of 32"; return false; }
+    if (mb < 1 || mb > 64) { error = "max_batch must be in [1,64]"; return false; }
+    HIPQ(hipSetDevice(m->device));
+    HIPQ(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    TkSizeOps so{&m->specs};
+    TkT x = so.alloc(mb, h, w, 3);
+    so.used = 0;
+    TkT o[3];
+    TkYoloV8n<TkSizeOps>::forward(so, x, o, m->nc);
+    arena_floats = so.used + 1024;
+    col_floats = so.col + 1024;
+    n_anchors = (h / 8) * (w / 8) + (h / 16) * (w / 16) + (h / 32) * (w / 32);
+    HIPQ(hipMalloc((void**)&arena, arena_floats * 4));
+    HIPQ(hipMalloc((void**)&col, col_floats * 4));
+    HIPQ(hipMalloc((void**)&input, (size_t)mb * h * w * 3 * 4));
+    HIPQ(hipMalloc((void**)&cand, (size_t)mb * n_anchors * sizeof(tk_yolo_cand_t)));
+    HIPQ(hipMalloc((void**)&order, (size_t)mb * TK_YOLO_MAX_CAND * 4));
+    HIPQ(hipMalloc((void**)&n_cand, (size_t)mb * 4));
+    HIPQ(hipMalloc((void**)&mask, (size_t)mb * TK_YOLO_MAX_CAND * (TK_YOLO_MAX_CAND / 64) * 8));
+    HIPQ(hipMalloc((void**)&kept, (size_t)mb * TK_OBJECT_DETECTOR_MAX_DETECTIONS * sizeof(TkDetection)));
+    HIPQ(hipMalloc((void**)&n_kept, (size_t)mb * 4));
+    return true;
+}
+
+bool TkDetector::enqueue(int B) {
+    TkGpuOps ops{this, stream};
+    arena_used = 0;
+    TkT x;
+    x.p = input; x.B = B; x.H = in_h; x.W = in_w; x.C = 3; x.ld = 3;
+    TkYoloV8n<TkGpuOps>::forward(ops, x, heads, model->nc);
+    hipLaunchKernelGGL(k_yolo_decode, dim3((n_anchors + 255) / 256, B), dim3(256), 0, stream, heads[0], heads[1], heads[2], model->nc, n_anchors, conf, cand);
+    hipLaunchKernelGGL(k_yolo_rank, dim3((n_anchors + 255) / 256, B), dim3(256), 0, stream, cand, n_anchors, order, n_cand);
+    hipLaunchKernelGGL(k_yolo_mask, dim3(TK_YOLO_MAX_CAND / 64 / 8, TK_YOLO_MAX_CAND / 8, B), dim3(8, 8), 0, stream, cand, n_anchors, order, n_cand, iou, mask);
+    hipLaunchKernelGGL(k_yolo_scan, dim3(B), dim3(64), 0, stream, cand, n_anchors, order, n_cand, mask, kept, n_kept);
+    HIPQ(hipGetLastError());
+    return true;
+}
+
+bool TkDetector::detect(int B, const uint8_t* const* frames, uint32_t w, uint32_t h, uint32_t stride, uint32_t bpp, std::vector<std::vector<TkDetection>>* out) {
+    if (B < 1 || B > max_batch) { error = "batch larger than the detector was created for"; return false; }
+    if (w < 2 || h < 2 || stride < w * bpp) { error = "frame geometry invalid (need w,h >= 2 and stride >= w*bpp)"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    const size_t fb = (size_t)stride * h;
+    if (fb * B > frame_cap) {
+        if (frame_dev) (void)hipFree(frame_dev);
+        frame_dev = nullptr;
+        HIPQ(hipMalloc((void**)&frame_dev, fb * B));
+        frame_cap = fb * B;
+    }
+    for (int b = 0; b < B; ++b) {
+        HIPQ(hipMemcpyAsync(frame_dev + fb * b, frames[b], fb, hipMemcpyHostToDevice, stream));
+        TkPreprocessArgs a{};
+        a.src = frame_dev + fb * b; a.in_w = w; a.in_h = h; a.in_stride = stride; a.bpp = bpp;
+        a.dst = input + (size_t)b * in_h * in_w * 3; a.out_w = in_w; a.out_h = in_h; a.nhwc = 1;
+        for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std_dev[c] = std_dev[c]; }
+        tk_launch_preprocess(a, stream);
+    }
+    if (!enqueue(B)) return false;
+    return fetch(B, out);
+}
+
+bool TkDetector::fetch(int B, std::vector<std::vector<TkDetection>>* out) {
+    std::vector<int32_t> nk(B);
+    std::vector<TkDetection> hk((size_t)B * TK_OBJECT_DETECTOR_MAX_DETECTIONS);
+    HIPQ(hipMemcpyAsync(nk.data(), n_kept, B * 4, hipMemcpyDeviceToHost, stream));
+    HIPQ(hipMemcpyAsync(hk.data(), kept, hk.size() * sizeof(TkDetection), hipMemcpyDeviceToHost, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    out->assign(B, {});
+    for (int b = 0; b < B; ++b)
+        (*out)[b].assign(hk.begin() + (size_t)b * TK_OBJECT_DETECTOR_MAX_DETECTIONS, hk.begin() + (size_t)b * TK_OBJECT_DETECTOR_MAX_DETECTIONS + nk[b]);
+    return true;
+}
+
+bool TkDetector::forward_tensor(int B, const float* nhwc_host, std::vector<float>* raw_out) {
+    if (B < 1 || B > max_batch) { error = "batch larger than the detector was created for"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    HIPQ(hipMemcpyAsync(input, nhwc_host, (size_t)B * in_h * in_w * 3 * 4, hipMemcpyHostToDevice, stream));
+    if (!enqueue(B)) return false;
+    const int no = 64 + model->nc;
+    raw_out->resize((size_t)B * n_anchors * no);
+    size_t off = 0;
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < 3; ++i) {
+            const size_t n = (size_t)heads[i].H * heads[i].W * no;
+            HIPQ(hipMemcpyAsync(raw_out->data() + off, heads[i].p + (size_t)b * n, n * 4, hipMemcpyDeviceToHost, stream));
+            off += n;
+        }
+    HIPQ(hipStreamSynchronize(stream));
+    return true;
+}
