@@ -30,7 +30,7 @@ def test_preprocess_stride_rgba_and_errors(gpu):
     f = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
     pad = np.zeros((20, 128), np.uint8)
     pad[:, :90] = f.reshape(20, 90)
-    assert np.array_equal(gpu.preprocess(pad, 32, 32, stride=128), gpu.preprocess(f, 32, 32))
+    assert np.array_equal(gpu.preprocess(pad, 32, 32, stride=128, width=30), gpu.preprocess(f, 32, 32))
     rgba = np.concatenate([f, np.full((20, 30, 1), 255, np.uint8)], 2)
     assert np.array_equal(gpu.preprocess(rgba, 32, 32, rgba=True), gpu.preprocess(f, 32, 32))
     import ctypes as C
@@ -58,8 +58,8 @@ def test_detector_full_frame_path_and_batch(gpu):
     """u8 frame -> preprocess -> network -> NMS -> original-frame rects, 160x160 network input, 2 frames"""
     rng = np.random.default_rng(8)
     fr = [rng.integers(0, 256, (120, 200, 3), dtype=np.uint8) for _ in range(2)]
-    det = gpu.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-3", width=160, height=160, conf=0.3, iou=0.5, max_batch=2)
-    orc = O.OracleYolo(nc=80, seed=5, cls_bias=-3.0)
+    det = gpu.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-1", width=160, height=160, conf=0.3, iou=0.5, max_batch=2)
+    orc = O.OracleYolo(nc=80, seed=5, cls_bias=-1.0)
     res = det.detect_batch(fr)
     one = det.detect(fr[1])
     assert one == res[1]

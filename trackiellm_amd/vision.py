@@ -33,14 +33,16 @@ class _DetectorConfig(C.Structure):
                 ("confidence_threshold", C.c_float), ("iou_threshold", C.c_float)]
 
 
-def make_frame(arr, stride=None, rgba=False):
+def make_frame(arr, stride=None, rgba=False, width=None):
+    """arr: uint8 [H][W][3|4], or a padded [H][stride] buffer together with width="""
     arr = np.ascontiguousarray(arr, dtype=np.uint8)
-    h, w = arr.shape[:2]
+    h = arr.shape[0]
+    w = width if width is not None else arr.shape[1]
     return VideoFrame(w, h, stride or arr.strides[0], 1 if rgba else 0, arr.ctypes.data), arr
 
 
-def preprocess(arr, tw, th, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), stride=None, rgba=False):
-    f, keep = make_frame(arr, stride, rgba)
+def preprocess(arr, tw, th, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), stride=None, rgba=False, width=None):
+    f, keep = make_frame(arr, stride, rgba, width)
     out = np.empty((3, th, tw), np.float32)
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
