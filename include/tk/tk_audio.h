@@ -1,0 +1,105 @@
+/*
+ * tk_audio.h — ASR + VAD streams of the tk_* C-ABI.
+ *   tk_asr_whisper_*   src/audio/tk_asr_whisper.h:36-47 (config), :53-58 (result), :82-162 (API);
+ *                      behaviour of src/audio/tk_asr_whisper.c:282-344 (30 s int16 buffer, overflow => reset,
+ *                      < 16000 samples and !final => empty result, final => buffer cleared, confidence = 0.9 constant)
+ *   tk_vad_silero_*    src/sensors/tk_vad_silero.h (API), src/sensors/tk_vad_silero.c:283-322 (state machine),
+ *                      :327-390 (30 ms window / 10 ms hop, time advances by the WINDOW length per step — kept),
+ *                      :393-470 (defaults), :488-600
+ * model_path forms: "synthetic://whisper-tiny.en?seed=6" | a TKWHSP1 container;  "synthetic://vad?seed=7".
+ * The single event enum is shared by both reference headers that define it.
+ */
+#ifndef TK_MI355X_AUDIO_H
+#define TK_MI355X_AUDIO_H
+
+#include "tk_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tk_asr_whisper_context_s tk_asr_whisper_context_t;
+
+typedef struct {
+    tk_path_t* model_path;
+    const char* language;
+    bool translate_to_en;
+    uint32_t sample_rate; /* must be 16000 */
+    void* user_data;
+    int n_threads;        /* ignored */
+    int max_context;
+    float word_threshold;
+} tk_asr_whisper_config_t;
+
+typedef struct {
+    char* text;
+    size_t text_length;
+    float confidence;
+    bool is_partial;
+} tk_asr_whisper_result_t;
+
+TK_API TK_NODISCARD tk_error_code_t tk_asr_whisper_create(tk_asr_whisper_context_t** out_context, const tk_asr_whisper_config_t* config);
+TK_API void tk_asr_whisper_destroy(tk_asr_whisper_context_t** context);
+TK_API TK_NODISCARD tk_error_code_t tk_asr_whisper_process_audio(tk_asr_whisper_context_t* context, const int16_t* audio_data, size_t frame_count,
+                                                                 bool is_final, tk_asr_whisper_result_t** out_result);
+TK_API void tk_asr_whisper_free_result(tk_asr_whisper_result_t** result);
+TK_API TK_NODISCARD tk_error_code_t tk_asr_whisper_reset(tk_asr_whisper_context_t* context);
+TK_API TK_NODISCARD tk_error_code_t tk_asr_whisper_set_language(tk_asr_whisper_context_t* context, const char* language);
+
+typedef struct tk_vad_silero_context_s tk_vad_silero_context_t;
+
+typedef struct {
+    tk_path_t* model_path;
+    uint32_t sample_rate; /* 8000, 16000 or 48000 */
+    void* user_data;
+    float threshold;
+    float min_silence_duration_ms;
+    float min_speech_duration_ms;
+    float speech_pad_ms;
+} tk_vad_silero_config_t;
+
+typedef struct {
+    bool is_speech_active;
+    float speech_probability;
+    float silence_duration_ms;
+    float speech_duration_ms;
+} tk_vad_silero_state_t;
+
+typedef enum { TK_VAD_EVENT_SPEECH_STARTED, TK_VAD_EVENT_SPEECH_ENDED } tk_vad_event_e;
+typedef tk_vad_event_e tk_vad_silero_event_e;
+typedef void (*tk_vad_silero_event_callback_t)(tk_vad_silero_event_e event, void* user_data);
+
+TK_API TK_NODISCARD tk_error_code_t tk_vad_silero_create(tk_vad_silero_context_t** out_context, const tk_vad_silero_config_t* config);
+TK_API void tk_vad_silero_destroy(tk_vad_silero_context_t** context);
+TK_API TK_NODISCARD tk_error_code_t tk_vad_silero_process_audio(tk_vad_silero_context_t* context, const int16_t* audio_data, size_t frame_count,
+                                                                float* out_probability);
+TK_API TK_NODISCARD tk_error_code_t tk_vad_silero_process_audio_with_events(tk_vad_silero_context_t* context, const int16_t* audio_data,
+                                                                            size_t frame_count, tk_vad_silero_event_callback_t callback,
+                                                                            void* user_data);
+TK_API TK_NODISCARD tk_error_code_t tk_vad_silero_get_state(tk_vad_silero_context_t* context, tk_vad_silero_state_t* out_state);
+TK_API TK_NODISCARD tk_error_code_t tk_vad_silero_reset(tk_vad_silero_context_t* context);
+TK_API TK_NODISCARD tk_error_code_t tk_vad_silero_set_threshold(tk_vad_silero_context_t* context, float threshold);
+
+/* ---- extensions (no reference counterpart) ---- */
+typedef struct {
+    int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_text_ctx, n_text_state, n_text_head, n_text_layer, n_vocab;
+} tk_mi355x_whisper_hparams_t;
+/* explicit geometry + batch (parity tests use a small geometry; bench uses tiny.en with max_batch = B) */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_create(tk_asr_whisper_context_t** out, const tk_mi355x_whisper_hparams_t* hp, uint64_t seed,
+                                                         int device, int max_batch);
+/* B utterances of n_samples int16 each -> exactly n_steps greedy tokens per utterance (forced, EOT ignored);
+ * optional outputs: mel [B][2*ctx][n_mels], enc [B][ctx][d], logits of the first sampled position [B][n_vocab] */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_transcribe_tokens(tk_asr_whisper_context_t* ctx, int batch, const int16_t* pcm, int n_samples,
+                                                                    int n_steps, int32_t* tokens_out, float* mel_out, float* enc_out,
+                                                                    float* logits_out);
+TK_API void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_steps);
+/* feed one window probability straight into the VAD state machine (30 ms step); returns -1 none, 0 started, 1 ended */
+TK_API int tk_mi355x_vad_step(tk_vad_silero_context_t* ctx, float probability);
+/* probabilities of n consecutive float windows of the model's window length */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_vad_probabilities(tk_vad_silero_context_t* ctx, const float* windows, int n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,220 @@
+/*
+ * tk_oracle_audio.cpp — TEST INFRASTRUCTURE ONLY (oracle) for the ASR / VAD streams.
+ *
+ * PARITY UNPINNED against the reference for the network arithmetic: whisper.cpp is #included but not shipped,
+ * declared or pinned (src/audio/tk_asr_whisper.c:24) and the Silero ONNX graph is absent.  The
+ * Whisper graph (trackiellm_amd/csrc/common/tk_whisper_graph.h) is walked here with scalar CPU ops and pinned against
+ * HF transformers' WhisperModel + WhisperFeatureExtractor (tests/golden/make_audio_golden.py).
+ * Restated from reference sources: the VAD state machine (src/sensors/tk_vad_silero.c:283-322) and its windowing
+ * (:327-390, 30 ms window, 10 ms hop, time advances by the window length), s16 -> f32 by /32768 (:78-82).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../trackiellm_amd/csrc/common/tk_whisper_graph.h"
+
+extern "C" void orc_gemm(const float* A, const float* B, float* C, const float* bias, const float* residual, int M, int N, int K, int lda, int ldb,
+                         int ldc, int ldr, int b_kn, int act, float alpha);
+
+static float sum256(const float* partial) {
+    float w[4];
+    for (int wv = 0; wv < 4; ++wv) {
+        float p[64];
+        for (int i = 0; i < 64; ++i) p[i] = partial[wv * 64 + i];
+        for (int s = 32; s >= 1; s >>= 1)
+            for (int i = 0; i < s; ++i) p[i] = p[i] + p[i + s];
+        w[wv] = p[0];
+    }
+    return ((w[0] + w[1]) + w[2]) + w[3];
+}
+
+struct CpuAudioOps {
+    std::vector<std::vector<float>> bufs;
+    float* alloc(size_t n) { bufs.emplace_back(n ? n : 1, 0.0f); return bufs.back().data(); }
+    int32_t* alloc_i32(size_t n) { return (int32_t*)alloc(n); }
+    void gemm(const TkGemm& g) {
+        const int nb = g.batch > 0 ? g.batch : 1;
+        for (int z = 0; z < nb; ++z) {
+            int64_t oA, oB, oC, oR;
+            if (g.batch_inner > 0) {
+                const int zo = z / g.batch_inner, zi = z % g.batch_inner;
+                oA = zo * g.sA2 + zi * g.sA; oB = zo * g.sB2 + zi * g.sB; oC = zo * g.sC2 + zi * g.sC; oR = zo * g.sR2 + zi * g.sR;
+            } else { oA = z * g.sA; oB = z * g.sB; oC = z * g.sC; oR = z * g.sR; }
+            orc_gemm(g.A + oA, g.B + oB, g.C + oC, g.bias, g.residual ? g.residual + oR : nullptr, g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr,
+                     g.b_kn, g.act, g.alpha);
+        }
+    }
+    void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) {
+        const int To = (T + 2 * pad - kw) / stride + 1;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < To; ++t)
+                for (int kx = 0; kx < kw; ++kx) {
+                    const int it = t * stride + kx - pad;
+                    for (int c = 0; c < C; ++c)
+                        col[(((int64_t)b * To + t) * kw + kx) * C + c] = (it >= 0 && it < T) ? x[((int64_t)b * T + it) * ldx + c] : 0.0f;
+                }
+    }
+    void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) {
+        for (int r = 0; r < rows; ++r) {
+            const float* xr = x + (int64_t)r * D;
+            float part[256];
+            for (int t = 0; t < 256; ++t) { float s = 0.0f; for (int i = t; i < D; i += 256) s = s + xr[i]; part[t] = s; }
+            const float mean = tk_divf(sum256(part), (float)D);
+            for (int t = 0; t < 256; ++t) { float q = 0.0f; for (int i = t; i < D; i += 256) { const float d = xr[i] - mean; q = tk_fmaf(d, d, q); } part[t] = q; }
+            const float var = tk_divf(sum256(part), (float)D);
+            const float rstd = tk_divf(1.0f, tk_sqrtf(var + TK_WH_LN_EPS));
+            for (int i = 0; i < D; ++i) y[(int64_t)r * D + i] = ((xr[i] - mean) * rstd) * w[i] + b[i];
+        }
+    }
+    void softmax_rows(float* x, int rows, int cols, int ld) {
+        for (int r = 0; r < rows; ++r) {
+            float* xr = x + (int64_t)r * ld;
+            float m = -INFINITY;
+            for (int i = 0; i < cols; ++i) m = tk_fmaxf(m, xr[i]);
+            float part[256];
+            for (int t = 0; t < 256; ++t) {
+                float s = 0.0f;
+                for (int i = t; i < cols; i += 256) { const float e = tk_expf(xr[i] - m); xr[i] = e; s = s + e; }
+                part[t] = s;
+            }
+            const float tot = sum256(part);
+            for (int i = 0; i < cols; ++i) xr[i] = tk_divf(xr[i], tot);
+        }
+    }
+    void add_rows(float* x, const float* add, int rows, int D, int add_rows) {
+        for (int64_t r = 0; r < rows; ++r)
+            for (int i = 0; i < D; ++i) x[r * D + i] = x[r * D + i] + add[(r % add_rows) * D + i];
+    }
+    void embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out) {
+        for (int r = 0; r < rows; ++r)
+            for (int i = 0; i < D; ++i) out[(int64_t)r * D + i] = table[(int64_t)idx[r] * D + i] + pos[(int64_t)pos_idx[r] * D + i];
+    }
+    void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out) {
+        for (int r = 0; r < rows; ++r) {
+            int best = 0;
+            for (int i = 1; i < cols; ++i) if (x[(int64_t)r * ld + i] > x[(int64_t)r * ld + best]) best = i;
+            out[r] = best;
+        }
+    }
+    void frames(const int16_t* pcm, int B, int n_samples, int pcm_stride, int n_total, int T, const float* window, float* out) {
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t)
+                for (int n = 0; n < TK_WH_NFFT; ++n) {
+                    int j = t * TK_WH_HOP + n - TK_WH_NFFT / 2;
+                    if (j < 0) j = -j;
+                    if (j >= n_total) j = 2 * (n_total - 1) - j;
+                    const float x = j < n_samples ? (float)pcm[(int64_t)b * pcm_stride + j] / 32768.0f : 0.0f;
+                    out[((int64_t)b * T + t) * TK_WH_NFFT + n] = x * window[n];
+                }
+    }
+    void power(const float* ri, int rows, int nb, float* out) {
+        for (int64_t r = 0; r < rows; ++r)
+            for (int f = 0; f < nb; ++f) { const float re = ri[r * 2 * nb + f], im = ri[r * 2 * nb + nb + f]; out[r * nb + f] = tk_fmaf(re, re, im * im); }
+    }
+    void logmel_finish(float* mel, int B, int per_b) {
+        for (int b = 0; b < B; ++b) {
+            float* m = mel + (int64_t)b * per_b;
+            float mx = -INFINITY;
+            for (int i = 0; i < per_b; ++i) { m[i] = tk_log10f(tk_fmaxf(m[i], 1e-10f)); mx = tk_fmaxf(mx, m[i]); }
+            const float fl = mx - 8.0f;
+            for (int i = 0; i < per_b; ++i) m[i] = (tk_fmaxf(m[i], fl) + 4.0f) * 0.25f;
+        }
+    }
+};
+
+struct orc_whisper {
+    TkWhisperHP hp;
+    TkWhManifest man;
+    std::vector<std::vector<float>> w;
+    std::vector<float*> wp;
+};
+
+extern "C" {
+
+orc_whisper* orc_whisper_create(const TkWhisperHP* hp, uint64_t seed) {
+    orc_whisper* m = new orc_whisper();
+    m->hp = *hp;
+    m->man = tk_whisper_manifest(*hp);
+    m->w.resize(m->man.t.size());
+    for (size_t i = 0; i < m->man.t.size(); ++i) {
+        m->w[i].resize((size_t)m->man.t[i].rows * m->man.t[i].cols);
+        tk_whisper_fill_tensor(*hp, m->man, (int)i, seed, m->w[i].data());
+        m->wp.push_back(m->w[i].data());
+    }
+    return m;
+}
+void orc_whisper_destroy(orc_whisper* m) { delete m; }
+int orc_whisper_tensor_count(orc_whisper* m) { return (int)m->man.t.size(); }
+int64_t orc_whisper_tensor_info(orc_whisper* m, int i, char* name, int cap, int64_t* rows, int64_t* cols) {
+    snprintf(name, cap, "%s", m->man.t[i].name.c_str());
+    *rows = m->man.t[i].rows; *cols = m->man.t[i].cols;
+    return *rows * *cols;
+}
+void orc_whisper_get_tensor(orc_whisper* m, int i, float* out) { memcpy(out, m->w[i].data(), m->w[i].size() * 4); }
+
+/* same contract as TkAsr::transcribe: prompt tokens then n_steps forced greedy tokens */
+void orc_whisper_transcribe(orc_whisper* m, int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps,
+                            int32_t* tokens_out, float* mel_out, float* enc_out, float* first_logits) {
+    const TkWhisperHP& h = m->hp;
+    CpuAudioOps ops;
+    ops.bufs.reserve(4096);
+    TkWhisperGraph<CpuAudioOps> g{h, m->man, m->wp.data()};
+    float* ml = g.mel(ops, pcm, B, n_samples, n_samples);
+    if (mel_out) memcpy(mel_out, ml, (size_t)B * h.n_frames() * h.n_mels * 4);
+    float* enc = g.encode(ops, ml, B);
+    if (enc_out) memcpy(enc_out, enc, (size_t)B * h.n_audio_ctx * h.n_audio_state * 4);
+    if (n_steps <= 0) return;
+    auto st = g.begin_decode(ops, enc, B);
+    const int total = n_prompt + n_steps - 1;
+    for (int p = 0; p < total; ++p) {
+        for (int b = 0; b < B; ++b) { st.tok[b] = p < n_prompt ? prompt[p] : st.next[b]; st.pos[b] = p; }
+        g.decode_step(ops, st, p);
+        if (p >= n_prompt - 1) {
+            const int step = p - (n_prompt - 1);
+            if (step == 0 && first_logits) memcpy(first_logits, st.logits, (size_t)B * h.n_vocab * 4);
+            for (int b = 0; b < B; ++b) tokens_out[(size_t)b * n_steps + step] = st.next[b];
+        }
+    }
+}
+
+/* ---- VAD ---- */
+void orc_vad_probabilities(uint64_t seed, int window, int hidden, const float* windows, int n, float* prob) {
+    std::vector<float> w1((size_t)window * hidden), b1(hidden), w2(hidden), b2(1), hid((size_t)n * hidden);
+    tk_vad_synth(seed, window, hidden, w1.data(), b1.data(), w2.data(), b2.data());
+    orc_gemm(windows, w1.data(), hid.data(), b1.data(), nullptr, n, hidden, window, window, window, hidden, 0, 0, 0, 1.0f);
+    for (int i = 0; i < n; ++i) {
+        float acc = 0.0f;
+        for (int k = 0; k < hidden; ++k) acc = tk_fmaf(tk_fmaxf(hid[(size_t)i * hidden + k], 0.0f), w2[k], acc);
+        prob[i] = tk_sigmoidf(acc + b2[0]);
+    }
+}
+
+typedef struct {
+    float threshold, min_silence_ms, min_speech_ms;
+    int active, triggered;
+    float prob, silence_ms, speech_ms, since_event_ms;
+} orc_vad_state_t;
+
+/* one step of the reference state machine (tk_vad_silero.c:283-322); returns -1 none, 0 started, 1 ended */
+int orc_vad_step(orc_vad_state_t* s, float probability, float dt_ms) {
+    const int before = s->active;
+    s->prob = probability;
+    s->since_event_ms += dt_ms;
+    if (probability >= s->threshold) {
+        s->speech_ms += dt_ms;
+        s->silence_ms = 0.0f;
+        if (!s->active && s->speech_ms >= s->min_speech_ms && !s->triggered) { s->active = 1; s->triggered = 1; s->since_event_ms = 0.0f; }
+    } else {
+        s->silence_ms += dt_ms;
+        s->speech_ms = 0.0f;
+        if (s->active && s->silence_ms >= s->min_silence_ms) { s->active = 0; s->triggered = 0; s->since_event_ms = 0.0f; }
+    }
+    if (!before && s->active) return 0;
+    if (before && !s->active) return 1;
+    return -1;
+}
+
+} /* extern "C" */

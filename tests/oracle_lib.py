@@ -273,3 +273,94 @@ def gemm(A, B, bias=None, residual=None, b_kn=False, act=0, alpha=1.0):
     L.orc_gemm(ptr(A), ptr(B), ptr(Cm), ptr(bias) if bias is not None else None, ptr(residual) if residual is not None else None,
                M, N, K, K, B.shape[1], N, N, int(b_kn), act, alpha)
     return Cm
+
+
+# ---------------------------------------------------------------- audio oracle bindings
+class WhisperHP(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+                                         "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "n_vocab")]
+
+
+def whisper_tiny_test():
+    return WhisperHP(80, 50, 64, 2, 2, 32, 64, 2, 2, 512)
+
+
+def whisper_tiny_en():
+    return WhisperHP(80, 1500, 384, 6, 4, 448, 384, 6, 4, 51864)
+
+
+def whisper_prompt(hp):
+    v = hp.n_vocab
+    return np.array([min(50257, v - 3), min(50362, v - 1)], np.int32)
+
+
+class OracleWhisper:
+    def __init__(self, hp, seed=6):
+        L = lib()
+        L.orc_whisper_create.restype = C.c_void_p
+        L.orc_whisper_create.argtypes = [C.POINTER(WhisperHP), C.c_uint64]
+        L.orc_whisper_destroy.argtypes = [C.c_void_p]
+        L.orc_whisper_tensor_count.argtypes = [C.c_void_p]
+        L.orc_whisper_tensor_info.restype = C.c_int64
+        L.orc_whisper_tensor_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.orc_whisper_get_tensor.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_whisper_transcribe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
+        self.hp = hp
+        self.h = L.orc_whisper_create(C.byref(hp), seed)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_whisper_destroy(self.h)
+            self.h = None
+
+    def tensors(self):
+        out = {}
+        for i in range(lib().orc_whisper_tensor_count(self.h)):
+            name = C.create_string_buffer(128)
+            r, c = C.c_int64(0), C.c_int64(0)
+            lib().orc_whisper_tensor_info(self.h, i, name, 128, C.byref(r), C.byref(c))
+            a = np.empty((r.value, c.value), np.float32)
+            lib().orc_whisper_get_tensor(self.h, i, ptr(a))
+            out[name.value.decode()] = a
+        return out
+
+    def transcribe(self, pcm, n_steps, want=("mel", "enc", "logits")):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        B, n = pcm.shape
+        hp = self.hp
+        prompt = whisper_prompt(hp)
+        toks = np.zeros((B, max(n_steps, 1)), np.int32)
+        mel = np.empty((B, 2 * hp.n_audio_ctx, hp.n_mels), np.float32)
+        enc = np.empty((B, hp.n_audio_ctx, hp.n_audio_state), np.float32)
+        lg = np.empty((B, hp.n_vocab), np.float32)
+        lib().orc_whisper_transcribe(self.h, B, ptr(pcm), n, ptr(prompt), len(prompt), n_steps, ptr(toks), ptr(mel), ptr(enc), ptr(lg))
+        return toks[:, :n_steps], mel, enc, lg
+
+
+def vad_probabilities(seed, windows, hidden=64):
+    windows = np.ascontiguousarray(windows, np.float32)
+    n, w = windows.shape
+    out = np.empty(n, np.float32)
+    L = lib()
+    L.orc_vad_probabilities.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_vad_probabilities(seed, w, hidden, ptr(windows), n, ptr(out))
+    return out
+
+
+class VadState(C.Structure):
+    _fields_ = [("threshold", C.c_float), ("min_silence_ms", C.c_float), ("min_speech_ms", C.c_float), ("active", C.c_int),
+                ("triggered", C.c_int), ("prob", C.c_float), ("silence_ms", C.c_float), ("speech_ms", C.c_float), ("since_event_ms", C.c_float)]
+
+
+def vad_run(probs, threshold=0.5, min_silence_ms=300.0, min_speech_ms=250.0, dt_ms=30.0):
+    """reference state machine over a probability trace -> list of (index, event)"""
+    L = lib()
+    L.orc_vad_step.restype = C.c_int
+    L.orc_vad_step.argtypes = [C.POINTER(VadState), C.c_float, C.c_float]
+    s = VadState(threshold, min_silence_ms, min_speech_ms, 0, 0, 0, 0, 0, 0)
+    ev = []
+    for i, p in enumerate(probs):
+        e = L.orc_vad_step(C.byref(s), float(p), dt_ms)
+        if e >= 0:
+            ev.append((i, e))
+    return ev, s

@@ -1,0 +1,93 @@
+"""GPU parity: log-mel, Whisper encoder/decoder tokens and the VAD against the oracle (bit-exact)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def hp_of(gpu, o):
+    return gpu.WhisperHP(*[getattr(o, n) for n, _ in o._fields_])
+
+
+def test_whisper_small_geometry_bit_exact(gpu):
+    g = np.load(os.path.join(GOLD, "whisper_tiny.npz"))
+    ohp = O.whisper_tiny_test()
+    asr = gpu.Asr(hp=hp_of(gpu, ohp), seed=6, max_batch=3)
+    orc = O.OracleWhisper(ohp, seed=6)
+    rng = np.random.default_rng(12)
+    pcm = np.concatenate([g["pcm"], np.clip(rng.normal(0, 3000, (1, 16000)), -32768, 32767).astype(np.int16)])
+    toks, mel, enc, lg = asr.transcribe_tokens(pcm, 8)
+    wt, wmel, wenc, wlg = orc.transcribe(pcm, 8)
+    assert np.array_equal(mel, wmel), np.abs(mel - wmel).max()
+    assert np.array_equal(enc, wenc), np.abs(enc - wenc).max()
+    assert np.array_equal(lg, wlg), np.abs(lg - wlg).max()
+    assert np.array_equal(toks, wt)                                                   # forced-decode ids bit-exact
+    assert np.abs(mel[:2] - g["hf_mel"]).max() < 2e-4 and np.array_equal(toks[:2, :6], g["oracle_tokens"])
+    # ragged / empty input: 100 samples, and batch of 1
+    t1, m1, _, _ = asr.transcribe_tokens(pcm[:1, :100], 2)
+    w1, wm1, _, _ = orc.transcribe(pcm[:1, :100], 2)
+    assert np.array_equal(t1, w1) and np.array_equal(m1, wm1)
+
+
+def test_whisper_tiny_en_full_size_encoder(gpu):
+    """BASELINE geometry (30 s window, 1500 positions, d 384): mel + encoder + 2 forced steps, one utterance of 1 s"""
+    ohp = O.whisper_tiny_en()
+    asr = gpu.Asr()                                     # reference surface: tk_asr_whisper_create, synthetic tiny.en
+    orc = O.OracleWhisper(ohp, seed=6)
+    rng = np.random.default_rng(2)
+    pcm = np.clip(rng.normal(0, 3000, (1, 16000)), -32768, 32767).astype(np.int16)
+    toks, mel, enc, lg = asr.transcribe_tokens(pcm, 2)
+    wt, wmel, wenc, wlg = orc.transcribe(pcm, 2)
+    assert np.array_equal(mel, wmel)
+    assert np.array_equal(enc, wenc), np.abs(enc - wenc).max()
+    assert np.array_equal(toks, wt) and np.array_equal(lg, wlg)
+
+
+def test_asr_reference_surface_buffering(gpu):
+    asr = gpu.Asr()
+    asr.set_decode_steps(3)
+    rng = np.random.default_rng(5)
+    chunk = np.clip(rng.normal(0, 3000, 8000), -32768, 32767).astype(np.int16)
+    text, n, conf, partial = asr.process_audio(chunk, False)
+    assert text is None and n == 0                                   # < 16000 samples and not final: empty result
+    text, n, conf, partial = asr.process_audio(chunk, False)
+    assert text and partial and abs(conf - 0.9) < 1e-7 and len(text.split()) == 3
+    text2, _, _, partial2 = asr.process_audio(chunk[:10], True)      # final: transcribes buffer, then clears it
+    assert text2 and not partial2
+    t3, n3, _, _ = asr.process_audio(chunk[:10], False)
+    assert t3 is None and n3 == 0
+    assert gpu.lib().tk_asr_whisper_process_audio(None, None, 0, False, None) == 1001
+
+
+def test_vad_probabilities_and_events(gpu):
+    vad = gpu.Vad()
+    rng = np.random.default_rng(3)
+    wins = rng.normal(0, 0.1, (40, 480)).astype(np.float32)
+    got = vad.probabilities(wins)
+    want = O.vad_probabilities(7, wins)
+    assert np.array_equal(got, want)
+    # state machine through the ABI == fixture traces
+    g = json.load(open(os.path.join(GOLD, "vad_state_machine.json")))
+    for name, case in g.items():
+        vad.reset()
+        ev = [[i, e] for i, p in enumerate(case["probabilities"]) for e in [vad.step(p)] if e >= 0]
+        assert ev == case["events"], name
+    # streaming entry: 1 s of PCM in two ragged chunks == windows 30 ms / hop 10 ms over the joined signal
+    vad.reset()
+    pcm = np.clip(rng.normal(0, 6000, 16000), -32768, 32767).astype(np.int16)
+    ev = vad.process_with_events(pcm[:5000]) + vad.process_with_events(pcm[5000:])
+    f = pcm.astype(np.float32) / np.float32(32768.0)
+    nwin = (16000 - 480) // 160 + 1
+    probs = O.vad_probabilities(7, np.stack([f[k * 160:k * 160 + 480] for k in range(nwin)]))
+    wev, ws = O.vad_run(probs)
+    assert ev == [e for _, e in wev]
+    st = vad.state()
+    assert st.is_speech_active == bool(ws.active) and np.float32(st.speech_probability) == probs[-1]
+    assert vad.set_threshold(1.5) == 1001 and vad.set_threshold(0.8) == 0
+    assert abs(vad.probability(pcm[:480]) - probs[0]) == 0

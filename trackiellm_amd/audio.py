@@ -1,0 +1,149 @@
+"""ASR + VAD streams: tk_asr_whisper_* / tk_vad_silero_* (+ batched extensions) over ctypes."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+from .llm import _Path
+
+
+class WhisperHP(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+                                         "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "n_vocab")]
+
+
+def WHISPER_TINY_EN():
+    return WhisperHP(80, 1500, 384, 6, 4, 448, 384, 6, 4, 51864)
+
+
+class _AsrConfig(C.Structure):
+    _fields_ = [("model_path", C.POINTER(_Path)), ("language", C.c_char_p), ("translate_to_en", C.c_bool), ("sample_rate", C.c_uint32),
+                ("user_data", C.c_void_p), ("n_threads", C.c_int), ("max_context", C.c_int), ("word_threshold", C.c_float)]
+
+
+class AsrResult(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("text_length", C.c_size_t), ("confidence", C.c_float), ("is_partial", C.c_bool)]
+
+
+class Asr:
+    def __init__(self, model="synthetic://whisper-tiny.en?seed=6", hp=None, seed=6, device=0, max_batch=1, sample_rate=16000):
+        self.h = C.c_void_p()
+        if hp is not None:
+            self.hp = hp
+            check(lib().tk_mi355x_asr_create(C.byref(self.h), C.byref(hp), C.c_uint64(seed), device, max_batch))
+        else:
+            self.hp = WHISPER_TINY_EN()
+            lib().tk_path_create.restype = C.POINTER(_Path)
+            p = lib().tk_path_create(model.encode())
+            cfg = _AsrConfig(p, b"en", False, sample_rate, None, 4, 16384, 0.01)
+            try:
+                check(lib().tk_asr_whisper_create(C.byref(self.h), C.byref(cfg)))
+            finally:
+                lib().tk_path_destroy(C.byref(p))
+
+    def process_audio(self, pcm, is_final):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        res = C.POINTER(AsrResult)()
+        check(lib().tk_asr_whisper_process_audio(self.h, pcm.ctypes.data_as(C.c_void_p), C.c_size_t(pcm.size), bool(is_final), C.byref(res)))
+        out = (res.contents.text, res.contents.text_length, res.contents.confidence, res.contents.is_partial)
+        out = (out[0].decode() if out[0] else None,) + out[1:]
+        lib().tk_asr_whisper_free_result(C.byref(res))
+        return out
+
+    def transcribe_tokens(self, pcm, n_steps, want_aux=True):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        B, n = pcm.shape
+        hp = self.hp
+        toks = np.zeros((B, n_steps), np.int32)
+        mel = np.empty((B, 2 * hp.n_audio_ctx, hp.n_mels), np.float32) if want_aux else None
+        enc = np.empty((B, hp.n_audio_ctx, hp.n_audio_state), np.float32) if want_aux else None
+        lg = np.empty((B, hp.n_vocab), np.float32) if want_aux else None
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        check(lib().tk_mi355x_asr_transcribe_tokens(self.h, B, p(pcm), n, n_steps, p(toks), p(mel), p(enc), p(lg)))
+        return toks, mel, enc, lg
+
+    def set_decode_steps(self, n):
+        lib().tk_mi355x_asr_set_decode_steps(self.h, n)
+
+    def reset(self):
+        check(lib().tk_asr_whisper_reset(self.h))
+
+    def close(self):
+        if self.h:
+            lib().tk_asr_whisper_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _VadConfig(C.Structure):
+    _fields_ = [("model_path", C.POINTER(_Path)), ("sample_rate", C.c_uint32), ("user_data", C.c_void_p), ("threshold", C.c_float),
+                ("min_silence_duration_ms", C.c_float), ("min_speech_duration_ms", C.c_float), ("speech_pad_ms", C.c_float)]
+
+
+class VadStateC(C.Structure):
+    _fields_ = [("is_speech_active", C.c_bool), ("speech_probability", C.c_float), ("silence_duration_ms", C.c_float),
+                ("speech_duration_ms", C.c_float)]
+
+
+_VAD_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
+
+class Vad:
+    def __init__(self, model="synthetic://vad?seed=7", sample_rate=16000, threshold=0.0, min_silence_ms=0.0, min_speech_ms=0.0):
+        lib().tk_path_create.restype = C.POINTER(_Path)
+        p = lib().tk_path_create(model.encode())
+        cfg = _VadConfig(p, sample_rate, None, threshold, min_silence_ms, min_speech_ms, 30.0)
+        self.h = C.c_void_p()
+        try:
+            check(lib().tk_vad_silero_create(C.byref(self.h), C.byref(cfg)))
+        finally:
+            lib().tk_path_destroy(C.byref(p))
+
+    def probability(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        out = C.c_float(0)
+        check(lib().tk_vad_silero_process_audio(self.h, pcm.ctypes.data_as(C.c_void_p), C.c_size_t(pcm.size), C.byref(out)))
+        return out.value
+
+    def process_with_events(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        events = []
+        cb = _VAD_CB(lambda e, u: events.append(e))
+        check(lib().tk_vad_silero_process_audio_with_events(self.h, pcm.ctypes.data_as(C.c_void_p), C.c_size_t(pcm.size), cb, None))
+        return events
+
+    def probabilities(self, windows):
+        windows = np.ascontiguousarray(windows, np.float32)
+        out = np.empty(windows.shape[0], np.float32)
+        check(lib().tk_mi355x_vad_probabilities(self.h, windows.ctypes.data_as(C.c_void_p), windows.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def step(self, p):
+        return lib().tk_mi355x_vad_step(self.h, C.c_float(p))
+
+    def state(self):
+        s = VadStateC()
+        check(lib().tk_vad_silero_get_state(self.h, C.byref(s)))
+        return s
+
+    def reset(self):
+        check(lib().tk_vad_silero_reset(self.h))
+
+    def set_threshold(self, t):
+        return lib().tk_vad_silero_set_threshold(self.h, C.c_float(t))
+
+    def close(self):
+        if self.h:
+            lib().tk_vad_silero_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,314 @@
+/*
+ * tk_abi_audio.cpp — tk_asr_whisper_* and tk_vad_silero_* on the HIP audio engine; host-side buffering and state
+ * machines restated from src/audio/tk_asr_whisper.c:282-344 and src/sensors/tk_vad_silero.c:283-390,488-600.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../audio/tk_audio_engine.h"
+#include "tk/tk_audio.h"
+
+#define TK_ASR_MAX_BUFFER (16000 * 30) /* MAX_AUDIO_BUFFER_SIZE: 30 s at 16 kHz */
+
+static tk_error_code_t afail(tk_error_code_t code, const std::string& why) {
+    tk_error_set_detail("%s", why.c_str());
+    return code;
+}
+
+static uint64_t seed_of(const std::string& p, uint64_t dflt) {
+    size_t k = p.find("seed=");
+    return k == std::string::npos ? dflt : strtoull(p.c_str() + k + 5, nullptr, 10);
+}
+
+struct tk_asr_whisper_context_s {
+    TkWhisperModel model;
+    TkAsr asr;
+    std::vector<int16_t> buffer;
+    size_t buffer_size = 0;
+    bool has_partial = false;
+    std::string last_text, language;
+    int decode_steps = 16;
+    int32_t sot = 0, nots = 0, eot = 0;
+};
+
+static bool have_gpu() {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+static tk_error_code_t asr_new(tk_asr_whisper_context_t** out, const TkWhisperHP& hp, const std::string& path, uint64_t seed, int device, int max_batch) {
+    if (!have_gpu()) return afail(TK_ERROR_GPU_DEVICE_NOT_FOUND, "no HIP device visible (the MI355X path has no CPU fallback)");
+    std::unique_ptr<tk_asr_whisper_context_s> c(new tk_asr_whisper_context_s());
+    if (!c->model.init(hp, device)) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+    if (path.empty() || path.compare(0, 12, "synthetic://") == 0) {
+        if (!c->model.fill_synthetic(seed)) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+    } else if (!c->model.load_file(path.c_str())) {
+        return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+    }
+    if (!c->asr.init(&c->model, max_batch)) return afail(TK_ERROR_GPU_MEMORY, c->asr.error);
+    c->buffer.assign(TK_ASR_MAX_BUFFER, 0);
+    const int v = hp.n_vocab;
+    c->sot = 50257 < v - 3 ? 50257 : v - 3;
+    c->nots = 50362 < v - 1 ? 50362 : v - 1;
+    c->eot = 50256 < v - 4 ? 50256 : v - 4;
+    *out = c.release();
+    return TK_SUCCESS;
+}
+
+extern "C" {
+
+tk_error_code_t tk_asr_whisper_create(tk_asr_whisper_context_t** out_context, const tk_asr_whisper_config_t* config) {
+    if (!out_context || !config || !config->model_path || !config->model_path->path_str) return TK_ERROR_INVALID_ARGUMENT;
+    if (config->sample_rate != 16000) return afail(TK_ERROR_INVALID_ARGUMENT, "Whisper needs 16 kHz audio");
+    const std::string path = config->model_path->path_str;
+    tk_error_code_t rc = asr_new(out_context, tk_whisper_tiny_en(), path, seed_of(path, 6), 0, 1);
+    if (rc == TK_SUCCESS && config->language) (*out_context)->language = config->language;
+    return rc;
+}
+
+tk_error_code_t tk_mi355x_asr_create(tk_asr_whisper_context_t** out, const tk_mi355x_whisper_hparams_t* hp, uint64_t seed, int device, int max_batch) {
+    if (!out || !hp) return TK_ERROR_INVALID_ARGUMENT;
+    TkWhisperHP h{hp->n_mels, hp->n_audio_ctx, hp->n_audio_state, hp->n_audio_head, hp->n_audio_layer,
+                  hp->n_text_ctx, hp->n_text_state, hp->n_text_head, hp->n_text_layer, hp->n_vocab};
+    return asr_new(out, h, "", seed, device, max_batch);
+}
+
+void tk_asr_whisper_destroy(tk_asr_whisper_context_t** context) {
+    if (!context || !*context) return;
+    delete *context;
+    *context = nullptr;
+}
+
+void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_steps) {
+    if (ctx && n_steps > 0) ctx->decode_steps = n_steps;
+}
+
+tk_error_code_t tk_mi355x_asr_transcribe_tokens(tk_asr_whisper_context_t* c, int batch, const int16_t* pcm, int n_samples, int n_steps,
+                                                int32_t* tokens_out, float* mel_out, float* enc_out, float* logits_out) {
+    if (!c || (!pcm && n_samples > 0) || !tokens_out || n_steps <= 0) return TK_ERROR_INVALID_ARGUMENT;
+    const int32_t prompt[2] = {c->sot, c->nots};
+    std::vector<float> mel, enc, lg;
+    if (!c->asr.transcribe(batch, pcm, n_samples, prompt, 2, n_steps, tokens_out, mel_out ? &mel : nullptr, enc_out ? &enc : nullptr,
+                           logits_out ? &lg : nullptr))
+        return afail(TK_ERROR_INFERENCE_FAILED, c->asr.error);
+    if (mel_out) memcpy(mel_out, mel.data(), mel.size() * 4);
+    if (enc_out) memcpy(enc_out, enc.data(), enc.size() * 4);
+    if (logits_out) memcpy(logits_out, lg.data(), lg.size() * 4);
+    return TK_SUCCESS;
+}
+
+static std::string piece_of(const tk_asr_whisper_context_s* c, int32_t id) {
+    /* no GPT-2 BPE vocabulary ships with synthetic / TKWHSP1 weights: ids are rendered symbolically */
+    char b[24];
+    snprintf(b, sizeof b, " w%d", id);
+    return b;
+}
+
+tk_error_code_t tk_asr_whisper_process_audio(tk_asr_whisper_context_t* c, const int16_t* audio_data, size_t frame_count, bool is_final,
+                                             tk_asr_whisper_result_t** out_result) {
+    if (!c || !audio_data || !out_result) return TK_ERROR_INVALID_ARGUMENT;
+    *out_result = NULL;
+    if (frame_count > TK_ASR_MAX_BUFFER) return afail(TK_ERROR_BUFFER_TOO_SMALL, "chunk longer than the 30 s buffer");
+    if (c->buffer_size + frame_count > TK_ASR_MAX_BUFFER) c->buffer_size = 0; /* reference: warn + reset */
+    memcpy(c->buffer.data() + c->buffer_size, audio_data, frame_count * sizeof(int16_t));
+    c->buffer_size += frame_count;
+    tk_asr_whisper_result_t* r = (tk_asr_whisper_result_t*)calloc(1, sizeof(tk_asr_whisper_result_t));
+    if (!r) return TK_ERROR_OUT_OF_MEMORY;
+    if (c->buffer_size < 16000 && !is_final) { *out_result = r; return TK_SUCCESS; } /* not enough audio yet: empty result */
+    std::vector<int32_t> toks(c->decode_steps);
+    tk_error_code_t rc = tk_mi355x_asr_transcribe_tokens(c, 1, c->buffer.data(), (int)c->buffer_size, c->decode_steps, toks.data(), nullptr, nullptr, nullptr);
+    if (rc != TK_SUCCESS) { free(r); return rc; }
+    std::string text;
+    for (int32_t t : toks) {
+        if (t == c->eot) break;
+        text += piece_of(c, t);
+    }
+    r->text = (char*)calloc(text.size() + 1, 1);
+    if (!r->text) { free(r); return TK_ERROR_OUT_OF_MEMORY; }
+    memcpy(r->text, text.data(), text.size());
+    r->text_length = text.size();
+    r->is_partial = !is_final;
+    r->confidence = 0.9f; /* the reference's placeholder constant (tk_asr_whisper.c:189) */
+    if (is_final) { c->buffer_size = 0; c->has_partial = false; c->last_text = text; }
+    else c->has_partial = true;
+    *out_result = r;
+    return TK_SUCCESS;
+}
+
+void tk_asr_whisper_free_result(tk_asr_whisper_result_t** result) {
+    if (!result || !*result) return;
+    free((*result)->text);
+    free(*result);
+    *result = NULL;
+}
+
+tk_error_code_t tk_asr_whisper_reset(tk_asr_whisper_context_t* c) {
+    if (!c) return TK_ERROR_INVALID_ARGUMENT;
+    c->buffer_size = 0;
+    c->has_partial = false;
+    c->last_text.clear();
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_asr_whisper_set_language(tk_asr_whisper_context_t* c, const char* language) {
+    if (!c || !language) return TK_ERROR_INVALID_ARGUMENT;
+    c->language = language;
+    return TK_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ VAD ------------------ */
+
+#define TK_VAD_MAX_BUFFER (16000 * 30)
+
+struct tk_vad_silero_context_s {
+    tk_vad_silero_config_t config;
+    TkVadModel model;
+    tk_vad_silero_state_t state;
+    float last_probability = 0.0f, time_since_last_event_ms = 0.0f;
+    bool triggered_speech_start = false;
+    std::vector<float> audio;
+    size_t audio_size = 0;
+    uint32_t sample_rate = 16000;
+    size_t window = 480, step = 160;
+};
+
+static void vad_update(tk_vad_silero_context_s* c, float probability, float dt_ms) {
+    c->last_probability = probability;
+    c->state.speech_probability = probability;
+    c->time_since_last_event_ms += dt_ms;
+    if (probability >= c->config.threshold) {
+        c->state.speech_duration_ms += dt_ms;
+        c->state.silence_duration_ms = 0.0f;
+        if (!c->state.is_speech_active && c->state.speech_duration_ms >= c->config.min_speech_duration_ms && !c->triggered_speech_start) {
+            c->state.is_speech_active = true;
+            c->triggered_speech_start = true;
+            c->time_since_last_event_ms = 0.0f;
+        }
+    } else {
+        c->state.silence_duration_ms += dt_ms;
+        c->state.speech_duration_ms = 0.0f;
+        if (c->state.is_speech_active && c->state.silence_duration_ms >= c->config.min_silence_duration_ms) {
+            c->state.is_speech_active = false;
+            c->triggered_speech_start = false;
+            c->time_since_last_event_ms = 0.0f;
+        }
+    }
+}
+
+tk_error_code_t tk_vad_silero_create(tk_vad_silero_context_t** out_context, const tk_vad_silero_config_t* config) {
+    if (!out_context || !config || !config->model_path) return TK_ERROR_INVALID_ARGUMENT;
+    if (config->sample_rate != 8000 && config->sample_rate != 16000 && config->sample_rate != 48000) return afail(TK_ERROR_INVALID_ARGUMENT, "unsupported sample rate");
+    *out_context = NULL;
+    if (!have_gpu()) return afail(TK_ERROR_GPU_DEVICE_NOT_FOUND, "no HIP device visible (the MI355X path has no CPU fallback)");
+    std::unique_ptr<tk_vad_silero_context_s> c(new tk_vad_silero_context_s());
+    c->config = *config;
+    c->config.model_path = NULL;
+    c->sample_rate = config->sample_rate;
+    if (c->config.threshold <= 0.0f) c->config.threshold = 0.5f;
+    if (c->config.min_silence_duration_ms <= 0.0f) c->config.min_silence_duration_ms = 300.0f;
+    if (c->config.min_speech_duration_ms <= 0.0f) c->config.min_speech_duration_ms = 250.0f;
+    if (c->config.speech_pad_ms < 0.0f) c->config.speech_pad_ms = 30.0f;
+    memset(&c->state, 0, sizeof c->state);
+    c->audio.assign(TK_VAD_MAX_BUFFER, 0.0f);
+    c->window = (size_t)c->sample_rate * 30 / 1000;
+    c->step = (size_t)c->sample_rate * 10 / 1000;
+    const std::string path = config->model_path->path_str ? config->model_path->path_str : "";
+    if (path.compare(0, 12, "synthetic://") != 0) return afail(TK_ERROR_MODEL_LOAD_FAILED, "only synthetic://vad is available: ONNX graphs are not interpreted");
+    if (!c->model.init(0, (int)c->window, 64) || !c->model.fill_synthetic(seed_of(path, 7))) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+    *out_context = c.release();
+    return TK_SUCCESS;
+}
+
+void tk_vad_silero_destroy(tk_vad_silero_context_t** context) {
+    if (!context || !*context) return;
+    delete *context;
+    *context = nullptr;
+}
+
+tk_error_code_t tk_mi355x_vad_probabilities(tk_vad_silero_context_t* c, const float* windows, int n, float* out) {
+    if (!c || !windows || !out || n < 0) return TK_ERROR_INVALID_ARGUMENT;
+    if (!c->model.infer(windows, n, out)) return afail(TK_ERROR_INFERENCE_FAILED, c->model.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_vad_silero_process_audio(tk_vad_silero_context_t* c, const int16_t* audio_data, size_t frame_count, float* out_probability) {
+    if (!c || !audio_data || !out_probability) return TK_ERROR_INVALID_ARGUMENT;
+    *out_probability = 0.0f;
+    /* stateless single-window probability: the model window is fixed, shorter input is zero padded, longer truncated */
+    std::vector<float> w(c->window, 0.0f);
+    for (size_t i = 0; i < frame_count && i < c->window; ++i) w[i] = (float)audio_data[i] / 32768.0f;
+    return tk_mi355x_vad_probabilities(c, w.data(), 1, out_probability);
+}
+
+int tk_mi355x_vad_step(tk_vad_silero_context_t* c, float probability) {
+    if (!c) return -1;
+    const bool before = c->state.is_speech_active;
+    vad_update(c, probability, (float)(c->window * 1000) / (float)c->sample_rate);
+    if (!before && c->state.is_speech_active) return 0;
+    if (before && !c->state.is_speech_active) return 1;
+    return -1;
+}
+
+tk_error_code_t tk_vad_silero_process_audio_with_events(tk_vad_silero_context_t* c, const int16_t* audio_data, size_t frame_count,
+                                                        tk_vad_silero_event_callback_t callback, void* user_data) {
+    if (!c || !audio_data) return TK_ERROR_INVALID_ARGUMENT;
+    if (frame_count > TK_VAD_MAX_BUFFER) return afail(TK_ERROR_BUFFER_TOO_SMALL, "chunk longer than the 30 s buffer");
+    if (c->audio_size + frame_count > TK_VAD_MAX_BUFFER) c->audio_size = 0; /* reference: warn + reset */
+    for (size_t i = 0; i < frame_count; ++i) c->audio[c->audio_size + i] = (float)audio_data[i] / 32768.0f;
+    c->audio_size += frame_count;
+    if (c->audio_size < c->window) return TK_SUCCESS;
+    /* every complete window in the buffer, hop = step: one batched GPU call, then the state machine in order */
+    size_t nwin = 0;
+    for (size_t p = 0; p + c->window <= c->audio_size; p += c->step) ++nwin;
+    std::vector<float> wins(nwin * c->window), prob(nwin);
+    for (size_t k = 0; k < nwin; ++k) memcpy(&wins[k * c->window], &c->audio[k * c->step], c->window * sizeof(float));
+    tk_error_code_t rc = tk_mi355x_vad_probabilities(c, wins.data(), (int)nwin, prob.data());
+    if (rc != TK_SUCCESS) return rc;
+    const float dt_ms = (float)(c->window * 1000) / (float)c->sample_rate; /* window, not hop: as the reference (:355) */
+    bool last = c->state.is_speech_active;
+    for (size_t k = 0; k < nwin; ++k) {
+        vad_update(c, prob[k], dt_ms);
+        if (callback) {
+            if (!last && c->state.is_speech_active) callback(TK_VAD_EVENT_SPEECH_STARTED, user_data);
+            else if (last && !c->state.is_speech_active) callback(TK_VAD_EVENT_SPEECH_ENDED, user_data);
+        }
+        last = c->state.is_speech_active;
+    }
+    const size_t processed = nwin * c->step;
+    if (processed > 0 && c->audio_size > processed) {
+        memmove(c->audio.data(), c->audio.data() + processed, (c->audio_size - processed) * sizeof(float));
+        c->audio_size -= processed;
+    } else if (processed > 0) {
+        c->audio_size = 0;
+    }
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_vad_silero_get_state(tk_vad_silero_context_t* c, tk_vad_silero_state_t* out_state) {
+    if (!c || !out_state) return TK_ERROR_INVALID_ARGUMENT;
+    *out_state = c->state;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_vad_silero_reset(tk_vad_silero_context_t* c) {
+    if (!c) return TK_ERROR_INVALID_ARGUMENT;
+    memset(&c->state, 0, sizeof c->state);
+    c->last_probability = 0.0f;
+    c->time_since_last_event_ms = 0.0f;
+    c->triggered_speech_start = false;
+    c->audio_size = 0;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_vad_silero_set_threshold(tk_vad_silero_context_t* c, float threshold) {
+    if (!c || threshold < 0.0f || threshold > 1.0f) return TK_ERROR_INVALID_ARGUMENT;
+    c->config.threshold = threshold;
+    return TK_SUCCESS;
+}
+
+} /* extern "C" */

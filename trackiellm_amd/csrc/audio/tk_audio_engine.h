@@ -1,0 +1,65 @@
+/*
+ * tk_audio_engine.h — ASR + VAD streams on the GPU.
+ *   TkWhisperModel / TkAsr  <->  whisper_init_from_file_with_params + whisper_full  (src/audio/tk_asr_whisper.c:238,142-147)
+ *   TkVadModel              <->  the Silero ONNX session run per 30 ms window       (src/sensors/tk_vad_silero.c:193-280)
+ */
+#ifndef TK_AUDIO_ENGINE_H
+#define TK_AUDIO_ENGINE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../common/tk_whisper_graph.h"
+
+class TkWhisperModel {
+public:
+    TkWhisperHP hp{};
+    TkWhManifest man;
+    int device = 0;
+    std::vector<float*> w; /* device tensors in manifest order */
+    std::string error;
+    ~TkWhisperModel();
+    bool init(const TkWhisperHP& hp, int device);
+    bool fill_synthetic(uint64_t seed);
+    bool set_tensor(int idx, const float* host, size_t n);
+    bool load_file(const char* path); /* "TKWHSP1\0" container */
+};
+
+class TkAsr {
+public:
+    TkWhisperModel* model = nullptr;
+    int max_batch = 1;
+    std::string error;
+    hipStream_t stream = nullptr;
+    ~TkAsr();
+    bool init(TkWhisperModel* m, int max_batch);
+    /* pcm[B][n_samples] (host), greedy decode of exactly n_steps tokens after the start-of-transcript prompt;
+     * tokens_out[B][n_steps]; optional copies of the mel / encoder output for parity tests */
+    bool transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps, int32_t* tokens_out,
+                    std::vector<float>* mel_out, std::vector<float>* enc_out, std::vector<float>* first_logits);
+
+private:
+    friend struct TkAudioGpuOps;
+    float* arena = nullptr;
+    size_t arena_floats = 0, arena_used = 0;
+    int16_t* pcm_dev = nullptr;
+    size_t pcm_cap = 0;
+};
+
+/* tiny MLP speech-probability model over one 30 ms window: sigmoid(w2 . relu(W1 x + b1) + b2) */
+class TkVadModel {
+public:
+    int device = 0, window = 480, hidden = 64;
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    std::string error;
+    ~TkVadModel();
+    bool init(int device, int window, int hidden);
+    bool fill_synthetic(uint64_t seed);
+    /* windows: [n][window] float on the host -> probabilities[n] */
+    bool infer(const float* windows_host, int n, float* prob_host);
+};
+
+#endif

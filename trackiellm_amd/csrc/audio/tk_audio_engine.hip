@@ -1,0 +1,312 @@
+#include "tk_audio_engine.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include "../nn/tk_nn_kernels.h"
+
+#define HIPQ(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            char b__[256];                                                                      \
+            snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            error = b__;                                                                        \
+            return false;                                                                       \
+        }                                                                                       \
+    } while (0)
+
+/* ---------------------------------------------------------------- log-mel front end kernels */
+
+/* frame t, tap n: s16 -> f32 (/32768, as the reference's VAD does, src/sensors/tk_vad_silero.c:78-82), reflect padding of
+ * n_fft/2 at both ends of the zero-padded 30 s window, times the Hann window */
+__global__ void k_frames(const int16_t* pcm, int n_samples, int pcm_stride, int n_total, int T, const float* window, float* out) {
+    const int b = blockIdx.z;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)T * TK_WH_NFFT) return;
+    const int t = (int)(i / TK_WH_NFFT), n = (int)(i % TK_WH_NFFT);
+    int j = t * TK_WH_HOP + n - TK_WH_NFFT / 2;
+    if (j < 0) j = -j;
+    if (j >= n_total) j = 2 * (n_total - 1) - j;
+    const float x = j < n_samples ? tk_divf((float)pcm[(int64_t)b * pcm_stride + j], 32768.0f) : 0.0f;
+    out[((int64_t)b * T + t) * TK_WH_NFFT + n] = x * window[n];
+}
+
+__global__ void k_power(const float* ri, int64_t rows, int nb, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nb) return;
+    const int64_t r = i / nb;
+    const int f = (int)(i % nb);
+    const float re = ri[r * 2 * nb + f], im = ri[r * 2 * nb + nb + f];
+    out[i] = tk_fmaf(re, re, im * im);
+}
+
+/* log10(max(x, 1e-10)); clamp to (max over the utterance) - 8; (x + 4) / 4.  One workgroup per batch element. */
+__global__ __launch_bounds__(1024) void k_logmel_finish(float* mel, int per_b) {
+    __shared__ float red[16];
+    float* m = mel + (int64_t)blockIdx.x * per_b;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < per_b; i += 1024) {
+        const float v = tk_log10f(tk_fmaxf(m[i], 1e-10f));
+        m[i] = v;
+        mx = tk_fmaxf(mx, v);
+    }
+    for (int s = 32; s >= 1; s >>= 1) mx = tk_fmaxf(mx, __shfl_xor(mx, s, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < 16; ++w) mx = tk_fmaxf(mx, red[w]);
+    const float floor_v = mx - 8.0f;
+    for (int i = threadIdx.x; i < per_b; i += 1024) m[i] = (tk_fmaxf(m[i], floor_v) + 4.0f) * 0.25f;
+}
+
+/* ---------------------------------------------------------------- GPU ops for the shared graph */
+
+struct TkAudioGpuOps {
+    TkAsr* a;
+    hipStream_t s;
+    float* alloc(size_t n) {
+        n = (n + 63) & ~(size_t)63;
+        float* p = a->arena + a->arena_used;
+        a->arena_used += n;
+        return p;
+    }
+    int32_t* alloc_i32(size_t n) { return (int32_t*)alloc(n); }
+    void gemm(const TkGemm& g) { tk_launch_gemm(g, s); }
+    void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) { tk_launch_im2col1d(x, B, T, C, ldx, kw, stride, pad, col, s); }
+    void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) { tk_launch_layernorm(x, rows, D, w, b, TK_WH_LN_EPS, y, s); }
+    void softmax_rows(float* x, int rows, int cols, int ld) { tk_launch_softmax_rows(x, rows, cols, ld, s); }
+    void add_rows(float* x, const float* add, int rows, int D, int add_rows) { tk_launch_add_rows(x, add, rows, D, add_rows, s); }
+    void embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out) {
+        tk_launch_embed_rows(table, pos, idx, pos_idx, rows, D, out, s);
+    }
+    void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out) { tk_launch_argmax_rows(x, rows, cols, ld, out, s); }
+    void frames(const int16_t* pcm, int B, int n_samples, int pcm_stride, int n_total, int T, const float* window, float* out) {
+        const int64_t per = (int64_t)T * TK_WH_NFFT;
+        hipLaunchKernelGGL(k_frames, dim3((unsigned)((per + 255) / 256), 1, B), dim3(256), 0, s, pcm, n_samples, pcm_stride, n_total, T, window, out);
+    }
+    void power(const float* ri, int rows, int nb, float* out) {
+        const int64_t n = (int64_t)rows * nb;
+        hipLaunchKernelGGL(k_power, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ri, (int64_t)rows, nb, out);
+    }
+    void logmel_finish(float* mel, int B, int per_b) { hipLaunchKernelGGL(k_logmel_finish, dim3(B), dim3(1024), 0, s, mel, per_b); }
+};
+
+/* sizing twin of the ops (counts arena floats for a given batch) */
+struct TkAudioSizeOps {
+    size_t used = 0;
+    float* alloc(size_t n) { used += (n + 63) & ~(size_t)63; return nullptr; }
+    int32_t* alloc_i32(size_t n) { return (int32_t*)alloc(n); }
+    void gemm(const TkGemm&) {}
+    void im2col1d(const float*, int, int, int, int, int, int, int, float*) {}
+    void layernorm(const float*, int, int, const float*, const float*, float*) {}
+    void softmax_rows(float*, int, int, int) {}
+    void add_rows(float*, const float*, int, int, int) {}
+    void embed_rows(const float*, const float*, const int32_t*, const int32_t*, int, int, float*) {}
+    void argmax_rows(const float*, int, int, int, int32_t*) {}
+    void frames(const int16_t*, int, int, int, int, int, const float*, float*) {}
+    void power(const float*, int, int, float*) {}
+    void logmel_finish(float*, int, int) {}
+};
+
+/* ---------------------------------------------------------------- model */
+
+TkWhisperModel::~TkWhisperModel() {
+    (void)hipSetDevice(device);
+    for (auto p : w) if (p) (void)hipFree(p);
+}
+
+bool TkWhisperModel::init(const TkWhisperHP& h, int dev) {
+    hp = h;
+    device = dev;
+    if (h.n_audio_state % h.n_audio_head || h.n_text_state % h.n_text_head || h.n_audio_state % 2 || h.n_mels <= 0 || h.n_audio_ctx <= 0 ||
+        h.n_text_ctx <= 0 || h.n_vocab <= 0) { error = "invalid Whisper hyper-parameters"; return false; }
+    man = tk_whisper_manifest(h);
+    HIPQ(hipSetDevice(device));
+    w.assign(man.t.size(), nullptr);
+    for (size_t i = 0; i < man.t.size(); ++i) HIPQ(hipMalloc((void**)&w[i], (size_t)man.t[i].rows * man.t[i].cols * 4));
+    return true;
+}
+
+bool TkWhisperModel::set_tensor(int idx, const float* host, size_t n) {
+    if (idx < 0 || idx >= (int)man.t.size() || n != (size_t)man.t[idx].rows * man.t[idx].cols) { error = "tensor index / size mismatch"; return false; }
+    HIPQ(hipSetDevice(device));
+    HIPQ(hipMemcpy(w[idx], host, n * 4, hipMemcpyHostToDevice));
+    return true;
+}
+
+bool TkWhisperModel::fill_synthetic(uint64_t seed) {
+    std::vector<float> buf;
+    for (size_t i = 0; i < man.t.size(); ++i) {
+        buf.resize((size_t)man.t[i].rows * man.t[i].cols);
+        tk_whisper_fill_tensor(hp, man, (int)i, seed, buf.data());
+        if (!set_tensor((int)i, buf.data(), buf.size())) return false;
+    }
+    return true;
+}
+
+bool TkWhisperModel::load_file(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { error = std::string("cannot open ") + path; return false; }
+    char magic[8];
+    int32_t n = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "TKWHSP1", 8) == 0 && fread(&n, 4, 1, f) == 1 && n == (int)man.t.size();
+    std::vector<float> buf;
+    /* the three frontend tables and the sinusoidal positions may be omitted (rows == 0 in the file): they are recomputed */
+    for (int i = 0; ok && i < n; ++i) {
+        int64_t d[2];
+        ok = fread(d, 8, 2, f) == 2;
+        if (!ok) break;
+        if (d[0] == 0) {
+            buf.resize((size_t)man.t[i].rows * man.t[i].cols);
+            tk_whisper_fill_tensor(hp, man, i, 0, buf.data());
+        } else {
+            ok = d[0] == man.t[i].rows && d[1] == man.t[i].cols;
+            buf.resize((size_t)d[0] * d[1]);
+            ok = ok && fread(buf.data(), 4, buf.size(), f) == buf.size();
+        }
+        ok = ok && set_tensor(i, buf.data(), buf.size());
+    }
+    fclose(f);
+    if (!ok && error.empty()) error = "not a TKWHSP1 container for this geometry";
+    return ok;
+}
+
+/* ---------------------------------------------------------------- ASR */
+
+TkAsr::~TkAsr() {
+    if (model) (void)hipSetDevice(model->device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (arena) (void)hipFree(arena);
+    if (pcm_dev) (void)hipFree(pcm_dev);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+bool TkAsr::init(TkWhisperModel* m, int mb) {
+    model = m;
+    max_batch = mb;
+    if (!m || mb < 1 || mb > 64) { error = "max_batch must be in [1,64]"; return false; }
+    HIPQ(hipSetDevice(m->device));
+    HIPQ(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    TkAudioSizeOps so;
+    std::vector<float*> nullw(m->man.t.size(), nullptr);
+    TkWhisperGraph<TkAudioSizeOps> g{m->hp, m->man, nullw.data()};
+    float* ml = g.mel(so, nullptr, mb, 0, 0);
+    float* enc = g.encode(so, ml, mb);
+    (void)g.begin_decode(so, enc, mb);
+    arena_floats = so.used + 4096;
+    HIPQ(hipMalloc((void**)&arena, arena_floats * 4));
+    return true;
+}
+
+bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps, int32_t* tokens_out,
+                       std::vector<float>* mel_out, std::vector<float>* enc_out, std::vector<float>* first_logits) {
+    const TkWhisperHP& h = model->hp;
+    if (B < 1 || B > max_batch) { error = "batch larger than the ASR context was created for"; return false; }
+    if (n_samples < 0 || n_samples > h.n_samples()) { error = "audio longer than the model window"; return false; }
+    if (n_prompt < 1 || n_prompt + n_steps > h.n_text_ctx) { error = "prompt + steps exceed the text context"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    const size_t need = (size_t)B * (n_samples > 0 ? n_samples : 1);
+    if (need > pcm_cap) {
+        if (pcm_dev) (void)hipFree(pcm_dev);
+        pcm_dev = nullptr;
+        HIPQ(hipMalloc((void**)&pcm_dev, need * 2));
+        pcm_cap = need;
+    }
+    if (n_samples > 0) HIPQ(hipMemcpyAsync(pcm_dev, pcm, (size_t)B * n_samples * 2, hipMemcpyHostToDevice, stream));
+    arena_used = 0;
+    TkAudioGpuOps ops{this, stream};
+    TkWhisperGraph<TkAudioGpuOps> g{h, model->man, model->w.data()};
+    float* ml = g.mel(ops, pcm_dev, B, n_samples, n_samples);
+    float* enc = g.encode(ops, ml, B);
+    auto st = g.begin_decode(ops, enc, B);
+    HIPQ(hipGetLastError());
+    if (mel_out) { mel_out->resize((size_t)B * h.n_frames() * h.n_mels); HIPQ(hipMemcpyAsync(mel_out->data(), ml, mel_out->size() * 4, hipMemcpyDeviceToHost, stream)); }
+    if (enc_out) { enc_out->resize((size_t)B * h.n_audio_ctx * h.n_audio_state); HIPQ(hipMemcpyAsync(enc_out->data(), enc, enc_out->size() * 4, hipMemcpyDeviceToHost, stream)); }
+    std::vector<int32_t> tok(B), pos(B);
+    const int total = n_prompt + n_steps - 1; /* the last generated token is not fed back */
+    for (int p = 0; p < total; ++p) {
+        if (p < n_prompt) {
+            for (int b = 0; b < B; ++b) tok[b] = prompt[p];
+            HIPQ(hipMemcpyAsync(st.tok, tok.data(), B * 4, hipMemcpyHostToDevice, stream));
+        } else {
+            HIPQ(hipMemcpyAsync(st.tok, st.next, B * 4, hipMemcpyDeviceToDevice, stream));
+        }
+        for (int b = 0; b < B; ++b) pos[b] = p;
+        HIPQ(hipMemcpyAsync(st.pos, pos.data(), B * 4, hipMemcpyHostToDevice, stream));
+        g.decode_step(ops, st, p);
+        if (p >= n_prompt - 1) {
+            const int step = p - (n_prompt - 1);
+            if (step == 0 && first_logits) {
+                first_logits->resize((size_t)B * h.n_vocab);
+                HIPQ(hipMemcpyAsync(first_logits->data(), st.logits, first_logits->size() * 4, hipMemcpyDeviceToHost, stream));
+            }
+            HIPQ(hipMemcpyAsync(tok.data(), st.next, B * 4, hipMemcpyDeviceToHost, stream));
+            HIPQ(hipStreamSynchronize(stream)); /* tok/pos staging buffers are reused next iteration */
+            for (int b = 0; b < B; ++b) tokens_out[(size_t)b * n_steps + step] = tok[b];
+        } else {
+            HIPQ(hipStreamSynchronize(stream));
+        }
+    }
+    HIPQ(hipGetLastError());
+    return true;
+}
+
+/* ---------------------------------------------------------------- VAD */
+
+TkVadModel::~TkVadModel() {
+    (void)hipSetDevice(device);
+    float* p[] = {w1, b1, w2, b2};
+    for (float* q : p) if (q) (void)hipFree(q);
+}
+
+bool TkVadModel::init(int dev, int win, int hid) {
+    device = dev; window = win; hidden = hid;
+    HIPQ(hipSetDevice(device));
+    HIPQ(hipMalloc((void**)&w1, (size_t)hid * win * 4));
+    HIPQ(hipMalloc((void**)&b1, (size_t)hid * 4));
+    HIPQ(hipMalloc((void**)&w2, (size_t)hid * 4));
+    HIPQ(hipMalloc((void**)&b2, 4));
+    return true;
+}
+
+bool TkVadModel::fill_synthetic(uint64_t seed) {
+    std::vector<float> a((size_t)hidden * window), b(hidden), c(hidden), d(1);
+    tk_vad_synth(seed, window, hidden, a.data(), b.data(), c.data(), d.data());
+    HIPQ(hipSetDevice(device));
+    HIPQ(hipMemcpy(w1, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+    HIPQ(hipMemcpy(b1, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    HIPQ(hipMemcpy(w2, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+    HIPQ(hipMemcpy(b2, d.data(), 4, hipMemcpyHostToDevice));
+    return true;
+}
+
+/* relu is not in TkAct: hidden = max(0, .) is folded into a tiny kernel together with the second layer */
+__global__ void k_vad_head(const float* hid, int n, int hidden, const float* w2, const float* b2, float* prob) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.0f;
+    for (int k = 0; k < hidden; ++k) acc = tk_fmaf(tk_fmaxf(hid[(int64_t)i * hidden + k], 0.0f), w2[k], acc);
+    prob[i] = tk_sigmoidf(acc + b2[0]);
+}
+
+bool TkVadModel::infer(const float* windows_host, int n, float* prob_host) {
+    if (n <= 0) return true;
+    HIPQ(hipSetDevice(device));
+    float *x = nullptr, *hbuf = nullptr, *p = nullptr;
+    HIPQ(hipMalloc((void**)&x, (size_t)n * window * 4));
+    HIPQ(hipMalloc((void**)&hbuf, (size_t)n * hidden * 4));
+    HIPQ(hipMalloc((void**)&p, (size_t)n * 4));
+    bool ok = hipMemcpy(x, windows_host, (size_t)n * window * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        TkGemm g{};
+        g.A = x; g.B = w1; g.C = hbuf; g.bias = b1; g.M = n; g.N = hidden; g.K = window; g.lda = window; g.ldb = window; g.ldc = hidden;
+        g.alpha = 1.0f; g.batch = 1;
+        tk_launch_gemm(g, nullptr);
+        hipLaunchKernelGGL(k_vad_head, dim3((n + 63) / 64), dim3(64), 0, nullptr, hbuf, n, hidden, w2, b2, p);
+        ok = hipMemcpy(prob_host, p, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(x); (void)hipFree(hbuf); (void)hipFree(p);
+    if (!ok) error = "VAD inference failed on the device";
+    return ok;
+}

@@ -1,0 +1,27 @@
+/* tk_gemm_desc.h — descriptor of the one fp32 GEMM both the HIP kernels and the oracle evaluate (no HIP types). */
+#ifndef TK_GEMM_DESC_H
+#define TK_GEMM_DESC_H
+
+#include <stdint.h>
+
+enum TkAct { TK_ACT_NONE = 0, TK_ACT_SILU = 1, TK_ACT_GELU = 2, TK_ACT_SIGMOID = 3 };
+
+struct TkGemm {
+    const float* A; /* [M][lda]  (k contiguous) */
+    const float* B; /* b_kn == 0: [N][ldb] (k contiguous);  b_kn == 1: [K][ldb] (n contiguous) */
+    float* C;       /* [M][ldc] */
+    const float* bias;     /* [N] or null */
+    const float* residual; /* [M][ldr] or null; added after the activation */
+    int M, N, K, lda, ldb, ldc, ldr;
+    int b_kn;
+    int act;
+    float alpha; /* out = act(alpha * acc + bias); alpha == 1 is skipped exactly */
+    int batch;
+    int64_t sA, sB, sC, sR; /* batch strides in floats */
+    /* optional second batch level: z = zo * batch_inner + zi ; offset = zo * s?2 + zi * s? (batch_inner == 0: single level) */
+    int batch_inner;
+    int64_t sA2, sB2, sC2, sR2;
+};
+
+
+#endif

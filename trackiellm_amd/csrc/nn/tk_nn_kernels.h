@@ -17,21 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum TkAct { TK_ACT_NONE = 0, TK_ACT_SILU = 1, TK_ACT_GELU = 2, TK_ACT_SIGMOID = 3 };
-
-struct TkGemm {
-    const float* A; /* [M][lda]  (k contiguous) */
-    const float* B; /* b_kn == 0: [N][ldb] (k contiguous);  b_kn == 1: [K][ldb] (n contiguous) */
-    float* C;       /* [M][ldc] */
-    const float* bias;     /* [N] or null */
-    const float* residual; /* [M][ldr] or null; added after the activation */
-    int M, N, K, lda, ldb, ldc, ldr;
-    int b_kn;
-    int act;
-    float alpha; /* out = act(alpha * acc + bias); alpha == 1 is skipped exactly */
-    int batch;
-    int64_t sA, sB, sC, sR; /* batch strides in floats */
-};
+#include "../common/tk_gemm_desc.h"
 
 void tk_launch_gemm(const TkGemm& g, hipStream_t s);
 
@@ -41,8 +27,13 @@ void tk_launch_im2col(const float* x, int B, int H, int W, int C, int ldx, int k
 void tk_launch_maxpool5(const float* x, int B, int H, int W, int C, int ldx, float* y, int ldy, hipStream_t s);
 void tk_launch_upsample2x(const float* x, int B, int H, int W, int C, int ldx, float* y, int ldy, hipStream_t s);
 void tk_launch_copy_cols(const float* x, int rows, int C, int ldx, float* y, int ldy, hipStream_t s);
+/* rows of [T][C] (row pitch ldx) -> col[b*To + t][(kx*C + c)], kernel width kw, zero padding `pad` on both ends */
+void tk_launch_im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col, hipStream_t s);
+/* out[r][:] = table[idx[r]][:] + pos[(pos0[r])][:] */
+void tk_launch_embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out, hipStream_t s);
+void tk_launch_argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out, hipStream_t s);
 void tk_launch_layernorm(const float* x, int rows, int D, const float* w, const float* b, float eps, float* y, hipStream_t s);
-void tk_launch_softmax_rows(float* x, int rows, int cols, int ld, int causal_offset, hipStream_t s);
+void tk_launch_softmax_rows(float* x, int rows, int cols, int ld, hipStream_t s);
 void tk_launch_add_rows(float* x, const float* add, int rows, int D, int add_rows, hipStream_t s);
 
 #endif

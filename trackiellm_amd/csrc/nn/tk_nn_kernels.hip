@@ -29,9 +29,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const float* A = g.A + (int64_t)blockIdx.z * g.sA;
-    const float* B = g.B + (int64_t)blockIdx.z * g.sB;
-    float* C = g.C + (int64_t)blockIdx.z * g.sC;
+    int64_t oA, oB, oC, oR;
+    if (g.batch_inner > 0) {
+        const int zo = blockIdx.z / g.batch_inner, zi = blockIdx.z % g.batch_inner;
+        oA = zo * g.sA2 + zi * g.sA; oB = zo * g.sB2 + zi * g.sB; oC = zo * g.sC2 + zi * g.sC; oR = zo * g.sR2 + zi * g.sR;
+    } else {
+        oA = (int64_t)blockIdx.z * g.sA; oB = (int64_t)blockIdx.z * g.sB; oC = (int64_t)blockIdx.z * g.sC; oR = (int64_t)blockIdx.z * g.sR;
+    }
+    const float* A = g.A + oA;
+    const float* B = g.B + oB;
+    float* C = g.C + oC;
     v16f acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     const int n = n0 + wn * 32 + (lane & 31);
     if (n >= g.N) return;
     const float bias = g.bias ? g.bias[n] : 0.0f;
-    const float* R = g.residual ? g.residual + (int64_t)blockIdx.z * g.sR : nullptr;
+    const float* R = g.residual ? g.residual + oR : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -224,13 +231,12 @@ void tk_launch_layernorm(const float* x, int rows, int D, const float* w, const 
     hipLaunchKernelGGL(k_layernorm, dim3(rows), dim3(256), 0, s, x, D, w, b, eps, y);
 }
 
-/* in-place row softmax; causal_offset >= 0: row r of a [rows][cols] block attends to columns <= r + causal_offset */
-__global__ __launch_bounds__(256) void k_softmax_rows(float* x, int cols, int ld, int causal_offset, int rows_per_batch) {
+/* in-place row softmax over the first `cols` entries of every row (row pitch ld) */
+__global__ __launch_bounds__(256) void k_softmax_rows(float* x, int cols, int ld) {
     __shared__ float red[4];
     const int64_t r = blockIdx.x;
     float* xr = x + r * ld;
-    int n = cols;
-    if (causal_offset >= 0) { const int lim = (int)(r % rows_per_batch) + causal_offset + 1; n = lim < cols ? lim : cols; }
+    const int n = cols;
     float m = -INFINITY;
     for (int i = threadIdx.x; i < n; i += 256) m = tk_fmaxf(m, xr[i]);
     for (int s = 32; s >= 1; s >>= 1) m = tk_fmaxf(m, __shfl_xor(m, s, 64));
@@ -243,8 +249,8 @@ __global__ __launch_bounds__(256) void k_softmax_rows(float* x, int cols, int ld
     const float tot = nn_block_sum256(s, red);
     for (int i = threadIdx.x; i < cols; i += 256) xr[i] = i < n ? tk_divf(xr[i], tot) : 0.0f;
 }
-void tk_launch_softmax_rows(float* x, int rows, int cols, int ld, int causal_offset, hipStream_t s) {
-    hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, s, x, cols, ld, causal_offset, rows);
+void tk_launch_softmax_rows(float* x, int rows, int cols, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, s, x, cols, ld);
 }
 
 __global__ void k_add_rows(float* x, const float* add, int64_t rows, int D, int add_rows) {
@@ -257,4 +263,63 @@ __global__ void k_add_rows(float* x, const float* add, int64_t rows, int D, int 
 void tk_launch_add_rows(float* x, const float* add, int rows, int D, int add_rows, hipStream_t s) {
     const int64_t total = (int64_t)rows * D;
     hipLaunchKernelGGL(k_add_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, add, (int64_t)rows, D, add_rows);
+}
+
+__global__ void k_im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, int To, float* col) {
+    const int64_t K = (int64_t)kw * C;
+    const int64_t total = (int64_t)B * To * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / K;
+        const int k = (int)(i % K);
+        const int c = k % C, kx = k / C;
+        const int t = (int)(row % To), b = (int)(row / To);
+        const int it = t * stride + kx - pad;
+        col[i] = (it >= 0 && it < T) ? x[((int64_t)b * T + it) * ldx + c] : 0.0f;
+    }
+}
+void tk_launch_im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col, hipStream_t s) {
+    const int To = (T + 2 * pad - kw) / stride + 1;
+    const int64_t total = (int64_t)B * To * kw * C;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_im2col1d, dim3((unsigned)blocks), dim3(256), 0, s, x, B, T, C, ldx, kw, stride, pad, To, col);
+}
+
+__global__ void k_embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int D, float* out) {
+    const int r = blockIdx.x;
+    const float* t = table + (int64_t)idx[r] * D;
+    const float* p = pos + (int64_t)pos_idx[r] * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) out[(int64_t)r * D + i] = t[i] + p[i];
+}
+void tk_launch_embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_embed_rows, dim3(rows), dim3(128), 0, s, table, pos, idx, pos_idx, D, out);
+}
+
+/* first index of the row maximum */
+__global__ __launch_bounds__(1024) void k_argmax_rows(const float* x, int cols, int ld, int32_t* out) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const float* xr = x + (int64_t)r * ld;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = t; i < cols; i += 1024) {
+        const float v = xr[i];
+        if (v > best) { best = v; idx = i; }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const float ov = __shfl_xor(best, s, 64);
+        const int oi = __shfl_xor(idx, s, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((t & 63) == 0) { bv[t >> 6] = best; bi[t >> 6] = idx; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[r] = idx;
+    }
+}
+void tk_launch_argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_argmax_rows, dim3(rows), dim3(1024), 0, s, x, cols, ld, out);
 }
