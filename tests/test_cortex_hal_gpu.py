@@ -1,0 +1,84 @@
+"""GPU: the reference's ROCm HAL surface and the minimal cortex loop (mirrors tests/tk_cortex_test.cpp of the reference)."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hal_dispatcher_preprocess_and_depth(gpu):
+    d = gpu.RocmDispatcher(0)
+    rng = np.random.default_rng(6)
+    frame = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    src = d.malloc(frame.nbytes)
+    dst = d.malloc(3 * 32 * 32 * 4)
+    d.upload(src, frame)
+    p = gpu.PreprocessParams(d.ptr(src), 64, 48, 64 * 3, d.ptr(dst), 32, 32, gpu.Float3(0.485, 0.456, 0.406), gpu.Float3(0.229, 0.224, 0.225),
+                             np.float32(1.0) / np.float32(255.0))
+    assert gpu.lib().tk_rocm_dispatch_preprocess_image(d.h, C.byref(p)) == 0
+    out = d.download(dst, (3, 32, 32), np.float32)
+    assert np.array_equal(out.view(np.uint32), O.preprocess(frame, 32, 32).view(np.uint32))      # canonical CPU formula
+    # kernel launcher with an explicit stream (tk_kernels_preprocess_image(params, stream))
+    assert gpu.lib().tk_kernels_preprocess_image(C.byref(p), d.stream()) == 0
+    assert np.array_equal(d.download(dst, (3, 32, 32), np.float32), out)
+    # depth post-process + unprojection
+    raw = rng.random((24, 40), dtype=np.float32)
+    raw[3, 5] = -1.0
+    a, b, pc = d.malloc(raw.nbytes), d.malloc(raw.nbytes), d.malloc(raw.size * 12)
+    d.upload(a, raw)
+    pp = gpu.DepthPostParams(d.ptr(a), 40, 24, d.ptr(b), 2.5, 0.25)
+    assert gpu.lib().tk_kernels_postprocess_depth_map(C.byref(pp), d.stream()) == 0
+    metric = d.download(b, (24, 40), np.float32)
+    assert np.array_equal(metric, raw * np.float32(2.5) + np.float32(0.25))
+    dp = gpu.DepthToPointsParams(d.ptr(b), 40, 24, d.ptr(pc), 50.0, 60.0, 20.0, 12.0)
+    assert gpu.lib().tk_rocm_dispatch_depth_to_point_cloud(d.h, C.byref(dp)) == 0
+    pts = d.download(pc, (24, 40, 3), np.float32)
+    u, v = np.meshgrid(np.arange(40, dtype=np.float32), np.arange(24, dtype=np.float32))
+    want = np.stack([(u - 20) * metric / np.float32(50), (v - 12) * metric / np.float32(60), metric], -1)
+    want[metric <= 0] = 0
+    assert np.array_equal(pts, want.astype(np.float32))
+    assert gpu.lib().tk_rocm_dispatch_upload_async(d.h, src, frame.ctypes.data_as(C.c_void_p), C.c_size_t(frame.nbytes + 1)) == 1001
+    for buf in (src, dst, a, b, pc):
+        d.free(buf)
+    d.close()
+
+
+def test_cortex_cycle_like_reference_test(gpu):
+    """reference tests/tk_cortex_test.cpp: one frame + 2 s of PCM, state-change callback must fire > 2 times"""
+    cx = gpu.Cortex(llm="synthetic://tiny?seed=4", detector="synthetic://yolov8n?seed=5&cls_bias=0.5")
+    cx.set_max_tokens(8)
+    assert cx.state() == 2                                       # IDLE after INITIALIZING
+    cx.start()
+    frame = np.full((480, 640, 3), 128, np.uint8)                # tk_cortex_test.cpp:79-84
+    assert cx.inject_frame(frame) == 0
+    rng = np.random.default_rng(2)
+    loud = np.clip(rng.normal(0, 9000, 16000), -32768, 32767).astype(np.int16)
+    quiet = np.zeros(16000, np.int16)                            # tk_cortex_test.cpp:90 (silence)
+    for chunk in np.split(np.concatenate([loud, quiet]), 20):    # 100 ms chunks like the reference's mock microphone
+        assert cx.inject_audio(chunk) == 0
+    deadline = time.time() + 60
+    # expected speech segments from the oracle VAD on the same signal (cortex thresholds 0.8 / 500 ms)
+    f = np.concatenate([loud, quiet]).astype(np.float32) / np.float32(32768.0)
+    nwin = (len(f) - 480) // 160 + 1
+    probs = O.vad_probabilities(7, np.stack([f[k * 160:k * 160 + 480] for k in range(nwin)]))
+    ev, _ = O.vad_run(probs, threshold=0.8, min_silence_ms=500.0)
+    want_segments = sum(1 for _, e in ev if e == 1)
+    while time.time() < deadline:
+        s = cx.stats()
+        if s.frames_processed >= 1 and s.llm_responses >= 1 + want_segments:
+            break
+        time.sleep(0.05)
+    cx.stop()
+    s = cx.stats()
+    assert s.frames_processed == 1 and s.frames_with_objects == 1
+    assert s.speech_segments == want_segments
+    assert s.llm_responses == 1 + want_segments and s.llm_tokens == 8 * s.llm_responses
+    assert len(cx.states) > 2                                    # the reference's pass criterion (tk_cortex_test.cpp:111-116)
+    assert 4 in cx.states and 5 in cx.states                     # PROCESSING and RESPONDING were reported
+    assert len(cx.last_response()) > 0
+    assert gpu.lib().tk_cortex_inject_video_frame(cx.h, None) == 1001
+    cx.close()

@@ -1,0 +1,306 @@
+/*
+ * tk_abi_cortex.cpp — minimal cortex: event queue (128, src/cortex/tk_cortex_main.c:527), one loop thread
+ * (:957-994), video ring of 4 (:542), VAD -> ASR -> LLM and detect -> LLM triggers (:1081, :1224-1237).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "tk/tk_audio.h"
+#include "tk/tk_cortex.h"
+#include "tk/tk_model_runner.h"
+#include "tk/tk_vision.h"
+
+#define TK_CORTEX_QUEUE_CAP 128
+#define TK_CORTEX_VIDEO_RING 4
+
+static const char* kCoco[80] = {"person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light", "fire hydrant",
+    "stop sign", "parking meter", "bench", "bird", "cat", "dog", "horse", "sheep", "cow", "elephant", "bear", "zebra", "giraffe", "backpack", "umbrella",
+    "handbag", "tie", "suitcase", "frisbee", "skis", "snowboard", "sports ball", "kite", "baseball bat", "baseball glove", "skateboard", "surfboard",
+    "tennis racket", "bottle", "wine glass", "cup", "fork", "knife", "spoon", "bowl", "banana", "apple", "sandwich", "orange", "broccoli", "carrot",
+    "hot dog", "pizza", "donut", "cake", "chair", "couch", "potted plant", "bed", "dining table", "toilet", "tv", "laptop", "mouse", "remote", "keyboard",
+    "cell phone", "microwave", "oven", "toaster", "sink", "refrigerator", "book", "clock", "vase", "scissors", "teddy bear", "hair drier", "toothbrush"};
+
+struct CortexEvent {
+    enum { VIDEO, SPEECH } kind;
+    int slot = 0;            /* video ring slot */
+    std::string text;        /* final transcription */
+};
+
+struct tk_cortex_s {
+    tk_cortex_config_t config;
+    tk_cortex_callbacks_t cb;
+    std::atomic<int> state{TK_STATE_UNINITIALIZED};
+    std::atomic<bool> stop{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<CortexEvent> queue;
+    struct Frame { tk_video_frame_t f; std::vector<uint8_t> data; } ring[TK_CORTEX_VIDEO_RING];
+    int ring_next = 0;
+    tk_object_detector_t* det = nullptr;
+    tk_asr_whisper_context_t* asr = nullptr;
+    tk_vad_silero_context_t* vad = nullptr;
+    tk_model_loader_t* loader = nullptr;
+    void* llm_model = nullptr;
+    tk_llm_runner_t* runner = nullptr;
+    std::mutex audio_mu;     /* VAD + speech accumulation happen on the injecting thread, like the reference's audio worker */
+    std::vector<int16_t> speech;
+    bool in_speech = false;
+    int max_tokens = 32;
+    tk_mi355x_cortex_stats_t stats{};
+    std::string last_response;
+    mutable std::mutex stat_mu;
+};
+
+static void set_state(tk_cortex_s* c, tk_system_state_e s) {
+    if (c->state.exchange(s) != s && c->cb.on_state_change) c->cb.on_state_change(s, c->config.user_data);
+}
+
+static tk_error_code_t mkpath(const char* s, const char* dflt, tk_path_t** out) { return tk_path_create_from_string(out, s ? s : dflt); }
+
+static void run_llm(tk_cortex_s* c, const std::string& prompt) {
+    set_state(c, TK_STATE_PROCESSING);
+    if (tk_llm_runner_prepare_generation(c->runner, prompt.c_str(), false) != TK_SUCCESS) { set_state(c, TK_STATE_IDLE); return; }
+    set_state(c, TK_STATE_RESPONDING);
+    std::string resp;
+    int n = 0;
+    for (; n < c->max_tokens && !c->stop.load(); ++n) {
+        const char* p = tk_llm_runner_generate_next_token(c->runner);
+        if (!p || p == TK_TOOL_CALL_TOKEN) break;
+        resp += p;
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->stat_mu);
+        c->stats.llm_responses++;
+        c->stats.llm_tokens += (uint64_t)n;
+        c->last_response = resp;
+    }
+    set_state(c, TK_STATE_IDLE);
+}
+
+extern "C" {
+
+tk_error_code_t tk_cortex_create(tk_cortex_t** out_cortex, const tk_cortex_config_t* config, tk_cortex_callbacks_t callbacks) {
+    if (!out_cortex || !config) return TK_ERROR_INVALID_ARGUMENT;
+    std::unique_ptr<tk_cortex_s> c(new tk_cortex_s());
+    c->config = *config;
+    c->cb = callbacks;
+    set_state(c.get(), TK_STATE_INITIALIZING);
+    const int dev = config->gpu_device_id >= 0 ? config->gpu_device_id : 0;
+    tk_error_code_t rc;
+    tk_path_t* p = nullptr;
+    auto fail = [&](tk_error_code_t e) { tk_cortex_t* raw = c.release(); tk_cortex_destroy(&raw); return e; };
+
+    if ((rc = mkpath(config->model_paths.object_detection_model, "synthetic://yolov8n?seed=5&cls_bias=-0.45", &p)) != TK_SUCCESS) return fail(rc);
+    tk_object_detector_config_t dc{};
+    dc.backend = TK_VISION_BACKEND_ROCM; dc.gpu_device_id = dev; dc.model_path = p; dc.input_width = 640; dc.input_height = 640;
+    dc.class_labels = kCoco; dc.class_count = 80; dc.confidence_threshold = 0.5f; dc.iou_threshold = 0.5f; /* tk_cortex_main.c:780, tk_vision_pipeline.c:377 */
+    rc = tk_object_detector_create(&c->det, &dc);
+    tk_path_destroy(&p);
+    if (rc != TK_SUCCESS) return fail(rc);
+
+    if ((rc = mkpath(config->model_paths.asr_model, "synthetic://whisper-tiny.en?seed=6", &p)) != TK_SUCCESS) return fail(rc);
+    tk_asr_whisper_config_t ac{};
+    ac.model_path = p; ac.language = config->user_language ? config->user_language : "en"; ac.sample_rate = 16000; ac.n_threads = 4; ac.max_context = 16384;
+    rc = tk_asr_whisper_create(&c->asr, &ac);
+    tk_path_destroy(&p);
+    if (rc != TK_SUCCESS) return fail(rc);
+
+    if ((rc = mkpath(config->model_paths.vad_model, "synthetic://vad?seed=7", &p)) != TK_SUCCESS) return fail(rc);
+    tk_vad_silero_config_t vc{};
+    vc.model_path = p; vc.sample_rate = 16000; vc.threshold = 0.8f; vc.min_silence_duration_ms = 500.0f; /* tk_cortex_main.c:881-882 */
+    rc = tk_vad_silero_create(&c->vad, &vc);
+    tk_path_destroy(&p);
+    if (rc != TK_SUCCESS) return fail(rc);
+
+    tk_model_loader_config_t lc{2, 1};
+    if ((rc = tk_model_loader_create(&c->loader, &lc)) != TK_SUCCESS) return fail(rc);
+    if ((rc = mkpath(config->model_paths.llm_model, "synthetic://mistral-7b?seed=4", &p)) != TK_SUCCESS) return fail(rc);
+    tk_model_load_params_t lp{};
+    lp.model_path = p; lp.model_type = TK_MODEL_FORMAT_GGUF; lp.gpu_layers = 99;
+    rc = tk_model_loader_load_model(c->loader, &lp, &c->llm_model);
+    tk_path_destroy(&p);
+    if (rc != TK_SUCCESS) return fail(rc);
+    tk_llm_config_t rcfg{4096, NULL, 0}; /* n_ctx 4096: tk_runner_lifecycle.c:48 */
+    if ((rc = tk_llm_runner_create(&c->runner, c->llm_model, &rcfg)) != TK_SUCCESS) return fail(rc);
+
+    set_state(c.get(), TK_STATE_IDLE);
+    *out_cortex = c.release();
+    return TK_SUCCESS;
+}
+
+void tk_cortex_destroy(tk_cortex_t** cortex) {
+    if (!cortex || !*cortex) return;
+    tk_cortex_s* c = *cortex;
+    c->stop.store(true);
+    c->cv.notify_all();
+    set_state(c, TK_STATE_SHUTDOWN);
+    if (c->runner) tk_llm_runner_destroy(&c->runner);
+    if (c->loader) { if (c->llm_model) (void)tk_model_loader_unload_model(c->loader, &c->llm_model); tk_model_loader_destroy(&c->loader); }
+    if (c->det) tk_object_detector_destroy(&c->det);
+    if (c->asr) tk_asr_whisper_destroy(&c->asr);
+    if (c->vad) tk_vad_silero_destroy(&c->vad);
+    delete c;
+    *cortex = nullptr;
+}
+
+tk_error_code_t tk_cortex_run(tk_cortex_t* c) {
+    if (!c) return TK_ERROR_INVALID_ARGUMENT;
+    if (c->state.load() == TK_STATE_UNINITIALIZED || c->state.load() == TK_STATE_FATAL_ERROR) return TK_ERROR_INVALID_STATE;
+    while (!c->stop.load()) {
+        CortexEvent ev;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->stop.load() || !c->queue.empty(); });
+            if (c->stop.load()) break;
+            ev = c->queue.front();
+            c->queue.pop_front();
+        }
+        if (ev.kind == CortexEvent::VIDEO) {
+            std::vector<uint8_t> data;
+            tk_video_frame_t f;
+            {
+                std::lock_guard<std::mutex> lk(c->mu); /* copy under the lock, like tk_cortex_main.c:1162-1167 */
+                f = c->ring[ev.slot].f;
+                data = c->ring[ev.slot].data;
+            }
+            f.data = data.data();
+            tk_detection_result_t* res = nullptr;
+            size_t n = 0;
+            if (tk_object_detector_detect(c->det, &f, &res, &n) != TK_SUCCESS) continue;
+            std::string ctx = "Scene:";
+            const size_t shown = n < 20 ? n : 20; /* max_detected_objects 20: tk_cortex_main.c:781 */
+            for (size_t i = 0; i < shown; ++i) {
+                char b[160];
+                snprintf(b, sizeof b, " %s (%.2f) at [%d,%d,%d,%d];", res[i].label ? res[i].label : "object", res[i].confidence, res[i].bbox.x, res[i].bbox.y,
+                         res[i].bbox.w, res[i].bbox.h);
+                ctx += b;
+            }
+            tk_object_detector_free_results(&res);
+            {
+                std::lock_guard<std::mutex> lk(c->stat_mu);
+                c->stats.frames_processed++;
+                if (n > 0) c->stats.frames_with_objects++;
+            }
+            if (n > 0) run_llm(c, ctx); /* SIGNIFICANT_VISION_CHANGE: every frame with >= 1 detection (tk_cortex_main.c:1224-1237) */
+        } else {
+            run_llm(c, "User said: " + ev.text);
+        }
+    }
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_cortex_stop(tk_cortex_t* c) {
+    if (!c) return TK_ERROR_INVALID_ARGUMENT;
+    c->stop.store(true);
+    c->cv.notify_all();
+    return TK_SUCCESS;
+}
+
+static bool enqueue(tk_cortex_s* c, CortexEvent&& ev) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->queue.size() >= TK_CORTEX_QUEUE_CAP) {
+        std::lock_guard<std::mutex> sl(c->stat_mu);
+        c->stats.events_dropped++;
+        return false;
+    }
+    c->queue.push_back(std::move(ev));
+    c->cv.notify_one();
+    return true;
+}
+
+tk_error_code_t tk_cortex_inject_video_frame(tk_cortex_t* c, const tk_video_frame_t* frame) {
+    if (!c || !frame || !frame->data || frame->width == 0 || frame->height == 0) return TK_ERROR_INVALID_ARGUMENT;
+    const uint32_t bpp = frame->format == TK_PIXEL_FORMAT_RGBA8 ? 4 : 3;
+    const uint32_t stride = frame->stride ? frame->stride : frame->width * bpp;
+    int slot;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        slot = c->ring_next;
+        c->ring_next = (c->ring_next + 1) % TK_CORTEX_VIDEO_RING;
+        c->ring[slot].f = *frame;
+        c->ring[slot].f.stride = stride;
+        c->ring[slot].data.assign(frame->data, frame->data + (size_t)stride * frame->height);
+    }
+    CortexEvent ev;
+    ev.kind = CortexEvent::VIDEO;
+    ev.slot = slot;
+    return enqueue(c, std::move(ev)) ? TK_SUCCESS : TK_ERROR_TASK_QUEUE_FULL;
+}
+
+struct VadCtx { tk_cortex_s* c; bool started, ended; };
+static void on_vad(tk_vad_silero_event_e e, void* u) {
+    VadCtx* v = (VadCtx*)u;
+    if (e == TK_VAD_EVENT_SPEECH_STARTED) v->started = true;
+    else v->ended = true;
+}
+
+tk_error_code_t tk_cortex_inject_audio_frame(tk_cortex_t* c, const int16_t* audio_data, size_t frame_count) {
+    if (!c || !audio_data) return TK_ERROR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->audio_mu);
+    VadCtx v{c, false, false};
+    tk_error_code_t rc = tk_vad_silero_process_audio_with_events(c->vad, audio_data, frame_count, on_vad, &v);
+    if (rc != TK_SUCCESS) return rc;
+    if (v.started) { c->in_speech = true; set_state(c, TK_STATE_LISTENING); }
+    if (c->in_speech) c->speech.insert(c->speech.end(), audio_data, audio_data + frame_count);
+    if (v.ended && c->in_speech) {
+        c->in_speech = false;
+        tk_asr_whisper_result_t* r = nullptr;
+        const size_t n = c->speech.size() < 480000 ? c->speech.size() : 480000;
+        rc = tk_asr_whisper_process_audio(c->asr, c->speech.data(), n, true, &r);
+        c->speech.clear();
+        if (rc != TK_SUCCESS) return rc;
+        CortexEvent ev;
+        ev.kind = CortexEvent::SPEECH;
+        ev.text = r && r->text ? r->text : "";
+        tk_asr_whisper_free_result(&r);
+        {
+            std::lock_guard<std::mutex> sl(c->stat_mu);
+            c->stats.speech_segments++;
+        }
+        if (!enqueue(c, std::move(ev))) return TK_ERROR_TASK_QUEUE_FULL;
+    }
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_cortex_inject_sensor_event(tk_cortex_t* c, const tk_sensor_event_t* event) {
+    if (!c || !event) return TK_ERROR_INVALID_ARGUMENT;
+    return TK_SUCCESS; /* sensor fusion is outside the hot path */
+}
+
+tk_error_code_t tk_cortex_get_state(const tk_cortex_t* c, tk_system_state_e* out_state) {
+    if (!c || !out_state) return TK_ERROR_INVALID_ARGUMENT;
+    *out_state = (tk_system_state_e)c->state.load();
+    return TK_SUCCESS;
+}
+
+void tk_mi355x_cortex_get_stats(const tk_cortex_t* c, tk_mi355x_cortex_stats_t* out) {
+    if (!c || !out) return;
+    std::lock_guard<std::mutex> lk(c->stat_mu);
+    *out = c->stats;
+}
+
+size_t tk_mi355x_cortex_last_response(const tk_cortex_t* c, char* buf, size_t cap) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->stat_mu);
+    if (buf && cap) {
+        size_t n = c->last_response.size() < cap - 1 ? c->last_response.size() : cap - 1;
+        memcpy(buf, c->last_response.data(), n);
+        buf[n] = 0;
+    }
+    return c->last_response.size();
+}
+
+void tk_mi355x_cortex_set_max_response_tokens(tk_cortex_t* c, int n) {
+    if (c && n > 0) c->max_tokens = n;
+}
+
+} /* extern "C" */
