@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--decode", type=int, default=128)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers => result marked invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--llm-only", action="store_true", help="configs[1] only: leave the detector / ASR / VAD streams out (marked in config)")
+    ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,6 +95,41 @@ def main():
     prompts = np.stack([splitmix_tokens(3 + 1000 * (rank * B + s), P, 3, hp.vocab) for s in range(B)])
     prompts[:, 0] = 1  # BOS
 
+    # perception streams: one 640x640 frame and 1 s of PCM per cycle, their own HIP streams, driven from host threads
+    fused = not args.llm_only
+    perc_ms = {"vision": [], "audio": []}
+    if fused:
+        import threading
+        det = tk.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", width=640, height=640, conf=0.5, iou=0.5,
+                                device=local_rank, max_batch=B)
+        asr = tk.Asr(hp=tk.WHISPER_TINY_EN(), seed=6, device=local_rank, max_batch=B)
+        vad = tk.Vad()
+        frng = np.random.default_rng(1 + rank)
+        frames = [frng.integers(0, 256, (640, 640, 3), dtype=np.uint8) for _ in range(B)]
+        prng = np.random.default_rng(2 + rank)
+        pcm = np.clip(prng.normal(0, 3000, (B, 16000)), -32768, 32767).astype(np.int16)
+        n_dets = [0]
+
+        def vision_pass():
+            t = time.time()
+            res = det.detect_batch(frames)
+            n_dets[0] = sum(len(r) for r in res)
+            perc_ms["vision"].append(1000 * (time.time() - t))
+
+        def audio_pass():
+            t = time.time()
+            for b in range(B):
+                vad.reset()
+                vad.process_with_events(pcm[b])
+            asr.transcribe_tokens(pcm, args.asr_steps, want_aux=False)
+            perc_ms["audio"].append(1000 * (time.time() - t))
+
+        def perception_async():
+            th = [threading.Thread(target=vision_pass), threading.Thread(target=audio_pass)]
+            for t in th:
+                t.start()
+            return th
+
     def barrier():
         if dist is not None:
             import torch
@@ -101,14 +138,25 @@ def main():
             torch.cuda.synchronize()
 
     def one_step():
+        # software pipeline: the LLM consumes the perception results of THIS cycle batch (produced during the previous
+        # step) while the detector / ASR / VAD streams already work on the next batch; every step runs all streams once
+        th = perception_async() if fused else []
         t_a = time.time()
         sess.prefill(prompts)
         t_b = time.time()
         toks, ms_step = sess.decode(B, N)
-        return toks, t_b - t_a, time.time() - t_b, ms_step
+        t_c = time.time()
+        for t in th:
+            t.join()
+        return toks, t_b - t_a, t_c - t_b, ms_step
 
+    if fused:
+        for t in perception_async():  # primes the pipeline (perception of the first timed batch)
+            t.join()
+        perc_ms["vision"].clear(); perc_ms["audio"].clear()
     for _ in range(args.warmup):
         one_step()
+    perc_ms["vision"].clear(); perc_ms["audio"].clear()
     barrier()
     t0 = time.time()
     pre_s = dec_s = 0.0
@@ -164,8 +212,10 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8 x q4_K/q6_K (i32 acc, f32 scales)",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: Mistral-7B Q4_K_M, 64-token prefill + 128-token greedy decode per cycle; "
-                               "vision/audio streams not yet in the timed region",
+        "config": {"workload": ("configs[3] fused cycle: YOLOv8n 640x640 frame (preprocess+network+NMS) + 1 s PCM (VAD + Whisper-tiny.en "
+                                "log-mel/encoder/%d forced decoder steps) + Mistral-7B Q4_K_M 64-token prefill and 128-token greedy decode, "
+                                "3 concurrent HIP streams" % args.asr_steps) if fused else
+                               "configs[1]: Mistral-7B Q4_K_M, 64-token prefill + 128-token greedy decode per cycle (LLM stream only)",
                    "concurrent_cycles_per_gpu": B, "prompt_tokens": P, "decode_tokens": N, "layers": hp.n_layer,
                    "k_split": [hp.ks_qkv, hp.ks_o, hp.ks_gateup, hp.ks_down], "parallelism": f"replicas x{world}"},
         "llm_tok_per_s": round(B * world * N / (dec_s / args.steps), 1),
@@ -173,6 +223,9 @@ def main():
         "model_load_s": round(t_load, 2), "weight_bytes_per_decode_step": int(model.weight_bytes),
         "roofline": roofline,
     }
+    if fused:
+        out["perception"] = {"vision_ms_per_batch": round(float(np.mean(perc_ms["vision"])), 2), "audio_ms_per_batch": round(float(np.mean(perc_ms["audio"])), 2),
+                             "detections_last_batch": n_dets[0], "overlapped_with_llm": True, "dtype": "f32 (exact fp32 MFMA chain)"}
     if args.layers != 32:
         out["invalid"] = "debug run with fewer layers"
     if not args.no_cpu_baseline and args.layers == 32:
