@@ -73,12 +73,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    from trackiellm_amd import dist as D
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = D.init("nccl", local_rank)
 
     import trackiellm_amd as tk
     if tk.lib().tk_mi355x_device_count() <= local_rank:
@@ -132,10 +129,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            D.barrier(dist, cuda=True)
 
     def one_step():
         # software pipeline: the LLM consumes the perception results of THIS cycle batch (produced during the previous
@@ -169,10 +163,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = D.max_over_ranks(dist, elapsed, cuda=True)
 
     if rank != 0:
         if dist is not None:
@@ -204,8 +195,7 @@ def main():
                 "algorithmic_bytes_per_launch": round(total_bytes / launches), "avg_launch_ms": round(avg_ms, 5),
                 "launches_per_decode_step": launches, "per_shape": shapes}
 
-    cycles = B * args.steps * world
-    value = cycles / elapsed
+    value = D.aggregate_throughput(B, args.steps, world, elapsed)
     dec_ms = float(np.mean(ms_steps))
     out = {
         "metric": "cortex cycles/sec (frame+1s audio+128 tok)", "value": round(value, 3), "unit": "cycles/s", "n_gpus": world,

@@ -75,9 +75,11 @@ static float orc_sum256(const float* partial) {
 
 void orc_rmsnorm(const float* x, const float* w, int n, float eps, float* out) {
     float partial[256];
+    /* thread t of 256 owns the float4 groups t, t+256, ... and squares them element by element (the kernel's 16-byte loads) */
     for (int t = 0; t < 256; ++t) {
         float a = 0.0f;
-        for (int i = t; i < n; i += 256) a = tk_fmaf(x[i], x[i], a);
+        for (int g = t; g < n / 4; g += 256)
+            for (int e = 0; e < 4; ++e) a = tk_fmaf(x[4 * g + e], x[4 * g + e], a);
         partial[t] = a;
     }
     float ss = orc_sum256(partial);

@@ -90,7 +90,7 @@ public:
     bool time_gemv(int layer, int which, int nrows, int iters, float* avg_ms, double* algo_bytes);
 
 private:
-    void enqueue_pass(int nrows, bool lm_head);
+    void enqueue_pass(int nrows, bool lm_head, bool fused_attn);
     uint16_t *kcache = nullptr, *vcache = nullptr;
     float *x = nullptr, *qbuf = nullptr, *partial = nullptr, *logits = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
     TkActQ8 act_d{}, act_qd{}, act_ff{};

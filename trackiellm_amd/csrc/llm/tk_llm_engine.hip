@@ -253,7 +253,7 @@ bool TkLlmSession::reset() {
 
 static TkGemvSeg seg_of(const TkDevTensor& t) { return TkGemvSeg{t.data, t.type, (int)(t.rows / TK_TILE_ROWS)}; }
 
-void TkLlmSession::enqueue_pass(int nrows, bool lm_head) {
+void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) {
     const TkLlmHParams& h = model->hp;
     const int D = h.d_model, QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim, FF = h.d_ff;
     hipStream_t s = stream;
@@ -266,9 +266,11 @@ void TkLlmSession::enqueue_pass(int nrows, bool lm_head) {
         a.nseg = 3; a.K = D; a.ks = h.ks_qkv; a.n_total = QD + 2 * KVD; a.nrows = nrows;
         a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
         tk_launch_gemv(a, s);
-        tk_launch_qkv_rope_append(partial, h.ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
-                                  qbuf, kcache, vcache, l, max_seq, max_ctx, s);
-        tk_launch_attention(qbuf, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
+        if (!fused_attn)
+            tk_launch_qkv_rope_append(partial, h.ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
+                                      qbuf, kcache, vcache, l, max_seq, max_ctx, s);
+        tk_launch_attention(qbuf, partial, h.ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
+                            h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
         TkGemvArgs o{};
         o.seg[0] = seg_of(L.o); o.nseg = 1; o.K = QD; o.ks = h.ks_o; o.n_total = D; o.nrows = nrows;
         o.aq = act_qd.aq; o.ad = act_qd.ad; o.abs = act_qd.abs; o.out = partial;
@@ -307,7 +309,11 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
     HIPQ(hipMemcpyAsync(d_pos, pos, nrows * 4, hipMemcpyHostToDevice, stream));
     HIPQ(hipMemcpyAsync(d_tok, tok, nrows * 4, hipMemcpyHostToDevice, stream));
     HIPQ(hipMemsetAsync(d_nsteps, 0, TK_ROW_SLOTS * 4, stream));
-    enqueue_pass(nrows, lm_head);
+    bool distinct = true; /* every sequence at most once in the pass -> rope/append can be fused into attention */
+    for (int a = 0; a < nrows && distinct; ++a)
+        for (int b = a + 1; b < nrows; ++b)
+            if (seq[a] == seq[b]) { distinct = false; break; }
+    enqueue_pass(nrows, lm_head, distinct);
     HIPQ(hipGetLastError());
     if (!lm_head) { HIPQ(hipStreamSynchronize(stream)); return true; }
     if (logits_host) HIPQ(hipMemcpyAsync(logits_host, logits, (size_t)nrows * model->hp.vocab * 4, hipMemcpyDeviceToHost, stream));
@@ -354,7 +360,7 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     if (use_graph && !graph_exec[nrows]) {
         hipGraph_t g = nullptr;
         HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        enqueue_pass(nrows, true);
+        enqueue_pass(nrows, true, true);
         HIPQ(hipStreamEndCapture(stream, &g));
         HIPQ(hipGraphInstantiate(&graph_exec[nrows], g, nullptr, nullptr, 0));
         HIPQ(hipGraphDestroy(g));
@@ -366,7 +372,7 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     HIPQ(hipEventRecord(e0, stream));
     for (int i = 0; i < n_steps; ++i) {
         if (use_graph) HIPQ(hipGraphLaunch(graph_exec[nrows], stream));
-        else enqueue_pass(nrows, true);
+        else enqueue_pass(nrows, true, true);
     }
     HIPQ(hipGetLastError());
     HIPQ(hipEventRecord(e1, stream));

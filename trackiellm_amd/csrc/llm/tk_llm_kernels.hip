@@ -196,57 +196,78 @@ __global__ __launch_bounds__(256) void k_rmsnorm_q8(float* __restrict__ x, const
     const int r = blockIdx.x, t = threadIdx.x;
     float* xr = x + (int64_t)r * D;
     float ss = 0.0f;
-    /* 16 elements per thread and pass: every load of the pass is issued before the first use so the
-     * row costs ~one memory round trip instead of one per element (the residual add is latency-bound) */
-    for (int base = 0; base < D; base += 256 * 16) {
-        float v[16], o[16];
+    /* Canonical order (oracle: orc_rmsnorm): thread t owns the float4 groups g = t, t + 256, ... of the row and
+     * accumulates x^2 over them element by element; 16-byte loads, 4 groups per pass, every load of a pass issued before
+     * its first use — the K-split partials of one row are up to 128 KB pulled through a single CU. */
+    const int ngrp = D / 4;
+    for (int g0 = 0; g0 < ngrp; g0 += 256 * 4) {
+        v4f v[4], o[4];
+        bool live[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = base + t + 256 * e;
-            v[e] = i < D ? xr[i] : 0.0f;
+        for (int e = 0; e < 4; ++e) {
+            const int g = g0 + t + 256 * e;
+            live[e] = g < ngrp;
+            v[e] = live[e] ? *(const v4f*)(xr + 4 * g) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
         }
         if (partial) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = base + t + 256 * e;
-                o[e] = i < D ? partial[(int64_t)r * n_total + i] : 0.0f;
+            for (int e = 0; e < 4; ++e) {
+                const int g = g0 + t + 256 * e;
+                o[e] = live[e] ? *(const v4f*)(partial + (int64_t)r * n_total + 4 * g) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
             }
             for (int s = 1; s < ks; ++s) {
-                float p[16];
+                v4f p[4];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = base + t + 256 * e;
-                    p[e] = i < D ? partial[((int64_t)s * TK_ROW_SLOTS + r) * n_total + i] : 0.0f;
+                for (int e = 0; e < 4; ++e) {
+                    const int g = g0 + t + 256 * e;
+                    p[e] = live[e] ? *(const v4f*)(partial + ((int64_t)s * TK_ROW_SLOTS + r) * n_total + 4 * g) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[e] = o[e] + p[e];
+                for (int e = 0; e < 4; ++e) o[e] = o[e] + p[e];
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = v[e] + o[e];
+            for (int e = 0; e < 4; ++e) v[e] = v[e] + o[e];
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = base + t + 256 * e;
-            if (i < D) {
-                if (partial) xr[i] = v[e];
-                hbuf[i] = v[e];
-                ss = tk_fmaf(v[e], v[e], ss);
+        for (int e = 0; e < 4; ++e) {
+            const int g = g0 + t + 256 * e;
+            if (live[e]) {
+                if (partial) *(v4f*)(xr + 4 * g) = v[e];
+                *(v4f*)(hbuf + 4 * g) = v[e];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ss = tk_fmaf(v[e][i], v[e][i], ss);
             }
         }
+    }
+    /* norm weights of this thread's first two chunks are requested before the reduction so their latency hides under it */
+    const int nchunk = D / 8;
+    v4f wa[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = t + 256 * u;
+        if (c < nchunk) { wa[u][0] = *(const v4f*)(w + 8 * c); wa[u][1] = *(const v4f*)(w + 8 * c + 4); }
     }
     float tot = block_sum256(ss, red);
     float mean = tk_divf(tot, (float)D);
     float scale = tk_divf(1.0f, tk_sqrtf(mean + eps));
-    for (int c = t; c < D / 8; c += 256) {
-        const v4f h0 = *(const v4f*)(hbuf + 8 * c), h1 = *(const v4f*)(hbuf + 8 * c + 4);
-        const v4f w0 = *(const v4f*)(w + 8 * c), w1 = *(const v4f*)(w + 8 * c + 4);
-        float v[8];
+    for (int c0 = t; c0 < nchunk; c0 += 512) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[i] = (h0[i] * scale) * w0[i];
-            v[4 + i] = (h1[i] * scale) * w1[i];
+        for (int u = 0; u < 2; ++u) {
+            const int c = c0 + 256 * u;
+            if (c < nchunk) { /* nchunk is a multiple of 32: half-waves enter together, as quantize_chunk8 needs */
+                v4f w0, w1;
+                if (c0 == t) { w0 = wa[u][0]; w1 = wa[u][1]; }
+                else { w0 = *(const v4f*)(w + 8 * c); w1 = *(const v4f*)(w + 8 * c + 4); }
+                const v4f h0 = *(const v4f*)(hbuf + 8 * c), h1 = *(const v4f*)(hbuf + 8 * c + 4);
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = (h0[i] * scale) * w0[i];
+                    v[4 + i] = (h1[i] * scale) * w1[i];
+                }
+                quantize_chunk8(v, c, r, out);
+            }
         }
-        quantize_chunk8(v, c, r, out);
     }
 }
 
@@ -561,49 +582,97 @@ void tk_launch_qkv_rope_append(const float* partial, int ks, int n_total, int n_
  * ------------------------------------------------------------------------------------------ */
 #define TK_ATT_MAX_GRP 4
 #define TK_ATT_TSPLIT 4 /* canonical: 4 interleaved partial sums over positions (t mod 4), added in order */
-template <int GRP>
-__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbuf, const uint16_t* __restrict__ kcache,
-                                                    const uint16_t* __restrict__ vcache, const int32_t* __restrict__ seq,
-                                                    const int32_t* __restrict__ pos, int n_head, int n_kv_head, int head_dim, int layer,
-                                                    int max_seq, int max_ctx, TkActQ8 out) {
+/*
+ * One workgroup per (row, group of GRP query heads that share a KV head).  GRP * head_dim must be a multiple of 256
+ * so the workgroup's outputs are whole Q8 blocks of the o-projection input.
+ * FUSED (decode passes: every sequence appears once): the workgroup first finishes its own q / k / v — K-split partial
+ * sums, RoPE, f16 rounding, cache append — and attends to its own position from LDS, which removes the separate
+ * k_qkv_rope_append launch.  Non-fused (prefill passes with several rows per sequence): the cache was appended before.
+ */
+template <int GRP, bool FUSED>
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbuf, const float* __restrict__ partial, int ks, int n_total,
+                                                    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                                    uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache, const int32_t* __restrict__ seq,
+                                                    const int32_t* __restrict__ pos, int n_head, int n_kv_head, int head_dim, int layer, int max_seq,
+                                                    int max_ctx, TkActQ8 out) {
     extern __shared__ float sh[];
-    const int kvh = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
+    const int vh = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
     constexpr int grp = GRP;
-    const int T = pos[r] + 1, sq = seq[r];
+    const int per_kv = (n_head / n_kv_head) / grp;   /* workgroups per KV head */
+    const int kvh = vh / per_kv;
+    const int p = pos[r], T = p + 1, sq = seq[r];
     const int W = grp * head_dim;              /* outputs of this WG */
     float* qs = sh;                            /* [grp][head_dim] */
     float* sc = qs + W;                        /* [grp][max_ctx] */
     float* red = sc + (size_t)grp * max_ctx;   /* [4 waves][grp] */
-    float* part = red + 4 * TK_ATT_MAX_GRP;    /* [TSPLIT][W] partial outputs, then [TSPLIT][grp] partial denominators */
-    float* lpart = part + TK_ATT_TSPLIT * W;
+    float* part = red + 4 * TK_ATT_MAX_GRP;    /* [TSPLIT][W] partial outputs */
+    float* lpart = part + TK_ATT_TSPLIT * W;   /* [TSPLIT][grp] partial denominators */
     float* obuf = lpart + TK_ATT_TSPLIT * TK_ATT_MAX_GRP; /* [W] */
-    const int QD = n_head * head_dim;
-    for (int i = t; i < W; i += 256) qs[i] = qbuf[(int64_t)r * QD + kvh * W + i];
-    __syncthreads();
-    const float att_scale = tk_divf(1.0f, tk_sqrtf((float)head_dim));
+    float* kcur = obuf + W;                    /* [head_dim] own position, f16-rounded (FUSED) */
+    float* vcur = kcur + head_dim;
+    const int QD = n_head * head_dim, KVD = n_kv_head * head_dim, half = head_dim / 2;
     const int64_t rowstride = (int64_t)n_kv_head * head_dim;
     const int64_t sbase = (((int64_t)layer * max_seq + sq) * max_ctx) * rowstride + (int64_t)kvh * head_dim;
+    if (FUSED) {
+        const float* cs = rope_cos + (int64_t)p * half;
+        const float* sn = rope_sin + (int64_t)p * half;
+        for (int idx = t; idx < (grp + 2) * half; idx += 256) {
+            const int hsel = idx / half, i = idx % half;
+            if (hsel < grp) {
+                const int col = vh * W + hsel * head_dim + 2 * i;
+                const float a = sum_partials(partial, ks, n_total, r, col), b = sum_partials(partial, ks, n_total, r, col + 1);
+                qs[hsel * head_dim + 2 * i] = tk_fmaf(-b, sn[i], a * cs[i]);
+                qs[hsel * head_dim + 2 * i + 1] = tk_fmaf(a, sn[i], b * cs[i]);
+            } else if (hsel == grp) {
+                const int col = QD + kvh * head_dim + 2 * i;
+                const float a = sum_partials(partial, ks, n_total, r, col), b = sum_partials(partial, ks, n_total, r, col + 1);
+                const uint16_t k0 = tk_f32_to_f16(tk_fmaf(-b, sn[i], a * cs[i])), k1 = tk_f32_to_f16(tk_fmaf(a, sn[i], b * cs[i]));
+                kcur[2 * i] = f16bits_to_f32(k0);
+                kcur[2 * i + 1] = f16bits_to_f32(k1);
+                if (vh % per_kv == 0) *(uint32_t*)(kcache + sbase + (int64_t)p * rowstride + 2 * i) = (uint32_t)k0 | ((uint32_t)k1 << 16);
+            } else {
+                const int col = QD + KVD + kvh * head_dim + 2 * i;
+                const uint16_t v0 = tk_f32_to_f16(sum_partials(partial, ks, n_total, r, col)), v1 = tk_f32_to_f16(sum_partials(partial, ks, n_total, r, col + 1));
+                vcur[2 * i] = f16bits_to_f32(v0);
+                vcur[2 * i + 1] = f16bits_to_f32(v1);
+                if (vh % per_kv == 0) *(uint32_t*)(vcache + sbase + (int64_t)p * rowstride + 2 * i) = (uint32_t)v0 | ((uint32_t)v1 << 16);
+            }
+        }
+    } else {
+        for (int i = t; i < W; i += 256) qs[i] = qbuf[(int64_t)r * QD + vh * W + i];
+    }
+    __syncthreads();
+    const float att_scale = tk_divf(1.0f, tk_sqrtf((float)head_dim));
+    const int Tc = FUSED ? T - 1 : T; /* positions served by the cache */
     float mx[GRP];
 #pragma unroll
     for (int h = 0; h < grp; ++h) mx[h] = -INFINITY;
     for (int tt = t; tt < T; tt += 256) {
-        const uint16_t* kr = kcache + sbase + (int64_t)tt * rowstride;
         float a[GRP];
 #pragma unroll
         for (int h = 0; h < grp; ++h) a[h] = 0.0f;
-        for (int i0 = 0; i0 < head_dim; i0 += 64) { /* 8 x 16 B of the key row in flight per pass */
-            uint4 kv[8];
+        if (tt < Tc) {
+            const uint16_t* kr = kcache + sbase + (int64_t)tt * rowstride;
+            for (int i0 = 0; i0 < head_dim; i0 += 64) { /* 8 x 16 B of the key row in flight per pass */
+                uint4 kv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) kv[u] = *(const uint4*)(kr + i0 + 8 * u);
+                for (int u = 0; u < 8; ++u) kv[u] = *(const uint4*)(kr + i0 + 8 * u);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float kf = f16bits_to_f32((kw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                    for (int e = 0; e < 8; ++e) {
+                        const float kf = f16bits_to_f32((kw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
 #pragma unroll
-                    for (int h = 0; h < grp; ++h) a[h] = tk_fmaf(qs[h * head_dim + i0 + 8 * u + e], kf, a[h]);
+                        for (int h = 0; h < grp; ++h) a[h] = tk_fmaf(qs[h * head_dim + i0 + 8 * u + e], kf, a[h]);
+                    }
                 }
+            }
+        } else {
+            for (int i = 0; i < head_dim; ++i) {
+                const float kf = kcur[i];
+#pragma unroll
+                for (int h = 0; h < grp; ++h) a[h] = tk_fmaf(qs[h * head_dim + i], kf, a[h]);
             }
         }
 #pragma unroll
@@ -627,7 +696,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     }
     __syncthreads();
     /* PV: wave j takes positions t = j (mod 4); lane owns dims (2*lane, 2*lane+1) [+128k] of every head, so one
-     * 4-byte V load feeds GRP heads.  Partials are combined in j order afterwards. */
+     * 4-byte V load feeds GRP heads; 16 loads in flight per lane.  Partials are combined in j order afterwards. */
     {
         const int j = t >> 6, lane = t & 63;
         for (int d0 = 2 * lane; d0 < head_dim; d0 += 128) {
@@ -635,32 +704,30 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
 #pragma unroll
             for (int h = 0; h < grp; ++h) { acc[h][0] = 0.0f; acc[h][1] = 0.0f; l[h] = 0.0f; }
             const uint16_t* vc = vcache + sbase + d0;
-            int tt = j;
-            for (; tt + 7 * TK_ATT_TSPLIT < T; tt += 8 * TK_ATT_TSPLIT) {
-                uint32_t vv[8];
+            /* 16 positions per batch, all loads issued together.  Out-of-range slots read a clamped address and enter
+             * with probability 0: fma(0, v, acc) == acc and l + 0 == l exactly, so the canonical order is untouched while
+             * the tail costs one memory round trip instead of one per position. */
+            for (int tt = j; tt < T; tt += 16 * TK_ATT_TSPLIT) {
+                uint32_t vv[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) vv[u] = *(const uint32_t*)(vc + (int64_t)(tt + u * TK_ATT_TSPLIT) * rowstride);
+                for (int u = 0; u < 16; ++u) {
+                    int pu = tt + u * TK_ATT_TSPLIT;
+                    pu = pu < Tc ? pu : (Tc > 0 ? Tc - 1 : 0);
+                    vv[u] = Tc > 0 ? *(const uint32_t*)(vc + (int64_t)pu * rowstride) : 0u;
+                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float v0 = f16bits_to_f32(vv[u] & 0xffffu), v1 = f16bits_to_f32(vv[u] >> 16);
+                for (int u = 0; u < 16; ++u) {
+                    const int pu = tt + u * TK_ATT_TSPLIT;
+                    float v0 = f16bits_to_f32(vv[u] & 0xffffu), v1 = f16bits_to_f32(vv[u] >> 16);
+                    if (FUSED && pu == Tc) { v0 = vcur[d0]; v1 = vcur[d0 + 1]; }
+                    const bool live = pu < T;
 #pragma unroll
                     for (int h = 0; h < grp; ++h) {
-                        const float p = sc[(size_t)h * max_ctx + tt + u * TK_ATT_TSPLIT];
-                        acc[h][0] = tk_fmaf(p, v0, acc[h][0]);
-                        acc[h][1] = tk_fmaf(p, v1, acc[h][1]);
-                        l[h] = l[h] + p;
+                        const float pr = live ? sc[(size_t)h * max_ctx + pu] : 0.0f;
+                        acc[h][0] = tk_fmaf(pr, v0, acc[h][0]);
+                        acc[h][1] = tk_fmaf(pr, v1, acc[h][1]);
+                        l[h] = l[h] + pr;
                     }
-                }
-            }
-            for (; tt < T; tt += TK_ATT_TSPLIT) {
-                const uint32_t vv = *(const uint32_t*)(vc + (int64_t)tt * rowstride);
-                const float v0 = f16bits_to_f32(vv & 0xffffu), v1 = f16bits_to_f32(vv >> 16);
-#pragma unroll
-                for (int h = 0; h < grp; ++h) {
-                    const float p = sc[(size_t)h * max_ctx + tt];
-                    acc[h][0] = tk_fmaf(p, v0, acc[h][0]);
-                    acc[h][1] = tk_fmaf(p, v1, acc[h][1]);
-                    l[h] = l[h] + p;
                 }
             }
 #pragma unroll
@@ -683,24 +750,32 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = obuf[8 * c + i];
-        quantize_chunk8(v, kvh * (W / 8) + c, r, out);
+        quantize_chunk8(v, vh * (W / 8) + c, r, out);
     }
 }
 
-void tk_launch_attention(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows,
-                         int n_head, int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, hipStream_t s) {
-    const int grp = n_head / n_kv_head;
+void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_total, const float* rope_cos, const float* rope_sin,
+                         uint16_t* kcache, uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows, int n_head, int n_kv_head,
+                         int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, bool fused, hipStream_t s) {
+    const int grp_real = n_head / n_kv_head;
+    /* smallest head group whose outputs are whole 256-wide Q8 blocks: more, shorter workgroups */
+    int grp = 1;
+    while ((grp * head_dim) % 256 && grp < grp_real) grp *= 2;
     const int W = grp * head_dim;
-    size_t lds = ((size_t)W + (size_t)grp * max_ctx + 4 * TK_ATT_MAX_GRP + (size_t)TK_ATT_TSPLIT * W + TK_ATT_TSPLIT * TK_ATT_MAX_GRP + W) * sizeof(float);
-#define TK_ATT_LAUNCH(G)                                                                                                             \
+    const int nwg = n_head / grp;
+    size_t lds = ((size_t)W + (size_t)grp * max_ctx + 4 * TK_ATT_MAX_GRP + (size_t)TK_ATT_TSPLIT * W + TK_ATT_TSPLIT * TK_ATT_MAX_GRP + W +
+                  2 * (size_t)head_dim) * sizeof(float);
+#define TK_ATT_LAUNCH(G, F)                                                                                                          \
     do {                                                                                                                             \
-        (void)hipFuncSetAttribute((const void*)k_attention<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-        hipLaunchKernelGGL(k_attention<G>, dim3(n_kv_head, nrows), dim3(256), lds, s, qbuf, kcache, vcache, seq, pos, n_head,           \
-                           n_kv_head, head_dim, layer, max_seq, max_ctx, out);                                                          \
+        (void)hipFuncSetAttribute((const void*)k_attention<G, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL((k_attention<G, F>), dim3(nwg, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin,   \
+                           kcache, vcache, seq, pos, n_head, n_kv_head, head_dim, layer, max_seq, max_ctx, out);                        \
     } while (0)
-    if (grp == 4) TK_ATT_LAUNCH(4);
-    else if (grp == 2) TK_ATT_LAUNCH(2);
-    else TK_ATT_LAUNCH(1);
+    if (fused) {
+        if (grp == 4) TK_ATT_LAUNCH(4, true); else if (grp == 2) TK_ATT_LAUNCH(2, true); else TK_ATT_LAUNCH(1, true);
+    } else {
+        if (grp == 4) TK_ATT_LAUNCH(4, false); else if (grp == 2) TK_ATT_LAUNCH(2, false); else TK_ATT_LAUNCH(1, false);
+    }
 #undef TK_ATT_LAUNCH
 }
 
