@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="concurrent cortex cycles per GPU (<=16)")
+    ap.add_argument("--batch", type=int, default=32, help="concurrent cortex cycles per GPU (<=32: two 16-row MFMA M-tiles)")
     ap.add_argument("--prompt", type=int, default=64)
     ap.add_argument("--decode", type=int, default=128)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers => result marked invalid")

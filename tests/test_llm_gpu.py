@@ -62,6 +62,27 @@ def test_tiny_ragged_multi_sequence(tiny):
         assert np.array_equal(gam, wam)
 
 
+def test_tiny_two_mtiles_24_rows(tiny):
+    """more than 16 rows per pass: second MFMA M-tile (rows 16..31), ragged over three sequences"""
+    gpu, model, sess, orc, hp = tiny
+    orc.reset()
+    rng = np.random.default_rng(17)
+    seq = np.array([0] * 10 + [1] * 9 + [3] * 5, np.int32)
+    pos = np.concatenate([np.arange(10), np.arange(9), np.arange(5)]).astype(np.int32)
+    tok = rng.integers(3, hp.vocab, 24).astype(np.int32)
+    want, wam = orc.forward(seq, pos, tok)
+    got, gam = sess.forward(seq, pos, tok)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.array_equal(gam, wam)
+    # then 32 decode rows would need 32 sequences: continue the three sequences one step each + 17th..: mixed 20-row pass
+    seq2 = np.array([0, 1, 3], np.int32)
+    pos2 = np.array([10, 9, 5], np.int32)
+    tok2 = rng.integers(3, hp.vocab, 3).astype(np.int32)
+    w2, _ = orc.forward(seq2, pos2, tok2)
+    g2, _ = sess.forward(seq2, pos2, tok2)
+    assert np.array_equal(g2.view(np.uint32), w2.view(np.uint32))
+
+
 def test_tiny_greedy_decode_ids(tiny):
     gpu, model, sess, orc, hp = tiny
     orc.reset()
@@ -164,6 +185,6 @@ def test_error_paths(gpu):
     sess = gpu.LlmSession(model, 1, 16)
     with pytest.raises(gpu.TkError):  # position beyond context
         sess.forward([0], [16], [5])
-    with pytest.raises(gpu.TkError):  # 17 rows
-        sess.forward(np.zeros(17, np.int32), np.arange(17, dtype=np.int32), np.full(17, 5, np.int32))
+    with pytest.raises(gpu.TkError):  # 33 rows
+        sess.forward(np.zeros(33, np.int32), np.arange(33, dtype=np.int32) % 16, np.full(33, 5, np.int32))
     assert gpu.lib().tk_mi355x_llm_forward(None, 1, None, None, None, None, None) == 1001

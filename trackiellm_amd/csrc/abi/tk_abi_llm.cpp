@@ -348,7 +348,7 @@ static tk_error_code_t feed(tk_llm_runner_s* r, const std::vector<int32_t>& toks
     size_t i = 0;
     while (i + 1 < toks.size()) {
         sq.clear(); ps.clear(); tk.clear();
-        while (i + 1 < toks.size() && sq.size() < TK_ROW_SLOTS) { sq.push_back(0); ps.push_back(r->n_past++); tk.push_back(toks[i++]); }
+        while (i + 1 < toks.size() && sq.size() < TK_MAX_ROWS) { sq.push_back(0); ps.push_back(r->n_past++); tk.push_back(toks[i++]); }
         if (!s.forward((int)sq.size(), sq.data(), ps.data(), tk.data(), nullptr, nullptr, false)) return fail(TK_ERROR_INFERENCE_FAILED, s.error);
     }
     int32_t z = 0, p = r->n_past++, t = toks.back(), am = -1;

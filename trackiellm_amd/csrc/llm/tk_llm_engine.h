@@ -74,7 +74,7 @@ public:
 
     ~TkLlmSession();
     bool init(TkLlmModel* m, int max_seq, int max_ctx);
-    /* one pass over nrows <= 16 rows; host arrays */
+    /* one pass over nrows <= 32 rows (two 16-row M-tiles); host arrays */
     bool forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
                  bool lm_head = true);
     /* prompts of equal length for sequences 0..nseq-1 (tokens[nseq][n_prompt]); leaves row r = sequence r
@@ -96,7 +96,7 @@ private:
     TkActQ8 act_d{}, act_qd{}, act_ff{};
     int32_t *d_seq = nullptr, *d_pos = nullptr, *d_tok = nullptr, *d_nsteps = nullptr, *d_hist = nullptr;
     int hist_cap = 0;
-    hipGraphExec_t graph_exec[TK_ROW_SLOTS + 1] = {};
+    hipGraphExec_t graph_exec[TK_MAX_ROWS + 1] = {};
 };
 
 #endif

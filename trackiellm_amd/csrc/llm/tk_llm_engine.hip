@@ -168,14 +168,15 @@ bool TkLlmModel::ready() const {
 /* ------------------------------------------------------------------ session ---------------- */
 
 static bool alloc_act(TkActQ8* a, int K, std::string& error) {
-    if (hipMalloc((void**)&a->aq, TK_AQ_BYTES(K)) != hipSuccess || hipMalloc((void**)&a->ad, TK_AD_FLOATS(K) * 4) != hipSuccess ||
-        hipMalloc((void**)&a->abs, TK_ABS_INTS(K) * 4) != hipSuccess) {
+    a->aq_ts = TK_AQ_BYTES(K); a->ad_ts = TK_AD_FLOATS(K); a->abs_ts = TK_ABS_INTS(K);
+    if (hipMalloc((void**)&a->aq, TK_MAX_TILES * a->aq_ts) != hipSuccess || hipMalloc((void**)&a->ad, TK_MAX_TILES * a->ad_ts * 4) != hipSuccess ||
+        hipMalloc((void**)&a->abs, TK_MAX_TILES * a->abs_ts * 4) != hipSuccess) {
         error = "out of device memory (activation buffers)";
         return false;
     }
-    (void)hipMemset(a->aq, 0, TK_AQ_BYTES(K));
-    (void)hipMemset(a->ad, 0, TK_AD_FLOATS(K) * 4);
-    (void)hipMemset(a->abs, 0, TK_ABS_INTS(K) * 4);
+    (void)hipMemset(a->aq, 0, TK_MAX_TILES * a->aq_ts);
+    (void)hipMemset(a->ad, 0, TK_MAX_TILES * a->ad_ts * 4);
+    (void)hipMemset(a->abs, 0, TK_MAX_TILES * a->abs_ts * 4);
     return true;
 }
 static void free_act(TkActQ8* a) {
@@ -200,22 +201,22 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     HIPQ(hipMalloc((void**)&vcache, kv * 2));
     HIPQ(hipMemset(kcache, 0, kv * 2));
     HIPQ(hipMemset(vcache, 0, kv * 2));
-    HIPQ(hipMalloc((void**)&x, (size_t)TK_ROW_SLOTS * h.d_model * 4));
-    HIPQ(hipMalloc((void**)&qbuf, (size_t)TK_ROW_SLOTS * QD * 4));
+    HIPQ(hipMalloc((void**)&x, (size_t)TK_MAX_ROWS * h.d_model * 4));
+    HIPQ(hipMalloc((void**)&qbuf, (size_t)TK_MAX_ROWS * QD * 4));
     size_t pmax = (size_t)h.ks_qkv * (QD + 2 * KVD);
     pmax = std::max(pmax, (size_t)h.ks_o * h.d_model);
     pmax = std::max(pmax, (size_t)h.ks_gateup * 2 * h.d_ff);
     pmax = std::max(pmax, (size_t)h.ks_down * h.d_model);
-    HIPQ(hipMalloc((void**)&partial, pmax * TK_ROW_SLOTS * 4));
-    HIPQ(hipMalloc((void**)&logits, (size_t)TK_ROW_SLOTS * h.vocab * 4));
+    HIPQ(hipMalloc((void**)&partial, pmax * TK_MAX_ROWS * 4));
+    HIPQ(hipMalloc((void**)&logits, (size_t)TK_MAX_ROWS * h.vocab * 4));
     if (!alloc_act(&act_d, h.d_model, error) || !alloc_act(&act_qd, QD, error) || !alloc_act(&act_ff, h.d_ff, error)) return false;
-    HIPQ(hipMalloc((void**)&d_seq, TK_ROW_SLOTS * 4));
-    HIPQ(hipMalloc((void**)&d_pos, TK_ROW_SLOTS * 4));
-    HIPQ(hipMalloc((void**)&d_tok, TK_ROW_SLOTS * 4));
-    HIPQ(hipMalloc((void**)&d_nsteps, TK_ROW_SLOTS * 4));
-    HIPQ(hipMemset(d_nsteps, 0, TK_ROW_SLOTS * 4));
+    HIPQ(hipMalloc((void**)&d_seq, TK_MAX_ROWS * 4));
+    HIPQ(hipMalloc((void**)&d_pos, TK_MAX_ROWS * 4));
+    HIPQ(hipMalloc((void**)&d_tok, TK_MAX_ROWS * 4));
+    HIPQ(hipMalloc((void**)&d_nsteps, TK_MAX_ROWS * 4));
+    HIPQ(hipMemset(d_nsteps, 0, TK_MAX_ROWS * 4));
     hist_cap = mctx;
-    HIPQ(hipMalloc((void**)&d_hist, (size_t)hist_cap * TK_ROW_SLOTS * 4));
+    HIPQ(hipMalloc((void**)&d_hist, (size_t)hist_cap * TK_MAX_ROWS * 4));
     /* RoPE table, double precision on the host (same formula as the oracle) */
     std::vector<float> cs((size_t)mctx * half), sn((size_t)mctx * half);
     for (int p = 0; p < mctx; ++p)
@@ -246,9 +247,13 @@ TkLlmSession::~TkLlmSession() {
 
 bool TkLlmSession::reset() {
     HIPQ(hipSetDevice(model->device));
-    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_ROW_SLOTS * 4, stream));
+    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_MAX_ROWS * 4, stream));
     HIPQ(hipStreamSynchronize(stream));
     return true;
+}
+
+static void set_act(TkGemvArgs& a, const TkActQ8& q) {
+    a.aq = q.aq; a.ad = q.ad; a.abs = q.abs; a.aq_ts = q.aq_ts; a.ad_ts = q.ad_ts; a.abs_ts = q.abs_ts;
 }
 
 static TkGemvSeg seg_of(const TkDevTensor& t) { return TkGemvSeg{t.data, t.type, (int)(t.rows / TK_TILE_ROWS)}; }
@@ -264,7 +269,7 @@ void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) {
         TkGemvArgs a{};
         a.seg[0] = seg_of(L.q); a.seg[1] = seg_of(L.k); a.seg[2] = seg_of(L.v);
         a.nseg = 3; a.K = D; a.ks = h.ks_qkv; a.n_total = QD + 2 * KVD; a.nrows = nrows;
-        a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
+        set_act(a, act_d); a.out = partial;
         tk_launch_gemv(a, s);
         if (!fused_attn)
             tk_launch_qkv_rope_append(partial, h.ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
@@ -273,31 +278,31 @@ void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) {
                             h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
         TkGemvArgs o{};
         o.seg[0] = seg_of(L.o); o.nseg = 1; o.K = QD; o.ks = h.ks_o; o.n_total = D; o.nrows = nrows;
-        o.aq = act_qd.aq; o.ad = act_qd.ad; o.abs = act_qd.abs; o.out = partial;
+        set_act(o, act_qd); o.out = partial;
         tk_launch_gemv(o, s);
         tk_launch_rmsnorm_q8(x, partial, h.ks_o, D, (const float*)L.ffn_norm.data, h.rms_eps, D, nrows, act_d, s);
         TkGemvArgs gu{};
         gu.seg[0] = seg_of(L.gate); gu.seg[1] = seg_of(L.up); gu.nseg = 2; gu.K = D; gu.ks = h.ks_gateup; gu.n_total = 2 * FF; gu.nrows = nrows;
-        gu.aq = act_d.aq; gu.ad = act_d.ad; gu.abs = act_d.abs; gu.out = partial;
+        set_act(gu, act_d); gu.out = partial;
         tk_launch_gemv(gu, s);
         tk_launch_swiglu_q8(partial, h.ks_gateup, FF, nrows, act_ff, s);
         TkGemvArgs dn{};
         dn.seg[0] = seg_of(L.down); dn.nseg = 1; dn.K = FF; dn.ks = h.ks_down; dn.n_total = D; dn.nrows = nrows;
-        dn.aq = act_ff.aq; dn.ad = act_ff.ad; dn.abs = act_ff.abs; dn.out = partial;
+        set_act(dn, act_ff); dn.out = partial;
         tk_launch_gemv(dn, s);
     }
     if (!lm_head) return; /* prompt rows whose logits nobody reads: K/V are already appended */
     tk_launch_rmsnorm_q8(x, partial, h.ks_down, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
     TkGemvArgs lm{};
     lm.seg[0] = seg_of(model->output); lm.nseg = 1; lm.K = D; lm.ks = 1; lm.n_total = h.vocab; lm.nrows = nrows;
-    lm.aq = act_d.aq; lm.ad = act_d.ad; lm.abs = act_d.abs; lm.out = logits;
+    set_act(lm, act_d); lm.out = logits;
     tk_launch_gemv(lm, s);
-    tk_launch_argmax(logits, h.vocab, nrows, d_tok, d_pos, d_nsteps, d_hist, TK_ROW_SLOTS, s);
+    tk_launch_argmax(logits, h.vocab, nrows, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
 }
 
 bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
                            bool lm_head) {
-    if (nrows <= 0 || nrows > TK_ROW_SLOTS) { error = "nrows must be in [1,16]"; return false; }
+    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,32]"; return false; }
     for (int r = 0; r < nrows; ++r) {
         if (seq[r] < 0 || seq[r] >= max_seq || pos[r] < 0 || pos[r] >= max_ctx || tok[r] < 0 || tok[r] >= model->hp.vocab) {
             error = "row out of range (sequence id, position or token id)";
@@ -308,7 +313,7 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
     HIPQ(hipMemcpyAsync(d_seq, seq, nrows * 4, hipMemcpyHostToDevice, stream));
     HIPQ(hipMemcpyAsync(d_pos, pos, nrows * 4, hipMemcpyHostToDevice, stream));
     HIPQ(hipMemcpyAsync(d_tok, tok, nrows * 4, hipMemcpyHostToDevice, stream));
-    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_ROW_SLOTS * 4, stream));
+    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_MAX_ROWS * 4, stream));
     bool distinct = true; /* every sequence at most once in the pass -> rope/append can be fused into attention */
     for (int a = 0; a < nrows && distinct; ++a)
         for (int b = a + 1; b < nrows; ++b)
@@ -323,7 +328,7 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
 }
 
 bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens_host) {
-    if (nseq <= 0 || nseq > TK_ROW_SLOTS || nseq > max_seq) { error = "nseq must be in [1, min(16, max_seq)]"; return false; }
+    if (nseq <= 0 || nseq > TK_MAX_ROWS || nseq > max_seq) { error = "nseq must be in [1, min(32, max_seq)]"; return false; }
     if (n_prompt <= 0 || n_prompt >= max_ctx) { error = "prompt does not fit the context"; return false; }
     /* all but the last prompt token: 16 rows per pass, positions ascending so causality holds inside a pass */
     std::vector<int32_t> sq, ps, tk;
@@ -336,7 +341,7 @@ bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_
     for (int s = 0; s < nseq; ++s)
         for (int p = 0; p + 1 < n_prompt; ++p) {
             sq.push_back(s); ps.push_back(p); tk.push_back(tokens[(size_t)s * n_prompt + p]);
-            if ((int)sq.size() == TK_ROW_SLOTS && !flush()) return false;
+            if ((int)sq.size() == TK_MAX_ROWS && !flush()) return false;
         }
     if (!flush()) return false;
     /* last prompt token of every sequence: row r == sequence r, sampled -> decode() continues from here */
@@ -345,11 +350,11 @@ bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_
 }
 
 bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
-    if (nrows <= 0 || nrows > TK_ROW_SLOTS) { error = "nrows must be in [1,16]"; return false; }
+    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,32]"; return false; }
     if (n_steps <= 0 || n_steps > hist_cap) { error = "n_steps exceeds the session context"; return false; }
     HIPQ(hipSetDevice(model->device));
     /* positions must stay inside the cache for the whole loop */
-    int32_t hpos[TK_ROW_SLOTS];
+    int32_t hpos[TK_MAX_ROWS];
     HIPQ(hipMemcpyAsync(hpos, d_pos, nrows * 4, hipMemcpyDeviceToHost, stream));
     HIPQ(hipStreamSynchronize(stream));
     for (int r = 0; r < nrows; ++r)
@@ -365,7 +370,7 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
         HIPQ(hipGraphInstantiate(&graph_exec[nrows], g, nullptr, nullptr, 0));
         HIPQ(hipGraphDestroy(g));
     }
-    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_ROW_SLOTS * 4, stream));
+    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_MAX_ROWS * 4, stream));
     hipEvent_t e0, e1;
     HIPQ(hipEventCreate(&e0));
     HIPQ(hipEventCreate(&e1));
@@ -376,7 +381,7 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     }
     HIPQ(hipGetLastError());
     HIPQ(hipEventRecord(e1, stream));
-    if (out_tokens_host) HIPQ(hipMemcpyAsync(out_tokens_host, d_hist, (size_t)n_steps * TK_ROW_SLOTS * 4, hipMemcpyDeviceToHost, stream));
+    if (out_tokens_host) HIPQ(hipMemcpyAsync(out_tokens_host, d_hist, (size_t)n_steps * TK_MAX_ROWS * 4, hipMemcpyDeviceToHost, stream));
     HIPQ(hipStreamSynchronize(stream));
     float ms = 0.0f;
     HIPQ(hipEventElapsedTime(&ms, e0, e1));
@@ -388,7 +393,7 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
 
 bool TkLlmSession::time_gemv(int layer, int which, int nrows, int iters, float* avg_ms, double* algo_bytes) {
     const TkLlmHParams& h = model->hp;
-    if (layer < 0 || layer >= h.n_layer || nrows < 1 || nrows > TK_ROW_SLOTS) { error = "bad layer / nrows"; return false; }
+    if (layer < 0 || layer >= h.n_layer || nrows < 1 || nrows > TK_MAX_ROWS) { error = "bad layer / nrows"; return false; }
     HIPQ(hipSetDevice(model->device));
     auto args_for = [&](int l, double* bytes) {
         const TkLlmLayer& L = model->layers[l];
@@ -396,24 +401,24 @@ bool TkLlmSession::time_gemv(int layer, int which, int nrows, int iters, float* 
         a.nrows = nrows;
         if (which == 0) { /* gate+up */
             a.seg[0] = seg_of(L.gate); a.seg[1] = seg_of(L.up); a.nseg = 2; a.K = h.d_model; a.ks = h.ks_gateup; a.n_total = 2 * h.d_ff;
-            a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
+            set_act(a, act_d); a.out = partial;
             *bytes = (double)L.gate.bytes + (double)L.up.bytes;
         } else if (which == 1) { /* down */
             a.seg[0] = seg_of(L.down); a.nseg = 1; a.K = h.d_ff; a.ks = h.ks_down; a.n_total = h.d_model;
-            a.aq = act_ff.aq; a.ad = act_ff.ad; a.abs = act_ff.abs; a.out = partial;
+            set_act(a, act_ff); a.out = partial;
             *bytes = (double)L.down.bytes;
         } else if (which == 4) { /* o */
             a.seg[0] = seg_of(L.o); a.nseg = 1; a.K = h.n_head * h.head_dim; a.ks = h.ks_o; a.n_total = h.d_model;
-            a.aq = act_qd.aq; a.ad = act_qd.ad; a.abs = act_qd.abs; a.out = partial;
+            set_act(a, act_qd); a.out = partial;
             *bytes = (double)L.o.bytes;
         } else if (which == 2) { /* qkv */
             a.seg[0] = seg_of(L.q); a.seg[1] = seg_of(L.k); a.seg[2] = seg_of(L.v); a.nseg = 3; a.K = h.d_model; a.ks = h.ks_qkv;
             a.n_total = (h.n_head + 2 * h.n_kv_head) * h.head_dim;
-            a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = partial;
+            set_act(a, act_d); a.out = partial;
             *bytes = (double)L.q.bytes + (double)L.k.bytes + (double)L.v.bytes;
         } else { /* lm head */
             a.seg[0] = seg_of(model->output); a.nseg = 1; a.K = h.d_model; a.ks = 1; a.n_total = h.vocab;
-            a.aq = act_d.aq; a.ad = act_d.ad; a.abs = act_d.abs; a.out = logits;
+            set_act(a, act_d); a.out = logits;
             *bytes = (double)model->output.bytes;
         }
         return a;

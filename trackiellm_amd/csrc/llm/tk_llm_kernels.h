@@ -23,7 +23,8 @@ struct TkGemvArgs {
     int K;        /* reduction length, multiple of 256*ks */
     int ks;       /* K-split count: partial sums land in out[ks][16][n_total] */
     int n_total;  /* sum of rows over segments */
-    int nrows;    /* live row slots (<= 16) */
+    int nrows;    /* live rows (<= TK_MAX_ROWS); rows 16.. use the second M-tile */
+    size_t aq_ts, ad_ts, abs_ts; /* M-tile strides of aq (bytes), ad (floats), abs (ints) */
     const int8_t* aq;
     const float* ad;
     const int32_t* abs;
@@ -34,6 +35,7 @@ struct TkActQ8 { /* quantised-activation buffers for one K */
     int8_t* aq;
     float* ad;
     int32_t* abs;
+    size_t aq_ts, ad_ts, abs_ts; /* M-tile strides */
 };
 
 /* weights */
@@ -56,6 +58,6 @@ void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ
 void tk_launch_argmax(const float* logits, int vocab, int nrows, int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride,
                       hipStream_t s);
 
-size_t tk_gemv_lds_bytes(int K, int ks);
+size_t tk_gemv_lds_bytes(int K, int ks, int mtiles);
 
 #endif

@@ -14,6 +14,8 @@
 #include "tk_llm_kernels.h"
 
 #include "../common/tk_exact_math.h"
+#include <stdlib.h>
+
 #include "../common/tk_ggml_blocks.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -178,11 +180,12 @@ __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot,
     }
     uint32_t lo = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) | ((uint32_t)(q[3] & 255) << 24);
     uint32_t hi = (uint32_t)(q[4] & 255) | ((uint32_t)(q[5] & 255) << 8) | ((uint32_t)(q[6] & 255) << 16) | ((uint32_t)(q[7] & 255) << 24);
-    *(uint2*)(out.aq + ((size_t)c * TK_ROW_SLOTS + slot) * 8) = make_uint2(lo, hi);
+    const int mt = slot >> 4, sl = slot & 15; /* M-tile and slot inside it */
+    *(uint2*)(out.aq + mt * out.aq_ts + ((size_t)c * TK_ROW_SLOTS + sl) * 8) = make_uint2(lo, hi);
     sum += __shfl_xor(sum, 1, TK_WAVE);
     sum += __shfl_xor(sum, 2, TK_WAVE);
-    if ((c & 3) == 0) out.abs[(size_t)(c >> 2) * TK_ROW_SLOTS + slot] = sum;
-    if ((c & 31) == 0) out.ad[(size_t)(c >> 5) * TK_ROW_SLOTS + slot] = amax > 0.0f ? tk_divf(amax, 127.0f) : 0.0f;
+    if ((c & 3) == 0) out.abs[mt * out.abs_ts + (size_t)(c >> 2) * TK_ROW_SLOTS + sl] = sum;
+    if ((c & 31) == 0) out.ad[mt * out.ad_ts + (size_t)(c >> 5) * TK_ROW_SLOTS + sl] = amax > 0.0f ? tk_divf(amax, 127.0f) : 0.0f;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_q8(float* __restrict__ x, const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int g = g0 + t + 256 * e;
-                    p[e] = live[e] ? *(const v4f*)(partial + ((int64_t)s * TK_ROW_SLOTS + r) * n_total + 4 * g) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                    p[e] = live[e] ? *(const v4f*)(partial + ((int64_t)s * TK_MAX_ROWS + r) * n_total + 4 * g) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = o[e] + p[e];
@@ -315,6 +318,8 @@ __device__ __forceinline__ FragQ6 load_q6(const uint8_t* tile, int lane) {
 
 __device__ __forceinline__ float f16bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
 
+/* one weight tile x one 16-row M-tile; a pass with two M-tiles calls it twice per tile (the nibble unpack is repeated,
+ * ~15 % more VALU, but the live register set stays that of a single tile: no spills at 4 tiles in flight) */
 __device__ __forceinline__ void block_q4(const FragQ4& f, const uint8_t* lds_act, const int* lds_abs, const float* lds_ad, int blk, int lane,
                                          float* acc) {
     const int g = lane >> 4;
@@ -392,9 +397,9 @@ __device__ __forceinline__ void block_q6(const FragQ6& f, const uint8_t* lds_act
     }
 }
 
-size_t tk_gemv_lds_bytes(int K, int ks) {
+size_t tk_gemv_lds_bytes(int K, int ks, int mtiles) {
     size_t Kr = (size_t)K / ks;
-    return Kr * TK_ROW_SLOTS + (Kr / 256) * TK_ROW_SLOTS * 4 + (Kr / 32) * TK_ROW_SLOTS * 4;
+    return (size_t)mtiles * (Kr * TK_ROW_SLOTS + (Kr / 256) * TK_ROW_SLOTS * 4 + (Kr / 32) * TK_ROW_SLOTS * 4);
 }
 
 /*
@@ -403,7 +408,8 @@ size_t tk_gemv_lds_bytes(int K, int ks) {
  * so (a) every CU streams the same number of 16-row tiles (+-1), (b) the K-range's int8 activations are
  * staged once per CU, (c) all waves of a CU walk disjoint contiguous tile runs.
  */
-template <int PF>
+/* TYPES: bit 0 = the launch contains Q4_K tiles, bit 1 = Q6_K tiles; single-type launches keep only one fragment ring in registers */
+template <int PF, int MT, int TYPES>
 __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int total_row_tiles) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
@@ -426,104 +432,148 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
         ++seg;
     }
     const int type = a.seg[seg].type;
-    const size_t tile_bytes = type == TK_TYPE_Q4_K ? TK_Q4K_TILE_BYTES : TK_Q6K_TILE_BYTES;
+    /* compile-time tile pitch in single-type launches: tile addresses become scalar base + immediate */
+    const size_t tile_bytes = TYPES == 1 ? (size_t)TK_Q4K_TILE_BYTES : TYPES == 2 ? (size_t)TK_Q6K_TILE_BYTES
+                                         : (type == TK_TYPE_Q4_K ? (size_t)TK_Q4K_TILE_BYTES : (size_t)TK_Q6K_TILE_BYTES);
     const uint8_t* tile = a.seg[seg].tiles + ((size_t)rt * nblk_total + blk0) * tile_bytes;
 
+    /* LDS: [MT] activation images, then [MT] block scales, then [MT] sub-block sums */
+    const size_t act_ts = (size_t)Kr * TK_ROW_SLOTS;
+    const int ad_ts = nb * TK_ROW_SLOTS, abs_ts = nb * 8 * TK_ROW_SLOTS;
     uint8_t* lds_act = lds;
-    float* lds_ad = (float*)(lds + (size_t)Kr * TK_ROW_SLOTS);
-    int* lds_abs = (int*)(lds_ad + nb * TK_ROW_SLOTS);
+    float* lds_ad = (float*)(lds + MT * act_ts);
+    int* lds_abs = (int*)(lds_ad + MT * ad_ts);
 
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][r] = 0.0f;
 
     /* The first PF weight tiles are requested before the activations are staged so HBM latency overlaps the LDS
      * fill.  Loop bodies below contain NO conditional loads: hipcc then keeps counted vmcnt waits and the next
      * group's tiles stay in flight under the current group's MFMAs (a branch around a load costs a vmcnt(0)). */
-    FragQ4 f4[PF];
-    FragQ6 f6[PF];
-    if (type == TK_TYPE_Q4_K) {
+    constexpr bool HAS4 = (TYPES & 1) != 0, HAS6 = (TYPES & 2) != 0;
+    const bool is4 = HAS4 && (!HAS6 || type == TK_TYPE_Q4_K);
+    FragQ4 f4[HAS4 ? PF : 1];
+    FragQ6 f6[HAS6 ? PF : 1];
+    if (HAS4 && is4) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) f4[u] = load_q4(tile + (size_t)u * tile_bytes, lane);
-    } else {
+        for (int u = 0; u < PF; ++u) f4[HAS4 ? u : 0] = load_q4(tile + (size_t)u * tile_bytes, lane);
+    }
+    if (HAS6 && !is4) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) f6[u] = load_q6(tile + (size_t)u * tile_bytes, lane);
+        for (int u = 0; u < PF; ++u) f6[HAS6 ? u : 0] = load_q6(tile + (size_t)u * tile_bytes, lane);
     }
     {
         /* activations: LDS-DMA (global_load_lds_dwordx4), one contiguous 1 KiB piece per wave-instruction, no VGPR
          * round trip and no per-piece wait: the whole K-range image is in flight at once. */
-        const uint8_t* src = (const uint8_t*)a.aq + (size_t)blk0 * 256 * TK_ROW_SLOTS;
         const int nw = nthr >> 6, npiece = Kr * TK_ROW_SLOTS / 1024;
-        for (int c = wave; c < npiece; c += nw)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(lds_act + c * 1024), 16, 0, 0);
-        /* block scales and sub-block sums: <= 2 x 16 B per thread, loaded together, stored together */
-        const uint4* sd = (const uint4*)(a.ad + (size_t)blk0 * TK_ROW_SLOTS);
-        const uint4* sb = (const uint4*)(a.abs + (size_t)blk0 * 8 * TK_ROW_SLOTS);
         const int nd = nb * 4, ns = nb * 32;
-        uint4 t0 = make_uint4(0, 0, 0, 0), t1[4];
-        if (tid < nd) t0 = sd[tid];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t1[k] = (tid + k * nthr < ns) ? sb[tid + k * nthr] : make_uint4(0, 0, 0, 0);
-        if (tid < nd) ((uint4*)lds_ad)[tid] = t0;
+        for (int m = 0; m < MT; ++m) {
+            const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)blk0 * 256 * TK_ROW_SLOTS;
+            for (int c = wave; c < npiece; c += nw)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(lds_act + m * act_ts + c * 1024), 16, 0, 0);
+        }
+        /* block scales and sub-block sums: <= 5 x 16 B per thread and tile, loaded together, stored together */
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (tid + k * nthr < ns) ((uint4*)lds_abs)[tid + k * nthr] = t1[k];
+        for (int m = 0; m < MT; ++m) {
+            const uint4* sd = (const uint4*)(a.ad + m * a.ad_ts + (size_t)blk0 * TK_ROW_SLOTS);
+            const uint4* sb = (const uint4*)(a.abs + m * a.abs_ts + (size_t)blk0 * 8 * TK_ROW_SLOTS);
+            uint4 t0 = make_uint4(0, 0, 0, 0), t1[4];
+            if (tid < nd) t0 = sd[tid];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t1[k] = (tid + k * nthr < ns) ? sb[tid + k * nthr] : make_uint4(0, 0, 0, 0);
+            if (tid < nd) ((uint4*)(lds_ad + m * ad_ts))[tid] = t0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tid + k * nthr < ns) ((uint4*)(lds_abs + m * abs_ts))[tid + k * nthr] = t1[k];
+        }
         __builtin_amdgcn_s_waitcnt(0); /* vmcnt(0): the LDS-DMA pieces have landed (the first weight tiles too) */
     }
     __syncthreads();
     if (!active) return;
 
-    if (type == TK_TYPE_Q4_K) {
-        for (int g = 0; g < ngrp - 1; ++g) {
+    if (HAS4 && is4) {
+        const uint8_t* tp = tile + PF * tile_bytes; /* one moving wave-uniform pointer: no per-load 64-bit VGPR address chains */
+#pragma unroll 1
+        for (int g = 0; g < ngrp - 1; ++g, tp += PF * tile_bytes) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                block_q4(f4[u], lds_act, lds_abs, lds_ad, g * PF + u, lane, acc);
-                f4[u] = load_q4(tile + (size_t)((g + 1) * PF + u) * tile_bytes, lane);
+                for (int m = 0; m < MT; ++m) { __builtin_amdgcn_sched_barrier(0); block_q4(f4[HAS4 ? u : 0], lds_act + m * act_ts, lds_abs + m * abs_ts, lds_ad + m * ad_ts, g * PF + u, lane, acc[m]); }
+                __builtin_amdgcn_sched_barrier(0);
+                f4[HAS4 ? u : 0] = load_q4(tp + u * tile_bytes, lane);
             }
         }
 #pragma unroll
-        for (int u = 0; u < PF; ++u) block_q4(f4[u], lds_act, lds_abs, lds_ad, (ngrp - 1) * PF + u, lane, acc);
-    } else {
-        for (int g = 0; g < ngrp - 1; ++g) {
+        for (int u = 0; u < PF; ++u) for (int m = 0; m < MT; ++m) { __builtin_amdgcn_sched_barrier(0); block_q4(f4[HAS4 ? u : 0], lds_act + m * act_ts, lds_abs + m * abs_ts, lds_ad + m * ad_ts, (ngrp - 1) * PF + u, lane, acc[m]); }
+    }
+    if (HAS6 && !is4) {
+        const uint8_t* tp = tile + PF * tile_bytes;
+#pragma unroll 1
+        for (int g = 0; g < ngrp - 1; ++g, tp += PF * tile_bytes) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                block_q6(f6[u], lds_act, lds_ad, g * PF + u, lane, acc);
-                f6[u] = load_q6(tile + (size_t)((g + 1) * PF + u) * tile_bytes, lane);
+                for (int m = 0; m < MT; ++m) { __builtin_amdgcn_sched_barrier(0); block_q6(f6[HAS6 ? u : 0], lds_act + m * act_ts, lds_ad + m * ad_ts, g * PF + u, lane, acc[m]); }
+                __builtin_amdgcn_sched_barrier(0);
+                f6[HAS6 ? u : 0] = load_q6(tp + u * tile_bytes, lane);
             }
         }
 #pragma unroll
-        for (int u = 0; u < PF; ++u) block_q6(f6[u], lds_act, lds_ad, (ngrp - 1) * PF + u, lane, acc);
+        for (int u = 0; u < PF; ++u) for (int m = 0; m < MT; ++m) { __builtin_amdgcn_sched_barrier(0); block_q6(f6[HAS6 ? u : 0], lds_act + m * act_ts, lds_ad + m * ad_ts, (ngrp - 1) * PF + u, lane, acc[m]); }
     }
 
     const int n = row_base + rt * TK_TILE_ROWS + (lane & 15);
     const int g = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int slot = 4 * g + r;
-        if (slot < a.nrows) a.out[((size_t)ksi * TK_ROW_SLOTS + slot) * a.n_total + n] = acc[r];
-    }
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m * TK_ROW_SLOTS + 4 * g + r;
+            if (row < a.nrows) a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n] = acc[m][r];
+        }
 }
 
 #define TK_NUM_CU 256
 void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     int row_tiles = 0;
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.seg[i].row_tiles;
-    size_t lds = tk_gemv_lds_bytes(a.K, a.ks);
-    static size_t lds_cap = 0; /* >64 KiB of dynamic LDS must be opted into once per process */
-    if (lds > lds_cap) {
-        (void)hipFuncSetAttribute((const void*)k_gemv_w4a8<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_gemv_w4a8<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_gemv_w4a8<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_cap = lds;
-    }
+    const int mt = a.nrows > TK_ROW_SLOTS ? 2 : 1;
+    size_t lds = tk_gemv_lds_bytes(a.K, a.ks, mt);
     int groups = TK_NUM_CU / a.ks;            /* workgroups per K-range */
     if (groups < 1) groups = 1;
     if (groups > row_tiles) groups = row_tiles;
     int waves = (row_tiles + groups - 1) / groups;
     while (waves > 8) { groups *= 2; waves = (row_tiles + groups - 1) / groups; } /* tall matrices: more than one WG per CU */
     const int nb = a.K / a.ks / 256;
-    if (nb % 4 == 0) hipLaunchKernelGGL(k_gemv_w4a8<4>, dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles);
-    else if (nb % 2 == 0) hipLaunchKernelGGL(k_gemv_w4a8<2>, dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles);
-    else hipLaunchKernelGGL(k_gemv_w4a8<1>, dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles);
+    /* tiles in flight per wave: the largest depth the register file holds without spilling for this M-tile count
+     * (tuning overrides: TK_GEMV_PF1 / TK_GEMV_PF2 = depth cap for 1 / 2 M-tiles, TK_GEMV_MIXED=1 forces the two-type kernel) */
+    static int cap1 = -1, cap2 = -1, force_mixed = -1;
+    if (cap1 < 0) {
+        const char* e1 = getenv("TK_GEMV_PF1"); const char* e2 = getenv("TK_GEMV_PF2"); const char* e3 = getenv("TK_GEMV_MIXED");
+        cap1 = e1 ? atoi(e1) : 2; cap2 = e2 ? atoi(e2) : 2; force_mixed = e3 ? atoi(e3) : -1;
+    }
+    const int cap = mt == 1 ? cap1 : cap2;
+    int pf = nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1);
+    while (pf > cap) pf /= 2;
+    int types = 0;
+    for (int i = 0; i < a.nseg; ++i) types |= a.seg[i].type == TK_TYPE_Q4_K ? 1 : 2;
+    /* measured on MI355X (profiles/r01_gemv_variants.txt): depth 2 never spills; with two M-tiles only the two-type kernel stays
+     * inside 256 VGPRs, so it is used for every 2-tile launch */
+    if (force_mixed > 0 || (force_mixed < 0 && mt == 2)) types = 3;
+#define TK_GEMV_LAUNCH(PFV, MTV, TYV)                                                                                              \
+    do {                                                                                                                           \
+        static size_t cap = 0; /* >64 KiB of dynamic LDS must be opted into once per kernel */                                     \
+        if (lds > cap) { (void)hipFuncSetAttribute((const void*)k_gemv_w4a8<PFV, MTV, TYV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cap = lds; } \
+        hipLaunchKernelGGL((k_gemv_w4a8<PFV, MTV, TYV>), dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles);      \
+    } while (0)
+#define TK_GEMV_TY(PFV, MTV) do { if (types == 1) TK_GEMV_LAUNCH(PFV, MTV, 1); else if (types == 2) TK_GEMV_LAUNCH(PFV, MTV, 2); else TK_GEMV_LAUNCH(PFV, MTV, 3); } while (0)
+    if (mt == 1) { if (pf == 4) TK_GEMV_TY(4, 1); else if (pf == 2) TK_GEMV_TY(2, 1); else TK_GEMV_TY(1, 1); }
+    else { if (pf == 4) TK_GEMV_TY(4, 2); else if (pf == 2) TK_GEMV_TY(2, 2); else TK_GEMV_TY(1, 2); }
+#undef TK_GEMV_TY
+#undef TK_GEMV_LAUNCH
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -532,7 +582,7 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
  * ------------------------------------------------------------------------------------------ */
 __device__ __forceinline__ float sum_partials(const float* partial, int ks, int n_total, int row, int col) {
     float o = partial[(int64_t)row * n_total + col];
-    for (int s = 1; s < ks; ++s) o = o + partial[((int64_t)s * TK_ROW_SLOTS + row) * n_total + col];
+    for (int s = 1; s < ks; ++s) o = o + partial[((int64_t)s * TK_MAX_ROWS + row) * n_total + col];
     return o;
 }
 
@@ -598,8 +648,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     extern __shared__ float sh[];
     const int vh = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
     constexpr int grp = GRP;
-    const int per_kv = (n_head / n_kv_head) / grp;   /* workgroups per KV head */
-    const int kvh = vh / per_kv;
+    const int kvh = vh / ((n_head / n_kv_head) / grp); /* several workgroups may share a KV head */
     const int p = pos[r], T = p + 1, sq = seq[r];
     const int W = grp * head_dim;              /* outputs of this WG */
     float* qs = sh;                            /* [grp][head_dim] */
@@ -608,8 +657,6 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     float* part = red + 4 * TK_ATT_MAX_GRP;    /* [TSPLIT][W] partial outputs */
     float* lpart = part + TK_ATT_TSPLIT * W;   /* [TSPLIT][grp] partial denominators */
     float* obuf = lpart + TK_ATT_TSPLIT * TK_ATT_MAX_GRP; /* [W] */
-    float* kcur = obuf + W;                    /* [head_dim] own position, f16-rounded (FUSED) */
-    float* vcur = kcur + head_dim;
     const int QD = n_head * head_dim, KVD = n_kv_head * head_dim, half = head_dim / 2;
     const int64_t rowstride = (int64_t)n_kv_head * head_dim;
     const int64_t sbase = (((int64_t)layer * max_seq + sq) * max_ctx) * rowstride + (int64_t)kvh * head_dim;
@@ -627,15 +674,12 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
                 const int col = QD + kvh * head_dim + 2 * i;
                 const float a = sum_partials(partial, ks, n_total, r, col), b = sum_partials(partial, ks, n_total, r, col + 1);
                 const uint16_t k0 = tk_f32_to_f16(tk_fmaf(-b, sn[i], a * cs[i])), k1 = tk_f32_to_f16(tk_fmaf(a, sn[i], b * cs[i]));
-                kcur[2 * i] = f16bits_to_f32(k0);
-                kcur[2 * i + 1] = f16bits_to_f32(k1);
-                if (vh % per_kv == 0) *(uint32_t*)(kcache + sbase + (int64_t)p * rowstride + 2 * i) = (uint32_t)k0 | ((uint32_t)k1 << 16);
+                /* every workgroup of the KV group stores the (identical) row: it re-reads its own store after the barrier */
+                *(uint32_t*)(kcache + sbase + (int64_t)p * rowstride + 2 * i) = (uint32_t)k0 | ((uint32_t)k1 << 16);
             } else {
                 const int col = QD + KVD + kvh * head_dim + 2 * i;
                 const uint16_t v0 = tk_f32_to_f16(sum_partials(partial, ks, n_total, r, col)), v1 = tk_f32_to_f16(sum_partials(partial, ks, n_total, r, col + 1));
-                vcur[2 * i] = f16bits_to_f32(v0);
-                vcur[2 * i + 1] = f16bits_to_f32(v1);
-                if (vh % per_kv == 0) *(uint32_t*)(vcache + sbase + (int64_t)p * rowstride + 2 * i) = (uint32_t)v0 | ((uint32_t)v1 << 16);
+                *(uint32_t*)(vcache + sbase + (int64_t)p * rowstride + 2 * i) = (uint32_t)v0 | ((uint32_t)v1 << 16);
             }
         }
     } else {
@@ -643,7 +687,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     }
     __syncthreads();
     const float att_scale = tk_divf(1.0f, tk_sqrtf((float)head_dim));
-    const int Tc = FUSED ? T - 1 : T; /* positions served by the cache */
+    const int Tc = T; /* every position, the row's own included, is served by the cache (global stores are visible after the barrier) */
     float mx[GRP];
 #pragma unroll
     for (int h = 0; h < grp; ++h) mx[h] = -INFINITY;
@@ -651,7 +695,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
         float a[GRP];
 #pragma unroll
         for (int h = 0; h < grp; ++h) a[h] = 0.0f;
-        if (tt < Tc) {
+        {
             const uint16_t* kr = kcache + sbase + (int64_t)tt * rowstride;
             for (int i0 = 0; i0 < head_dim; i0 += 64) { /* 8 x 16 B of the key row in flight per pass */
                 uint4 kv[8];
@@ -667,12 +711,6 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
                         for (int h = 0; h < grp; ++h) a[h] = tk_fmaf(qs[h * head_dim + i0 + 8 * u + e], kf, a[h]);
                     }
                 }
-            }
-        } else {
-            for (int i = 0; i < head_dim; ++i) {
-                const float kf = kcur[i];
-#pragma unroll
-                for (int h = 0; h < grp; ++h) a[h] = tk_fmaf(qs[h * head_dim + i], kf, a[h]);
             }
         }
 #pragma unroll
@@ -719,7 +757,6 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
                 for (int u = 0; u < 16; ++u) {
                     const int pu = tt + u * TK_ATT_TSPLIT;
                     float v0 = f16bits_to_f32(vv[u] & 0xffffu), v1 = f16bits_to_f32(vv[u] >> 16);
-                    if (FUSED && pu == Tc) { v0 = vcur[d0]; v1 = vcur[d0 + 1]; }
                     const bool live = pu < T;
 #pragma unroll
                     for (int h = 0; h < grp; ++h) {

@@ -31,7 +31,8 @@
  *                    one contiguous run that is memcpy'd into LDS
  *      ad  : float  [K/256][16]        block scale amax/127
  *      abs : int32  [K/32][16]         per-sub-block sums of the int8 values (the Q4_K "min" term)
- *  "row slot" b < 16 is a (sequence, position) row of the current pass.
+ *  "row slot" b < 16 is a (sequence, position) row of the current pass; a pass holds up to TK_MAX_TILES such
+ *  16-row M-tiles (row r lives in tile r / 16, slot r % 16), each with its own aq / ad / abs image.
  */
 #ifndef TK_LLM_LAYOUT_H
 #define TK_LLM_LAYOUT_H
@@ -41,8 +42,11 @@
 #define TK_TILE_ROWS 16
 #define TK_Q4K_TILE_BYTES 2304
 #define TK_Q6K_TILE_BYTES 3360
-#define TK_ROW_SLOTS 16
+#define TK_ROW_SLOTS 16  /* rows of one MFMA M-tile */
+#define TK_MAX_TILES 2   /* M-tiles per pass: a weight tile is unpacked once and multiplied against both */
+#define TK_MAX_ROWS (TK_ROW_SLOTS * TK_MAX_TILES)
 
+/* per M-tile sizes; tile m of a buffer starts at m * (these) */
 #define TK_AQ_BYTES(K) ((size_t)(K) * TK_ROW_SLOTS)
 #define TK_AD_FLOATS(K) ((size_t)(K) / 256 * TK_ROW_SLOTS)
 #define TK_ABS_INTS(K) ((size_t)(K) / 32 * TK_ROW_SLOTS)
