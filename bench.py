@@ -190,8 +190,13 @@ def main():
             launches += cnt
     avg_ms = total_ms / launches
     achieved = total_bytes / total_ms / 1e6  # GB/s
+    # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction applied)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
+    if os.path.exists(pmc) and B > 16:
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_average_launch")
     roofline = {"bound": "hbm", "kernel": "k_gemv_w4a8", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(total_bytes / launches), "avg_launch_ms": round(avg_ms, 5),
                 "launches_per_decode_step": launches, "per_shape": shapes}
 
