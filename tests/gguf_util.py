@@ -1,0 +1,98 @@
+"""Minimal GGUF v3 writer for tests (public GGUF specification; test infrastructure only)."""
+import struct
+
+import numpy as np
+
+GGUF_U32, GGUF_F32, GGUF_STRING, GGUF_ARRAY, GGUF_I32 = 4, 6, 8, 9, 5
+
+
+def _s(b):
+    b = b.encode() if isinstance(b, str) else b
+    return struct.pack("<Q", len(b)) + b
+
+
+def write_gguf(path, kv, tensors, align=32):
+    """kv: list of (key, type, value); tensors: list of (name, dims(ne0 first), ggml_type, bytes)"""
+    out = bytearray(b"GGUF" + struct.pack("<IQQ", 3, len(tensors), len(kv)))
+    for key, t, v in kv:
+        out += _s(key) + struct.pack("<I", t)
+        if t == GGUF_U32:
+            out += struct.pack("<I", v)
+        elif t == GGUF_I32:
+            out += struct.pack("<i", v)
+        elif t == GGUF_F32:
+            out += struct.pack("<f", v)
+        elif t == GGUF_STRING:
+            out += _s(v)
+        elif t == GGUF_ARRAY:
+            et, items = v
+            out += struct.pack("<IQ", et, len(items))
+            if et == GGUF_STRING:
+                for it in items:
+                    out += _s(it)
+            elif et == GGUF_F32:
+                out += np.asarray(items, np.float32).tobytes()
+            elif et == GGUF_I32:
+                out += np.asarray(items, np.int32).tobytes()
+    off = 0
+    offs = []
+    for name, dims, typ, data in tensors:
+        offs.append(off)
+        off += (len(data) + align - 1) // align * align
+    for (name, dims, typ, data), o in zip(tensors, offs):
+        out += _s(name) + struct.pack("<I", len(dims)) + b"".join(struct.pack("<Q", d) for d in dims) + struct.pack("<IQ", typ, o)
+    out += b"\0" * ((-len(out)) % align)
+    for name, dims, typ, data in tensors:
+        out += bytes(data) + b"\0" * ((-len(data)) % align)
+    open(path, "wb").write(bytes(out))
+
+
+def test_vocab(vocab):
+    toks = ["<unk>", "<s>", "</s>"] + ["<0x%02X>" % b for b in range(256)] + ["▁", "▁he", "llo", "▁hello", "he", "l", "o", "h", "e",
+                                                                               "▁w", "or", "ld", "▁world", "w", "r", "d"]
+    toks += ["tok%d" % i for i in range(len(toks), vocab)]
+    return toks[:vocab]
+
+
+def expected_piece(vocab, tid):
+    if tid < 3:
+        return b""
+    if tid < 259:
+        return bytes([tid - 3])
+    return test_vocab(vocab)[tid].replace("▁", " ").encode()
+
+
+def write_llama_gguf(path, orc, cfg, with_vocab=True):
+    """serialise an OracleLlm (tests/oracle_lib.py) as a llama-architecture GGUF"""
+    import oracle_lib as O
+    names = ["attn_norm", "attn_q", "attn_k", "attn_v", "attn_output", "ffn_norm", "ffn_gate", "ffn_up", "ffn_down"]
+    kv = [("general.architecture", GGUF_STRING, "llama"), ("llama.block_count", GGUF_U32, cfg.n_layer),
+          ("llama.embedding_length", GGUF_U32, cfg.d_model), ("llama.feed_forward_length", GGUF_U32, cfg.d_ff),
+          ("llama.attention.head_count", GGUF_U32, cfg.n_head), ("llama.attention.head_count_kv", GGUF_U32, cfg.n_kv_head),
+          ("llama.rope.dimension_count", GGUF_U32, cfg.head_dim), ("llama.context_length", GGUF_U32, 4096),
+          ("llama.attention.layer_norm_rms_epsilon", GGUF_F32, cfg.rms_eps), ("llama.rope.freq_base", GGUF_F32, cfg.rope_theta)]
+    if with_vocab:
+        toks = ["<unk>", "<s>", "</s>"] + ["<0x%02X>" % b for b in range(256)] + ["▁", "▁he", "llo", "▁hello", "he", "l", "o", "h", "e",
+                                                                                   "▁w", "or", "ld", "▁world", "w", "r", "d"]
+        toks += ["tok%d" % i for i in range(len(toks), cfg.vocab)]
+        scores = [0.0] * 259 + [-1.0, -2.0, -3.0, -1.5, -4.0, -9.0, -9.0, -9.0, -9.0, -5.0, -6.0, -7.0, -2.5, -9.0, -9.0, -9.0]
+        scores += [-100.0] * (cfg.vocab - len(scores))
+        types = [2, 3, 3] + [6] * 256 + [1] * (cfg.vocab - 259)
+        kv += [("tokenizer.ggml.model", GGUF_STRING, "llama"), ("tokenizer.ggml.tokens", GGUF_ARRAY, (GGUF_STRING, toks[:cfg.vocab])),
+               ("tokenizer.ggml.scores", GGUF_ARRAY, (GGUF_F32, scores[:cfg.vocab])), ("tokenizer.ggml.token_type", GGUF_ARRAY, (GGUF_I32, types[:cfg.vocab])),
+               ("tokenizer.ggml.bos_token_id", GGUF_U32, 1), ("tokenizer.ggml.eos_token_id", GGUF_U32, 2)]
+    tensors = []
+
+    def add(name, layer, which, rows, cols):
+        t, buf = orc.get_tensor(layer, which)
+        tensors.append((name, [cols, rows] if rows > 1 else [cols], t, buf.tobytes()))
+
+    D, QD, KVD, FF, V = cfg.d_model, cfg.n_head * cfg.head_dim, cfg.n_kv_head * cfg.head_dim, cfg.d_ff, cfg.vocab
+    add("token_embd.weight", -1, O.T_TOKEN_EMBD, V, D)
+    add("output_norm.weight", -1, O.T_OUT_NORM, 1, D)
+    add("output.weight", -1, O.T_OUTPUT, V, D)
+    shapes = [(1, D), (QD, D), (KVD, D), (KVD, D), (D, QD), (1, D), (FF, D), (FF, D), (D, FF)]
+    for l in range(cfg.n_layer):
+        for w, (r, c) in enumerate(shapes):
+            add(f"blk.{l}.{names[w]}.weight", l, w, r, c)
+    write_gguf(path, kv, tensors)

@@ -188,3 +188,36 @@ def test_error_paths(gpu):
     with pytest.raises(gpu.TkError):  # 33 rows
         sess.forward(np.zeros(33, np.int32), np.arange(33, dtype=np.int32) % 16, np.full(33, 5, np.int32))
     assert gpu.lib().tk_mi355x_llm_forward(None, 1, None, None, None, None, None) == 1001
+
+
+def test_gguf_checkpoint_end_to_end(gpu, tmp_path):
+    """a GGUF file (llama arch, Q4_K/Q6_K/F32 tensors, SentencePiece vocab) through tk_model_loader + tk_llm_runner"""
+    import gguf_util
+    cfg = O.tiny_config()
+    orc = O.OracleLlm(cfg, seed=4)
+    path = str(tmp_path / "tiny.gguf")
+    gguf_util.write_llama_gguf(path, orc, cfg)
+    loader = gpu.ModelLoader()
+    h = loader.load(path)
+    hp = gpu.LlmHParams()
+    gpu.lib().tk_mi355x_llm_model_get_hparams(h, __import__("ctypes").byref(hp))
+    orc2 = O.OracleLlm(oracle_cfg_from(hp, 64, 1), seed=4)
+    runner = gpu.LlmRunner(h, context_size=64)
+    runner.prepare("hello world")
+    # llama SPM: " hello world" -> [bos, "▁hello", "▁world"]
+    ids = [1, 259 + 3, 259 + 12]
+    _, am = orc2.forward([0, 0, 0], [0, 1, 2], ids, want_logits=False)
+    cur = int(am[-1])
+    for i in range(6):
+        piece = runner.next_token()
+        if cur == 2:
+            assert piece is None
+            break
+        assert piece == gguf_util.expected_piece(cfg.vocab, cur), (i, cur, piece)
+        _, am = orc2.forward([0], [3 + i], [cur], want_logits=False)
+        cur = int(am[0])
+    runner.close()
+    loader.unload(h)
+    loader.close()
+    with pytest.raises(gpu.TkError):
+        gpu.ModelLoader().load(str(tmp_path / "nope.gguf"))
