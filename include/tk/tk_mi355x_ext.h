@@ -37,6 +37,8 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_set_tensor(tk_mi355x_llm
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_load_gguf(tk_mi355x_llm_model_t** out, const char* path, int device);
 /* parses GGUF metadata only (runs without a GPU); n_vocab_tokens optional */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_gguf_probe(const char* path, tk_mi355x_llm_hparams_t* out, int32_t* n_vocab_tokens);
+/* token ids of `text` under the vocabulary of a GGUF file (CPU only); returns the count (may exceed cap) or -1 */
+TK_API int tk_mi355x_gguf_tokenize(const char* path, const char* text, int add_bos, int32_t* ids, int cap);
 TK_API void tk_mi355x_llm_model_get_hparams(const tk_mi355x_llm_model_t* m, tk_mi355x_llm_hparams_t* out);
 TK_API uint64_t tk_mi355x_llm_model_weight_bytes(const tk_mi355x_llm_model_t* m);
 TK_API void tk_mi355x_llm_model_destroy(tk_mi355x_llm_model_t** m);

@@ -4,6 +4,11 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the oracle is OpenMP code: a GPU box exposes hundreds of logical CPUs but grants a 16-core share, and an
+# oversubscribed team makes the tiny-model oracle calls crawl
+_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, _cores))))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

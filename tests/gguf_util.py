@@ -48,8 +48,7 @@ def write_gguf(path, kv, tensors, align=32):
 
 
 def test_vocab(vocab):
-    toks = ["<unk>", "<s>", "</s>"] + ["<0x%02X>" % b for b in range(256)] + ["▁", "▁he", "llo", "▁hello", "he", "l", "o", "h", "e",
-                                                                               "▁w", "or", "ld", "▁world", "w", "r", "d"]
+    toks = ["<unk>", "<s>", "</s>"] + ["<0x%02X>" % b for b in range(256)] + ["▁", "▁he", "ll", "llo", "▁hello", "he", "l", "o", "h", "e", "▁w", "or", "▁wor", "ld", "▁world", "w", "r", "d"]
     toks += ["tok%d" % i for i in range(len(toks), vocab)]
     return toks[:vocab]
 
@@ -72,10 +71,9 @@ def write_llama_gguf(path, orc, cfg, with_vocab=True):
           ("llama.rope.dimension_count", GGUF_U32, cfg.head_dim), ("llama.context_length", GGUF_U32, 4096),
           ("llama.attention.layer_norm_rms_epsilon", GGUF_F32, cfg.rms_eps), ("llama.rope.freq_base", GGUF_F32, cfg.rope_theta)]
     if with_vocab:
-        toks = ["<unk>", "<s>", "</s>"] + ["<0x%02X>" % b for b in range(256)] + ["▁", "▁he", "llo", "▁hello", "he", "l", "o", "h", "e",
-                                                                                   "▁w", "or", "ld", "▁world", "w", "r", "d"]
+        toks = ["<unk>", "<s>", "</s>"] + ["<0x%02X>" % b for b in range(256)] + ["▁", "▁he", "ll", "llo", "▁hello", "he", "l", "o", "h", "e", "▁w", "or", "▁wor", "ld", "▁world", "w", "r", "d"]
         toks += ["tok%d" % i for i in range(len(toks), cfg.vocab)]
-        scores = [0.0] * 259 + [-1.0, -2.0, -3.0, -1.5, -4.0, -9.0, -9.0, -9.0, -9.0, -5.0, -6.0, -7.0, -2.5, -9.0, -9.0, -9.0]
+        scores = [0.0] * 259 + [-1.0, -2.0, -3.5, -3.0, -1.5, -4.0, -9.0, -9.0, -9.0, -9.0, -5.0, -6.0, -2.2, -7.0, -2.5, -9.0, -9.0, -9.0]
         scores += [-100.0] * (cfg.vocab - len(scores))
         types = [2, 3, 3] + [6] * 256 + [1] * (cfg.vocab - 259)
         kv += [("tokenizer.ggml.model", GGUF_STRING, "llama"), ("tokenizer.ggml.tokens", GGUF_ARRAY, (GGUF_STRING, toks[:cfg.vocab])),

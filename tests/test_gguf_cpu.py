@@ -42,3 +42,20 @@ def test_probe_error_paths(tmp_path):
     trunc.write_bytes(open(p, "rb").read()[:4000])
     rc, _, _ = probe(str(trunc))
     assert rc in (3004, 4000)
+
+
+def test_sentencepiece_bpe_tokenizer(tmp_path):
+    import trackiellm_amd as tk
+    cfg = O.tiny_config()
+    p = str(tmp_path / "tiny.gguf")
+    gguf_util.write_llama_gguf(p, O.OracleLlm(cfg, seed=4), cfg)
+    ids = np.zeros(32, np.int32)
+
+    def tok(text, bos=1):
+        n = tk.lib().tk_mi355x_gguf_tokenize(p.encode(), text.encode(), bos, ids.ctypes.data_as(C.c_void_p), 32)
+        return ids[:n].tolist()
+
+    assert tok("hello world") == [1, 263, 273]                     # score-ordered bigram merges: [bos, "▁hello", "▁world"]
+    assert tok("hello", 0) == [263]
+    assert tok("hé") == [1, 259, 267, 3 + 0xC3, 3 + 0xA9]          # "▁", "h", then <0xXX> byte fallback for the unknown character
+    assert tok("") == [1, 259]                                     # llama adds the space prefix even to empty text

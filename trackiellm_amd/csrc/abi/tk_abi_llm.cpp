@@ -148,6 +148,19 @@ tk_error_code_t tk_mi355x_gguf_probe(const char* path, tk_mi355x_llm_hparams_t* 
     return TK_SUCCESS;
 }
 
+/* tokenises with the vocabulary stored in a GGUF file (CPU only; byte tokens when the file has no vocabulary) */
+int tk_mi355x_gguf_tokenize(const char* path, const char* text, int add_bos, int32_t* ids, int cap) {
+    if (!path || !text || !ids || cap <= 0) return -1;
+    TkGgufFile f;
+    if (!f.open(path)) { tk_error_set_detail("%s", f.error.c_str()); return -1; }
+    TkTokenizer t;
+    if (!f.tokens.empty()) t.init_spm(f.tokens, f.scores, f.token_type, (int)f.get("tokenizer.ggml.bos_token_id", 1), (int)f.get("tokenizer.ggml.eos_token_id", 2));
+    else t.init_bytes(1 << 30);
+    std::vector<int32_t> v = t.encode(text, add_bos != 0);
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) ids[i] = v[i];
+    return (int)v.size();
+}
+
 tk_error_code_t tk_mi355x_llm_model_load_gguf(tk_mi355x_llm_model_t** out, const char* path, int device) {
     if (!out || !path) return TK_ERROR_INVALID_ARGUMENT;
     tk_mi355x_llm_hparams_t h{};
