@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--decode", type=int, default=128)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers => result marked invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sessions", type=int, default=3,
+                    help="independent decode groups of --batch cycles run concurrently on their own HIP streams (fills the "
+                         "launch/ramp bubbles of one group with another group's kernels); concurrent cycles = sessions * batch")
     ap.add_argument("--llm-only", action="store_true", help="configs[1] only: leave the detector / ASR / VAD streams out (marked in config)")
     ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     args = ap.parse_args()
@@ -80,6 +83,7 @@ def main():
     import trackiellm_amd as tk
     if tk.lib().tk_mi355x_device_count() <= local_rank:
         raise SystemExit("bench.py needs one MI355X per rank: no fallback path exists")
+    tk.lib().tk_mi355x_set_default_device(local_rank)
 
     B, P, N = args.batch, args.prompt, args.decode
     hp = tk.MISTRAL_7B()
@@ -87,38 +91,46 @@ def main():
     t0 = time.time()
     model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4)
     hp = model.hparams
-    sess = tk.LlmSession(model, B, P + N + 8)
+    G = max(1, args.sessions)
+    sessions = [tk.LlmSession(model, B, P + N + 8) for _ in range(G)]
+    sess = sessions[0]
     t_load = time.time() - t0
-    prompts = np.stack([splitmix_tokens(3 + 1000 * (rank * B + s), P, 3, hp.vocab) for s in range(B)])
-    prompts[:, 0] = 1  # BOS
+    prompts = []
+    for g in range(G):
+        pr = np.stack([splitmix_tokens(3 + 1000 * ((rank * G + g) * B + s), P, 3, hp.vocab) for s in range(B)])
+        pr[:, 0] = 1  # BOS
+        prompts.append(pr)
+    import threading
 
     # perception streams: one 640x640 frame and 1 s of PCM per cycle, their own HIP streams, driven from host threads
     fused = not args.llm_only
     perc_ms = {"vision": [], "audio": []}
     if fused:
-        import threading
         det = tk.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", width=640, height=640, conf=0.5, iou=0.5,
                                 device=local_rank, max_batch=B)
         asr = tk.Asr(hp=tk.WHISPER_TINY_EN(), seed=6, device=local_rank, max_batch=B)
         vad = tk.Vad()
         frng = np.random.default_rng(1 + rank)
-        frames = [frng.integers(0, 256, (640, 640, 3), dtype=np.uint8) for _ in range(B)]
+        frames = [frng.integers(0, 256, (640, 640, 3), dtype=np.uint8) for _ in range(G * B)]
         prng = np.random.default_rng(2 + rank)
-        pcm = np.clip(prng.normal(0, 3000, (B, 16000)), -32768, 32767).astype(np.int16)
+        pcm = np.clip(prng.normal(0, 3000, (G * B, 16000)), -32768, 32767).astype(np.int16)
         n_dets = [0]
 
-        def vision_pass():
+        def vision_pass():  # one frame per concurrent cycle, B frames per detector call
             t = time.time()
-            res = det.detect_batch(frames)
-            n_dets[0] = sum(len(r) for r in res)
+            n = 0
+            for g in range(G):
+                n += sum(len(r) for r in det.detect_batch(frames[g * B:(g + 1) * B]))
+            n_dets[0] = n
             perc_ms["vision"].append(1000 * (time.time() - t))
 
-        def audio_pass():
+        def audio_pass():  # one second of PCM per concurrent cycle
             t = time.time()
-            for b in range(B):
+            for b in range(G * B):
                 vad.reset()
                 vad.process_with_events(pcm[b])
-            asr.transcribe_tokens(pcm, args.asr_steps, want_aux=False)
+            for g in range(G):
+                asr.transcribe_tokens(pcm[g * B:(g + 1) * B], args.asr_steps, want_aux=False)
             perc_ms["audio"].append(1000 * (time.time() - t))
 
         def perception_async():
@@ -135,14 +147,22 @@ def main():
         # software pipeline: the LLM consumes the perception results of THIS cycle batch (produced during the previous
         # step) while the detector / ASR / VAD streams already work on the next batch; every step runs all streams once
         th = perception_async() if fused else []
-        t_a = time.time()
-        sess.prefill(prompts)
-        t_b = time.time()
-        toks, ms_step = sess.decode(B, N)
-        t_c = time.time()
-        for t in th:
+        res = [None] * G
+
+        def llm_group(g):
+            t_a = time.time()
+            sessions[g].prefill(prompts[g])
+            t_b = time.time()
+            toks, ms_step = sessions[g].decode(B, N)
+            res[g] = (toks, t_b - t_a, time.time() - t_b, ms_step)
+
+        lt = [threading.Thread(target=llm_group, args=(g,)) for g in range(1, G)]
+        for t in lt:
+            t.start()
+        llm_group(0)
+        for t in lt + th:
             t.join()
-        return toks, t_b - t_a, t_c - t_b, ms_step
+        return res[0][0], float(np.mean([r[1] for r in res])), float(np.mean([r[2] for r in res])), float(np.mean([r[3] for r in res]))
 
     if fused:
         for t in perception_async():  # primes the pipeline (perception of the first timed batch)
@@ -200,7 +220,7 @@ def main():
                 "algorithmic_bytes_per_launch": round(total_bytes / launches), "avg_launch_ms": round(avg_ms, 5),
                 "launches_per_decode_step": launches, "per_shape": shapes}
 
-    value = D.aggregate_throughput(B, args.steps, world, elapsed)
+    value = D.aggregate_throughput(G * B, args.steps, world, elapsed)
     dec_ms = float(np.mean(ms_steps))
     out = {
         "metric": "cortex cycles/sec (frame+1s audio+128 tok)", "value": round(value, 3), "unit": "cycles/s", "n_gpus": world,
@@ -211,9 +231,9 @@ def main():
                                 "log-mel/encoder/%d forced decoder steps) + Mistral-7B Q4_K_M 64-token prefill and 128-token greedy decode, "
                                 "3 concurrent HIP streams" % args.asr_steps) if fused else
                                "configs[1]: Mistral-7B Q4_K_M, 64-token prefill + 128-token greedy decode per cycle (LLM stream only)",
-                   "concurrent_cycles_per_gpu": B, "prompt_tokens": P, "decode_tokens": N, "layers": hp.n_layer,
+                   "concurrent_cycles_per_gpu": G * B, "decode_groups": G, "rows_per_llm_pass": B, "prompt_tokens": P, "decode_tokens": N, "layers": hp.n_layer,
                    "k_split": [hp.ks_qkv, hp.ks_o, hp.ks_gateup, hp.ks_down], "parallelism": f"replicas x{world}"},
-        "llm_tok_per_s": round(B * world * N / (dec_s / args.steps), 1),
+        "llm_tok_per_s": round(G * B * world * N / (dec_s / args.steps), 1),
         "decode_ms_per_step": round(dec_ms, 4), "prefill_s_per_cycle_batch": round(pre_s / args.steps, 4),
         "model_load_s": round(t_load, 2), "weight_bytes_per_decode_step": int(model.weight_bytes),
         "roofline": roofline,

@@ -26,6 +26,10 @@ typedef struct tk_mi355x_llm_session_s tk_mi355x_llm_session_t;
 
 TK_API const char* tk_mi355x_version(void);
 TK_API int tk_mi355x_device_count(void);
+/* HIP device used by the reference entry points whose config carries no device id (tk_vad_silero_create,
+ * tk_asr_whisper_create, tk_preprocessor_*, tk_model_loader_load_model); default 0.  One process per GPU sets its rank's device. */
+TK_API void tk_mi355x_set_default_device(int device);
+TK_API int tk_mi355x_get_default_device(void);
 
 /* models ----------------------------------------------------------------------------------- */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_create(tk_mi355x_llm_model_t** out, const tk_mi355x_llm_hparams_t* hp, int device);

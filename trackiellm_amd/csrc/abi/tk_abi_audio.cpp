@@ -12,6 +12,7 @@
 
 #include "../audio/tk_audio_engine.h"
 #include "tk/tk_audio.h"
+#include "tk/tk_mi355x_ext.h"
 
 #define TK_ASR_MAX_BUFFER (16000 * 30) /* MAX_AUDIO_BUFFER_SIZE: 30 s at 16 kHz */
 
@@ -66,7 +67,7 @@ tk_error_code_t tk_asr_whisper_create(tk_asr_whisper_context_t** out_context, co
     if (!out_context || !config || !config->model_path || !config->model_path->path_str) return TK_ERROR_INVALID_ARGUMENT;
     if (config->sample_rate != 16000) return afail(TK_ERROR_INVALID_ARGUMENT, "Whisper needs 16 kHz audio");
     const std::string path = config->model_path->path_str;
-    tk_error_code_t rc = asr_new(out_context, tk_whisper_tiny_en(), path, seed_of(path, 6), 0, 1);
+    tk_error_code_t rc = asr_new(out_context, tk_whisper_tiny_en(), path, seed_of(path, 6), tk_mi355x_get_default_device(), 1);
     if (rc == TK_SUCCESS && config->language) (*out_context)->language = config->language;
     return rc;
 }
@@ -219,7 +220,7 @@ tk_error_code_t tk_vad_silero_create(tk_vad_silero_context_t** out_context, cons
     c->step = (size_t)c->sample_rate * 10 / 1000;
     const std::string path = config->model_path->path_str ? config->model_path->path_str : "";
     if (path.compare(0, 12, "synthetic://") != 0) return afail(TK_ERROR_MODEL_LOAD_FAILED, "only synthetic://vad is available: ONNX graphs are not interpreted");
-    if (!c->model.init(0, (int)c->window, 64) || !c->model.fill_synthetic(seed_of(path, 7))) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+    if (!c->model.init(tk_mi355x_get_default_device(), (int)c->window, 64) || !c->model.fill_synthetic(seed_of(path, 7))) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
     *out_context = c.release();
     return TK_SUCCESS;
 }

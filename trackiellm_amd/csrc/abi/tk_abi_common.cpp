@@ -76,6 +76,10 @@ void tk_path_destroy(tk_path_t** path) {
     *path = NULL;
 }
 
+static int g_default_device = 0;
+void tk_mi355x_set_default_device(int device) { g_default_device = device < 0 ? 0 : device; }
+int tk_mi355x_get_default_device(void) { return g_default_device; }
+
 const char* tk_mi355x_version(void) { return "trackie-mi355x 0.1 (gfx950)"; }
 
 int tk_mi355x_device_count(void) {

@@ -294,12 +294,12 @@ tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_m
         if (name == "mistral-7b") h = tk_mi355x_llm_hparams_t{32, 4096, 32, 8, 128, 14336, 32000, 1e-5f, 10000.0f, 0, 0, 0, 0, 1};
         else if (name == "tiny") h = tk_mi355x_llm_hparams_t{2, 256, 8, 2, 64, 512, 512, 1e-5f, 10000.0f, 0, 0, 0, 0, 1};
         else return fail(TK_ERROR_FILE_NOT_FOUND, "unknown synthetic model: " + name);
-        rc = tk_mi355x_llm_model_create(&m, &h, 0);
+        rc = tk_mi355x_llm_model_create(&m, &h, tk_mi355x_get_default_device());
         if (rc == TK_SUCCESS) rc = tk_mi355x_llm_model_fill_synthetic(m, seed);
         if (rc != TK_SUCCESS) { tk_mi355x_llm_model_destroy(&m); return rc; }
         m->path = path;
     } else {
-        rc = tk_mi355x_llm_model_load_gguf(&m, path.c_str(), 0);
+        rc = tk_mi355x_llm_model_load_gguf(&m, path.c_str(), tk_mi355x_get_default_device());
         if (rc != TK_SUCCESS) return rc;
     }
     loader->models.push_back(m);

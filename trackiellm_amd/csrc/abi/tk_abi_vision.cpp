@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../vision/tk_vision_engine.h"
+#include "tk/tk_mi355x_ext.h"
 #include "tk/tk_vision.h"
 
 struct tk_object_detector_s {
@@ -171,6 +172,7 @@ tk_error_code_t tk_preprocessor_resize_and_normalize_to_chw(const tk_video_frame
     if (frame->width < 2 || frame->height < 2) return vfail(TK_ERROR_INVALID_ARGUMENT, "frame must be at least 2x2");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return vfail(TK_ERROR_GPU_DEVICE_NOT_FOUND, "no HIP device visible");
+    if (hipSetDevice(tk_mi355x_get_default_device()) != hipSuccess) return vfail(TK_ERROR_GPU_ROCM_ERROR, "hipSetDevice failed");
     const uint32_t bpp = (uint32_t)bytes_per_pixel(frame);
     const uint32_t stride = frame->stride ? frame->stride : frame->width * bpp;
     if (stride < frame->width * bpp) return vfail(TK_ERROR_INVALID_ARGUMENT, "stride smaller than a row");

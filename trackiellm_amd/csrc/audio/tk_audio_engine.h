@@ -54,6 +54,9 @@ class TkVadModel {
 public:
     int device = 0, window = 480, hidden = 64;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    float *x = nullptr, *hbuf = nullptr, *p = nullptr; /* grow-only scratch */
+    int cap = 0;
+    hipStream_t stream = nullptr;
     std::string error;
     ~TkVadModel();
     bool init(int device, int window, int hidden);

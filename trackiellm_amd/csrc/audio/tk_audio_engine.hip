@@ -256,8 +256,10 @@ bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* 
 
 TkVadModel::~TkVadModel() {
     (void)hipSetDevice(device);
-    float* p[] = {w1, b1, w2, b2};
-    for (float* q : p) if (q) (void)hipFree(q);
+    if (stream) (void)hipStreamSynchronize(stream);
+    float* ptrs[] = {w1, b1, w2, b2, x, hbuf, p};
+    for (float* q : ptrs) if (q) (void)hipFree(q);
+    if (stream) (void)hipStreamDestroy(stream);
 }
 
 bool TkVadModel::init(int dev, int win, int hid) {
@@ -293,20 +295,27 @@ __global__ void k_vad_head(const float* hid, int n, int hidden, const float* w2,
 bool TkVadModel::infer(const float* windows_host, int n, float* prob_host) {
     if (n <= 0) return true;
     HIPQ(hipSetDevice(device));
-    float *x = nullptr, *hbuf = nullptr, *p = nullptr;
-    HIPQ(hipMalloc((void**)&x, (size_t)n * window * 4));
-    HIPQ(hipMalloc((void**)&hbuf, (size_t)n * hidden * 4));
-    HIPQ(hipMalloc((void**)&p, (size_t)n * 4));
-    bool ok = hipMemcpy(x, windows_host, (size_t)n * window * 4, hipMemcpyHostToDevice) == hipSuccess;
-    if (ok) {
-        TkGemm g{};
-        g.A = x; g.B = w1; g.C = hbuf; g.bias = b1; g.M = n; g.N = hidden; g.K = window; g.lda = window; g.ldb = window; g.ldc = hidden;
-        g.alpha = 1.0f; g.batch = 1;
-        tk_launch_gemm(g, nullptr);
-        hipLaunchKernelGGL(k_vad_head, dim3((n + 63) / 64), dim3(64), 0, nullptr, hbuf, n, hidden, w2, b2, p);
-        ok = hipMemcpy(prob_host, p, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!stream) HIPQ(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (n > cap) { /* grow-only scratch: no allocation on the steady-state path */
+        if (x) (void)hipFree(x);
+        if (hbuf) (void)hipFree(hbuf);
+        if (p) (void)hipFree(p);
+        x = hbuf = p = nullptr;
+        cap = 0;
+        const int want = n < 128 ? 128 : n;
+        HIPQ(hipMalloc((void**)&x, (size_t)want * window * 4));
+        HIPQ(hipMalloc((void**)&hbuf, (size_t)want * hidden * 4));
+        HIPQ(hipMalloc((void**)&p, (size_t)want * 4));
+        cap = want;
     }
-    (void)hipFree(x); (void)hipFree(hbuf); (void)hipFree(p);
-    if (!ok) error = "VAD inference failed on the device";
-    return ok;
+    HIPQ(hipMemcpyAsync(x, windows_host, (size_t)n * window * 4, hipMemcpyHostToDevice, stream));
+    TkGemm g{};
+    g.A = x; g.B = w1; g.C = hbuf; g.bias = b1; g.M = n; g.N = hidden; g.K = window; g.lda = window; g.ldb = window; g.ldc = hidden;
+    g.alpha = 1.0f; g.batch = 1;
+    tk_launch_gemm(g, stream);
+    hipLaunchKernelGGL(k_vad_head, dim3((n + 63) / 64), dim3(64), 0, stream, hbuf, n, hidden, w2, b2, p);
+    HIPQ(hipGetLastError());
+    HIPQ(hipMemcpyAsync(prob_host, p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    return true;
 }

@@ -6,6 +6,7 @@
 
 #include <math.h>
 #include <algorithm>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -363,8 +364,12 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     const char* ng = getenv("TK_MI355X_NO_GRAPH");
     const bool use_graph = !(ng && ng[0] == '1');
     if (use_graph && !graph_exec[nrows]) {
+        /* one capture at a time per process; relaxed mode: other host threads (detector / ASR / VAD streams) keep calling
+         * allocation and copy APIs while this stream records */
+        static std::mutex capture_mu;
+        std::lock_guard<std::mutex> lk(capture_mu);
         hipGraph_t g = nullptr;
-        HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
         enqueue_pass(nrows, true, true);
         HIPQ(hipStreamEndCapture(stream, &g));
         HIPQ(hipGraphInstantiate(&graph_exec[nrows], g, nullptr, nullptr, 0));

@@ -131,8 +131,159 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     }
 }
 
+/*
+ * Large-shape variant: 128x128 output tile per workgroup, each of the 4 waves owns 64x64 = 2x2 MFMA tiles (4 accumulators),
+ * k slabs of 32 double-buffered in LDS: the next slab's global loads are issued before the current slab's 64 MFMAs and
+ * written to the other buffer afterwards, one barrier per slab.  Same k-ordered chain per output element as k_gemm_f32.
+ */
+#define LBM 128
+#define LBN 128
+__global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
+    extern __shared__ float lsm[]; /* [2][LBM*LDS_LD] A, then [2][LBN*LDS_LD] B */
+    float* As = lsm;
+    float* Bs = lsm + 2 * LBM * LDS_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    int64_t oA, oB, oC, oR;
+    if (g.batch_inner > 0) {
+        const int zo = blockIdx.z / g.batch_inner, zi = blockIdx.z % g.batch_inner;
+        oA = zo * g.sA2 + zi * g.sA; oB = zo * g.sB2 + zi * g.sB; oC = zo * g.sC2 + zi * g.sC; oR = zo * g.sR2 + zi * g.sR;
+    } else {
+        oA = (int64_t)blockIdx.z * g.sA; oB = (int64_t)blockIdx.z * g.sB; oC = (int64_t)blockIdx.z * g.sC; oR = (int64_t)blockIdx.z * g.sR;
+    }
+    const float* A = g.A + oA;
+    const float* B = g.B + oB;
+    float* C = g.C + oC;
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
+    const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & 15) == 0;
+    float ra[4][4], rb[4][4]; /* register staging of the next slab: 4 float4 per thread per operand */
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int e = tid + 256 * h;
+            { /* A: row = e / 8, 4 consecutive k */
+                const int row = e >> 3, kc = (e & 7) * 4;
+                const int m = m0 + row, k = k0 + kc;
+                ra[h][0] = ra[h][1] = ra[h][2] = ra[h][3] = 0.0f;
+                if (m < g.M) {
+                    const float* p = A + (int64_t)m * g.lda + k;
+                    if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; ra[h][0] = t.x; ra[h][1] = t.y; ra[h][2] = t.z; ra[h][3] = t.w; }
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (k + i < g.K) ra[h][i] = p[i];
+                    }
+                }
+            }
+            rb[h][0] = rb[h][1] = rb[h][2] = rb[h][3] = 0.0f;
+            if (!g.b_kn) {
+                const int row = e >> 3, kc = (e & 7) * 4;
+                const int n = n0 + row, k = k0 + kc;
+                if (n < g.N) {
+                    const float* p = B + (int64_t)n * g.ldb + k;
+                    if (b_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; rb[h][0] = t.x; rb[h][1] = t.y; rb[h][2] = t.z; rb[h][3] = t.w; }
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[h][i] = p[i];
+                    }
+                }
+            } else { /* B is [K][N]: 4 consecutive n of one k */
+                const int kk = e >> 5, nc = (e & 31) * 4;
+                const int k = k0 + kk, n = n0 + nc;
+                if (k < g.K) {
+                    const float* p = B + (int64_t)k * g.ldb + n;
+                    if (b_vec && n + 3 < g.N) { const float4 t = *(const float4*)p; rb[h][0] = t.x; rb[h][1] = t.y; rb[h][2] = t.z; rb[h][3] = t.w; }
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (n + i < g.N) rb[h][i] = p[i];
+                    }
+                }
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* as = As + buf * LBM * LDS_LD;
+        float* bs = Bs + buf * LBN * LDS_LD;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int e = tid + 256 * h;
+            const int row = e >> 3, kc = (e & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) as[row * LDS_LD + kc + i] = ra[h][i];
+            if (!g.b_kn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bs[row * LDS_LD + kc + i] = rb[h][i];
+            } else {
+                const int kk = e >> 5, nc = (e & 31) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bs[(nc + i) * LDS_LD + kk] = rb[h][i];
+            }
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        const bool more = k0 + BK < g.K;
+        if (more) gload(k0 + BK);
+        const float* ap = As + buf * LBM * LDS_LD + (wm * 64 + (lane & 31)) * LDS_LD + (lane >> 5);
+        const float* bp = Bs + buf * LBN * LDS_LD + (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = ap[kk], a1 = ap[32 * LDS_LD + kk], b0 = bp[kk], b1 = bp[32 * LDS_LD + kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const float* R = g.residual ? g.residual + oR : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < g.M) {
+                    float v = acc[i][j][r];
+                    if (g.alpha != 1.0f) v = v * g.alpha;
+                    v = v + bias;
+                    v = apply_act(v, g.act);
+                    if (R) v = v + R[(int64_t)m * g.ldr + n];
+                    C[(int64_t)m * g.ldc + n] = v;
+                }
+            }
+    }
+}
+
 void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch > 0 ? g.batch : 1);
+    const int nz = g.batch > 0 ? g.batch : 1;
+    if (g.M >= 256 && g.N >= 96) {
+        const size_t lds = (size_t)2 * (LBM + LBN) * LDS_LD * sizeof(float);
+        static bool opted = false;
+        if (!opted) { (void)hipFuncSetAttribute((const void*)k_gemm_f32_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); opted = true; }
+        dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
+        hipLaunchKernelGGL(k_gemm_f32_big, grid, dim3(256), lds, s, g);
+        return;
+    }
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nz);
     hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, s, g);
 }
 
