@@ -194,31 +194,34 @@ def main():
     n_layer = hp.n_layer
     q6_layers = [l for l in range(n_layer) if l < n_layer // 8 or l >= 7 * n_layer // 8 or (l - n_layer // 8) % 3 == 2]
     q4_layers = [l for l in range(n_layer) if l not in q6_layers]
-    shapes = {}
-    total_ms = total_bytes = 0.0
-    launches = 0
-    for name, which, per_layer in (("gate_up", 0, True), ("down", 1, True), ("qkv", 2, True), ("o", 4, True), ("lm_head", 3, False)):
-        groups = ([("q6", q6_layers), ("q4", q4_layers)] if which in (1, 2) else [("", list(range(n_layer)))]) if per_layer else [("", [0])]
-        for tag, layers in groups:
-            if not layers:
-                continue
-            ms, nbytes = sess.time_gemv(layers[0], which, B, 50)
-            cnt = len(layers) if per_layer else 1
-            shapes[name + ("_" + tag if tag else "")] = {"ms": round(ms, 5), "GBps": round(nbytes / ms / 1e6, 1), "launches_per_step": cnt}
-            total_ms += ms * cnt
-            total_bytes += nbytes * cnt
-            launches += cnt
-    avg_ms = total_ms / launches
-    achieved = total_bytes / total_ms / 1e6  # GB/s
+
+    def gemv_roofline(rows):
+        shapes = {}
+        total_ms = total_bytes = 0.0
+        launches = 0
+        for name, which, per_layer in (("gate_up", 0, True), ("down", 1, True), ("qkv", 2, True), ("o", 4, True), ("lm_head", 3, False)):
+            groups = ([("q6", q6_layers), ("q4", q4_layers)] if which in (1, 2) else [("", list(range(n_layer)))]) if per_layer else [("", [0])]
+            for tag, layers in groups:
+                if not layers:
+                    continue
+                ms, nbytes = sess.time_gemv(layers[0], which, rows, 50)
+                cnt = len(layers) if per_layer else 1
+                shapes[name + ("_" + tag if tag else "")] = {"ms": round(ms, 5), "GBps": round(nbytes / ms / 1e6, 1), "launches_per_step": cnt}
+                total_ms += ms * cnt
+                total_bytes += nbytes * cnt
+                launches += cnt
+        achieved = total_bytes / total_ms / 1e6  # GB/s
+        return {"bound": "hbm", "kernel": "k_gemv_w4a8", "rows_per_pass": rows, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": round(total_bytes / launches),
+                "avg_launch_ms": round(total_ms / launches, 5), "launches_per_decode_step": launches, "per_shape": shapes}
+
+    roofline = gemv_roofline(B)
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction applied)
-    traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
     if os.path.exists(pmc) and B > 16:
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_average_launch")
-    roofline = {"bound": "hbm", "kernel": "k_gemv_w4a8", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(total_bytes / launches), "avg_launch_ms": round(avg_ms, 5),
-                "launches_per_decode_step": launches, "per_shape": shapes}
+        roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_average_launch")
+    # the same kernel at 16 rows per pass (one MFMA M-tile): less integer work per weight byte, closer to the HBM bound
+    roofline_16 = gemv_roofline(16) if B > 16 else None
 
     value = D.aggregate_throughput(G * B, args.steps, world, elapsed)
     dec_ms = float(np.mean(ms_steps))
@@ -238,6 +241,8 @@ def main():
         "model_load_s": round(t_load, 2), "weight_bytes_per_decode_step": int(model.weight_bytes),
         "roofline": roofline,
     }
+    if roofline_16 is not None:
+        out["roofline_16_rows"] = {k: roofline_16[k] for k in ("rows_per_pass", "achieved", "peak", "unit", "frac", "avg_launch_ms", "per_shape")}
     if fused:
         out["perception"] = {"vision_ms_per_batch": round(float(np.mean(perc_ms["vision"])), 2), "audio_ms_per_batch": round(float(np.mean(perc_ms["audio"])), 2),
                              "detections_last_batch": n_dets[0], "overlapped_with_llm": True, "dtype": "f32 (exact fp32 MFMA chain)"}

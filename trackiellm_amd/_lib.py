@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtrackie_mi355x.so")
+LIB_PATH = os.environ.get("TK_MI355X_LIB", os.path.join(HERE, "libtrackie_mi355x.so"))  # override: diagnostic builds only
 _lib = None
 
 

@@ -169,15 +169,15 @@ bool TkLlmModel::ready() const {
 /* ------------------------------------------------------------------ session ---------------- */
 
 static bool alloc_act(TkActQ8* a, int K, std::string& error) {
-    a->aq_ts = TK_AQ_BYTES(K); a->ad_ts = TK_AD_FLOATS(K); a->abs_ts = TK_ABS_INTS(K);
+    a->aq_ts = TK_AQ_BYTES(K); a->ad_ts = TK_AD_FLOATS(K); a->abs_ts = TK_ABS_BYTES(K);
     if (hipMalloc((void**)&a->aq, TK_MAX_TILES * a->aq_ts) != hipSuccess || hipMalloc((void**)&a->ad, TK_MAX_TILES * a->ad_ts * 4) != hipSuccess ||
-        hipMalloc((void**)&a->abs, TK_MAX_TILES * a->abs_ts * 4) != hipSuccess) {
+        hipMalloc((void**)&a->abs, TK_MAX_TILES * a->abs_ts) != hipSuccess) {
         error = "out of device memory (activation buffers)";
         return false;
     }
     (void)hipMemset(a->aq, 0, TK_MAX_TILES * a->aq_ts);
     (void)hipMemset(a->ad, 0, TK_MAX_TILES * a->ad_ts * 4);
-    (void)hipMemset(a->abs, 0, TK_MAX_TILES * a->abs_ts * 4);
+    (void)hipMemset(a->abs, 0, TK_MAX_TILES * a->abs_ts);
     return true;
 }
 static void free_act(TkActQ8* a) {
@@ -444,10 +444,27 @@ bool TkLlmSession::time_gemv(int layer, int which, int nrows, int iters, float* 
     HIPQ(hipEventCreate(&e0));
     HIPQ(hipEventCreate(&e1));
     for (size_t i = 0; i < set.size(); ++i) tk_launch_gemv(set[i], stream);
+    /* launched the way decode() launches them: as nodes of a hipGraph (unless TK_MI355X_NO_GRAPH=1, see decode()) */
+    const char* ng = getenv("TK_MI355X_NO_GRAPH");
+    const bool use_graph = !(ng && ng[0] == '1');
+    hipGraphExec_t ge = nullptr;
+    if (use_graph) {
+        static std::mutex capture_mu;
+        std::lock_guard<std::mutex> lk(capture_mu);
+        hipGraph_t g = nullptr;
+        HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+        for (int i = 0; i < iters; ++i) tk_launch_gemv(set[(size_t)i % set.size()], stream);
+        HIPQ(hipStreamEndCapture(stream, &g));
+        HIPQ(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HIPQ(hipGraphDestroy(g));
+        HIPQ(hipGraphLaunch(ge, stream)); /* warm */
+    }
     HIPQ(hipEventRecord(e0, stream));
-    for (int i = 0; i < iters; ++i) tk_launch_gemv(set[(size_t)i % set.size()], stream);
+    if (use_graph) HIPQ(hipGraphLaunch(ge, stream));
+    else for (int i = 0; i < iters; ++i) tk_launch_gemv(set[(size_t)i % set.size()], stream);
     HIPQ(hipEventRecord(e1, stream));
     HIPQ(hipStreamSynchronize(stream));
+    if (ge) (void)hipGraphExecDestroy(ge);
     float ms = 0.0f;
     HIPQ(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = ms / iters;

@@ -27,14 +27,14 @@ struct TkGemvArgs {
     size_t aq_ts, ad_ts, abs_ts; /* M-tile strides of aq (bytes), ad (floats), abs (ints) */
     const int8_t* aq;
     const float* ad;
-    const int32_t* abs;
+    const int8_t* abs; /* sub-block sums as (l, h) int8 images: [K/256][2][16][8] */
     float* out;
 };
 
 struct TkActQ8 { /* quantised-activation buffers for one K */
     int8_t* aq;
     float* ad;
-    int32_t* abs;
+    int8_t* abs; /* (l, h) images of the sub-block sums, 256 B per 256-block */
     size_t aq_ts, ad_ts, abs_ts; /* M-tile strides */
 };
 

@@ -14,11 +14,13 @@
 #include "tk_llm_kernels.h"
 
 #include "../common/tk_exact_math.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../common/tk_ggml_blocks.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define TK_WAVE 64
@@ -184,7 +186,11 @@ __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot,
     *(uint2*)(out.aq + mt * out.aq_ts + ((size_t)c * TK_ROW_SLOTS + sl) * 8) = make_uint2(lo, hi);
     sum += __shfl_xor(sum, 1, TK_WAVE);
     sum += __shfl_xor(sum, 2, TK_WAVE);
-    if ((c & 3) == 0) out.abs[mt * out.abs_ts + (size_t)(c >> 2) * TK_ROW_SLOTS + sl] = sum;
+    if ((c & 3) == 0) { /* sub-block sum as two int8: sum = 64 * h + l, l in [0, 63], h in [-64, 63]  (|sum| <= 32 * 127) */
+        int8_t* mb = out.abs + mt * out.abs_ts + (size_t)(c >> 5) * 256 + (size_t)sl * 8 + ((c >> 2) & 7);
+        mb[0] = (int8_t)(sum & 63);
+        mb[128] = (int8_t)(sum >> 6);
+    }
     if ((c & 31) == 0) out.ad[mt * out.ad_ts + (size_t)(c >> 5) * TK_ROW_SLOTS + sl] = amax > 0.0f ? tk_divf(amax, 127.0f) : 0.0f;
 }
 
@@ -320,57 +326,113 @@ __device__ __forceinline__ float f16bits_to_f32(uint32_t h) { return (float)__bu
 
 /* one weight tile x one 16-row M-tile; a pass with two M-tiles calls it twice per tile (the nibble unpack is repeated,
  * ~15 % more VALU, but the live register set stays that of a single tile: no spills at 4 tiles in flight) */
-__device__ __forceinline__ void block_q4(const FragQ4& f, const uint8_t* lds_act, const int* lds_abs, const float* lds_ad, int blk, int lane,
-                                         float* acc) {
-    const int g = lane >> 4;
-    const v4i zero = {0, 0, 0, 0};
-    int P[4] = {0, 0, 0, 0}, M[4] = {0, 0, 0, 0};
+/* a * b + c for |a|, |b| < 2^23 (v_mad_i32_i24, full rate; a 32-bit v_mul_lo is quarter rate).  Every use multiplies a
+ * 6/8-bit scale with one MFMA partial (|.| <= 32 * 127 * 15 for Q4_K, 16 * 127 * 128 for Q6_K), so it is exact. */
+__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
+/* 6-bit (scale, min) pairs of a Q4_K header as byte vectors: sc/mn 0..3 in *_lo, 4..7 in *_hi (one byte each) */
+__device__ __forceinline__ void q4k_scales(const uint4& h, uint32_t* sc_lo, uint32_t* sc_hi, uint32_t* mn_lo, uint32_t* mn_hi) {
+    const uint32_t s0 = h.y, s1 = h.z, s2 = h.w;
+    *sc_lo = s0 & 0x3F3F3F3Fu;
+    *mn_lo = s1 & 0x3F3F3F3Fu;
+    *sc_hi = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
+    *mn_hi = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
+}
+
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+/* both 16-bit halves of q (four nibble bytes, each <= 15) times s <= 7: no byte carries, one v_pk_mul_lo_u16 */
+__device__ __forceinline__ uint32_t pk_scale(uint32_t q, unsigned short s) {
+    const v2u16 r = __builtin_bit_cast(v2u16, q) * (v2u16){s, s};
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+/*
+ * One Q4_K weight tile (16 weight rows x 256 k) against MT 16-row M-tiles of int8 activations.
+ *
+ *   sum_k a_k w_k  =  d * sum_j sc_j (a . q)_j  -  dmin * sum_j mn_j bsum_j          (per weight row, 8 sub-blocks j)
+ *
+ * Both integer sums run on the matrix cores with no per-sub-block VALU work on the results:
+ *  - the 6-bit sub-block scale is split sc = 8 sh + sl (3 bits each) and folded into the B operand: q * sl and q * sh stay
+ *    inside int8 (<= 105), so P = 8 * sum_j (a . q sh_j) + sum_j (a . q sl_j) accumulates over all eight sub-blocks INSIDE
+ *    two MFMA accumulators; two sub-blocks share one v_mfma_i32_16x16x64_i8 (the k order inside an MFMA is free as long as
+ *    A and B agree, and they do: both come from the same (sub-block, 8-wide k slice) pairs);
+ *  - the "min" term is a tiny int8 contraction of its own: the 6-bit mins are the B operand (k-slots 0..7 of lane group 0,
+ *    zero elsewhere) and the sub-block sums arrive as two int8 images l, h with bsum = 64 h + l, so M = 64 C_h + C_l.
+ * Integer-exact: P and M equal the scalar sums of the oracle bit for bit; the two fp32 FMAs per block are the oracle's.
+ */
+/* B operands of one Q4_K tile, ready for the matrix cores; the packed fragment is dead once this exists, so the
+ * registers of the fragment can take the next tile's load while the MFMAs of this one run */
+struct OpsQ4 { v4i bl[4], bh[4]; long bm; float dw, dmin; };
+
+__device__ __forceinline__ void unpack_q4(const FragQ4& f, int lane, OpsQ4& o) {
     const uint32_t qs[8] = {f.q0.x, f.q0.y, f.q0.z, f.q0.w, f.q1.x, f.q1.y, f.q1.z, f.q1.w};
-    const uint32_t s0 = f.h.y, s1 = f.h.z, s2 = f.h.w;
+    uint32_t sc_lo, sc_hi, mn_lo, mn_hi;
+    q4k_scales(f.h, &sc_lo, &sc_hi, &mn_lo, &mn_hi);
+    /* 3-bit digits of the eight scales, one per 16-bit half: D[2 * (j >> 2) + (j & 1)] holds scale j in half (j >> 1) & 1 */
+    const uint32_t dl_lo = sc_lo & 0x07070707u, dl_hi = sc_hi & 0x07070707u;
+    const uint32_t dh_lo = (sc_lo >> 3) & 0x07070707u, dh_hi = (sc_hi >> 3) & 0x07070707u;
+    const uint32_t DL[4] = {dl_lo & 0x00FF00FFu, (dl_lo >> 8) & 0x00FF00FFu, dl_hi & 0x00FF00FFu, (dl_hi >> 8) & 0x00FF00FFu};
+    const uint32_t DH[4] = {dh_lo & 0x00FF00FFu, (dh_lo >> 8) & 0x00FF00FFu, dh_hi & 0x00FF00FFu, (dh_hi >> 8) & 0x00FF00FFu};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t x = qs[j];
         const uint32_t lo = x & 0x0F0F0F0Fu;
         const uint32_t hi = (x >> 4) & 0x0F0F0F0Fu;
-        const long b = (long)(((unsigned long)hi << 32) | lo);
-        const long a = *(const long*)(lds_act + (size_t)(blk * 8 + j) * 512 + lane * 8);
-        const v4i c = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, zero, 0, 0, 0);
-        int sc, m;
-        if (j < 4) {
-            sc = (s0 >> (8 * j)) & 63;
-            m = (s1 >> (8 * j)) & 63;
-        } else {
-            const int jj = j - 4;
-            sc = ((s2 >> (8 * jj)) & 0xF) | (((s0 >> (8 * jj + 6)) & 3) << 4);
-            m = ((s2 >> (8 * jj + 4)) & 0xF) | (((s1 >> (8 * jj + 6)) & 3) << 4);
-        }
-        const v4i bs = *(const v4i*)(lds_abs + (blk * 8 + j) * TK_ROW_SLOTS + 4 * g);
+        const int di = 2 * (j >> 2) + (j & 1), sh = 16 * ((j >> 1) & 1), e = j & 1;
+        const unsigned short sl = (unsigned short)(DL[di] >> sh), shh = (unsigned short)(DH[di] >> sh);
+        o.bl[j >> 1][2 * e] = (int)pk_scale(lo, sl);
+        o.bl[j >> 1][2 * e + 1] = (int)pk_scale(hi, sl);
+        o.bh[j >> 1][2 * e] = (int)pk_scale(lo, shh);
+        o.bh[j >> 1][2 * e + 1] = (int)pk_scale(hi, shh);
+    }
+    o.bm = (lane >> 4) == 0 ? (long)(((unsigned long)mn_hi << 32) | mn_lo) : 0L;
+    o.dw = f16bits_to_f32(f.h.x & 0xffffu);
+    o.dmin = f16bits_to_f32(f.h.x >> 16);
+}
+
+template <int MT>
+__device__ __forceinline__ void mma_q4(const OpsQ4& o, const uint8_t* lds_act, const uint8_t* lds_amn, const float* lds_ad, size_t act_ts, int amn_ts,
+                                       int ad_ts, int blk, int lane, float (*acc)[4]) {
+    const int g = lane >> 4;
+    const v4i zero = {0, 0, 0, 0};
+    v4i Pl[MT], Ph[MT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            P[r] += sc * c[r];
-            M[r] += m * bs[r];
+    for (int m = 0; m < MT; ++m) Pl[m] = Ph[m] = zero;
+    const uint8_t* ap = lds_act + (size_t)blk * 8 * 512 + lane * 8;
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const v2i a0 = *(const v2i*)(ap + m * act_ts + (2 * j2) * 512);
+            const v2i a1 = *(const v2i*)(ap + m * act_ts + (2 * j2 + 1) * 512);
+            const v4i a = {a0.x, a0.y, a1.x, a1.y};
+            Pl[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, o.bl[j2], Pl[m], 0, 0, 0);
+            Ph[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, o.bh[j2], Ph[m], 0, 0, 0);
         }
     }
-    const float dw = f16bits_to_f32(f.h.x & 0xffffu);
-    const float dmin = f16bits_to_f32(f.h.x >> 16);
-    const v4f da = *(const v4f*)(lds_ad + blk * TK_ROW_SLOTS + 4 * g);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float s1f = dw * da[r];
-        const float s2f = dmin * da[r];
-        acc[r] = tk_fmaf(s1f, (float)P[r], acc[r]);
-        acc[r] = tk_fmaf(-s2f, (float)M[r], acc[r]);
+    for (int m = 0; m < MT; ++m) {
+        const uint8_t* mp = lds_amn + m * amn_ts + (size_t)blk * 256 + (lane & 15) * 8;
+        const v4i cl = __builtin_amdgcn_mfma_i32_16x16x32_i8(*(const long*)mp, o.bm, zero, 0, 0, 0);
+        const v4i ch = __builtin_amdgcn_mfma_i32_16x16x32_i8(*(const long*)(mp + 128), o.bm, zero, 0, 0, 0);
+        const v4f da = *(const v4f*)(lds_ad + m * ad_ts + blk * TK_ROW_SLOTS + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int P = (Ph[m][r] << 3) + Pl[m][r];
+            const int M = (ch[r] << 6) + cl[r];
+            acc[m][r] = tk_fmaf(o.dw * da[r], (float)P, acc[m][r]);
+            acc[m][r] = tk_fmaf(-(o.dmin * da[r]), (float)M, acc[m][r]);
+        }
     }
 }
 
-__device__ __forceinline__ void block_q6(const FragQ6& f, const uint8_t* lds_act, const float* lds_ad, int blk, int lane, float* acc) {
-    const int g = lane >> 4;
-    const v4i zero = {0, 0, 0, 0};
-    const long mask_a = (g < 2) ? -1L : 0L;
-    int P[4] = {0, 0, 0, 0};
+/* Q6_K: int8 operands 4 (q - 32) and the sixteen int8 group scales (one per 16 k: two per sub-block, applied to the two
+ * half-masked MFMA results of the sub-block) */
+struct OpsQ6 { long b[8]; uint32_t sc[4]; float dw; };
+
+__device__ __forceinline__ void unpack_q6(const FragQ6& f, OpsQ6& o) {
     const uint32_t qs[8] = {f.q0.x, f.q0.y, f.q0.z, f.q0.w, f.q1.x, f.q1.y, f.q1.z, f.q1.w};
     const uint32_t qh[4] = {f.qh.x, f.qh.y, f.qh.z, f.qh.w};
-    const uint32_t scw[4] = {f.sc.x, f.sc.y, f.sc.z, f.sc.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t x = qs[j];
@@ -378,28 +440,53 @@ __device__ __forceinline__ void block_q6(const FragQ6& f, const uint8_t* lds_act
         const int e = j & 1;
         const uint32_t lo = ((x << 2) & 0x3C3C3C3Cu) | ((H << (6 - 4 * e)) & 0xC0C0C0C0u);
         const uint32_t hi = ((x >> 2) & 0x3C3C3C3Cu) | ((H << (4 - 4 * e)) & 0xC0C0C0C0u);
-        const long b = (long)(((unsigned long)hi << 32) | lo);
-        const long a = *(const long*)(lds_act + (size_t)(blk * 8 + j) * 512 + lane * 8);
-        const v4i ca = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b & mask_a, zero, 0, 0, 0);
-        const v4i cb = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b & ~mask_a, zero, 0, 0, 0);
-        const uint32_t w = scw[j >> 1];
+        o.b[j] = (long)(((unsigned long)hi << 32) | lo);
+    }
+    o.sc[0] = f.sc.x; o.sc[1] = f.sc.y; o.sc[2] = f.sc.z; o.sc[3] = f.sc.w;
+    o.dw = f16bits_to_f32(f.d);
+}
+
+template <int MT>
+__device__ __forceinline__ void mma_q6(const OpsQ6& o, const uint8_t* lds_act, const float* lds_ad, size_t act_ts, int ad_ts, int blk, int lane,
+                                       float (*acc)[4]) {
+    const int g = lane >> 4;
+    const v4i zero = {0, 0, 0, 0};
+    const long mask_a = (g < 2) ? -1L : 0L;
+    int P[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[m][r] = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = j & 1;
+        const uint32_t w = o.sc[j >> 1];
         const int sca = (int)(int8_t)(w >> (16 * e));
         const int scb = (int)(int8_t)(w >> (16 * e + 8));
+        const long ba = o.b[j] & mask_a, bb = o.b[j] & ~mask_a;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) P[r] += sca * ca[r] + scb * cb[r];
+        for (int m = 0; m < MT; ++m) {
+            const long a = *(const long*)(lds_act + m * act_ts + (size_t)(blk * 8 + j) * 512 + lane * 8);
+            const v4i ca = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, ba, zero, 0, 0, 0);
+            const v4i cb = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, bb, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[m][r] = mad24(scb, cb[r], mad24(sca, ca[r], P[m][r]));
+        }
     }
-    const float dw = f16bits_to_f32(f.d);
-    const v4f da = *(const v4f*)(lds_ad + blk * TK_ROW_SLOTS + 4 * g);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float s1f = (dw * da[r]) * 0.25f; /* operand bytes are 4*(q-32): exact power-of-two fold */
-        acc[r] = tk_fmaf(s1f, (float)P[r], acc[r]);
+    for (int m = 0; m < MT; ++m) {
+        const v4f da = *(const v4f*)(lds_ad + m * ad_ts + blk * TK_ROW_SLOTS + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s1f = (o.dw * da[r]) * 0.25f; /* operand bytes are 4*(q-32): exact power-of-two fold */
+            acc[m][r] = tk_fmaf(s1f, (float)P[m][r], acc[m][r]);
+        }
     }
 }
 
 size_t tk_gemv_lds_bytes(int K, int ks, int mtiles) {
     size_t Kr = (size_t)K / ks;
-    return (size_t)mtiles * (Kr * TK_ROW_SLOTS + (Kr / 256) * TK_ROW_SLOTS * 4 + (Kr / 32) * TK_ROW_SLOTS * 4);
+    return (size_t)mtiles * (Kr * TK_ROW_SLOTS + (Kr / 256) * TK_ROW_SLOTS * 4 + (Kr / 256) * 256);
 }
 
 /*
@@ -409,6 +496,11 @@ size_t tk_gemv_lds_bytes(int K, int ks, int mtiles) {
  * staged once per CU, (c) all waves of a CU walk disjoint contiguous tile runs.
  */
 /* TYPES: bit 0 = the launch contains Q4_K tiles, bit 1 = Q6_K tiles; single-type launches keep only one fragment ring in registers */
+#ifndef TK_ABLATE
+#define TK_ABLATE 0
+#endif
+/* TK_ABLATE (diagnostic builds only, never shipped), bit mask: 1 = no weight loads inside the loop, 2 = no block math, 4 = no activation staging
+ * (3 = launch + staging + epilogue only, 7 = launch + epilogue only), 8 = no epilogue stores, 16 = no prologue tile loads */
 template <int PF, int MT, int TYPES>
 __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int total_row_tiles) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -439,10 +531,10 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
 
     /* LDS: [MT] activation images, then [MT] block scales, then [MT] sub-block sums */
     const size_t act_ts = (size_t)Kr * TK_ROW_SLOTS;
-    const int ad_ts = nb * TK_ROW_SLOTS, abs_ts = nb * 8 * TK_ROW_SLOTS;
+    const int ad_ts = nb * TK_ROW_SLOTS, abs_ts = nb * 256; /* per-tile strides: floats, bytes */
     uint8_t* lds_act = lds;
     float* lds_ad = (float*)(lds + MT * act_ts);
-    int* lds_abs = (int*)(lds_ad + MT * ad_ts);
+    uint8_t* lds_abs = (uint8_t*)(lds_ad + MT * ad_ts); /* sub-block sums as (l, h) int8 images, 256 B per block */
 
     float acc[MT][4];
 #pragma unroll
@@ -457,11 +549,11 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
     const bool is4 = HAS4 && (!HAS6 || type == TK_TYPE_Q4_K);
     FragQ4 f4[HAS4 ? PF : 1];
     FragQ6 f6[HAS6 ? PF : 1];
-    if (HAS4 && is4) {
+    if (HAS4 && is4 && !(TK_ABLATE & 16)) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) f4[HAS4 ? u : 0] = load_q4(tile + (size_t)u * tile_bytes, lane);
     }
-    if (HAS6 && !is4) {
+    if (HAS6 && !is4 && !(TK_ABLATE & 16)) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) f6[HAS6 ? u : 0] = load_q6(tile + (size_t)u * tile_bytes, lane);
     }
@@ -469,19 +561,25 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
         /* activations: LDS-DMA (global_load_lds_dwordx4), one contiguous 1 KiB piece per wave-instruction, no VGPR
          * round trip and no per-piece wait: the whole K-range image is in flight at once. */
         const int nw = nthr >> 6, npiece = Kr * TK_ROW_SLOTS / 1024;
-        const int nd = nb * 4, ns = nb * 32;
+        const int nd = nb * 4, ns = nb * 16; /* uint4 counts of the scale and (l, h) images */
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)blk0 * 256 * TK_ROW_SLOTS;
-            for (int c = wave; c < npiece; c += nw)
+            if (TK_ABLATE & 4) break;
+            /* the CUs of one XCD (blockIdx / 8 = index inside the XCD) all stage the same image from the same L2: each starts at
+             * its own piece so they do not hammer one L2 channel in lock step */
+            const int rot = (int)((blockIdx.x >> 3) & 31) * npiece >> 5;
+            for (int c0 = wave; c0 < npiece; c0 += nw) {
+                const int c = c0 + rot < npiece ? c0 + rot : c0 + rot - npiece;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024 + lane * 16),
                                                  (__attribute__((address_space(3))) void*)(lds_act + m * act_ts + c * 1024), 16, 0, 0);
+            }
         }
         /* block scales and sub-block sums: <= 5 x 16 B per thread and tile, loaded together, stored together */
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const uint4* sd = (const uint4*)(a.ad + m * a.ad_ts + (size_t)blk0 * TK_ROW_SLOTS);
-            const uint4* sb = (const uint4*)(a.abs + m * a.abs_ts + (size_t)blk0 * 8 * TK_ROW_SLOTS);
+            const uint4* sb = (const uint4*)(a.abs + m * a.abs_ts + (size_t)blk0 * 256);
             uint4 t0 = make_uint4(0, 0, 0, 0), t1[4];
             if (tid < nd) t0 = sd[tid];
 #pragma unroll
@@ -496,19 +594,30 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
     __syncthreads();
     if (!active) return;
 
+    /* steady state per tile: unpack (frees the packed fragment) -> request the tile PF blocks ahead into the same registers ->
+     * MFMAs; so a tile has PF - 1 blocks of MFMA time plus its own to arrive */
     if (HAS4 && is4) {
         const uint8_t* tp = tile + PF * tile_bytes; /* one moving wave-uniform pointer: no per-load 64-bit VGPR address chains */
 #pragma unroll 1
         for (int g = 0; g < ngrp - 1; ++g, tp += PF * tile_bytes) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                for (int m = 0; m < MT; ++m) { __builtin_amdgcn_sched_barrier(0); block_q4(f4[HAS4 ? u : 0], lds_act + m * act_ts, lds_abs + m * abs_ts, lds_ad + m * ad_ts, g * PF + u, lane, acc[m]); }
+                if ((TK_ABLATE & 2)) { acc[0][0] += __builtin_bit_cast(float, f4[HAS4 ? u : 0].q0.x ^ f4[HAS4 ? u : 0].q1.y ^ f4[HAS4 ? u : 0].h.z); }
+                OpsQ4 o;
+                if (!(TK_ABLATE & 2)) { __builtin_amdgcn_sched_barrier(0); unpack_q4(f4[HAS4 ? u : 0], lane, o); }
                 __builtin_amdgcn_sched_barrier(0);
-                f4[HAS4 ? u : 0] = load_q4(tp + u * tile_bytes, lane);
+                if ((TK_ABLATE & 1) == 0) f4[HAS4 ? u : 0] = load_q4(tp + u * tile_bytes, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(TK_ABLATE & 2)) mma_q4<MT>(o, lds_act, lds_abs, lds_ad, act_ts, abs_ts, ad_ts, g * PF + u, lane, acc);
             }
         }
 #pragma unroll
-        for (int u = 0; u < PF; ++u) for (int m = 0; m < MT; ++m) { __builtin_amdgcn_sched_barrier(0); block_q4(f4[HAS4 ? u : 0], lds_act + m * act_ts, lds_abs + m * abs_ts, lds_ad + m * ad_ts, (ngrp - 1) * PF + u, lane, acc[m]); }
+        for (int u = 0; u < PF; ++u) {
+            OpsQ4 o;
+            __builtin_amdgcn_sched_barrier(0);
+            unpack_q4(f4[HAS4 ? u : 0], lane, o);
+            mma_q4<MT>(o, lds_act, lds_abs, lds_ad, act_ts, abs_ts, ad_ts, (ngrp - 1) * PF + u, lane, acc);
+        }
     }
     if (HAS6 && !is4) {
         const uint8_t* tp = tile + PF * tile_bytes;
@@ -516,13 +625,22 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
         for (int g = 0; g < ngrp - 1; ++g, tp += PF * tile_bytes) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                for (int m = 0; m < MT; ++m) { __builtin_amdgcn_sched_barrier(0); block_q6(f6[HAS6 ? u : 0], lds_act + m * act_ts, lds_ad + m * ad_ts, g * PF + u, lane, acc[m]); }
+                if ((TK_ABLATE & 2)) { acc[0][0] += __builtin_bit_cast(float, f6[HAS6 ? u : 0].q0.x ^ f6[HAS6 ? u : 0].q1.y ^ f6[HAS6 ? u : 0].qh.z ^ f6[HAS6 ? u : 0].sc.w ^ f6[HAS6 ? u : 0].d); }
+                OpsQ6 o;
+                if (!(TK_ABLATE & 2)) { __builtin_amdgcn_sched_barrier(0); unpack_q6(f6[HAS6 ? u : 0], o); }
                 __builtin_amdgcn_sched_barrier(0);
-                f6[HAS6 ? u : 0] = load_q6(tp + u * tile_bytes, lane);
+                if ((TK_ABLATE & 1) == 0) f6[HAS6 ? u : 0] = load_q6(tp + u * tile_bytes, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(TK_ABLATE & 2)) mma_q6<MT>(o, lds_act, lds_ad, act_ts, ad_ts, g * PF + u, lane, acc);
             }
         }
 #pragma unroll
-        for (int u = 0; u < PF; ++u) for (int m = 0; m < MT; ++m) { __builtin_amdgcn_sched_barrier(0); block_q6(f6[HAS6 ? u : 0], lds_act + m * act_ts, lds_ad + m * ad_ts, (ngrp - 1) * PF + u, lane, acc[m]); }
+        for (int u = 0; u < PF; ++u) {
+            OpsQ6 o;
+            __builtin_amdgcn_sched_barrier(0);
+            unpack_q6(f6[HAS6 ? u : 0], o);
+            mma_q6<MT>(o, lds_act, lds_ad, act_ts, ad_ts, (ngrp - 1) * PF + u, lane, acc);
+        }
     }
 
     const int n = row_base + rt * TK_TILE_ROWS + (lane & 15);
@@ -532,7 +650,7 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m * TK_ROW_SLOTS + 4 * g + r;
-            if (row < a.nrows) a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n] = acc[m][r];
+            if (row < a.nrows && (!(TK_ABLATE & 8) || (blockIdx.x == 0 && tid == 0))) __builtin_nontemporal_store(acc[m][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
         }
 }
 
@@ -548,21 +666,24 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     int waves = (row_tiles + groups - 1) / groups;
     while (waves > 8) { groups *= 2; waves = (row_tiles + groups - 1) / groups; } /* tall matrices: more than one WG per CU */
     const int nb = a.K / a.ks / 256;
-    /* tiles in flight per wave: the largest depth the register file holds without spilling for this M-tile count
-     * (tuning overrides: TK_GEMV_PF1 / TK_GEMV_PF2 = depth cap for 1 / 2 M-tiles, TK_GEMV_MIXED=1 forces the two-type kernel) */
-    static int cap1 = -1, cap2 = -1, force_mixed = -1;
-    if (cap1 < 0) {
-        const char* e1 = getenv("TK_GEMV_PF1"); const char* e2 = getenv("TK_GEMV_PF2"); const char* e3 = getenv("TK_GEMV_MIXED");
-        cap1 = e1 ? atoi(e1) : 2; cap2 = e2 ? atoi(e2) : 2; force_mixed = e3 ? atoi(e3) : -1;
+    /* tiles in flight per wave: the largest depth the register file holds without spilling, per (M-tiles, tile types) variant —
+     * from the compiler's resource report and timings on MI355X (profiles/r01_gemv_variants.txt).
+     * Tuning overrides: TK_GEMV_CAPS="a,b,c,d,e,f" = depth caps for (1 M-tile: Q4, Q6, mixed; 2 M-tiles: Q4, Q6, mixed),
+     * TK_GEMV_MIXED=1 forces the two-type kernel. */
+    static int caps[2][3] = {{2, 2, 2}, {2, 2, 2}};
+    static int force_mixed = -1;
+    if (force_mixed < 0) {
+        const char* e1 = getenv("TK_GEMV_CAPS"); const char* e3 = getenv("TK_GEMV_MIXED");
+        if (e1) sscanf(e1, "%d,%d,%d,%d,%d,%d", &caps[0][0], &caps[0][1], &caps[0][2], &caps[1][0], &caps[1][1], &caps[1][2]);
+        force_mixed = e3 ? atoi(e3) : 0;
     }
-    const int cap = mt == 1 ? cap1 : cap2;
-    int pf = nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1);
-    while (pf > cap) pf /= 2;
     int types = 0;
     for (int i = 0; i < a.nseg; ++i) types |= a.seg[i].type == TK_TYPE_Q4_K ? 1 : 2;
-    /* measured on MI355X (profiles/r01_gemv_variants.txt): depth 2 never spills; with two M-tiles only the two-type kernel stays
-     * inside 256 VGPRs, so it is used for every 2-tile launch */
-    if (force_mixed > 0 || (force_mixed < 0 && mt == 2)) types = 3;
+    /* a Q6-only launch with two M-tiles spills as a single-type kernel at depth 2; the two-type kernel does not */
+    if (force_mixed > 0 || (mt == 2 && types == 2)) types = 3;
+    const int cap = caps[mt - 1][types - 1];
+    int pf = nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1);
+    while (pf > cap) pf /= 2;
 #define TK_GEMV_LAUNCH(PFV, MTV, TYV)                                                                                              \
     do {                                                                                                                           \
         static size_t cap = 0; /* >64 KiB of dynamic LDS must be opted into once per kernel */                                     \

@@ -30,7 +30,9 @@
  *      aq  : int8   [K/32 sub-block][4 g][16 row slot][8]   == the MFMA A-operand image; a K-range is
  *                    one contiguous run that is memcpy'd into LDS
  *      ad  : float  [K/256][16]        block scale amax/127
- *      abs : int32  [K/32][16]         per-sub-block sums of the int8 values (the Q4_K "min" term)
+ *      abs : int8   [K/256][2][16][8]  per-sub-block sums of the int8 values (the Q4_K "min" term) split as
+ *                                      sum = 64 h + l: image 0 holds l (0..63), image 1 holds h, byte j = sub-block j —
+ *                                      the A operand of the MFMA that contracts them with the 6-bit mins
  *  "row slot" b < 16 is a (sequence, position) row of the current pass; a pass holds up to TK_MAX_TILES such
  *  16-row M-tiles (row r lives in tile r / 16, slot r % 16), each with its own aq / ad / abs image.
  */
@@ -49,6 +51,6 @@
 /* per M-tile sizes; tile m of a buffer starts at m * (these) */
 #define TK_AQ_BYTES(K) ((size_t)(K) * TK_ROW_SLOTS)
 #define TK_AD_FLOATS(K) ((size_t)(K) / 256 * TK_ROW_SLOTS)
-#define TK_ABS_INTS(K) ((size_t)(K) / 32 * TK_ROW_SLOTS)
+#define TK_ABS_BYTES(K) ((size_t)(K) / 256 * 256)
 
 #endif
