@@ -60,15 +60,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="concurrent cortex cycles per GPU (<=32: two 16-row MFMA M-tiles)")
+    ap.add_argument("--batch", type=int, default=128, help="concurrent cortex cycles per decode group = rows per LLM pass (<=128: eight 16-row MFMA M-tiles)")
     ap.add_argument("--prompt", type=int, default=64)
     ap.add_argument("--decode", type=int, default=128)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers => result marked invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sessions", type=int, default=3,
+    ap.add_argument("--sessions", type=int, default=2,
                     help="independent decode groups of --batch cycles run concurrently on their own HIP streams (fills the "
                          "launch/ramp bubbles of one group with another group's kernels); concurrent cycles = sessions * batch")
     ap.add_argument("--llm-only", action="store_true", help="configs[1] only: leave the detector / ASR / VAD streams out (marked in config)")
+    ap.add_argument("--perception-batch", type=int, default=32, help="frames / utterances per detector / ASR call")
     ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     args = ap.parse_args()
 
@@ -106,9 +107,10 @@ def main():
     fused = not args.llm_only
     perc_ms = {"vision": [], "audio": []}
     if fused:
+        PB = min(B, args.perception_batch)  # frames / utterances per detector / ASR call
         det = tk.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", width=640, height=640, conf=0.5, iou=0.5,
-                                device=local_rank, max_batch=B)
-        asr = tk.Asr(hp=tk.WHISPER_TINY_EN(), seed=6, device=local_rank, max_batch=B)
+                                device=local_rank, max_batch=PB)
+        asr = tk.Asr(hp=tk.WHISPER_TINY_EN(), seed=6, device=local_rank, max_batch=PB)
         vad = tk.Vad()
         frng = np.random.default_rng(1 + rank)
         frames = [frng.integers(0, 256, (640, 640, 3), dtype=np.uint8) for _ in range(G * B)]
@@ -116,11 +118,11 @@ def main():
         pcm = np.clip(prng.normal(0, 3000, (G * B, 16000)), -32768, 32767).astype(np.int16)
         n_dets = [0]
 
-        def vision_pass():  # one frame per concurrent cycle, B frames per detector call
+        def vision_pass():  # one frame per concurrent cycle, PB frames per detector call
             t = time.time()
             n = 0
-            for g in range(G):
-                n += sum(len(r) for r in det.detect_batch(frames[g * B:(g + 1) * B]))
+            for i in range(0, G * B, PB):
+                n += sum(len(r) for r in det.detect_batch(frames[i:i + PB]))
             n_dets[0] = n
             perc_ms["vision"].append(1000 * (time.time() - t))
 
@@ -129,8 +131,8 @@ def main():
             for b in range(G * B):
                 vad.reset()
                 vad.process_with_events(pcm[b])
-            for g in range(G):
-                asr.transcribe_tokens(pcm[g * B:(g + 1) * B], args.asr_steps, want_aux=False)
+            for i in range(0, G * B, PB):
+                asr.transcribe_tokens(pcm[i:i + PB], args.asr_steps, want_aux=False)
             perc_ms["audio"].append(1000 * (time.time() - t))
 
         def perception_async():
@@ -211,15 +213,22 @@ def main():
                 total_bytes += nbytes * cnt
                 launches += cnt
         achieved = total_bytes / total_ms / 1e6  # GB/s
-        return {"bound": "hbm", "kernel": "k_gemv_w4a8", "rows_per_pass": rows, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        kernel = "k_gemm_w4a8" if rows > 32 else "k_gemv_w4a8"  # > 32 rows: the K-streamed batched variant of the same arithmetic
+        return {"bound": "hbm", "kernel": kernel, "rows_per_pass": rows, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": round(total_bytes / launches),
                 "avg_launch_ms": round(total_ms / launches, 5), "launches_per_decode_step": launches, "per_shape": shapes}
 
     roofline = gemv_roofline(B)
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction applied)
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
-    if os.path.exists(pmc) and B > 16:
-        roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_average_launch")
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_b128.json" if B > 32 else "r01_pmc_gemv.json")
+    if os.path.exists(pmc):
+        pj = json.load(open(pmc))
+        if pj.get("rows_per_pass") == B:
+            roofline["traffic"] = pj.get("hbm_bytes_per_average_launch")
+    # the same launches priced against the matrix cores: 2 int8 ops per (row, weight); 16x16x64 i8 MFMA = 2x the bf16 rate
+    n_weights = roofline["algorithmic_bytes_per_launch"] / 0.5625 * 0.97  # ~Q4_K bytes/weight; reported for orientation only
+    roofline["int8_tops"] = round(2.0 * B * n_weights / (roofline["avg_launch_ms"] * 1e-3) / 1e12, 1)
+    roofline["int8_peak_tops"] = 5000.0
     # the same kernel at 16 rows per pass (one MFMA M-tile): less integer work per weight byte, closer to the HBM bound
     roofline_16 = gemv_roofline(16) if B > 16 else None
 

@@ -51,13 +51,15 @@ TK_API void tk_mi355x_llm_model_destroy(tk_mi355x_llm_model_t** m);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_session_create(tk_mi355x_llm_session_t** out, tk_mi355x_llm_model_t* m, int max_seq,
                                                                  int max_ctx);
 TK_API void tk_mi355x_llm_session_destroy(tk_mi355x_llm_session_t** s);
-/* one pass over nrows <= 32 (sequence, position, token) rows; logits [nrows][vocab] and argmax [nrows] optional */
+/* rows one pass can hold (16-row MFMA M-tiles x 8): the row capacity of forward(), the column count of decode()'s out_tokens */
+TK_API int tk_mi355x_llm_max_rows(void);
+/* one pass over nrows <= tk_mi355x_llm_max_rows() (sequence, position, token) rows; logits [nrows][vocab] and argmax [nrows] optional */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_forward(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos,
                                                           const int32_t* tok, float* logits, int32_t* argmax);
 /* equal-length prompts for sequences 0..nseq-1; first_tokens[nseq] optional */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_prefill(tk_mi355x_llm_session_t* s, int nseq, int n_prompt, const int32_t* tokens,
                                                           int32_t* first_tokens);
-/* greedy decode of n_steps tokens for rows 0..nrows-1, hipGraph replay; out_tokens[n_steps][32] (TK_MAX_ROWS columns) */
+/* greedy decode of n_steps tokens for rows 0..nrows-1, hipGraph replay; out_tokens[n_steps][tk_mi355x_llm_max_rows()] */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t* s, int nrows, int n_steps, int32_t* out_tokens,
                                                          float* ms_per_step);
 /* HIP-event timing of one GEMV launch on the session stream: which = 0 gate+up, 1 down, 2 qkv, 3 lm_head, 4 o */

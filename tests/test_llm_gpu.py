@@ -132,6 +132,53 @@ def test_mistral_shaped_layer_bit_exact(gpu):
         assert np.array_equal(gam, wam)
 
 
+@pytest.mark.parametrize("nrows", [33, 48, 64, 65, 100, 128])
+def test_tiny_batched_pass_rows(gpu, nrows):
+    """passes of more than 32 rows take the K-streamed batched kernel (4 or 8 M-tiles per weight tile, folded Q6_K):
+    ragged rows over several sequences, then one decode row per sequence — bit-exact logits"""
+    hp = gpu.TINY()
+    model = gpu.LlmModel(hp).fill_synthetic(21)
+    hp = model.hparams
+    nseq = 7
+    sess = gpu.LlmSession(model, nseq, 64)
+    orc = O.OracleLlm(oracle_cfg_from(hp, 64, nseq), seed=21)
+    rng = np.random.default_rng(nrows)
+    lens = np.full(nseq, nrows // nseq)
+    lens[: nrows - lens.sum()] += 1
+    seq = np.concatenate([np.full(n, s) for s, n in enumerate(lens)]).astype(np.int32)
+    pos = np.concatenate([np.arange(n) for n in lens]).astype(np.int32)
+    tok = rng.integers(3, hp.vocab, nrows).astype(np.int32)
+    want, wam = orc.forward(seq, pos, tok)
+    got, gam = sess.forward(seq, pos, tok)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.array_equal(gam, wam)
+    seq2 = np.arange(nseq, dtype=np.int32)
+    tok2 = rng.integers(3, hp.vocab, nseq).astype(np.int32)
+    w2, _ = orc.forward(seq2, lens.astype(np.int32), tok2)
+    g2, _ = sess.forward(seq2, lens.astype(np.int32), tok2)
+    assert np.array_equal(g2.view(np.uint32), w2.view(np.uint32))
+
+
+def test_mistral_shaped_layer_batched_bit_exact(gpu):
+    """the Mistral-7B-shaped layer again through the batched kernel: 40 rows (4 M-tiles) and 128 rows (8 M-tiles), Q4_K and Q6_K tensors"""
+    hp = gpu.MISTRAL_7B()
+    hp.n_layer = 1
+    model = gpu.LlmModel(hp).fill_synthetic(4)
+    hp = model.hparams
+    rng = np.random.default_rng(2)
+    for nrows in (40, 128):
+        sess = gpu.LlmSession(model, nrows, 8)
+        orc = O.OracleLlm(oracle_cfg_from(hp, 8, nrows), seed=4)
+        seq = np.arange(nrows, dtype=np.int32)
+        for p in range(2):
+            tok = rng.integers(3, hp.vocab, nrows).astype(np.int32)
+            want, wam = orc.forward(seq, np.full(nrows, p, np.int32), tok)
+            got, gam = sess.forward(seq, np.full(nrows, p, np.int32), tok)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+            assert np.array_equal(gam, wam)
+        sess.close()
+
+
 def test_reference_runner_surface(gpu):
     """tk_model_loader_* + tk_llm_runner_* as the reference's Rust GgufRunner drives them"""
     loader = gpu.ModelLoader()
@@ -185,8 +232,9 @@ def test_error_paths(gpu):
     sess = gpu.LlmSession(model, 1, 16)
     with pytest.raises(gpu.TkError):  # position beyond context
         sess.forward([0], [16], [5])
-    with pytest.raises(gpu.TkError):  # 33 rows
-        sess.forward(np.zeros(33, np.int32), np.arange(33, dtype=np.int32) % 16, np.full(33, 5, np.int32))
+    n_over = gpu.lib().tk_mi355x_llm_max_rows() + 1
+    with pytest.raises(gpu.TkError):  # one row more than a pass holds
+        sess.forward(np.zeros(n_over, np.int32), np.arange(n_over, dtype=np.int32) % 16, np.full(n_over, 5, np.int32))
     assert gpu.lib().tk_mi355x_llm_forward(None, 1, None, None, None, None, None) == 1001
 
 

@@ -224,6 +224,8 @@ tk_error_code_t tk_mi355x_llm_prefill(tk_mi355x_llm_session_t* s, int nseq, int 
     return TK_SUCCESS;
 }
 
+int tk_mi355x_llm_max_rows(void) { return TK_MAX_ROWS; }
+
 tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t* s, int nrows, int n_steps, int32_t* out_tokens, float* ms_per_step) {
     if (!s) return TK_ERROR_INVALID_ARGUMENT;
     if (!s->session.decode(nrows, n_steps, out_tokens)) return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);

@@ -303,7 +303,7 @@ void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) {
 
 bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
                            bool lm_head) {
-    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,32]"; return false; }
+    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,128]"; return false; }
     for (int r = 0; r < nrows; ++r) {
         if (seq[r] < 0 || seq[r] >= max_seq || pos[r] < 0 || pos[r] >= max_ctx || tok[r] < 0 || tok[r] >= model->hp.vocab) {
             error = "row out of range (sequence id, position or token id)";
@@ -329,7 +329,7 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
 }
 
 bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens_host) {
-    if (nseq <= 0 || nseq > TK_MAX_ROWS || nseq > max_seq) { error = "nseq must be in [1, min(32, max_seq)]"; return false; }
+    if (nseq <= 0 || nseq > TK_MAX_ROWS || nseq > max_seq) { error = "nseq must be in [1, min(128, max_seq)]"; return false; }
     if (n_prompt <= 0 || n_prompt >= max_ctx) { error = "prompt does not fit the context"; return false; }
     /* all but the last prompt token: 16 rows per pass, positions ascending so causality holds inside a pass */
     std::vector<int32_t> sq, ps, tk;
@@ -351,7 +351,7 @@ bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_
 }
 
 bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
-    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,32]"; return false; }
+    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,128]"; return false; }
     if (n_steps <= 0 || n_steps > hist_cap) { error = "n_steps exceeds the session context"; return false; }
     HIPQ(hipSetDevice(model->device));
     /* positions must stay inside the cache for the whole loop */

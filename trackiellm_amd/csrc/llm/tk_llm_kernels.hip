@@ -654,17 +654,334 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
         }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Batched passes (33..128 rows: prefill chunks, wide decode batches): same work mapping and the same per-row arithmetic as
+ * k_gemv_w4a8, but the weight tile is unpacked ONCE and multiplied against MT = 4 or 8 M-tiles, so the dequantisation VALU
+ * work and the HBM bytes per row drop by MT.  The K-range's activations no longer fit in LDS, so they stream through a
+ * two-slot ring of 256-k blocks (MT x {4 KiB int8 image, 256 B sub-block sums, 64 B scales} each):
+ *
+ *   every TK_RING_BLOCKS blocks:  s_waitcnt vmcnt(0) -> my DMA pieces of this slot (and my weight tile) have landed
+ *                                 barrier            -> everybody's pieces have; everybody is done with the other slot
+ *                                 DMA the next TK_RING_BLOCKS blocks into the other slot
+ *   every block:                  unpack tile b, request tile b+1 into the same registers, MT x MFMA chains with the LDS operand reads
+ *                                 of M-tile m+1 issued before the MFMAs of M-tile m and the fp32 FMAs of m-1 filling the MFMA shadow
+ *
+ * so a slot's activations have a whole slot time (> 2 us) and the next weight tile a whole block time to arrive.
+ * Q6_K tiles are folded like Q4_K ones here: v = scale * (q - 32) (14 bits signed) is split v = 64 vh + vl (vl 0..63,
+ * vh -64..64, both int8) with packed 16-bit arithmetic, once per tile, so each M-tile costs 8 chained MFMAs and no VALU
+ * scale work.  Integer-exact like everything else: P is the oracle's integer.
+ * ------------------------------------------------------------------------------------------ */
+typedef short v2s16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_ashr16(uint32_t x, int n) {
+    const v2s16 r = __builtin_bit_cast(v2s16, x) >> (v2s16){(short)n, (short)n};
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_shl16(uint32_t x, int n) {
+    const v2u16 r = __builtin_bit_cast(v2u16, x) << (v2u16){(unsigned short)n, (unsigned short)n};
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_mul16(uint32_t x, short s) {
+    const v2s16 r = __builtin_bit_cast(v2s16, x) * (v2s16){s, s};
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+/* four int8 operand bytes b_t = 4 q_t of one dword -> the two digit dwords of v_t = s * q_t */
+__device__ __forceinline__ void q6_digits(uint32_t b, short s, int* vl, int* vh) {
+    const uint32_t qe = pk_ashr16(pk_shl16(b, 8), 10); /* (q_0, q_2) sign-extended to 16 bits */
+    const uint32_t qo = pk_ashr16(b, 10);              /* (q_1, q_3) */
+    const uint32_t we = pk_mul16(qe, s), wo = pk_mul16(qo, s);
+    const uint32_t le = we & 0x003F003Fu, lo = wo & 0x003F003Fu;
+    const uint32_t he = pk_ashr16(we, 6), ho = pk_ashr16(wo, 6);
+    /* bytes (e.0, o.0, e.2, o.2): v_perm_b32 selector, source bytes 0..3 = second operand, 4..7 = first */
+    *vl = (int)__builtin_amdgcn_perm(lo, le, 0x06020400u);
+    *vh = (int)__builtin_amdgcn_perm(ho, he, 0x06020400u);
+}
+
+__device__ __forceinline__ void unpack_q6_fold(const FragQ6& f, int lane, OpsQ4& o) { /* bm / dmin stay unused: Q6_K has no min term */
+    const uint32_t qs[8] = {f.q0.x, f.q0.y, f.q0.z, f.q0.w, f.q1.x, f.q1.y, f.q1.z, f.q1.w};
+    const uint32_t qh[4] = {f.qh.x, f.qh.y, f.qh.z, f.qh.w};
+    const uint32_t scw[4] = {f.sc.x, f.sc.y, f.sc.z, f.sc.w};
+    const int upper = (lane >> 5) & 1; /* lane groups 2, 3 hold k 16..31 of every sub-block: the second group scale */
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t x = qs[j];
+        const uint32_t H = qh[j >> 1];
+        const int e = j & 1;
+        const uint32_t lo = ((x << 2) & 0x3C3C3C3Cu) | ((H << (6 - 4 * e)) & 0xC0C0C0C0u);
+        const uint32_t hi = ((x >> 2) & 0x3C3C3C3Cu) | ((H << (4 - 4 * e)) & 0xC0C0C0C0u);
+        const short s = (short)(int8_t)(scw[j >> 1] >> (16 * e + 8 * upper));
+        int l0, h0, l1, h1;
+        q6_digits(lo, s, &l0, &h0);
+        q6_digits(hi, s, &l1, &h1);
+        o.bl[j >> 1][2 * e] = l0; o.bl[j >> 1][2 * e + 1] = l1;
+        o.bh[j >> 1][2 * e] = h0; o.bh[j >> 1][2 * e + 1] = h1;
+    }
+    o.dw = f16bits_to_f32(f.d);
+}
+
+/* A-side operands of one M-tile of one ring block, read from LDS one tile AHEAD of the MFMAs that consume them */
+struct ATile { v4i a[4]; long ml, mh; v4f da; };
+template <bool MINS>
+__device__ __forceinline__ void lds_tile(ATile& t, const uint8_t* act, const uint8_t* amn, const uint8_t* ad, int lane) {
+    const uint8_t* ap = act + lane * 8;
+    if (TK_ABLATE & 64) {
+        for (int j2 = 0; j2 < 4; ++j2) t.a[j2] = (v4i){lane, j2, lane + j2, 1};
+        t.ml = lane; t.mh = lane + 1; t.da = (v4f){1.0f, 2.0f, 3.0f, 4.0f};
+        return;
+    }
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+        const v2i a0 = *(const v2i*)(ap + (2 * j2) * 512);
+        const v2i a1 = *(const v2i*)(ap + (2 * j2 + 1) * 512);
+        t.a[j2] = (v4i){a0.x, a0.y, a1.x, a1.y};
+    }
+    if (MINS) {
+        const uint8_t* mp = amn + (lane & 15) * 8;
+        t.ml = *(const long*)mp;
+        t.mh = *(const long*)(mp + 128);
+    }
+    t.da = *(const v4f*)(ad + 16 * (lane >> 4));
+}
+/* integer results of one M-tile, finished (two fp32 FMAs per row) while the next tile's MFMAs run */
+struct PTile { v4i pl, ph, cl, ch; v4f da; };
+
+#define TK_RING_TILE_BYTES (256 * TK_ROW_SLOTS + 256 + TK_ROW_SLOTS * 4) /* one M-tile of one 256-k block: image + sums + scales */
+#define TK_RING_BLOCKS 2 /* 256-k blocks per ring slot: 2 slots x 2 blocks x 8 M-tiles = 138 KiB of the 160 KiB LDS */
+
+/* diagnostic builds: TK_ABLATE bit 32 = batched kernel without MFMAs (operands xor-ed so nothing is dead), 64 = without LDS operand reads,
+ * 128 = without the per-step barrier and ring refill (first block's activations reused) */
+#if TK_ABLATE & 32
+#define TK_MFMA64(a, b, c, x, y, z) ((c) ^ (a) ^ (b))
+#define TK_MFMA32(a, b, c, x, y, z) ((c) ^ (v4i){(int)(a), (int)((a) >> 32), (int)(b), (int)((b) >> 32)})
+#else
+#define TK_MFMA64 __builtin_amdgcn_mfma_i32_16x16x64_i8
+#define TK_MFMA32 __builtin_amdgcn_mfma_i32_16x16x32_i8
+#endif
+template <bool Q4>
+__device__ __forceinline__ void finish_tile(const PTile& R, const OpsQ4& o, float* acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc[r] = tk_fmaf(o.dw * R.da[r], (float)((R.ph[r] << (Q4 ? 3 : 6)) + R.pl[r]), acc[r]);
+        if (Q4) acc[r] = tk_fmaf(-(o.dmin * R.da[r]), (float)((R.ch[r] << 6) + R.cl[r]), acc[r]);
+    }
+}
+
+/* one 256-k block: NT weight tiles (operands in registers) x MT M-tiles (operands streamed from the LDS ring, each read once
+ * for all NT weight tiles) */
+template <int MT, int NT, bool Q4>
+__device__ __forceinline__ void gemm_block(const OpsQ4 (&o)[NT], const uint8_t* chunk, int lane, float (&acc)[NT][MT][4]) {
+    constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 256;
+    const v4i zero = {0, 0, 0, 0};
+    ATile T[2];
+    PTile R[NT];
+    lds_tile<Q4>(T[0], chunk, chunk + OFF_AMN, chunk + OFF_AD, lane);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m + 1 < MT) lds_tile<Q4>(T[(m + 1) & 1], chunk + (m + 1) * 4096, chunk + OFF_AMN + (m + 1) * 256, chunk + OFF_AD + (m + 1) * 64, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        const ATile& t = T[m & 1];
+        PTile c[NT];
+#pragma unroll
+        for (int w = 0; w < NT; ++w) {
+            c[w].pl = TK_MFMA64(t.a[0], o[w].bl[0], zero, 0, 0, 0);
+            c[w].ph = TK_MFMA64(t.a[0], o[w].bh[0], zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j2 = 1; j2 < 4; ++j2)
+#pragma unroll
+            for (int w = 0; w < NT; ++w) {
+                c[w].pl = TK_MFMA64(t.a[j2], o[w].bl[j2], c[w].pl, 0, 0, 0);
+                c[w].ph = TK_MFMA64(t.a[j2], o[w].bh[j2], c[w].ph, 0, 0, 0);
+            }
+#pragma unroll
+        for (int w = 0; w < NT; ++w) {
+            if (Q4) {
+                c[w].cl = TK_MFMA32(t.ml, o[w].bm, zero, 0, 0, 0);
+                c[w].ch = TK_MFMA32(t.mh, o[w].bm, zero, 0, 0, 0);
+            }
+            c[w].da = t.da;
+        }
+        if (m > 0) {
+#pragma unroll
+            for (int w = 0; w < NT; ++w) finish_tile<Q4>(R[w], o[w], acc[w][m - 1]);
+        }
+#pragma unroll
+        for (int w = 0; w < NT; ++w) R[w] = c[w];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int w = 0; w < NT; ++w) finish_tile<Q4>(R[w], o[w], acc[w][MT - 1]);
+}
+
+/* NT = weight tiles per wave: 2 (adjacent row tiles, same tensor) when a CU owns enough tiles to keep four such waves busy —
+ * the LDS operand stream, the bound of this kernel, is then read once per TWO weight tiles */
+template <int MT, int TYPES, int NT>
+__global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a, int groups, int total_row_tiles) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int CH = MT * TK_RING_TILE_BYTES;   /* one block of the ring */
+    constexpr int CB = TK_RING_BLOCKS;            /* blocks per ring slot = per barrier */
+    constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = blockDim.x >> 6;
+    const int nb = a.K / a.ks / 256;
+    const int nblk_total = a.K / 256;
+    const int ksi = blockIdx.x % a.ks;
+    const int blk0 = ksi * nb;
+
+    int rt = NT * (blockIdx.x / a.ks + wave * groups); /* first of this wave's NT adjacent row tiles */
+    const bool active = rt < total_row_tiles;
+    if (!active) rt = 0;
+    int seg = 0, row_base = 0;
+    while (seg < a.nseg - 1 && rt >= a.seg[seg].row_tiles) {
+        rt -= a.seg[seg].row_tiles;
+        row_base += a.seg[seg].row_tiles * TK_TILE_ROWS;
+        ++seg;
+    }
+    const int type = a.seg[seg].type;
+    constexpr bool HAS4 = (TYPES & 1) != 0, HAS6 = (TYPES & 2) != 0;
+    const bool is4 = HAS4 && (!HAS6 || type == TK_TYPE_Q4_K);
+    const size_t tile_bytes = is4 ? (size_t)TK_Q4K_TILE_BYTES : (size_t)TK_Q6K_TILE_BYTES;
+    const size_t tile_pitch = (size_t)nblk_total * tile_bytes; /* to the same block of the next row tile */
+    const uint8_t* tile = a.seg[seg].tiles + ((size_t)rt * nblk_total + blk0) * tile_bytes;
+
+    float acc[NT][MT][4];
+#pragma unroll
+    for (int w = 0; w < NT; ++w)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[w][m][r] = 0.0f;
+
+    /* ring staging: 6 MT LDS-DMA pieces per block (4 x 1 KiB image, 256 B sums, 64 B scales per M-tile), dealt round-robin to the waves */
+    auto stage = [&](int c, int slot) {
+        uint8_t* dst = lds + slot * CH;
+        for (int p = wave; p < 6 * MT; p += nw) {
+            if (p < 4 * MT) {
+                const int m = p >> 2, q = p & 3;
+                const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)(blk0 + c) * 4096 + q * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + m * 4096 + q * 1024), 16, 0, 0);
+            } else if (p < 5 * MT) {
+                const int m = p - 4 * MT;
+                const uint8_t* src = (const uint8_t*)a.abs + m * a.abs_ts + (size_t)(blk0 + c) * 256 + lane * 16;
+                if (lane < 16)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + OFF_AMN + m * 256), 16, 0, 0);
+            } else {
+                const int m = p - 5 * MT;
+                const uint8_t* src = (const uint8_t*)(a.ad + m * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS) + lane * 16;
+                if (lane < 4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + OFF_AD + m * 64), 16, 0, 0);
+            }
+        }
+    };
+
+    FragQ4 f4[HAS4 ? NT : 1];
+    FragQ6 f6[HAS6 ? NT : 1];
+    if (active) {
+#pragma unroll
+        for (int w = 0; w < NT; ++w) {
+            if (HAS4 && is4) f4[HAS4 ? w : 0] = load_q4(tile + w * tile_pitch, lane);
+            if (HAS6 && !is4) f6[HAS6 ? w : 0] = load_q6(tile + w * tile_pitch, lane);
+        }
+    }
+    for (int i = 0; i < CB && i < nb; ++i) stage(i, i);
+
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+        if (b % CB == 0 && (!(TK_ABLATE & 128) || b == 0)) { /* chunk boundary: CB blocks per barrier */
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (!(TK_ABLATE & 128))
+                for (int i = 0; i < CB && b + CB + i < nb; ++i) stage(b + CB + i, ((b / CB + 1) & 1) * CB + i);
+        }
+        if (!active) continue;
+        const uint8_t* chunk = lds + ((TK_ABLATE & 128) ? 0 : (((b / CB) & 1) * CB + b % CB)) * CH;
+        const uint8_t* next = tile + (size_t)(b + 1 < nb ? b + 1 : b) * tile_bytes; /* the last step re-requests its own tile: no branch around a load */
+        OpsQ4 o[NT];
+        if (HAS4 && is4) {
+#pragma unroll
+            for (int w = 0; w < NT; ++w) unpack_q4(f4[HAS4 ? w : 0], lane, o[w]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int w = 0; w < NT; ++w) f4[HAS4 ? w : 0] = load_q4(next + w * tile_pitch, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_block<MT, NT, true>(o, chunk, lane, acc);
+        }
+        if (HAS6 && !is4) {
+#pragma unroll
+            for (int w = 0; w < NT; ++w) unpack_q6_fold(f6[HAS6 ? w : 0], lane, o[w]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int w = 0; w < NT; ++w) f6[HAS6 ? w : 0] = load_q6(next + w * tile_pitch, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_block<MT, NT, false>(o, chunk, lane, acc);
+        }
+    }
+    if (!active) return;
+
+    const int g = lane >> 4;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) {
+        const int n = row_base + (rt + w) * TK_TILE_ROWS + (lane & 15);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * TK_ROW_SLOTS + 4 * g + r;
+                if (row < a.nrows) __builtin_nontemporal_store(acc[w][m][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
+            }
+    }
+}
+
 #define TK_NUM_CU 256
 void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     int row_tiles = 0;
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.seg[i].row_tiles;
-    const int mt = a.nrows > TK_ROW_SLOTS ? 2 : 1;
-    size_t lds = tk_gemv_lds_bytes(a.K, a.ks, mt);
     int groups = TK_NUM_CU / a.ks;            /* workgroups per K-range */
     if (groups < 1) groups = 1;
     if (groups > row_tiles) groups = row_tiles;
     int waves = (row_tiles + groups - 1) / groups;
     while (waves > 8) { groups *= 2; waves = (row_tiles + groups - 1) / groups; } /* tall matrices: more than one WG per CU */
+    int types = 0;
+    for (int i = 0; i < a.nseg; ++i) types |= a.seg[i].type == TK_TYPE_Q4_K ? 1 : 2;
+    if (a.nrows > 2 * TK_ROW_SLOTS) { /* batched passes: K-streamed activations, 4 or 8 M-tiles per weight tile */
+        const int mtb = a.nrows > 4 * TK_ROW_SLOTS ? 8 : 4;
+        const size_t ldsb = (size_t)2 * TK_RING_BLOCKS * mtb * TK_RING_TILE_BYTES;
+        /* weight tiles per wave: 1.  TK_GEMM_NT=2 selects two adjacent tiles per wave (tensor row counts are multiples of 64, so a
+         * pair never straddles two tensors): it halves the LDS operand stream but leaves one wave per SIMD, and measured 25 % slower
+         * on MI355X (profiles/r01_gemm_batched.txt) — kept as a tuning knob, parity-tested */
+        static int force_nt = -1;
+        if (force_nt < 0) { const char* e = getenv("TK_GEMM_NT"); force_nt = e ? atoi(e) : 0; }
+        bool even = true;
+        for (int i = 0; i < a.nseg; ++i) even = even && a.seg[i].row_tiles % 2 == 0;
+        const int nt = (force_nt == 2 && even) ? 2 : 1;
+        if (nt == 2) {
+            const int pairs = row_tiles / 2;
+            groups = TK_NUM_CU / a.ks;
+            if (groups < 1) groups = 1;
+            if (groups > pairs) groups = pairs;
+            waves = (pairs + groups - 1) / groups;
+            while (waves > 4) { groups *= 2; waves = (pairs + groups - 1) / groups; }
+        }
+#define TK_GEMM_LAUNCH(MTV, TYV, NTV)                                                                                              \
+    do {                                                                                                                           \
+        static bool opted = false;                                                                                                 \
+        if (!opted) { (void)hipFuncSetAttribute((const void*)k_gemm_w4a8<MTV, TYV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TK_RING_BLOCKS * 8 * TK_RING_TILE_BYTES); opted = true; } \
+        hipLaunchKernelGGL((k_gemm_w4a8<MTV, TYV, NTV>), dim3(groups * a.ks), dim3(64 * waves), ldsb, s, a, groups, row_tiles);     \
+    } while (0)
+#define TK_GEMM_TY(MTV, NTV) do { if (types == 1) TK_GEMM_LAUNCH(MTV, 1, NTV); else if (types == 2) TK_GEMM_LAUNCH(MTV, 2, NTV); else TK_GEMM_LAUNCH(MTV, 3, NTV); } while (0)
+        if (mtb == 4) { if (nt == 2) TK_GEMM_TY(4, 2); else TK_GEMM_TY(4, 1); }
+        else { if (nt == 2) TK_GEMM_TY(8, 2); else TK_GEMM_TY(8, 1); }
+#undef TK_GEMM_TY
+#undef TK_GEMM_LAUNCH
+        return;
+    }
+    const int mt = a.nrows > TK_ROW_SLOTS ? 2 : 1;
+    size_t lds = tk_gemv_lds_bytes(a.K, a.ks, mt);
     const int nb = a.K / a.ks / 256;
     /* tiles in flight per wave: the largest depth the register file holds without spilling, per (M-tiles, tile types) variant —
      * from the compiler's resource report and timings on MI355X (profiles/r01_gemv_variants.txt).
@@ -677,8 +994,6 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
         if (e1) sscanf(e1, "%d,%d,%d,%d,%d,%d", &caps[0][0], &caps[0][1], &caps[0][2], &caps[1][0], &caps[1][1], &caps[1][2]);
         force_mixed = e3 ? atoi(e3) : 0;
     }
-    int types = 0;
-    for (int i = 0; i < a.nseg; ++i) types |= a.seg[i].type == TK_TYPE_Q4_K ? 1 : 2;
     /* a Q6-only launch with two M-tiles spills as a single-type kernel at depth 2; the two-type kernel does not */
     if (force_mixed > 0 || (mt == 2 && types == 2)) types = 3;
     const int cap = caps[mt - 1][types - 1];

@@ -91,7 +91,7 @@ class LlmSession:
         return first
 
     def decode(self, nrows, n_steps):
-        out = np.empty((n_steps, 32), dtype=np.int32)  # TK_MAX_ROWS columns
+        out = np.empty((n_steps, lib().tk_mi355x_llm_max_rows()), dtype=np.int32)
         ms = C.c_float(0)
         check(lib().tk_mi355x_llm_decode(self.h, nrows, n_steps, _p(out), C.byref(ms)))
         return out[:, :nrows].copy(), ms.value
