@@ -69,6 +69,9 @@ def main():
                     help="independent decode groups of --batch cycles run concurrently on their own HIP streams (fills the "
                          "launch/ramp bubbles of one group with another group's kernels); concurrent cycles = sessions * batch")
     ap.add_argument("--llm-only", action="store_true", help="configs[1] only: leave the detector / ASR / VAD streams out (marked in config)")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the isolated per-shape timing of the dominant kernel (the roofline object); profile THIS command with "
+                         "rocprofv3 --kernel-trace to compare its kernel durations with the HIP-event numbers (tools/roofline_check.py)")
     ap.add_argument("--perception-batch", type=int, default=32, help="frames / utterances per detector / ASR call")
     ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     args = ap.parse_args()
@@ -104,6 +107,8 @@ def main():
     import threading
 
     # perception streams: one 640x640 frame and 1 s of PCM per cycle, their own HIP streams, driven from host threads
+    if args.roofline_only:
+        args.llm_only, args.steps, args.warmup, args.no_cpu_baseline = True, 0, 0, True
     fused = not args.llm_only
     perc_ms = {"vision": [], "audio": []}
     if fused:
@@ -226,12 +231,18 @@ def main():
         if pj.get("rows_per_pass") == B:
             roofline["traffic"] = pj.get("hbm_bytes_per_average_launch")
     # the same launches priced against the matrix cores: 2 int8 ops per (row, weight); 16x16x64 i8 MFMA = 2x the bf16 rate
-    n_weights = roofline["algorithmic_bytes_per_launch"] / 0.5625 * 0.97  # ~Q4_K bytes/weight; reported for orientation only
-    roofline["int8_tops"] = round(2.0 * B * n_weights / (roofline["avg_launch_ms"] * 1e-3) / 1e12, 1)
+    qd, kvd = hp.n_head * hp.head_dim, hp.n_kv_head * hp.head_dim
+    w_step = hp.n_layer * (hp.d_model * (qd + 2 * kvd) + qd * hp.d_model + 3 * hp.d_model * hp.d_ff) + hp.vocab * hp.d_model
+    roofline["int8_tops"] = round(2.0 * B * w_step / (roofline["avg_launch_ms"] * 1e-3 * roofline["launches_per_decode_step"]) / 1e12, 1)
     roofline["int8_peak_tops"] = 5000.0
     # the same kernel at 16 rows per pass (one MFMA M-tile): less integer work per weight byte, closer to the HBM bound
     roofline_16 = gemv_roofline(16) if B > 16 else None
 
+    if args.roofline_only:
+        print(json.dumps({"metric": "cortex cycles/sec (frame+1s audio+128 tok)", "value": None, "unit": "cycles/s", "n_gpus": world,
+                          "note": "roofline-only run: no timed steps", "roofline": roofline,
+                          "roofline_16_rows": roofline_16 and {k: roofline_16[k] for k in ("rows_per_pass", "achieved", "frac", "avg_launch_ms", "per_shape")}}))
+        return
     value = D.aggregate_throughput(G * B, args.steps, world, elapsed)
     dec_ms = float(np.mean(ms_steps))
     out = {

@@ -426,6 +426,9 @@ bool TkLlmSession::time_gemv(int layer, int which, int nrows, int iters, float* 
             set_act(a, act_d); a.out = logits;
             *bytes = (double)model->output.bytes;
         }
+        /* algorithmic bytes of one launch: the weight tiles once, the int8 activation images (+ block scales and sub-block sums) once,
+         * the fp32 K-split partial outputs once */
+        *bytes += (double)nrows * ((double)a.K + (double)a.K / 256.0 * (4.0 + 16.0)) + (double)a.ks * nrows * (double)a.n_total * 4.0;
         return a;
     };
     /* every layer whose tensors have the same types as `layer`: cycling through them keeps each launch on

@@ -183,7 +183,8 @@ __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot,
     uint32_t lo = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) | ((uint32_t)(q[3] & 255) << 24);
     uint32_t hi = (uint32_t)(q[4] & 255) | ((uint32_t)(q[5] & 255) << 8) | ((uint32_t)(q[6] & 255) << 16) | ((uint32_t)(q[7] & 255) << 24);
     const int mt = slot >> 4, sl = slot & 15; /* M-tile and slot inside it */
-    *(uint2*)(out.aq + mt * out.aq_ts + ((size_t)c * TK_ROW_SLOTS + sl) * 8) = make_uint2(lo, hi);
+    /* image order [K/64][4 g][16 slot][2 sub-blocks][8]: c = 4 * sub-block + g; a lane's operand of one x64 MFMA is one 16-byte read */
+    *(uint2*)(out.aq + mt * out.aq_ts + (size_t)(c >> 3) * 1024 + ((size_t)(c & 3) * TK_ROW_SLOTS + sl) * 16 + ((c >> 2) & 1) * 8) = make_uint2(lo, hi);
     sum += __shfl_xor(sum, 1, TK_WAVE);
     sum += __shfl_xor(sum, 2, TK_WAVE);
     if ((c & 3) == 0) { /* sub-block sum as two int8: sum = 64 * h + l, l in [0, 63], h in [-64, 63]  (|sum| <= 32 * 127) */
@@ -398,14 +399,12 @@ __device__ __forceinline__ void mma_q4(const OpsQ4& o, const uint8_t* lds_act, c
     v4i Pl[MT], Ph[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) Pl[m] = Ph[m] = zero;
-    const uint8_t* ap = lds_act + (size_t)blk * 8 * 512 + lane * 8;
+    const uint8_t* ap = lds_act + (size_t)blk * 4096 + lane * 16;
 #pragma unroll
     for (int j2 = 0; j2 < 4; ++j2) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const v2i a0 = *(const v2i*)(ap + m * act_ts + (2 * j2) * 512);
-            const v2i a1 = *(const v2i*)(ap + m * act_ts + (2 * j2 + 1) * 512);
-            const v4i a = {a0.x, a0.y, a1.x, a1.y};
+            const v4i a = *(const v4i*)(ap + m * act_ts + j2 * 1024);
             Pl[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, o.bl[j2], Pl[m], 0, 0, 0);
             Ph[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, o.bh[j2], Ph[m], 0, 0, 0);
         }
@@ -466,7 +465,7 @@ __device__ __forceinline__ void mma_q6(const OpsQ6& o, const uint8_t* lds_act, c
         const long ba = o.b[j] & mask_a, bb = o.b[j] & ~mask_a;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const long a = *(const long*)(lds_act + m * act_ts + (size_t)(blk * 8 + j) * 512 + lane * 8);
+            const long a = *(const long*)(lds_act + m * act_ts + (size_t)blk * 4096 + (j >> 1) * 1024 + lane * 16 + (j & 1) * 8);
             const v4i ca = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, ba, zero, 0, 0, 0);
             const v4i cb = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, bb, zero, 0, 0, 0);
 #pragma unroll
@@ -724,7 +723,7 @@ __device__ __forceinline__ void unpack_q6_fold(const FragQ6& f, int lane, OpsQ4&
 struct ATile { v4i a[4]; long ml, mh; v4f da; };
 template <bool MINS>
 __device__ __forceinline__ void lds_tile(ATile& t, const uint8_t* act, const uint8_t* amn, const uint8_t* ad, int lane) {
-    const uint8_t* ap = act + lane * 8;
+    const uint8_t* ap = act + lane * 16;
     if (TK_ABLATE & 64) {
         for (int j2 = 0; j2 < 4; ++j2) t.a[j2] = (v4i){lane, j2, lane + j2, 1};
         t.ml = lane; t.mh = lane + 1; t.da = (v4f){1.0f, 2.0f, 3.0f, 4.0f};
@@ -732,9 +731,7 @@ __device__ __forceinline__ void lds_tile(ATile& t, const uint8_t* act, const uin
     }
 #pragma unroll
     for (int j2 = 0; j2 < 4; ++j2) {
-        const v2i a0 = *(const v2i*)(ap + (2 * j2) * 512);
-        const v2i a1 = *(const v2i*)(ap + (2 * j2 + 1) * 512);
-        t.a[j2] = (v4i){a0.x, a0.y, a1.x, a1.y};
+        t.a[j2] = *(const v4i*)(ap + j2 * 1024);
     }
     if (MINS) {
         const uint8_t* mp = amn + (lane & 15) * 8;
@@ -747,7 +744,12 @@ __device__ __forceinline__ void lds_tile(ATile& t, const uint8_t* act, const uin
 struct PTile { v4i pl, ph, cl, ch; v4f da; };
 
 #define TK_RING_TILE_BYTES (256 * TK_ROW_SLOTS + 256 + TK_ROW_SLOTS * 4) /* one M-tile of one 256-k block: image + sums + scales */
-#define TK_RING_BLOCKS 2 /* 256-k blocks per ring slot: 2 slots x 2 blocks x 8 M-tiles = 138 KiB of the 160 KiB LDS */
+#ifndef TK_GEMM_LDS_DEPTH
+#define TK_GEMM_LDS_DEPTH 2
+#endif
+#ifndef TK_RING_BLOCKS
+#define TK_RING_BLOCKS 1 /* 256-k blocks per ring slot (per barrier): 2 slots x 1 block x 8 M-tiles = 69 KiB, two workgroups fit a CU */
+#endif
 
 /* diagnostic builds: TK_ABLATE bit 32 = batched kernel without MFMAs (operands xor-ed so nothing is dead), 64 = without LDS operand reads,
  * 128 = without the per-step barrier and ring refill (first block's activations reused) */
@@ -773,14 +775,17 @@ template <int MT, int NT, bool Q4>
 __device__ __forceinline__ void gemm_block(const OpsQ4 (&o)[NT], const uint8_t* chunk, int lane, float (&acc)[NT][MT][4]) {
     constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 256;
     const v4i zero = {0, 0, 0, 0};
-    ATile T[2];
+    constexpr int AD = TK_GEMM_LDS_DEPTH; /* M-tiles of LDS operand reads in flight ahead of the MFMAs */
+    ATile T[AD + 1];
     PTile R[NT];
-    lds_tile<Q4>(T[0], chunk, chunk + OFF_AMN, chunk + OFF_AD, lane);
+#pragma unroll
+    for (int m = 0; m < AD && m < MT; ++m) lds_tile<Q4>(T[m], chunk + m * 4096, chunk + OFF_AMN + m * 256, chunk + OFF_AD + m * 64, lane);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        if (m + 1 < MT) lds_tile<Q4>(T[(m + 1) & 1], chunk + (m + 1) * 4096, chunk + OFF_AMN + (m + 1) * 256, chunk + OFF_AD + (m + 1) * 64, lane);
+        if (m + AD < MT)
+            lds_tile<Q4>(T[(m + AD) % (AD + 1)], chunk + (m + AD) * 4096, chunk + OFF_AMN + (m + AD) * 256, chunk + OFF_AD + (m + AD) * 64, lane);
         __builtin_amdgcn_sched_barrier(0);
-        const ATile& t = T[m & 1];
+        const ATile& t = T[m % (AD + 1)];
         PTile c[NT];
 #pragma unroll
         for (int w = 0; w < NT; ++w) {
@@ -959,6 +964,10 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
         bool even = true;
         for (int i = 0; i < a.nseg; ++i) even = even && a.seg[i].row_tiles % 2 == 0;
         const int nt = (force_nt == 2 && even) ? 2 : 1;
+        /* waves per workgroup: with <= 4 (TK_GEMM_MAXWAVES) a CU holds two workgroups whose barrier phases drift apart */
+        static int maxw = -1;
+        if (maxw < 0) { const char* e = getenv("TK_GEMM_MAXWAVES"); maxw = e ? atoi(e) : 8; if (maxw < 1 || maxw > 8) maxw = 8; }
+        while (waves > maxw) { groups *= 2; waves = (row_tiles + groups - 1) / groups; }
         if (nt == 2) {
             const int pairs = row_tiles / 2;
             groups = TK_NUM_CU / a.ks;

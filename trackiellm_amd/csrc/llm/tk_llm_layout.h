@@ -27,8 +27,10 @@
  *  Tiles of one 16-row group are contiguous over k:  tiles[row_tile][block].
  *
  *  Activations (Q8_K-style, the reference CPU engine's numerics — oracle/tk_oracle_llm.cpp):
- *      aq  : int8   [K/32 sub-block][4 g][16 row slot][8]   == the MFMA A-operand image; a K-range is
- *                    one contiguous run that is memcpy'd into LDS
+ *      aq  : int8   [K/64][4 g][16 row slot][2 sub-blocks][8]   == the A-operand image of v_mfma_i32_16x16x64_i8: lane
+ *                    (slot, g) reads its 16 bytes (k-slice g of two consecutive 32-wide sub-blocks) with ONE ds_read_b128
+ *                    (1.6x the LDS bandwidth of two 8-byte reads on gfx950, tools/lds_rate.hip); a K-range is one
+ *                    contiguous run that is DMA'd into LDS
  *      ad  : float  [K/256][16]        block scale amax/127
  *      abs : int8   [K/256][2][16][8]  per-sub-block sums of the int8 values (the Q4_K "min" term) split as
  *                                      sum = 64 h + l: image 0 holds l (0..63), image 1 holds h, byte j = sub-block j —
