@@ -66,6 +66,18 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int layer, int which, int nrows, int iters, float* avg_ms,
                                                             double* algorithmic_bytes);
 
+/* ---- tool-call grammar (GBNF) — the sampling constraint of tk_llm_runner_prepare_generation(..., use_tool_grammar = true)
+ * (reference: src/ai_models/grammars/tool_call.gbnf via llama.cpp's grammar sampler, tk_runner_lifecycle.c:59,
+ * tk_runner_streaming.c:44-48,69-75).  gbnf == NULL selects the built-in tool-call grammar.  No GPU involved. ---- */
+/* how many leading bytes of `text` the grammar accepts, and whether the grammar is complete after them */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_grammar_check(const char* gbnf, const char* text, int32_t* n_accepted, int32_t* complete);
+/* allowed[b] = 1 when byte b may follow `prefix` (which must itself be accepted) */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_grammar_next_bytes(const char* gbnf, const char* prefix, uint8_t allowed[256], int32_t* complete);
+/* text accepted by the grammar in the current generation: the tool call to read after tk_llm_runner_generate_next_token
+ * returned the sentinel (const char*)1; valid until the next prepare_generation */
+struct tk_llm_runner_s;
+TK_API const char* tk_mi355x_llm_runner_tool_call_text(struct tk_llm_runner_s* runner);
+
 #ifdef __cplusplus
 }
 #endif

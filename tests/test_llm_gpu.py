@@ -216,6 +216,85 @@ def test_reference_runner_surface(gpu):
     loader.close()
 
 
+def _piece_of(tok):
+    """display piece of a token of the synthetic byte vocabulary (csrc/llm/tk_tokenizer.h)"""
+    if 3 <= tok < 259:
+        return bytes([tok - 3])
+    return b"" if tok < 3 else (" t%d" % tok).encode()
+
+
+@pytest.mark.parametrize("seed", [4, 6, 8, 13])  # 4, 8: the grammar completes ("{ ... }"); 6, 13: long strings with multi-byte pieces, context end
+def test_tool_grammar_constrained_generation(gpu, seed):
+    """use_tool_grammar = true: greedy sampling runs over the tokens the GBNF grammar allows (mask applied by k_argmax on the
+    device), the completed grammar returns the sentinel (const char*)1 without decoding (tk_runner_streaming.c:69-75).
+    Checked against the oracle's logits with the constraint restated here token by token."""
+    import ctypes as C
+    L = gpu.lib()
+    loader = gpu.ModelLoader()
+    h = loader.load("synthetic://tiny?seed=%d" % seed)
+    n_ctx = 96
+    runner = gpu.LlmRunner(h, context_size=n_ctx)
+    runner.prepare("call", use_tool_grammar=True)
+    got, ended = [], None
+    for _ in range(n_ctx):
+        p = runner.next_token()
+        if p is None or p == "<tool_call>":
+            ended = p
+            break
+        got.append(p)
+    text = b"".join(got)
+
+    def accepted(bs):
+        n, c = C.c_int32(), C.c_int32()
+        assert L.tk_mi355x_grammar_check(None, bs, C.byref(n), C.byref(c)) == 0
+        return n.value == len(bs), bool(c.value)
+
+    # the oracle with the same constraint: arg max over the tokens whose piece keeps the text inside the grammar
+    hp = gpu.LlmHParams()
+    L.tk_mi355x_llm_model_get_hparams(h, C.byref(hp))
+    orc = O.OracleLlm(oracle_cfg_from(hp, n_ctx, 1), seed=seed)
+    ids = [1] + [3 + b for b in b"call"]
+    logits, _ = orc.forward([0] * len(ids), list(range(len(ids))), ids)
+    lg, pos, want, sofar, want_end = logits[-1], len(ids), [], b"", None
+    while True:
+        best = None
+        for t in np.argsort(-lg, kind="stable"):
+            pc = _piece_of(int(t))
+            if int(t) == 2:
+                ok = accepted(sofar)[1]
+            else:
+                ok = bool(pc) and accepted(sofar + pc)[0]
+            if ok:
+                best = int(t)
+                break
+        assert best is not None
+        if best == 2:
+            want_end = None
+            break
+        sofar += _piece_of(best)
+        if accepted(sofar)[1]:
+            want_end = "<tool_call>"
+            break
+        if pos + 1 >= n_ctx:
+            break
+        want.append(_piece_of(best))
+        lg = orc.forward([0], [pos], [best])[0][0]
+        pos += 1
+    assert got == want
+    assert ended == want_end
+    ok, done = accepted(text)
+    assert ok
+    if ended == "<tool_call>":
+        L.tk_mi355x_llm_runner_tool_call_text.restype = C.c_char_p
+        call = L.tk_mi355x_llm_runner_tool_call_text(runner.h)
+        assert accepted(call) == (True, True) and call.startswith(text)
+        import json
+        assert isinstance(json.loads(call.decode("utf-8", "replace")), dict)
+    runner.close()
+    loader.unload(h)
+    loader.close()
+
+
 def test_error_paths(gpu):
     import ctypes as C
     hp = gpu.TINY()

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../llm/tk_gguf.h"
+#include "../llm/tk_grammar.h"
 #include "../llm/tk_llm_engine.h"
 #include "../llm/tk_tokenizer.h"
 #include "../common/tk_ggml_blocks.h"
@@ -240,6 +241,38 @@ tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int layer, i
     return TK_SUCCESS;
 }
 
+/* grammar engine entry points (no GPU involved): used by the CPU tests and by hosts that want the tool-call text */
+tk_error_code_t tk_mi355x_grammar_check(const char* gbnf, const char* text, int32_t* n_accepted, int32_t* complete) {
+    if (!text || !n_accepted || !complete) return TK_ERROR_INVALID_ARGUMENT;
+    TkGrammar g;
+    std::string err;
+    if (!g.parse(gbnf ? gbnf : TK_DEFAULT_TOOL_CALL_GBNF, &err)) return fail(TK_ERROR_CONFIG_PARSE_FAILED, "GBNF: " + err);
+    TkGrammarState st;
+    st.init(&g);
+    int32_t n = 0;
+    for (const char* c = text; *c; ++c, ++n)
+        if (!st.accept((uint8_t)*c)) break;
+    *n_accepted = n;
+    *complete = st.complete() ? 1 : 0;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_grammar_next_bytes(const char* gbnf, const char* prefix, uint8_t allowed[256], int32_t* complete) {
+    if (!prefix || !allowed || !complete) return TK_ERROR_INVALID_ARGUMENT;
+    TkGrammar g;
+    std::string err;
+    if (!g.parse(gbnf ? gbnf : TK_DEFAULT_TOOL_CALL_GBNF, &err)) return fail(TK_ERROR_CONFIG_PARSE_FAILED, "GBNF: " + err);
+    TkGrammarState st;
+    st.init(&g);
+    if (!st.accept(std::string(prefix))) return fail(TK_ERROR_INVALID_ARGUMENT, "prefix is not in the grammar");
+    for (int b = 0; b < 256; ++b) {
+        TkGrammarState t = st;
+        allowed[b] = t.accept((uint8_t)b) ? 1 : 0;
+    }
+    *complete = st.complete() ? 1 : 0;
+    return TK_SUCCESS;
+}
+
 /* ------------------------------------------------------------------ reference surface ------ */
 
 struct tk_model_loader_s {
@@ -333,7 +366,48 @@ struct tk_llm_runner_s {
     bool is_processing = false;
     std::string piece;
     std::string system_prompt;
+    /* tool-call grammar (reference: tk_runner_lifecycle.c:59 loads it at create, tk_runner_streaming.c:44-48 arms it per generation) */
+    TkGrammar grammar;
+    bool has_grammar = false;
+    bool grammar_on = false;
+    TkGrammarState gstate;
+    TkTokenTrie trie;
+    bool trie_built = false;
+    std::vector<uint32_t> mask;
+    std::string tool_call_text; /* what the grammar has accepted so far: the tool call the host reads after the sentinel */
+    /* allowed-token bits for the next sample, or nullptr when sampling is unconstrained */
+    const uint32_t* next_mask() {
+        if (!grammar_on) return nullptr;
+        if (!trie_built) {
+            std::vector<std::string> pieces((size_t)model->model.hp.vocab);
+            for (int i = 0; i < (int)pieces.size(); ++i) pieces[i] = (i == model->tok.eos) ? std::string() : model->tok.piece(i);
+            trie.build(pieces);
+            trie_built = true;
+        }
+        gstate.mask(trie, model->tok.eos, &mask);
+        return mask.data();
+    }
 };
+
+/* the reference reads the grammar from a cwd-relative path; fall back to the built-in text of the same language */
+static std::string load_tool_grammar_text() {
+    const char* env = getenv("TK_TOOL_GRAMMAR");
+    const char* paths[2] = {env, "src/ai_models/grammars/tool_call.gbnf"};
+    for (const char* path : paths) {
+        if (!path) continue;
+        FILE* f = fopen(path, "rb");
+        if (!f) continue;
+        std::string text;
+        char buf[4096];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+        fclose(f);
+        return text;
+    }
+    return TK_DEFAULT_TOOL_CALL_GBNF;
+}
+
+const char* tk_mi355x_llm_runner_tool_call_text(tk_llm_runner_t* runner) { return runner ? runner->tool_call_text.c_str() : NULL; }
 
 tk_error_code_t tk_llm_runner_create(tk_llm_runner_t** out_runner, void* model_handle, const tk_llm_config_t* config) {
     if (!out_runner || !model_handle || !config) return TK_ERROR_INVALID_ARGUMENT;
@@ -343,6 +417,9 @@ tk_error_code_t tk_llm_runner_create(tk_llm_runner_t** out_runner, void* model_h
     if (config->system_prompt) r->system_prompt = config->system_prompt;
     tk_error_code_t rc = tk_mi355x_llm_session_create(&r->session, r->model, 1, r->n_ctx);
     if (rc != TK_SUCCESS) return rc;
+    std::string gerr;
+    r->has_grammar = r->grammar.parse(load_tool_grammar_text(), &gerr);
+    if (!r->has_grammar) tk_error_set_detail("tool-call grammar rejected (%s): tool grammar disabled", gerr.c_str()); /* the reference logs and goes on */
     *out_runner = r.release();
     return TK_SUCCESS;
 }
@@ -367,14 +444,18 @@ static tk_error_code_t feed(tk_llm_runner_s* r, const std::vector<int32_t>& toks
         if (!s.forward((int)sq.size(), sq.data(), ps.data(), tk.data(), nullptr, nullptr, false)) return fail(TK_ERROR_INFERENCE_FAILED, s.error);
     }
     int32_t z = 0, p = r->n_past++, t = toks.back(), am = -1;
-    if (!s.forward(1, &z, &p, &t, nullptr, &am, true)) return fail(TK_ERROR_INFERENCE_FAILED, s.error);
+    if (!s.forward(1, &z, &p, &t, nullptr, &am, true, r->next_mask())) return fail(TK_ERROR_INFERENCE_FAILED, s.error);
     r->pending = am;
     return TK_SUCCESS;
 }
 
 tk_error_code_t tk_llm_runner_prepare_generation(tk_llm_runner_t* runner, const char* prompt, bool use_tool_grammar) {
     if (!runner || !prompt) return TK_ERROR_INVALID_ARGUMENT;
-    (void)use_tool_grammar; /* GBNF-constrained sampling is SURVEY.md §8(f) rank 1, not part of this path yet */
+    /* greedy sampling constrained by the tool-call grammar: the arg max runs over the tokens the grammar allows (mask applied on
+     * the device), the reference's llama_sampling_set_grammar(sctx, grammar or NULL) (tk_runner_streaming.c:44-48) */
+    runner->grammar_on = use_tool_grammar && runner->has_grammar;
+    if (runner->grammar_on) runner->gstate.init(&runner->grammar);
+    runner->tool_call_text.clear();
     std::vector<int32_t> toks = runner->model->tok.encode(prompt, true);
     runner->n_past = 0; /* llama_kv_cache_clear: positions restart, stale cache rows are never attended */
     runner->pending = -1;
@@ -388,9 +469,25 @@ const char* tk_llm_runner_generate_next_token(tk_llm_runner_t* runner) {
     if (!runner || !runner->is_processing) return NULL;
     const int32_t id = runner->pending;
     if (id < 0 || id == runner->model->tok.eos) { runner->is_processing = false; return NULL; }
+    if (runner->grammar_on) {
+        /* llama_sampling_accept: advance the grammar by the sampled token; then the reference's "grammar rule completed" test
+         * (tk_runner_streaming.c:69-75): the token is NOT decoded, generation pauses, the sentinel address is returned */
+        const std::string pc = runner->model->tok.piece(id);
+        if (!runner->gstate.accept(pc)) { /* cannot happen with the mask applied */
+            tk_error_set_detail("sampled token %d is outside the grammar", id);
+            runner->is_processing = false;
+            return NULL;
+        }
+        runner->tool_call_text += pc;
+        if (runner->gstate.complete()) {
+            runner->is_processing = false;
+            runner->grammar_on = false; /* the tool response and what follows it are free text */
+            return (const char*)1;
+        }
+    }
     if (runner->n_past + 1 >= runner->n_ctx) { runner->is_processing = false; return NULL; }
     int32_t z = 0, p = runner->n_past, t = id, am = -1;
-    if (!runner->session->session.forward(1, &z, &p, &t, nullptr, &am, true)) {
+    if (!runner->session->session.forward(1, &z, &p, &t, nullptr, &am, true, runner->next_mask())) {
         tk_error_set_detail("%s", runner->session->session.error.c_str());
         runner->is_processing = false;
         return NULL;

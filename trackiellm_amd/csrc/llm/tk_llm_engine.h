@@ -74,9 +74,10 @@ public:
 
     ~TkLlmSession();
     bool init(TkLlmModel* m, int max_seq, int max_ctx);
-    /* one pass over nrows <= 32 rows (two 16-row M-tiles); host arrays */
+    /* one pass over nrows <= TK_MAX_ROWS rows (16-row M-tiles); host arrays.  allow_mask (optional, (vocab + 31) / 32 words,
+     * bit t = token t may be sampled) constrains the arg max of every row of this pass: grammar-constrained greedy sampling */
     bool forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
-                 bool lm_head = true);
+                 bool lm_head = true, const uint32_t* allow_mask = nullptr);
     /* prompts of equal length for sequences 0..nseq-1 (tokens[nseq][n_prompt]); leaves row r = sequence r
      * holding the first sampled token so decode() can follow; first_tokens_host[nseq] optional */
     bool prefill(int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens_host);
@@ -95,6 +96,8 @@ private:
     float *x = nullptr, *qbuf = nullptr, *partial = nullptr, *logits = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
     TkActQ8 act_d{}, act_qd{}, act_ff{};
     int32_t *d_seq = nullptr, *d_pos = nullptr, *d_tok = nullptr, *d_nsteps = nullptr, *d_hist = nullptr;
+    uint32_t* d_mask = nullptr; /* allowed-token bits of the current pass, or unused */
+    bool mask_on = false;
     int hist_cap = 0;
     hipGraphExec_t graph_exec[TK_MAX_ROWS + 1] = {};
 };

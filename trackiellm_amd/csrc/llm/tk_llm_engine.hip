@@ -218,6 +218,7 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     HIPQ(hipMemset(d_nsteps, 0, TK_MAX_ROWS * 4));
     hist_cap = mctx;
     HIPQ(hipMalloc((void**)&d_hist, (size_t)hist_cap * TK_MAX_ROWS * 4));
+    HIPQ(hipMalloc((void**)&d_mask, ((size_t)h.vocab + 31) / 32 * 4));
     /* RoPE table, double precision on the host (same formula as the oracle) */
     std::vector<float> cs((size_t)mctx * half), sn((size_t)mctx * half);
     for (int p = 0; p < mctx; ++p)
@@ -240,7 +241,7 @@ TkLlmSession::~TkLlmSession() {
     if (model) (void)hipSetDevice(model->device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto& g : graph_exec) if (g) (void)hipGraphExecDestroy(g);
-    void* ptrs[] = {kcache, vcache, x, qbuf, partial, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist};
+    void* ptrs[] = {kcache, vcache, x, qbuf, partial, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     free_act(&act_d); free_act(&act_qd); free_act(&act_ff);
     if (stream) (void)hipStreamDestroy(stream);
@@ -298,11 +299,11 @@ void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) {
     lm.seg[0] = seg_of(model->output); lm.nseg = 1; lm.K = D; lm.ks = 1; lm.n_total = h.vocab; lm.nrows = nrows;
     set_act(lm, act_d); lm.out = logits;
     tk_launch_gemv(lm, s);
-    tk_launch_argmax(logits, h.vocab, nrows, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
+    tk_launch_argmax(logits, h.vocab, nrows, mask_on ? d_mask : nullptr, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
 }
 
 bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
-                           bool lm_head) {
+                           bool lm_head, const uint32_t* allow_mask) {
     if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,128]"; return false; }
     for (int r = 0; r < nrows; ++r) {
         if (seq[r] < 0 || seq[r] >= max_seq || pos[r] < 0 || pos[r] >= max_ctx || tok[r] < 0 || tok[r] >= model->hp.vocab) {
@@ -319,7 +320,10 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
     for (int a = 0; a < nrows && distinct; ++a)
         for (int b = a + 1; b < nrows; ++b)
             if (seq[a] == seq[b]) { distinct = false; break; }
+    if (allow_mask && lm_head) HIPQ(hipMemcpyAsync(d_mask, allow_mask, ((size_t)model->hp.vocab + 31) / 32 * 4, hipMemcpyHostToDevice, stream));
+    mask_on = allow_mask != nullptr && lm_head;
     enqueue_pass(nrows, lm_head, distinct);
+    mask_on = false;
     HIPQ(hipGetLastError());
     if (!lm_head) { HIPQ(hipStreamSynchronize(stream)); return true; }
     if (logits_host) HIPQ(hipMemcpyAsync(logits_host, logits, (size_t)nrows * model->hp.vocab * 4, hipMemcpyDeviceToHost, stream));

@@ -1286,8 +1286,8 @@ void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ
  * greedy sampling: first index of the maximum; feeds the next step entirely on-device
  * (tok <- argmax, pos <- pos + 1, history append) so a decode loop is a pure graph replay.
  * ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab, int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist,
-                                                  int hist_stride) {
+__global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab, const uint32_t* allow, int32_t* tok, int32_t* pos, int32_t* nsteps,
+                                                  int32_t* hist, int hist_stride) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     const int r = blockIdx.x, t = threadIdx.x;
@@ -1295,8 +1295,9 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab,
     float best = -INFINITY;
     int idx = 0x7fffffff;
     for (int i = t; i < vocab; i += 1024) {
+        if (allow && !((allow[i >> 5] >> (i & 31)) & 1u)) continue; /* grammar-constrained sampling: arg max over the allowed tokens */
         const float v = lg[i];
-        if (v > best) { best = v; idx = i; }
+        if (v > best || idx == 0x7fffffff) { best = v; idx = i; } /* the first allowed token wins ties and -inf logits */
     }
     for (int s = 32; s >= 1; s >>= 1) {
         const float ov = __shfl_xor(best, s, TK_WAVE);
@@ -1318,7 +1319,7 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab,
     }
 }
 
-void tk_launch_argmax(const float* logits, int vocab, int nrows, int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(k_argmax, dim3(nrows), dim3(1024), 0, s, logits, vocab, tok, pos, nsteps, hist, hist_stride);
+void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow, int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist,
+                      int hist_stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_argmax, dim3(nrows), dim3(1024), 0, s, logits, vocab, allow, tok, pos, nsteps, hist, hist_stride);
 }
