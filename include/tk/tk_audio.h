@@ -94,6 +94,12 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_transcribe_tokens(tk_asr_whisp
                                                                     int n_steps, int32_t* tokens_out, float* mel_out, float* enc_out,
                                                                     float* logits_out);
 TK_API void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_steps);
+/* geometry of a created context (a whisper.cpp ggml checkpoint brings its own) */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_get_hparams(tk_asr_whisper_context_t* ctx, tk_mi355x_whisper_hparams_t* out);
+/* whisper.cpp "ggml" checkpoint (the file tk_asr_whisper_config_t.model_path names, src/audio/tk_asr_whisper.c:238): parse header,
+ * filter bank, vocabulary and tensor directory and check that every tensor of the graph is present; no GPU involved */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_whisper_ggml_probe(const char* path, tk_mi355x_whisper_hparams_t* out, int32_t* n_tokens,
+                                                                 int32_t* n_tensors);
 /* feed one window probability straight into the VAD state machine (30 ms step); returns -1 none, 0 started, 1 ended */
 TK_API int tk_mi355x_vad_step(tk_vad_silero_context_t* ctx, float probability);
 /* probabilities of n consecutive float windows of the model's window length */

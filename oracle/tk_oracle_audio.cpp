@@ -154,6 +154,8 @@ int64_t orc_whisper_tensor_info(orc_whisper* m, int i, char* name, int cap, int6
     return *rows * *cols;
 }
 void orc_whisper_get_tensor(orc_whisper* m, int i, float* out) { memcpy(out, m->w[i].data(), m->w[i].size() * 4); }
+/* replace tensor i (manifest order, rows x cols floats): lets a test run the oracle on the weights it wrote into a checkpoint file */
+void orc_whisper_set_tensor(orc_whisper* m, int i, const float* in) { memcpy(m->w[i].data(), in, m->w[i].size() * 4); }
 
 /* same contract as TkAsr::transcribe: prompt tokens then n_steps forced greedy tokens */
 void orc_whisper_transcribe(orc_whisper* m, int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps,

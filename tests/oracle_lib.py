@@ -324,6 +324,20 @@ class OracleWhisper:
             out[name.value.decode()] = a
         return out
 
+    def set_tensors(self, tensors):
+        """name -> [rows, cols] float32 arrays, any subset of tensors()"""
+        L = lib()
+        L.orc_whisper_set_tensor.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        for i in range(L.orc_whisper_tensor_count(self.h)):
+            name = C.create_string_buffer(128)
+            r, c = C.c_int64(0), C.c_int64(0)
+            L.orc_whisper_tensor_info(self.h, i, name, 128, C.byref(r), C.byref(c))
+            a = tensors.get(name.value.decode())
+            if a is not None:
+                a = np.ascontiguousarray(a, np.float32)
+                assert a.shape == (r.value, c.value)
+                L.orc_whisper_set_tensor(self.h, i, ptr(a))
+
     def transcribe(self, pcm, n_steps, want=("mel", "enc", "logits")):
         pcm = np.ascontiguousarray(pcm, np.int16)
         B, n = pcm.shape

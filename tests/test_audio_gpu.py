@@ -49,6 +49,36 @@ def test_whisper_tiny_en_full_size_encoder(gpu):
     assert np.array_equal(toks, wt) and np.array_equal(lg, wlg)
 
 
+def test_whisper_ggml_checkpoint_end_to_end(gpu, tmp_path):
+    """a whisper.cpp ggml .bin (f16 weights) goes in through tk_asr_whisper_create's model_path; geometry, filter bank and vocabulary
+    come from the file; mel / encoder / logits / forced ids equal the oracle run on the same (f16-rounded) weights"""
+    import ggml_whisper_util as G
+    ohp = O.whisper_tiny_test()
+    orc = O.OracleWhisper(ohp, seed=9)
+    T = orc.tensors()
+    rounded, file_t = G.checkpoint_tensors(T, ohp)
+    orc.set_tensors(rounded)
+    vocab = [(" w%d" % i).encode() for i in range(ohp.n_vocab - 7)]
+    path = tmp_path / "ggml-small.bin"
+    G.write_ggml(path, ohp, T["frontend.mel_filters"], vocab, file_t)
+    asr = gpu.Asr(model=str(path))
+    assert [getattr(asr.hp, n) for n, _ in asr.hp._fields_] == [getattr(ohp, n) for n, _ in ohp._fields_]
+    rng = np.random.default_rng(3)
+    pcm = np.clip(rng.normal(0, 3000, (1, 16000)), -32768, 32767).astype(np.int16)
+    toks, mel, enc, lg = asr.transcribe_tokens(pcm, 6)
+    wt, wmel, wenc, wlg = orc.transcribe(pcm, 6)
+    assert np.array_equal(mel, wmel) and np.array_equal(enc, wenc) and np.array_equal(lg, wlg)
+    assert np.array_equal(toks, wt)
+    # the reference surface renders ids through the file's vocabulary (specials render as nothing)
+    asr.set_decode_steps(6)
+    text, n, conf, partial = asr.process_audio(pcm[0], True)
+    want = "".join(vocab[t].decode() for t in wt[0] if t < len(vocab))
+    eot = ohp.n_vocab - 4
+    if eot in list(wt[0]):
+        want = "".join(vocab[t].decode() for t in list(wt[0])[: list(wt[0]).index(eot)] if t < len(vocab))
+    assert (text or "") == want
+
+
 def test_asr_reference_surface_buffering(gpu):
     asr = gpu.Asr()
     asr.set_decode_steps(3)

@@ -40,6 +40,7 @@ class Asr:
                 check(lib().tk_asr_whisper_create(C.byref(self.h), C.byref(cfg)))
             finally:
                 lib().tk_path_destroy(C.byref(p))
+            check(lib().tk_mi355x_asr_get_hparams(self.h, C.byref(self.hp)))  # a ggml checkpoint brings its own geometry
 
     def process_audio(self, pcm, is_final):
         pcm = np.ascontiguousarray(pcm, np.int16)

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../audio/tk_audio_engine.h"
+#include "../audio/tk_whisper_ggml.h"
 #include "tk/tk_audio.h"
 #include "tk/tk_mi355x_ext.h"
 
@@ -35,6 +36,7 @@ struct tk_asr_whisper_context_s {
     std::string last_text, language;
     int decode_steps = 16;
     int32_t sot = 0, nots = 0, eot = 0;
+    std::vector<std::string> vocab; /* token id -> bytes, from a ggml checkpoint */
 };
 
 static bool have_gpu() {
@@ -45,18 +47,29 @@ static bool have_gpu() {
 static tk_error_code_t asr_new(tk_asr_whisper_context_t** out, const TkWhisperHP& hp, const std::string& path, uint64_t seed, int device, int max_batch) {
     if (!have_gpu()) return afail(TK_ERROR_GPU_DEVICE_NOT_FOUND, "no HIP device visible (the MI355X path has no CPU fallback)");
     std::unique_ptr<tk_asr_whisper_context_s> c(new tk_asr_whisper_context_s());
-    if (!c->model.init(hp, device)) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
-    if (path.empty() || path.compare(0, 12, "synthetic://") == 0) {
-        if (!c->model.fill_synthetic(seed)) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
-    } else if (!c->model.load_file(path.c_str())) {
-        return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+    const bool synthetic = path.empty() || path.compare(0, 12, "synthetic://") == 0;
+    if (!synthetic && TkWhisperGgml::is_ggml(path.c_str())) {
+        /* the reference's checkpoint format (whisper.cpp ggml .bin): geometry, filter bank, vocabulary and weights come from the file */
+        TkWhisperGgml g;
+        if (!g.open(path.c_str())) return afail(TK_ERROR_MODEL_LOAD_FAILED, g.error);
+        if (!c->model.init(g.hp, device)) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+        if (!c->model.load_ggml(g)) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+        c->vocab.swap(g.vocab);
+    } else {
+        if (!c->model.init(hp, device)) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+        if (synthetic) {
+            if (!c->model.fill_synthetic(seed)) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+        } else if (!c->model.load_file(path.c_str())) {
+            return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+        }
     }
     if (!c->asr.init(&c->model, max_batch)) return afail(TK_ERROR_GPU_MEMORY, c->asr.error);
     c->buffer.assign(TK_ASR_MAX_BUFFER, 0);
-    const int v = hp.n_vocab;
-    c->sot = 50257 < v - 3 ? 50257 : v - 3;
-    c->nots = 50362 < v - 1 ? 50362 : v - 1;
-    c->eot = 50256 < v - 4 ? 50256 : v - 4;
+    const int v = c->model.hp.n_vocab;
+    const int ml = v >= 51865 ? 1 : 0; /* multilingual vocabularies have one more text token: the special ids move up by one */
+    c->sot = 50257 + ml < v - 3 ? 50257 + ml : v - 3;
+    c->nots = 50362 + ml < v - 1 ? 50362 + ml : v - 1;
+    c->eot = 50256 + ml < v - 4 ? 50256 + ml : v - 4;
     *out = c.release();
     return TK_SUCCESS;
 }
@@ -77,6 +90,35 @@ tk_error_code_t tk_mi355x_asr_create(tk_asr_whisper_context_t** out, const tk_mi
     TkWhisperHP h{hp->n_mels, hp->n_audio_ctx, hp->n_audio_state, hp->n_audio_head, hp->n_audio_layer,
                   hp->n_text_ctx, hp->n_text_state, hp->n_text_head, hp->n_text_layer, hp->n_vocab};
     return asr_new(out, h, "", seed, device, max_batch);
+}
+
+tk_error_code_t tk_mi355x_asr_get_hparams(tk_asr_whisper_context_t* ctx, tk_mi355x_whisper_hparams_t* out) {
+    if (!ctx || !out) return TK_ERROR_INVALID_ARGUMENT;
+    const TkWhisperHP& h = ctx->model.hp;
+    *out = tk_mi355x_whisper_hparams_t{h.n_mels, h.n_audio_ctx, h.n_audio_state, h.n_audio_head, h.n_audio_layer,
+                                       h.n_text_ctx, h.n_text_state, h.n_text_head, h.n_text_layer, h.n_vocab};
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_whisper_ggml_probe(const char* path, tk_mi355x_whisper_hparams_t* out, int32_t* n_tokens, int32_t* n_tensors) {
+    if (!path || !out) return TK_ERROR_INVALID_ARGUMENT;
+    TkWhisperGgml g;
+    if (!g.open(path)) return afail(TK_ERROR_MODEL_LOAD_FAILED, g.error);
+    const TkWhisperHP& h = g.hp;
+    *out = tk_mi355x_whisper_hparams_t{h.n_mels, h.n_audio_ctx, h.n_audio_state, h.n_audio_head, h.n_audio_layer,
+                                       h.n_text_ctx, h.n_text_state, h.n_text_head, h.n_text_layer, h.n_vocab};
+    if (n_tokens) *n_tokens = (int32_t)g.vocab.size();
+    if (n_tensors) *n_tensors = (int32_t)g.tensors.size();
+    /* every tensor the graph needs must be there with the right element count */
+    const TkWhManifest man = tk_whisper_manifest(h);
+    for (int i = 0; i < (int)man.t.size(); ++i) {
+        if (i == man.hann || i == man.dft || i == man.melw) continue;
+        bool ok = false;
+        for (const auto& t : g.tensors)
+            if (t.name == man.t[i].name) { ok = t.count == man.t[i].rows * man.t[i].cols; break; }
+        if (!ok) return afail(TK_ERROR_MODEL_VERIFICATION_FAILED, "tensor " + man.t[i].name + " is missing or has the wrong size");
+    }
+    return TK_SUCCESS;
 }
 
 void tk_asr_whisper_destroy(tk_asr_whisper_context_t** context) {
@@ -104,6 +146,7 @@ tk_error_code_t tk_mi355x_asr_transcribe_tokens(tk_asr_whisper_context_t* c, int
 }
 
 static std::string piece_of(const tk_asr_whisper_context_s* c, int32_t id) {
+    if (!c->vocab.empty()) return id >= 0 && id < (int)c->vocab.size() ? c->vocab[(size_t)id] : std::string(); /* specials render as nothing */
     /* no GPT-2 BPE vocabulary ships with synthetic / TKWHSP1 weights: ids are rendered symbolically */
     char b[24];
     snprintf(b, sizeof b, " w%d", id);

@@ -26,6 +26,8 @@ public:
     bool fill_synthetic(uint64_t seed);
     bool set_tensor(int idx, const float* host, size_t n);
     bool load_file(const char* path); /* "TKWHSP1\0" container */
+    /* whisper.cpp ggml checkpoint (f16 / f32), already opened: every manifest tensor must be present except the hann / DFT tables */
+    bool load_ggml(class TkWhisperGgml& g);
 };
 
 class TkAsr {

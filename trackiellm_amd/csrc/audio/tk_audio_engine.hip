@@ -1,4 +1,5 @@
 #include "tk_audio_engine.h"
+#include "tk_whisper_ggml.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -170,6 +171,21 @@ bool TkWhisperModel::load_file(const char* path) {
     fclose(f);
     if (!ok && error.empty()) error = "not a TKWHSP1 container for this geometry";
     return ok;
+}
+
+bool TkWhisperModel::load_ggml(TkWhisperGgml& g) {
+    std::vector<float> buf;
+    for (int i = 0; i < (int)man.t.size(); ++i) {
+        bool found = false;
+        if (!g.read(man, i, &buf, &found)) {
+            if (found) { error = g.error; return false; }
+            if (i != man.hann && i != man.dft) { error = "tensor " + man.t[i].name + " is missing from the checkpoint"; return false; }
+            buf.resize((size_t)man.t[i].rows * man.t[i].cols);
+            tk_whisper_fill_tensor(hp, man, i, 0, buf.data()); /* analysis window and DFT twiddles are computed, not stored */
+        }
+        if (!set_tensor(i, buf.data(), buf.size())) return false;
+    }
+    return true;
 }
 
 /* ---------------------------------------------------------------- ASR */
