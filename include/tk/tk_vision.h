@@ -54,6 +54,9 @@ TK_API TK_NODISCARD tk_error_code_t tk_preprocessor_resize_and_normalize_to_chw(
 /* ---- extensions (no reference counterpart) ---- */
 /* B frames of identical geometry in one pass (one per concurrent cortex cycle); results[i] / counts[i] per frame */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_set_max_batch(tk_object_detector_t* detector, int max_batch);
+/* ONNX detector file (tk_object_detector_config_t.model_path, src/vision/tk_object_detector.c:93-152): parse the Conv initialisers
+ * (no ONNX Runtime, no GPU) and check them against the YOLOv8n graph this path runs; n_convs / n_params optional */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_onnx_probe(const char* path, int32_t* n_convs, int64_t* n_params);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_detect_batch(tk_object_detector_t* detector, int n_frames, const tk_video_frame_t* frames,
                                                                     tk_detection_result_t** out_results, size_t* out_counts);
 /* test hook: run the network on a pre-processed NHWC fp32 tensor [B][H][W][3]; raw head maps [B][anchors][64+nc] */

@@ -54,6 +54,32 @@ def test_detector_head_maps_bit_exact(gpu):
         assert np.array_equal(boxes, wb)
 
 
+def test_detector_weights_from_onnx_file(gpu, tmp_path):
+    """an .onnx detector file (Conv initialisers in execution order + DFL conv, raw and packed float storage) goes in through
+    tk_object_detector_create's model_path: head maps equal the oracle that owns the same weights"""
+    import onnx_util as X
+    orc = O.OracleYolo(nc=80, seed=11, cls_bias=-3.0)
+    path = tmp_path / "yolov8n.onnx"
+    path.write_bytes(X.yolo_model(orc.layers(), raw=False))
+    det = gpu.ObjectDetector(model=str(path), width=64, height=64, conf=0.05)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 64, 64, 3)).astype(np.float32)
+    raw = det.forward_raw(x)
+    want = orc.forward(x)
+    assert np.array_equal(raw, want), np.abs(raw - want).max()
+    # f16 storage: weights are the f16-rounded ones (biases stay f32): compare with a detector fed through the flat container path
+    h16 = [dict(L, w=L["w"].astype(np.float16).astype(np.float32)) for L in orc.layers()]
+    path.write_bytes(X.yolo_model(orc.layers(), f16=True))
+    det16 = gpu.ObjectDetector(model=str(path), width=64, height=64, conf=0.05)
+    flat = tmp_path / "flat.tkyolo"
+    with open(flat, "wb") as f:
+        f.write(b"TKYOLO1\0" + np.array([len(h16), 80], np.int32).tobytes())
+        for L in h16:
+            f.write(np.array([L["cin"], L["cout"], L["k"], L["s"]], np.int32).tobytes() + L["w"].tobytes() + L["b"].tobytes())
+    detf = gpu.ObjectDetector(model=str(flat), width=64, height=64, conf=0.05)
+    assert np.array_equal(det16.forward_raw(x), detf.forward_raw(x))
+
+
 def test_detector_full_frame_path_and_batch(gpu):
     """u8 frame -> preprocess -> network -> NMS -> original-frame rects, 160x160 network input, 2 frames"""
     rng = np.random.default_rng(8)

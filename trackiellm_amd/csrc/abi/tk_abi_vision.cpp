@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "../vision/tk_onnx_weights.h"
 #include "../vision/tk_vision_engine.h"
 #include "tk/tk_mi355x_ext.h"
 #include "tk/tk_vision.h"
@@ -55,6 +56,9 @@ tk_error_code_t tk_object_detector_create(tk_object_detector_t** out_detector, c
     if (path.compare(0, 12, "synthetic://") == 0) {
         if (!d->model.fill_synthetic((uint64_t)query_param(path, "seed", 5), (float)query_param(path, "cls_bias", -4.0)))
             return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
+    } else if (path.size() > 5 && path.compare(path.size() - 5, 5, ".onnx") == 0) {
+        /* the reference's detector file: its Conv initialisers feed this path's own YOLOv8n graph (no ONNX Runtime) */
+        if (!d->model.load_onnx(path.c_str())) return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
     } else if (!d->model.load_file(path.c_str())) {
         return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
     }
@@ -63,6 +67,25 @@ tk_error_code_t tk_object_detector_create(tk_object_detector_t** out_detector, c
     d->det->conf = config->confidence_threshold;
     d->det->iou = config->iou_threshold;
     *out_detector = d.release();
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_onnx_probe(const char* path, int32_t* n_convs, int64_t* n_params) {
+    if (!path) return TK_ERROR_INVALID_ARGUMENT;
+    TkOnnxWeights ox;
+    if (!ox.load(path)) return vfail(TK_ERROR_MODEL_LOAD_FAILED, ox.error);
+    int64_t p = 0;
+    for (const auto& c : ox.convs) p += (int64_t)c.w.size() + (int64_t)c.b.size();
+    if (n_convs) *n_convs = (int32_t)ox.convs.size();
+    if (n_params) *n_params = p;
+    /* YOLOv8n check: the 63 convolutions of the graph, in order, plus optionally the DFL projection */
+    const std::vector<TkConvSpec> specs = TkYoloV8n<int>::specs(ox.convs.size() >= 63 ? ox.convs[62].cout : TK_YOLO_NC);
+    size_t n = ox.convs.size();
+    if (n == specs.size() + 1 && ox.convs.back().cout == 1 && ox.convs.back().cin == TK_YOLO_REG_MAX) --n;
+    if (n != specs.size()) return vfail(TK_ERROR_MODEL_VERIFICATION_FAILED, "not a YOLOv8n graph: " + std::to_string(ox.convs.size()) + " Conv nodes");
+    for (size_t i = 0; i < n; ++i)
+        if (ox.convs[i].cout != specs[i].cout || ox.convs[i].cin != specs[i].cin || ox.convs[i].kh != specs[i].k || ox.convs[i].kw != specs[i].k)
+            return vfail(TK_ERROR_MODEL_VERIFICATION_FAILED, "Conv " + std::to_string(i) + " does not match the YOLOv8n graph");
     return TK_SUCCESS;
 }
 

@@ -42,6 +42,8 @@ public:
     bool fill_synthetic(uint64_t seed, float cls_bias);
     bool set_layer(int idx, const float* w_host, const float* b_host);
     bool load_file(const char* path); /* "TKYOLO1\0" flat container: see INTEGRATION.md */
+    /* Conv initialisers of an Ultralytics YOLOv8 ONNX export, in execution order (vision/tk_onnx_weights.h); the trailing DFL conv is skipped */
+    bool load_onnx(const char* path);
     size_t param_count() const;
 };
 

@@ -1,4 +1,5 @@
 #include "tk_vision_engine.h"
+#include "tk_onnx_weights.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -133,6 +134,31 @@ bool TkYoloModel::load_file(const char* path) {
     fclose(f);
     if (!ok && error.empty()) error = "not a TKYOLO1 container for this geometry";
     return ok;
+}
+
+bool TkYoloModel::load_onnx(const char* path) {
+    TkOnnxWeights ox;
+    if (!ox.load(path)) { error = ox.error; return false; }
+    /* 63 graph convolutions, optionally followed by the DFL projection conv [1][16][1][1] */
+    size_t n = ox.convs.size();
+    if (n == specs.size() + 1 && ox.convs.back().cout == 1 && ox.convs.back().cin == TK_YOLO_REG_MAX && ox.convs.back().kh == 1) --n;
+    if (n != specs.size()) { error = "the ONNX graph has " + std::to_string(ox.convs.size()) + " Conv nodes, YOLOv8n has " + std::to_string(specs.size()) + " (+ DFL)"; return false; }
+    std::vector<float> hw;
+    for (size_t i = 0; i < n; ++i) {
+        const TkConvSpec& s = specs[i];
+        const TkOnnxConv& c = ox.convs[i];
+        if (c.cout != s.cout || c.cin != s.cin || c.kh != s.k || c.kw != s.k) {
+            error = "Conv " + std::to_string(i) + " is [" + std::to_string(c.cout) + "][" + std::to_string(c.cin) + "][" + std::to_string(c.kh) + "][" + std::to_string(c.kw) +
+                    "], the YOLOv8n graph expects [" + std::to_string(s.cout) + "][" + std::to_string(s.cin) + "][" + std::to_string(s.k) + "][" + std::to_string(s.k) + "]";
+            return false;
+        }
+        hw.resize(c.w.size());
+        for (int o = 0; o < s.cout; ++o) /* [cout][cin][kh][kw] -> [cout][kh][kw][cin] */
+            for (int ci = 0; ci < s.cin; ++ci)
+                for (int k = 0; k < s.k * s.k; ++k) hw[((size_t)o * s.k * s.k + k) * s.cin + ci] = c.w[((size_t)o * s.cin + ci) * s.k * s.k + k];
+        if (!set_layer((int)i, hw.data(), c.b.data())) return false;
+    }
+    return true;
 }
 
 /* ------------------------------------------------------------------------------------------ graph ops on the GPU */
