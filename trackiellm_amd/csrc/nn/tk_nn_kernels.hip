@@ -21,7 +21,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 /*
  * 64x64 output tile per workgroup, 4 waves in 2x2, one 32x32 fp32 MFMA accumulator per wave.
  * A/B k-slabs of 32 are staged through LDS with 16 B coalesced loads (row pitch 33 floats:
- * the 32 lanes of an MFMA operand read hit 32 different banks).
+ * the 32 lanes of an MFMA operand read hit 32 different banks); the next slab's global loads are
+ * issued before the current slab's MFMAs, so small launches (a few workgroups, the Whisper decoder
+ * steps) are not a chain of exposed load latencies.
  */
 __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     __shared__ float As[BM * LDS_LD];
@@ -44,69 +46,76 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
     const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & 15) == 0;
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        /* stage A: 64 rows x 32 k; thread -> (row = e / 8, 4 consecutive k) for e = tid, tid + 256 */
+    float ra[2][4], rb[2][4]; /* the next k slab on its way from global memory while the current one feeds the MFMAs */
+
+    /* A: 64 rows x 32 k, thread -> (row = e / 8, 4 consecutive k) for e = tid, tid + 256; B likewise ([N][K]) or, for [K][N],
+     * 4 consecutive n of one k (scattered transposed into LDS) */
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = tid + 256 * h;
+            {
+                const int row = e >> 3, kc = (e & 7) * 4;
+                const int m = m0 + row, k = k0 + kc;
+                ra[h][0] = ra[h][1] = ra[h][2] = ra[h][3] = 0.0f;
+                if (m < g.M) {
+                    const float* p = A + (int64_t)m * g.lda + k;
+                    if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; ra[h][0] = t.x; ra[h][1] = t.y; ra[h][2] = t.z; ra[h][3] = t.w; }
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (k + i < g.K) ra[h][i] = p[i];
+                    }
+                }
+            }
+            rb[h][0] = rb[h][1] = rb[h][2] = rb[h][3] = 0.0f;
+            if (!g.b_kn) {
+                const int row = e >> 3, kc = (e & 7) * 4;
+                const int n = n0 + row, k = k0 + kc;
+                if (n < g.N) {
+                    const float* p = B + (int64_t)n * g.ldb + k;
+                    if (b_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; rb[h][0] = t.x; rb[h][1] = t.y; rb[h][2] = t.z; rb[h][3] = t.w; }
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[h][i] = p[i];
+                    }
+                }
+            } else {
+                const int kk = e >> 4, nc = (e & 15) * 4;
+                const int k = k0 + kk, n = n0 + nc;
+                if (k < g.K) {
+                    const float* p = B + (int64_t)k * g.ldb + n;
+                    if (b_vec && n + 3 < g.N) { const float4 t = *(const float4*)p; rb[h][0] = t.x; rb[h][1] = t.y; rb[h][2] = t.z; rb[h][3] = t.w; }
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (n + i < g.N) rb[h][i] = p[i];
+                    }
+                }
+            }
+        }
+    };
+    auto lstore = [&]() {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int e = tid + 256 * h;
             const int row = e >> 3, kc = (e & 7) * 4;
-            const int m = m0 + row, k = k0 + kc;
-            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (m < g.M) {
-                const float* p = A + (int64_t)m * g.lda + k;
-                if (a_vec && k + 3 < g.K) {
-                    const float4 t = *(const float4*)p;
-                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (k + i < g.K) v[i] = p[i];
-                }
-            }
+            for (int i = 0; i < 4; ++i) As[row * LDS_LD + kc + i] = ra[h][i];
+            if (!g.b_kn) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) As[row * LDS_LD + kc + i] = v[i];
-        }
-        if (!g.b_kn) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int e = tid + 256 * h;
-                const int row = e >> 3, kc = (e & 7) * 4;
-                const int n = n0 + row, k = k0 + kc;
-                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (n < g.N) {
-                    const float* p = B + (int64_t)n * g.ldb + k;
-                    if (b_vec && k + 3 < g.K) {
-                        const float4 t = *(const float4*)p;
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) if (k + i < g.K) v[i] = p[i];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) Bs[row * LDS_LD + kc + i] = v[i];
-            }
-        } else { /* B is [K][N]: read 4 consecutive n of one k, scatter transposed */
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int e = tid + 256 * h;
+                for (int i = 0; i < 4; ++i) Bs[row * LDS_LD + kc + i] = rb[h][i];
+            } else {
                 const int kk = e >> 4, nc = (e & 15) * 4;
-                const int k = k0 + kk, n = n0 + nc;
-                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (k < g.K) {
-                    const float* p = B + (int64_t)k * g.ldb + n;
-                    if (b_vec && n + 3 < g.N) {
-                        const float4 t = *(const float4*)p;
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) if (n + i < g.N) v[i] = p[i];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) Bs[(nc + i) * LDS_LD + kk] = v[i];
+                for (int i = 0; i < 4; ++i) Bs[(nc + i) * LDS_LD + kk] = rb[h][i];
             }
         }
+    };
+
+    gload(0);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        lstore();
         __syncthreads();
+        if (k0 + BK < g.K) gload(k0 + BK); /* in flight under this slab's 16 MFMAs */
         const float* ap = As + (wm * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
         const float* bp = Bs + (wn * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
 #pragma unroll
