@@ -6,6 +6,14 @@
 
 #include "../nn/tk_nn_kernels.h"
 
+/* Perception streams run at the highest stream priority: their kernels are small and many, and behind the LLM's large GEMM
+ * launches they would otherwise queue for a free CU at every step (the fused cycle's critical path becomes queueing, not work). */
+static inline hipError_t tk_create_perception_stream(hipStream_t* s) {
+    int lo = 0, hi = 0; /* numerically lower = higher priority */
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+}
+
 #define HIPQ(expr)                                                                              \
     do {                                                                                        \
         hipError_t e__ = (expr);                                                                \
@@ -203,7 +211,7 @@ bool TkAsr::init(TkWhisperModel* m, int mb) {
     max_batch = mb;
     if (!m || mb < 1 || mb > 64) { error = "max_batch must be in [1,64]"; return false; }
     HIPQ(hipSetDevice(m->device));
-    HIPQ(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIPQ(tk_create_perception_stream(&stream));
     TkAudioSizeOps so;
     std::vector<float*> nullw(m->man.t.size(), nullptr);
     TkWhisperGraph<TkAudioSizeOps> g{m->hp, m->man, nullw.data()};
@@ -311,7 +319,7 @@ __global__ void k_vad_head(const float* hid, int n, int hidden, const float* w2,
 bool TkVadModel::infer(const float* windows_host, int n, float* prob_host) {
     if (n <= 0) return true;
     HIPQ(hipSetDevice(device));
-    if (!stream) HIPQ(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (!stream) HIPQ(tk_create_perception_stream(&stream));
     if (n > cap) { /* grow-only scratch: no allocation on the steady-state path */
         if (x) (void)hipFree(x);
         if (hbuf) (void)hipFree(hbuf);

@@ -6,6 +6,14 @@
 
 #include "../nn/tk_nn_kernels.h"
 
+/* Perception streams run at the highest stream priority: their kernels are small and many, and behind the LLM's large GEMM
+ * launches they would otherwise queue for a free CU at every step (the fused cycle's critical path becomes queueing, not work). */
+static inline hipError_t tk_create_perception_stream(hipStream_t* s) {
+    int lo = 0, hi = 0; /* numerically lower = higher priority */
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+}
+
 #define HIPQ(expr)                                                                              \
     do {                                                                                        \
         hipError_t e__ = (expr);                                                                \
@@ -327,7 +335,7 @@ bool TkDetector::init(TkYoloModel* m, int w, int h, int mb) {
     if (!m || w <= 0 || h <= 0 || (w % 32) || (h % 32)) { error = "detector input must be a positive multiple of 32"; return false; }
     if (mb < 1 || mb > 64) { error = "max_batch must be in [1,64]"; return false; }
     HIPQ(hipSetDevice(m->device));
-    HIPQ(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIPQ(tk_create_perception_stream(&stream));
     TkSizeOps so{&m->specs};
     TkT x = so.alloc(mb, h, w, 3);
     so.used = 0;
