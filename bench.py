@@ -69,6 +69,9 @@ def main():
                     help="independent decode groups of --batch cycles run concurrently on their own HIP streams (fills the "
                          "launch/ramp bubbles of one group with another group's kernels); concurrent cycles = sessions * batch")
     ap.add_argument("--llm-only", action="store_true", help="configs[1] only: leave the detector / ASR / VAD streams out (marked in config)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="opt-in: the ranks form ONE layer-sharded LLM pipeline (RCCL send / recv of the residual stream between consecutive "
+                         "GPUs, SURVEY.md 8e) instead of independent replicas; LLM stream only; --sessions row groups keep the stages busy")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the isolated per-shape timing of the dominant kernel (the roofline object); profile THIS command with "
                          "rocprofv3 --kernel-trace to compare its kernel durations with the HIP-event numbers (tools/roofline_check.py)")
@@ -105,6 +108,38 @@ def main():
         pr[:, 0] = 1  # BOS
         prompts.append(pr)
     import threading
+
+    if args.pipeline:
+        # one model, layers split over the ranks; every rank builds the same weights and walks the same pass order
+        if dist is None:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            dist = D.init("gloo")
+        cuda_t = world > 1
+        big = tk.LlmSession(model, G * B, P + N + 8)
+        pipe = D.LlmPipeline(dist, big, hp.n_layer, hp.d_model, cuda_tensors=cuda_t)
+        same = [np.stack([splitmix_tokens(3 + 1000 * (g * B + s_), P, 3, hp.vocab) for s_ in range(B)]) for g in range(G)]
+        for pr in same:
+            pr[:, 0] = 1
+        for _ in range(args.warmup):
+            pipe.generate(same, N)
+        D.barrier(dist, cuda=cuda_t)
+        t0 = time.time()
+        for _ in range(args.steps):
+            pipe.generate(same, N)
+        D.barrier(dist, cuda=cuda_t)
+        elapsed = D.max_over_ranks(dist, time.time() - t0, cuda=cuda_t)
+        if rank == 0:
+            print(json.dumps({"metric": "cortex cycles/sec (frame+1s audio+128 tok)", "value": round(G * B * args.steps / elapsed, 3), "unit": "cycles/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 2),
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8 x q4_K/q6_K (i32 acc, f32 scales)",
+                              "data": "synthetic",
+                              "config": {"workload": "configs[1] LLM stream only, layer-sharded: Mistral-7B Q4_K_M, 64-token prefill + 128-token greedy decode "
+                                                     "per cycle, host-driven passes (no hipGraph), %d row groups of %d" % (G, B),
+                                         "concurrent_cycles": G * B, "layers_per_rank": [pipe.bounds[r + 1] - pipe.bounds[r] for r in range(world)],
+                                         "parallelism": "pipeline x%d (RCCL send/recv of [rows, 4096] fp32 between consecutive stages)" % world},
+                              "llm_tok_per_s": round(G * B * N * args.steps / elapsed, 1)}))
+        dist.destroy_process_group()
+        return
 
     # perception streams: one 640x640 frame and 1 s of PCM per cycle, their own HIP streams, driven from host threads
     if args.roofline_only:

@@ -56,6 +56,14 @@ TK_API int tk_mi355x_llm_max_rows(void);
 /* one pass over nrows <= tk_mi355x_llm_max_rows() (sequence, position, token) rows; logits [nrows][vocab] and argmax [nrows] optional */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_forward(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos,
                                                           const int32_t* tok, float* logits, int32_t* argmax);
+/* one pipeline stage of a pass (the LLM layer-sharded over GPUs): layers [layer0, layer1) of this rank's model.  The
+ * first stage starts from tok (x_in NULL), later stages from the residual stream x_in [nrows][d_model] fp32; every stage but the last
+ * writes the stream to x_out; the last (head != 0, layer1 == n_layer) samples into argmax[nrows].  x_on_host != 0: x_in / x_out are
+ * host pointers (gloo), else device pointers on this session's GPU (RCCL send / recv buffers).  Synchronous.  Bit-identical to
+ * tk_mi355x_llm_forward whatever the split. */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_forward_stage(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos,
+                                                                const int32_t* tok, const float* x_in, float* x_out, int x_on_host, int layer0,
+                                                                int layer1, int head, int32_t* argmax);
 /* equal-length prompts for sequences 0..nseq-1; first_tokens[nseq] optional */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_prefill(tk_mi355x_llm_session_t* s, int nseq, int n_prompt, const int32_t* tokens,
                                                           int32_t* first_tokens);

@@ -227,6 +227,14 @@ tk_error_code_t tk_mi355x_llm_prefill(tk_mi355x_llm_session_t* s, int nseq, int 
 
 int tk_mi355x_llm_max_rows(void) { return TK_MAX_ROWS; }
 
+tk_error_code_t tk_mi355x_llm_forward_stage(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok,
+                                            const float* x_in, float* x_out, int x_on_host, int layer0, int layer1, int head, int32_t* argmax) {
+    if (!s || !seq || !pos) return TK_ERROR_INVALID_ARGUMENT;
+    if (!s->session.forward_stage(nrows, seq, pos, tok, x_in, x_out, x_on_host != 0, layer0, layer1, head != 0, argmax))
+        return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);
+    return TK_SUCCESS;
+}
+
 tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t* s, int nrows, int n_steps, int32_t* out_tokens, float* ms_per_step) {
     if (!s) return TK_ERROR_INVALID_ARGUMENT;
     if (!s->session.decode(nrows, n_steps, out_tokens)) return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);

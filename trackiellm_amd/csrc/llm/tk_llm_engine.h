@@ -78,6 +78,12 @@ public:
      * bit t = token t may be sampled) constrains the arg max of every row of this pass: grammar-constrained greedy sampling */
     bool forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
                  bool lm_head = true, const uint32_t* allow_mask = nullptr);
+    /* one pipeline stage of a pass: layers [l0, l1) on this GPU.  The first stage starts from `tok` (x_in == nullptr), later stages
+     * from the residual stream x_in [nrows][d_model] fp32; every stage but the last writes the stream to x_out; the last one
+     * (head == true, l1 == n_layer) samples.  x_on_host: x_in / x_out are host pointers (gloo transport), otherwise device
+     * pointers (RCCL transport).  Bit-identical to forward() whatever the split. */
+    bool forward_stage(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, const float* x_in, float* x_out, bool x_on_host,
+                       int l0, int l1, bool head, int32_t* argmax_host);
     /* prompts of equal length for sequences 0..nseq-1 (tokens[nseq][n_prompt]); leaves row r = sequence r
      * holding the first sampled token so decode() can follow; first_tokens_host[nseq] optional */
     bool prefill(int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens_host);
@@ -92,6 +98,7 @@ public:
 
 private:
     void enqueue_pass(int nrows, bool lm_head, bool fused_attn);
+    void enqueue_range(int nrows, int l0, int l1, bool embed, bool fold_out, bool lm_head, bool fused_attn);
     uint16_t *kcache = nullptr, *vcache = nullptr;
     float *x = nullptr, *qbuf = nullptr, *partial = nullptr, *logits = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
     TkActQ8 act_d{}, act_qd{}, act_ff{};

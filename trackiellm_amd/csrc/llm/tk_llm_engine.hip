@@ -260,14 +260,19 @@ static void set_act(TkGemvArgs& a, const TkActQ8& q) {
 
 static TkGemvSeg seg_of(const TkDevTensor& t) { return TkGemvSeg{t.data, t.type, (int)(t.rows / TK_TILE_ROWS)}; }
 
-void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) {
+void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) { enqueue_range(nrows, 0, model->hp.n_layer, true, false, lm_head, fused_attn); }
+
+/* layers [l0, l1) of one pass.  embed: the residual stream starts from the token embeddings (first pipeline stage), otherwise x
+ * already holds it.  fold_out: finish the last layer's residual update so x is the complete stream (it leaves this GPU).
+ * head: final norm + lm_head + arg max (last stage). */
+void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fold_out, bool lm_head, bool fused_attn) {
     const TkLlmHParams& h = model->hp;
     const int D = h.d_model, QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim, FF = h.d_ff;
     hipStream_t s = stream;
-    tk_launch_embed(model->token_embd.data, D, d_tok, nrows, x, s);
-    for (int l = 0; l < h.n_layer; ++l) {
+    if (embed) tk_launch_embed(model->token_embd.data, D, d_tok, nrows, x, s);
+    for (int l = l0; l < l1; ++l) {
         const TkLlmLayer& L = model->layers[l];
-        tk_launch_rmsnorm_q8(x, l == 0 ? nullptr : partial, h.ks_down, D, (const float*)L.attn_norm.data, h.rms_eps, D, nrows, act_d, s);
+        tk_launch_rmsnorm_q8(x, l == l0 ? nullptr : partial, h.ks_down, D, (const float*)L.attn_norm.data, h.rms_eps, D, nrows, act_d, s);
         TkGemvArgs a{};
         a.seg[0] = seg_of(L.q); a.seg[1] = seg_of(L.k); a.seg[2] = seg_of(L.v);
         a.nseg = 3; a.K = D; a.ks = h.ks_qkv; a.n_total = QD + 2 * KVD; a.nrows = nrows;
@@ -293,8 +298,11 @@ void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) {
         set_act(dn, act_ff); dn.out = partial;
         tk_launch_gemv(dn, s);
     }
-    if (!lm_head) return; /* prompt rows whose logits nobody reads: K/V are already appended */
-    tk_launch_rmsnorm_q8(x, partial, h.ks_down, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
+    if (!lm_head) { /* prompt rows whose logits nobody reads (K/V are already appended), or a pipeline stage that hands x on */
+        if (fold_out && l1 > l0) tk_launch_residual_fold(x, partial, h.ks_down, D, D, nrows, s);
+        return;
+    }
+    tk_launch_rmsnorm_q8(x, l1 > l0 ? partial : nullptr, h.ks_down, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
     TkGemvArgs lm{};
     lm.seg[0] = seg_of(model->output); lm.nseg = 1; lm.K = D; lm.ks = 1; lm.n_total = h.vocab; lm.nrows = nrows;
     set_act(lm, act_d); lm.out = logits;
@@ -328,6 +336,38 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
     if (!lm_head) { HIPQ(hipStreamSynchronize(stream)); return true; }
     if (logits_host) HIPQ(hipMemcpyAsync(logits_host, logits, (size_t)nrows * model->hp.vocab * 4, hipMemcpyDeviceToHost, stream));
     if (argmax_host) HIPQ(hipMemcpyAsync(argmax_host, d_tok, nrows * 4, hipMemcpyDeviceToHost, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    return true;
+}
+
+bool TkLlmSession::forward_stage(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, const float* x_in, float* x_out, bool x_on_host,
+                                 int l0, int l1, bool head, int32_t* argmax_host) {
+    const TkLlmHParams& h = model->hp;
+    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,128]"; return false; }
+    if (l0 < 0 || l1 < l0 || l1 > h.n_layer) { error = "bad layer range"; return false; }
+    if ((tok == nullptr) == (x_in == nullptr)) { error = "a stage starts from tokens (first stage) or from a residual stream, not both"; return false; }
+    if (head && l1 != h.n_layer) { error = "the head belongs to the stage that ends at the last layer"; return false; }
+    if (!head && !x_out) { error = "a stage without the head must hand its residual stream on"; return false; }
+    for (int r = 0; r < nrows; ++r)
+        if (seq[r] < 0 || seq[r] >= max_seq || pos[r] < 0 || pos[r] >= max_ctx || (tok && (tok[r] < 0 || tok[r] >= h.vocab))) {
+            error = "row out of range (sequence id, position or token id)";
+            return false;
+        }
+    HIPQ(hipSetDevice(model->device));
+    HIPQ(hipMemcpyAsync(d_seq, seq, nrows * 4, hipMemcpyHostToDevice, stream));
+    HIPQ(hipMemcpyAsync(d_pos, pos, nrows * 4, hipMemcpyHostToDevice, stream));
+    if (tok) HIPQ(hipMemcpyAsync(d_tok, tok, nrows * 4, hipMemcpyHostToDevice, stream));
+    HIPQ(hipMemsetAsync(d_nsteps, 0, TK_MAX_ROWS * 4, stream));
+    const size_t xb = (size_t)nrows * h.d_model * 4;
+    if (x_in) HIPQ(hipMemcpyAsync(x, x_in, xb, x_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream));
+    bool distinct = true;
+    for (int a = 0; a < nrows && distinct; ++a)
+        for (int b = a + 1; b < nrows; ++b)
+            if (seq[a] == seq[b]) { distinct = false; break; }
+    enqueue_range(nrows, l0, l1, tok != nullptr, !head, head, distinct);
+    HIPQ(hipGetLastError());
+    if (!head) HIPQ(hipMemcpyAsync(x_out, x, xb, x_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, stream));
+    else if (argmax_host) HIPQ(hipMemcpyAsync(argmax_host, d_tok, nrows * 4, hipMemcpyDeviceToHost, stream));
     HIPQ(hipStreamSynchronize(stream));
     return true;
 }

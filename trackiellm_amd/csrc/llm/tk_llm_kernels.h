@@ -47,6 +47,7 @@ void tk_launch_repack(int type, const void* blocks, int64_t rows, int64_t K, uin
 void tk_launch_embed(const void* embd_q4k, int D, const int32_t* tok, int nrows, float* x, hipStream_t s);
 void tk_launch_rmsnorm_q8(float* x, const float* partial, int ks, int n_total_partial, const float* w, float eps, int D, int nrows,
                           TkActQ8 out, hipStream_t s);
+void tk_launch_residual_fold(float* x, const float* partial, int ks, int n_total, int D, int nrows, hipStream_t s);
 void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s);
 void tk_launch_qkv_rope_append(const float* partial, int ks, int n_total, int n_head, int n_kv_head, int head_dim, const float* rope_cos,
                                const float* rope_sin, const int32_t* seq, const int32_t* pos, int nrows, float* qbuf, uint16_t* kcache,

@@ -281,6 +281,22 @@ __global__ __launch_bounds__(256) void k_rmsnorm_q8(float* __restrict__ x, const
     }
 }
 
+/* x += (p_0 + p_1 + ... + p_{ks-1}), exactly the residual update k_rmsnorm_q8 performs before it normalises: used where the
+ * residual stream leaves this GPU (pipeline-stage boundary) and the next layer's norm runs elsewhere */
+__global__ __launch_bounds__(256) void k_residual_fold(float* __restrict__ x, const float* __restrict__ partial, int ks, int n_total, int D) {
+    const int r = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (4 * g >= D) return;
+    v4f o = *(const v4f*)(partial + (int64_t)r * n_total + 4 * g);
+    for (int s = 1; s < ks; ++s) o = o + *(const v4f*)(partial + ((int64_t)s * TK_MAX_ROWS + r) * n_total + 4 * g);
+    v4f* xp = (v4f*)(x + (int64_t)r * D + 4 * g);
+    *xp = *xp + o;
+}
+
+void tk_launch_residual_fold(float* x, const float* partial, int ks, int n_total, int D, int nrows, hipStream_t s) {
+    hipLaunchKernelGGL(k_residual_fold, dim3((D / 4 + 255) / 256, nrows), dim3(256), 0, s, x, partial, ks, n_total, D);
+}
+
 void tk_launch_rmsnorm_q8(float* x, const float* partial, int ks, int n_total_partial, const float* w, float eps, int D, int nrows,
                           TkActQ8 out, hipStream_t s) {
     hipLaunchKernelGGL(k_rmsnorm_q8, dim3(nrows), dim3(256), (D + 4) * sizeof(float), s, x, partial, ks, n_total_partial, w, eps, D, out);

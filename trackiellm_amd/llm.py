@@ -83,6 +83,20 @@ class LlmSession:
         check(lib().tk_mi355x_llm_forward(self.h, n, _p(seq), _p(pos), _p(tok), _p(logits), _p(am)))
         return logits, am
 
+    def forward_stage(self, seq, pos, layer0, layer1, tok=None, x_in=None, x_out=None, head=False, on_host=True):
+        """layers [layer0, layer1) of one pass (pipeline stage).  x_in / x_out: float32 [n][d_model] numpy arrays (on_host) or raw
+        device addresses (ints, e.g. torch_tensor.data_ptr()) on this session's GPU.  Returns arg max ids when head."""
+        seq = np.ascontiguousarray(seq, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        n = len(seq)
+        if tok is not None:
+            tok = np.ascontiguousarray(tok, dtype=np.int32)
+        am = np.empty(n, dtype=np.int32) if head else None
+        ptr = (lambda a: _p(a)) if on_host else (lambda a: None if a is None else C.c_void_p(int(a)))
+        check(lib().tk_mi355x_llm_forward_stage(self.h, n, _p(seq), _p(pos), _p(tok), ptr(x_in), ptr(x_out), 1 if on_host else 0,
+                                                layer0, layer1, 1 if head else 0, _p(am)))
+        return am
+
     def prefill(self, tokens):
         tokens = np.ascontiguousarray(tokens, dtype=np.int32)
         nseq, n_prompt = tokens.shape
