@@ -2,8 +2,10 @@
  * tk_vision.h — detector stream of the tk_* C-ABI.
  *   tk_object_detector_*                         src/vision/tk_object_detector.h:42-57 (config), :66-71 (result), :99-166 (API)
  *   tk_preprocessor_resize_and_normalize_to_chw  src/vision/tk_image_preprocessor.h:49-56
- * model_path forms: "synthetic://yolov8n?seed=5&cls_bias=-4" or a TKYOLO1 weight container
- * (ONNX graphs are not parsed — the network topology is fixed: YOLOv8n, nc = class_count).
+ *   tk_classify_dominant_color / _door_state    src/vision/tk_attribute_classifier.h (per-box attributes, tk_vision_pipeline.c:462-485)
+ *   tk_vision_pipeline_* / tk_vision_result_*    src/vision/tk_vision_pipeline.h:118-335, restricted to the object-detection analysis
+ * model_path forms: an Ultralytics YOLOv8n .onnx, a TKYOLO1 weight container or "synthetic://yolov8n?seed=5&cls_bias=-4"
+ * (the network topology is fixed: YOLOv8n, nc = class_count).
  * Results: score-descending, at most 500, class-aware NMS applied, bbox in ORIGINAL frame pixels.
  * `label` is borrowed from config.class_labels (never freed by the library; the reference's
  * tk_vision_result_destroy frees it wrongly, src/vision/tk_vision_pipeline.c:297-299 — not replicated).
@@ -50,6 +52,75 @@ TK_API void tk_object_detector_update_thresholds(tk_object_detector_t* detector,
 TK_API TK_NODISCARD tk_error_code_t tk_preprocessor_resize_and_normalize_to_chw(const tk_video_frame_t* frame, float* out_tensor,
                                                                                 uint32_t target_width, uint32_t target_height,
                                                                                 const float mean[3], const float std_dev[3]);
+
+/* ---- per-box attributes: host frame in, strdup'ed name out (caller frees), computed on the GPU, bit-identical to the reference's CPU
+ * loops.  Like the reference the frame is read as tightly packed RGB8 (width * 3 bytes per row). ---- */
+TK_API TK_NODISCARD tk_error_code_t tk_classify_dominant_color(const tk_video_frame_t* frame, const tk_rect_t* bbox, char** out_color_name);
+TK_API TK_NODISCARD tk_error_code_t tk_classify_door_state(const tk_video_frame_t* frame, const tk_rect_t* bbox, char** out_state_name);
+
+/* ---- vision pipeline, object-detection analysis only (depth / OCR / fusion / navigation are out of scope: their flags are accepted
+ * and never set in valid_analyses_mask) ---- */
+typedef struct tk_vision_pipeline_s tk_vision_pipeline_t;
+typedef struct tk_vision_result_s tk_vision_result_t;
+typedef uint32_t tk_vision_analysis_flags_t;
+enum {
+    TK_VISION_ANALYZE_NONE = 0, TK_VISION_ANALYZE_OBJECT_DETECTION = 1 << 0, TK_VISION_ANALYZE_DEPTH_ESTIMATION = 1 << 1,
+    TK_VISION_ANALYZE_OCR = 1 << 2, TK_VISION_ANALYZE_FUSION_DISTANCE = 1 << 3, TK_VISION_ANALYZE_NAVIGATION_CUES = 1 << 4,
+    TK_VISION_ANALYZE_SCENE_GRAPH = 1 << 5
+};
+typedef uint32_t tk_vision_valid_result_flags_t;
+enum {
+    TK_VISION_RESULT_NONE = 0, TK_VISION_RESULT_OBJECT_DETECTION = 1 << 0, TK_VISION_RESULT_DEPTH_ESTIMATION = 1 << 1,
+    TK_VISION_RESULT_OCR = 1 << 2, TK_VISION_RESULT_FUSION_DISTANCE = 1 << 3, TK_VISION_RESULT_NAVIGATION_CUES = 1 << 4
+};
+typedef struct {
+    tk_vision_backend_e backend;
+    int gpu_device_id;
+    tk_path_t* object_detection_model_path;
+    tk_path_t* depth_estimation_model_path; /* ignored */
+    tk_path_t* tesseract_data_path;         /* ignored */
+    float object_confidence_threshold;
+    uint32_t max_detected_objects;
+    float focal_length_x;
+    float focal_length_y;
+} tk_vision_pipeline_config_t;
+typedef struct {
+    float object_confidence_threshold;
+    float iou_threshold;
+    bool enable_object_detection;
+    bool enable_depth_estimation;
+} tk_vision_runtime_config_t;
+typedef struct {
+    uint32_t class_id;
+    const char* label;      /* owned by the object here (a copy): tk_vision_result_destroy frees it, as the reference's does */
+    float confidence;
+    tk_rect_t bbox;
+    float distance_meters;  /* 0: fusion is out of scope */
+    float width_meters;
+    float height_meters;
+    bool is_partially_occluded;
+    char* recognized_text;  /* NULL: OCR is out of scope */
+    char* attributes;       /* "color:<name>" (+ ",state:open|closed" for labels containing "door"); owned by the object */
+} tk_vision_object_t;
+typedef struct { char* text; float confidence; tk_rect_t bbox; } tk_vision_text_block_t;
+typedef struct { uint32_t width; uint32_t height; float* data; } tk_vision_depth_map_t;
+struct tk_vision_result_s {
+    uint64_t source_frame_timestamp_ns;
+    tk_vision_valid_result_flags_t valid_analyses_mask;
+    size_t object_count;
+    tk_vision_object_t* objects;
+    size_t text_block_count;
+    tk_vision_text_block_t* text_blocks; /* always NULL */
+    tk_vision_depth_map_t* depth_map;    /* always NULL */
+    char* serialized_scene_graph;        /* always NULL */
+};
+TK_API TK_NODISCARD tk_error_code_t tk_vision_pipeline_create(tk_vision_pipeline_t** out_pipeline, const tk_vision_pipeline_config_t* config);
+TK_API void tk_vision_pipeline_destroy(tk_vision_pipeline_t** pipeline);
+TK_API TK_NODISCARD tk_error_code_t tk_vision_pipeline_update_config(tk_vision_pipeline_t* pipeline, const tk_vision_runtime_config_t* config);
+TK_API TK_NODISCARD tk_error_code_t tk_vision_pipeline_process_frame(tk_vision_pipeline_t* pipeline, const tk_video_frame_t* video_frame,
+                                                                     tk_vision_analysis_flags_t analysis_flags, const tk_rect_t* ocr_roi,
+                                                                     uint64_t timestamp_ns, tk_vision_result_t** out_result);
+TK_API void tk_vision_result_destroy(tk_vision_result_t** result);
 
 /* ---- extensions (no reference counterpart) ---- */
 /* B frames of identical geometry in one pass (one per concurrent cortex cycle); results[i] / counts[i] per frame */

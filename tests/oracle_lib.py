@@ -204,6 +204,33 @@ def ref_preprocess(frame, tw, th, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     return out
 
 
+class _RefFrame(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("stride", C.c_uint32), ("format", C.c_int), ("data", C.c_void_p)]
+
+
+class _RefRect(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int)]
+
+
+def ref_attributes(frame, rect):
+    """the COMPILED reference classifiers (oracle/_ref/libtkref_attr.so): frame uint8 [H][W][3] contiguous, rect (x, y, w, h) ->
+    (colour name, door state)"""
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libtkref_attr.so"))
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    frame = np.ascontiguousarray(frame, np.uint8)
+    f = _RefFrame(frame.shape[1], frame.shape[0], frame.shape[1] * 3, 0, frame.ctypes.data)
+    r = _RefRect(*[int(v) for v in rect])
+    out = []
+    for fn in (L.tk_classify_dominant_color, L.tk_classify_door_state):
+        fn.argtypes = [C.POINTER(_RefFrame), C.POINTER(_RefRect), C.POINTER(C.c_void_p)]
+        p = C.c_void_p()
+        assert fn(C.byref(f), C.byref(r), C.byref(p)) == 0
+        out.append(C.string_at(p).decode())
+        libc.free(p)
+    return tuple(out)
+
+
 def have_ref():
     return os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libtkref_preprocess.so"))
 

@@ -102,6 +102,58 @@ def test_detector_full_frame_path_and_batch(gpu):
     assert det.detect(fr[0]) == []                                            # empty result set
 
 
+@pytest.mark.skipif(not O.have_ref() or not os.path.exists(os.path.join(O.ROOT, "oracle", "_ref", "libtkref_attr.so")), reason="compiled reference not built")
+def test_box_attributes_equal_the_compiled_reference(gpu):
+    """tk_classify_dominant_color / tk_classify_door_state on the GPU against the reference's own C compiled from its sources:
+    random frames and boxes (also partly outside the frame for the colour histogram), saturated primaries, grays, a striped door"""
+    rng = np.random.default_rng(2)
+    frames = [rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)]
+    prim = np.zeros((40, 72, 3), np.uint8)
+    for i, c in enumerate([(255, 0, 0), (255, 255, 0), (0, 255, 0), (0, 255, 255), (0, 0, 255), (255, 0, 255), (0, 0, 0), (255, 255, 255), (128, 128, 128)]):
+        prim[:, 8 * i:8 * i + 8] = c
+    frames.append(prim)
+    stripes = np.full((60, 60, 3), 30, np.uint8)
+    stripes[0::4] = 220
+    stripes[1::4] = 220                                   # two bright rows, two dark rows: the rows above and below always differ by 190
+    frames.append(stripes)
+    frames.append((rng.integers(0, 4, (50, 50, 1)) * 60 + rng.integers(0, 20, (50, 50, 3))).astype(np.uint8))  # low saturation
+    for f in frames:
+        H, W = f.shape[:2]
+        boxes = [(0, 0, W, H), (3, 2, 9, 7), (W // 2, H // 2, W // 2, H // 2), (1, 1, W - 2, H - 2)]
+        boxes += [tuple(int(v) for v in (rng.integers(1, W - 8), rng.integers(1, H - 8), rng.integers(3, 8), rng.integers(3, 8))) for _ in range(6)]
+        for b in boxes:
+            assert gpu.classify_attributes(f, b) == O.ref_attributes(f, b), (f.shape, b)
+        b = (W - 6, H - 6, 12, 12)   # partly outside: colour only (the reference's door loop has no bounds check; its colour loop skips)
+        big = np.zeros((H + 16, W, 3), np.uint8)
+        big[:H] = f                  # the reference's door loop reads rows past the box: give it memory to read
+        assert gpu.classify_attributes(f, b)[0] == O.ref_attributes(big[:H], b)[0]
+    for i, name in enumerate(["red", "yellow", "green", "cyan", "blue", "magenta", "black", "white", "gray"]):
+        assert gpu.classify_attributes(prim, (8 * i, 0, 8, 40))[0] == name
+    assert gpu.classify_attributes(stripes, (5, 5, 40, 40))[1] == "closed"
+    assert gpu.classify_attributes(prim, (0, 0, 8, 40))[1] == "open"
+
+
+def test_vision_pipeline_object_detection(gpu):
+    """tk_vision_pipeline_*: detections copied into tk_vision_object_t with the per-box colour attribute of the resident frame"""
+    rng = np.random.default_rng(9)
+    frame = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    pipe = gpu.VisionPipeline(conf=0.5, max_objects=12)
+    det = gpu.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", conf=0.5)
+    ts, mask, objs = pipe.process(frame, flags=1 | 2 | 4, timestamp_ns=77)
+    want = det.detect(frame)[:12]
+    assert ts == 77 and mask == 1                      # depth / OCR requested, never reported
+    assert [(o[0], o[1], o[3]) for o in objs] == [(w[0], w[1], w[3]) for w in want]
+    assert len(objs) > 0
+    for cls, label, conf, bbox, attr in objs:
+        assert attr == ("color:" + gpu.classify_attributes(frame, bbox)[0]).encode()
+    assert pipe.process(frame, flags=2)[1:] == (0, [])   # object detection not requested
+    pipe.update(0.5, 0.5, enable=False)
+    assert pipe.process(frame, flags=1)[1:] == (0, [])
+    pipe.update(0.999, 0.5, enable=True)
+    assert pipe.process(frame, flags=1)[1] == 1
+    pipe.close()
+
+
 def test_detector_errors(gpu):
     with pytest.raises(gpu.TkError) as e:
         gpu.ObjectDetector(backend=0)

@@ -222,4 +222,159 @@ tk_error_code_t tk_preprocessor_resize_and_normalize_to_chw(const tk_video_frame
     return rc;
 }
 
+/* ------------------------------------------------------------------ per-box attributes ------ */
+
+static const char* const TK_COLOR_NAMES[9] = {"red", "yellow", "green", "cyan", "blue", "magenta", "black", "white", "gray"};
+
+static tk_error_code_t classify_one(const tk_video_frame_t* frame, const tk_rect_t* bbox, int32_t* color, int32_t* door) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return vfail(TK_ERROR_GPU_DEVICE_NOT_FOUND, "no HIP device visible");
+    const int32_t r[4] = {bbox->x, bbox->y, bbox->w, bbox->h};
+    std::string err;
+    if (!tk_classify_boxes_host(tk_mi355x_get_default_device(), frame->data, frame->width, frame->height, 1, r, color, door, &err))
+        return vfail(TK_ERROR_GPU_ROCM_ERROR, err);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_classify_dominant_color(const tk_video_frame_t* frame, const tk_rect_t* bbox, char** out_color_name) {
+    if (!frame || !frame->data || !bbox || !out_color_name) return TK_ERROR_INVALID_ARGUMENT;
+    int32_t c = 0;
+    tk_error_code_t rc = classify_one(frame, bbox, &c, nullptr);
+    if (rc != TK_SUCCESS) return rc;
+    *out_color_name = strdup(TK_COLOR_NAMES[c]);
+    return *out_color_name ? TK_SUCCESS : TK_ERROR_OUT_OF_MEMORY;
+}
+
+tk_error_code_t tk_classify_door_state(const tk_video_frame_t* frame, const tk_rect_t* bbox, char** out_state_name) {
+    if (!frame || !frame->data || !bbox || !out_state_name) return TK_ERROR_INVALID_ARGUMENT;
+    int32_t d = 0;
+    tk_error_code_t rc = classify_one(frame, bbox, nullptr, &d);
+    if (rc != TK_SUCCESS) return rc;
+    *out_state_name = strdup(d ? "closed" : "open");
+    return *out_state_name ? TK_SUCCESS : TK_ERROR_OUT_OF_MEMORY;
+}
+
+/* ------------------------------------------------------------------ vision pipeline (object detection only) ------ */
+
+static const char* const TK_COCO_LABELS[80] = {
+    "person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light", "fire hydrant", "stop sign",
+    "parking meter", "bench", "bird", "cat", "dog", "horse", "sheep", "cow", "elephant", "bear", "zebra", "giraffe", "backpack", "umbrella",
+    "handbag", "tie", "suitcase", "frisbee", "skis", "snowboard", "sports ball", "kite", "baseball bat", "baseball glove", "skateboard",
+    "surfboard", "tennis racket", "bottle", "wine glass", "cup", "fork", "knife", "spoon", "bowl", "banana", "apple", "sandwich", "orange",
+    "broccoli", "carrot", "hot dog", "pizza", "donut", "cake", "chair", "couch", "potted plant", "bed", "dining table", "toilet", "tv", "laptop",
+    "mouse", "remote", "keyboard", "cell phone", "microwave", "oven", "toaster", "sink", "refrigerator", "book", "clock", "vase", "scissors",
+    "teddy bear", "hair drier", "toothbrush"};
+
+struct tk_vision_pipeline_s {
+    tk_object_detector_t* detector = nullptr;
+    std::mutex mu;
+    bool detection_enabled = false;
+    uint32_t max_objects = 0;
+};
+
+tk_error_code_t tk_vision_pipeline_create(tk_vision_pipeline_t** out_pipeline, const tk_vision_pipeline_config_t* config) {
+    if (!out_pipeline || !config) return TK_ERROR_INVALID_ARGUMENT;
+    if (!config->object_detection_model_path) return vfail(TK_ERROR_INVALID_ARGUMENT, "object_detection_model_path missing");
+    std::unique_ptr<tk_vision_pipeline_s> p(new tk_vision_pipeline_s());
+    /* the reference's detector configuration (tk_vision_pipeline.c:368-379): 640x640, the 80 COCO labels, IoU 0.5 */
+    tk_object_detector_config_t dc{};
+    dc.backend = config->backend;
+    dc.gpu_device_id = config->gpu_device_id;
+    dc.model_path = config->object_detection_model_path;
+    dc.input_width = 640;
+    dc.input_height = 640;
+    dc.class_labels = (const char**)TK_COCO_LABELS;
+    dc.class_count = 80;
+    dc.confidence_threshold = config->object_confidence_threshold;
+    dc.iou_threshold = 0.5f;
+    /* a detector that fails to load disables the analysis, it does not fail the pipeline (tk_vision_pipeline.c:380-385) */
+    if (tk_object_detector_create(&p->detector, &dc) != TK_SUCCESS) p->detector = nullptr;
+    p->detection_enabled = p->detector != nullptr;
+    p->max_objects = config->max_detected_objects;
+    *out_pipeline = p.release();
+    return TK_SUCCESS;
+}
+
+void tk_vision_pipeline_destroy(tk_vision_pipeline_t** pipeline) {
+    if (!pipeline || !*pipeline) return;
+    if ((*pipeline)->detector) tk_object_detector_destroy(&(*pipeline)->detector);
+    delete *pipeline;
+    *pipeline = nullptr;
+}
+
+tk_error_code_t tk_vision_pipeline_update_config(tk_vision_pipeline_t* pipeline, const tk_vision_runtime_config_t* config) {
+    if (!pipeline || !config) return TK_ERROR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(pipeline->mu);
+    pipeline->detection_enabled = config->enable_object_detection;
+    if (pipeline->detector) tk_object_detector_update_thresholds(pipeline->detector, config->object_confidence_threshold, config->iou_threshold);
+    return TK_SUCCESS;
+}
+
+void tk_vision_result_destroy(tk_vision_result_t** result) {
+    if (!result || !*result) return;
+    tk_vision_result_t* r = *result;
+    for (size_t i = 0; i < r->object_count; ++i) {
+        free((void*)r->objects[i].label);
+        free(r->objects[i].recognized_text);
+        free(r->objects[i].attributes);
+    }
+    free(r->objects);
+    free(r);
+    *result = nullptr;
+}
+
+tk_error_code_t tk_vision_pipeline_process_frame(tk_vision_pipeline_t* pipeline, const tk_video_frame_t* video_frame,
+                                                 tk_vision_analysis_flags_t analysis_flags, const tk_rect_t* ocr_roi, uint64_t timestamp_ns,
+                                                 tk_vision_result_t** out_result) {
+    (void)ocr_roi;
+    if (!pipeline || !video_frame || !out_result) return TK_ERROR_INVALID_ARGUMENT;
+    tk_vision_result_t* result = (tk_vision_result_t*)calloc(1, sizeof(tk_vision_result_t));
+    if (!result) return TK_ERROR_OUT_OF_MEMORY;
+    result->source_frame_timestamp_ns = timestamp_ns;
+    bool enabled;
+    {
+        std::lock_guard<std::mutex> lk(pipeline->mu);
+        enabled = pipeline->detection_enabled;
+    }
+    if (enabled && (analysis_flags & TK_VISION_ANALYZE_OBJECT_DETECTION) && pipeline->detector) {
+        /* perform_object_detection (tk_vision_pipeline.c:435-494): detections -> objects, then the per-box attributes; a failure is
+         * logged and the frame goes on without this analysis (:190-197) */
+        tk_detection_result_t* det = nullptr;
+        size_t n = 0;
+        bool ok = video_frame->data && tk_object_detector_detect(pipeline->detector, video_frame, &det, &n) == TK_SUCCESS;
+        if (ok && pipeline->max_objects && n > pipeline->max_objects) n = pipeline->max_objects; /* results are score-descending */
+        if (ok && n > 0) {
+            result->objects = (tk_vision_object_t*)calloc(n, sizeof(tk_vision_object_t));
+            ok = result->objects != nullptr;
+        }
+        std::vector<int32_t> rects(4 * n), color(n, -1), door(n, 0);
+        bool have_attr = false;
+        if (ok && n > 0) {
+            for (size_t i = 0; i < n; ++i) { rects[4 * i] = det[i].bbox.x; rects[4 * i + 1] = det[i].bbox.y; rects[4 * i + 2] = det[i].bbox.w; rects[4 * i + 3] = det[i].bbox.h; }
+            /* the frame the detector just pre-processed is still on the device; RGBA / padded frames have no attribute pass (the
+             * reference reads them as packed RGB8 and classifies garbage) */
+            have_attr = pipeline->detector->det->classify_boxes(0, (int)n, rects.data(), color.data(), door.data());
+        }
+        if (ok) {
+            for (size_t i = 0; i < n; ++i) {
+                tk_vision_object_t& o = result->objects[i];
+                o.class_id = det[i].class_id;
+                o.label = det[i].label ? strdup(det[i].label) : nullptr;
+                o.confidence = det[i].confidence;
+                o.bbox = det[i].bbox;
+                if (have_attr) {
+                    std::string a = std::string("color:") + TK_COLOR_NAMES[color[i]];
+                    if (det[i].label && strstr(det[i].label, "door")) a += std::string(",state:") + (door[i] ? "closed" : "open");
+                    o.attributes = strdup(a.c_str());
+                }
+            }
+            result->object_count = n;
+            result->valid_analyses_mask |= TK_VISION_RESULT_OBJECT_DETECTION;
+        }
+        if (det) tk_object_detector_free_results(&det);
+    }
+    *out_result = result;
+    return TK_SUCCESS;
+}
+
 } /* extern "C" */

@@ -63,6 +63,11 @@ public:
     /* test hooks: run the network on an already pre-processed NHWC tensor / fetch the raw head maps */
     bool forward_tensor(int B, const float* nhwc_host, std::vector<float>* raw_out /* [B][8400][64+nc] */);
     bool fetch(int B, std::vector<std::vector<TkDetection>>* out); /* download the NMS survivors of the last enqueue */
+    /* per-box attributes on frame b of the last detect() batch, still resident on the device (reference: the CPU loops of
+     * src/vision/tk_attribute_classifier.c run per detection, tk_vision_pipeline.c:462-485): rects[n] = {x, y, w, h} in frame pixels;
+     * color[n] = dominant-colour bin 0..8, door_closed[n] = 1 when the strong-vertical-edge density exceeds 10 % */
+    bool classify_boxes(int b, int n, const int32_t* rects, int32_t* color, int32_t* door_closed);
+
     bool enqueue(int B); /* pre-processed input already in `input`; network + decode + NMS on `stream` */
     float* input = nullptr;        /* [B][H][W][3] */
     int n_anchors = 0;
@@ -71,6 +76,11 @@ private:
     friend struct TkGpuOps;
     uint8_t* frame_dev = nullptr;
     size_t frame_cap = 0;
+    uint32_t last_w = 0, last_h = 0, last_stride = 0; /* geometry of the frames of the last detect() */
+    int last_B = 0;
+    int32_t* attr_dev = nullptr; /* [cap][4] rects then [cap][2] results */
+    int attr_cap = 0;
+    bool run_attributes(const uint8_t* frame, uint32_t w, uint32_t h, int n, const int32_t* rects, int32_t* color, int32_t* door_closed);
     float* arena = nullptr;
     size_t arena_floats = 0, arena_used = 0;
     float* col = nullptr;
@@ -83,5 +93,10 @@ private:
     TkDetection* kept = nullptr;        /* [B][MAX_DET] */
     int32_t* n_kept = nullptr;          /* [B] */
 };
+
+/* the same classification on a host frame (tightly packed RGB8), temporary device buffers on `device`: the reference's stand-alone
+ * tk_classify_dominant_color / tk_classify_door_state entry points */
+bool tk_classify_boxes_host(int device, const uint8_t* frame, uint32_t w, uint32_t h, int n, const int32_t* rects, int32_t* color,
+                            int32_t* door_closed, std::string* error);
 
 #endif

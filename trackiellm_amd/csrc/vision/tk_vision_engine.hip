@@ -325,7 +325,7 @@ __global__ void k_yolo_scan(const tk_yolo_cand_t* cand, int n_anchors, const int
 TkDetector::~TkDetector() {
     if (model) (void)hipSetDevice(model->device);
     if (stream) (void)hipStreamSynchronize(stream);
-    void* ptrs[] = {frame_dev, arena, col, input, cand, order, n_cand, mask, kept, n_kept};
+    void* ptrs[] = {frame_dev, arena, col, input, cand, order, n_cand, mask, kept, n_kept, attr_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -389,8 +389,132 @@ bool TkDetector::detect(int B, const uint8_t* const* frames, uint32_t w, uint32_
         for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std_dev[c] = std_dev[c]; }
         tk_launch_preprocess(a, stream);
     }
+    last_w = w; last_h = h; last_stride = stride; last_B = B;
     if (!enqueue(B)) return false;
     return fetch(B, out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Per-box attributes (reference: src/vision/tk_attribute_classifier.c, run per detection by tk_vision_pipeline.c:462-485).
+ * One workgroup per box; both classifiers are byte / integer histograms over the box's pixels, so the counts are exact whatever
+ * the order the threads visit them in, and the fp32 / fp64 arithmetic of the HSV test is the reference's, operation for operation:
+ *   r,g,b = u8 / 255.0f;  v = max, delta = max - min, s = delta / max  (s = 0 when max = 0)
+ *   h = 60 * ((g - b) / delta | 2 + (b - r) / delta | 4 + (r - g) / delta), + 360 when negative   (the constants are doubles in the
+ *   reference: a float op double op rounds once more on the store to float, reproduced with explicit double arithmetic)
+ *   s < 0.1 (double compare): black (v < 0.1) / white (v > 0.9) / gray, else six 60-degree hue bins starting at 330.
+ * Dominant colour = first bin with the maximum count.  Like the reference the frame is read as tightly packed RGB8
+ * (row pitch = 3 * width, :56); pixels outside the frame are skipped (:54).
+ * Door state: count interior pixels whose luminance (integer 299/587/114 per mille) differs by more than 100 between the rows above
+ * and below; closed when count / (w * h) > 0.1.  The reference does not bounds-check this loop (:113-117); out-of-frame pixels are
+ * skipped here.
+ * ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ int tk_color_bin(uint8_t R, uint8_t G, uint8_t B) {
+    const float r = tk_divf((float)R, 255.0f), g = tk_divf((float)G, 255.0f), b = tk_divf((float)B, 255.0f);
+    const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
+    const float delta = mx - mn, v = mx;
+    float s = 0.0f, h = 0.0f;
+    if ((double)mx > 0.0) {
+        s = tk_divf(delta, mx);
+        if (r >= mx) h = tk_divf(g - b, delta);
+        else if (g >= mx) h = (float)(2.0 + (double)tk_divf(b - r, delta));
+        else h = (float)(4.0 + (double)tk_divf(r - g, delta));
+        h = (float)((double)h * 60.0);
+        if ((double)h < 0.0) h = (float)((double)h + 360.0);
+    }
+    if ((double)s < 0.1) return (double)v < 0.1 ? 6 : ((double)v > 0.9 ? 7 : 8);
+    if (h < 30.0f || h >= 330.0f) return 0;
+    if (h < 90.0f) return 1;
+    if (h < 150.0f) return 2;
+    if (h < 210.0f) return 3;
+    if (h < 270.0f) return 4;
+    if (h < 330.0f) return 5;
+    return -1; /* NaN hue: the reference counts the pixel in no bin */
+}
+
+__device__ __forceinline__ int tk_luma(const uint8_t* p) { return (int)(uint8_t)((p[0] * 299 + p[1] * 587 + p[2] * 114) / 1000); }
+
+__global__ __launch_bounds__(256) void k_box_attributes(const uint8_t* frame, int W, int H, const int32_t* rects, int32_t* out) {
+    __shared__ int bins[9];
+    __shared__ int edges;
+    const int box = blockIdx.x, t = threadIdx.x;
+    const int bx = rects[4 * box], by = rects[4 * box + 1], bw = rects[4 * box + 2], bh = rects[4 * box + 3];
+    if (t < 9) bins[t] = 0;
+    if (t == 0) edges = 0;
+    __syncthreads();
+    const int64_t npix = (bw > 0 && bh > 0) ? (int64_t)bw * bh : 0;
+    for (int64_t i = t; i < npix; i += 256) {
+        const int x = bx + (int)(i % bw), y = by + (int)(i / bw);
+        if (x < 0 || x >= W || y < 0 || y >= H) continue;
+        const uint8_t* p = frame + ((int64_t)y * W + x) * 3;
+        const int c = tk_color_bin(p[0], p[1], p[2]);
+        if (c >= 0) atomicAdd(&bins[c], 1);
+        const int lx = x - bx, ly = y - by; /* door-state loop: interior of the box, rows above / below inside the frame */
+        if (lx >= 1 && lx < bw - 1 && ly >= 1 && ly < bh - 1 && y >= 1 && y < H - 1) {
+            const int d = tk_luma(p - (int64_t)W * 3) - tk_luma(p + (int64_t)W * 3);
+            if ((d < 0 ? -d : d) > 100) atomicAdd(&edges, 1);
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        int best = 0;
+        for (int i = 1; i < 9; ++i)
+            if (bins[i] > bins[best]) best = i;
+        out[2 * box] = best;
+        const float density = tk_divf((float)edges, (float)(bw * bh));
+        out[2 * box + 1] = (double)density > 0.1 ? 1 : 0;
+    }
+}
+
+bool TkDetector::run_attributes(const uint8_t* frame, uint32_t w, uint32_t h, int n, const int32_t* rects, int32_t* color, int32_t* door_closed) {
+    if (n <= 0) return true;
+    if (n > attr_cap) {
+        if (attr_dev) (void)hipFree(attr_dev);
+        attr_dev = nullptr;
+        attr_cap = 0;
+        HIPQ(hipMalloc((void**)&attr_dev, (size_t)n * 6 * 4));
+        attr_cap = n;
+    }
+    int32_t* res = attr_dev + (size_t)attr_cap * 4;
+    HIPQ(hipMemcpyAsync(attr_dev, rects, (size_t)n * 16, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_box_attributes, dim3(n), dim3(256), 0, stream, frame, (int)w, (int)h, attr_dev, res);
+    std::vector<int32_t> hr((size_t)n * 2);
+    HIPQ(hipMemcpyAsync(hr.data(), res, (size_t)n * 8, hipMemcpyDeviceToHost, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    for (int i = 0; i < n; ++i) {
+        if (color) color[i] = hr[2 * i];
+        if (door_closed) door_closed[i] = hr[2 * i + 1];
+    }
+    return true;
+}
+
+bool TkDetector::classify_boxes(int b, int n, const int32_t* rects, int32_t* color, int32_t* door_closed) {
+    if (b < 0 || b >= last_B || !frame_dev) { error = "no frame of that index is resident (call detect first)"; return false; }
+    if (last_stride != last_w * 3) { error = "attribute classification reads tightly packed RGB8 frames, as the reference does"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    return run_attributes(frame_dev + (size_t)last_stride * last_h * b, last_w, last_h, n, rects, color, door_closed);
+}
+
+bool tk_classify_boxes_host(int device, const uint8_t* frame, uint32_t w, uint32_t h, int n, const int32_t* rects, int32_t* color,
+                            int32_t* door_closed, std::string* error) {
+    if (n <= 0) return true;
+    uint8_t* df = nullptr;
+    int32_t* dr = nullptr;
+    const size_t fb = (size_t)w * h * 3;
+    bool ok = hipSetDevice(device) == hipSuccess && hipMalloc((void**)&df, fb) == hipSuccess && hipMalloc((void**)&dr, (size_t)n * 6 * 4) == hipSuccess;
+    std::vector<int32_t> hr((size_t)n * 2);
+    if (ok) ok = hipMemcpy(df, frame, fb, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dr, rects, (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_box_attributes, dim3(n), dim3(256), 0, nullptr, df, (int)w, (int)h, dr, dr + (size_t)n * 4);
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(hr.data(), dr + (size_t)n * 4, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (df) (void)hipFree(df);
+    if (dr) (void)hipFree(dr);
+    if (!ok) { if (error) *error = "HIP error in the attribute classifier"; return false; }
+    for (int i = 0; i < n; ++i) {
+        if (color) color[i] = hr[2 * i];
+        if (door_closed) door_closed[i] = hr[2 * i + 1];
+    }
+    return true;
 }
 
 bool TkDetector::fetch(int B, std::vector<std::vector<TkDetection>>* out) {

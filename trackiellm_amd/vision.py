@@ -123,3 +123,77 @@ class ObjectDetector:
             self.close()
         except Exception:
             pass
+
+
+def classify_attributes(arr, rect):
+    """tk_classify_dominant_color + tk_classify_door_state on one box (x, y, w, h) of a uint8 [H][W][3] frame -> (colour, state)"""
+    f, keep = make_frame(arr)
+    r = Rect(*[int(v) for v in rect])
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    out = []
+    for fn in (lib().tk_classify_dominant_color, lib().tk_classify_door_state):
+        p = C.c_void_p()
+        check(fn(C.byref(f), C.byref(r), C.byref(p)))
+        out.append(C.string_at(p).decode())
+        libc.free(p)
+    return tuple(out)
+
+
+class _PipelineConfig(C.Structure):
+    _fields_ = [("backend", C.c_int), ("gpu_device_id", C.c_int), ("object_detection_model_path", C.POINTER(_Path)),
+                ("depth_estimation_model_path", C.POINTER(_Path)), ("tesseract_data_path", C.POINTER(_Path)),
+                ("object_confidence_threshold", C.c_float), ("max_detected_objects", C.c_uint32), ("focal_length_x", C.c_float),
+                ("focal_length_y", C.c_float)]
+
+
+class _RuntimeConfig(C.Structure):
+    _fields_ = [("object_confidence_threshold", C.c_float), ("iou_threshold", C.c_float), ("enable_object_detection", C.c_bool),
+                ("enable_depth_estimation", C.c_bool)]
+
+
+class VisionObject(C.Structure):
+    _fields_ = [("class_id", C.c_uint32), ("label", C.c_char_p), ("confidence", C.c_float), ("bbox", Rect), ("distance_meters", C.c_float),
+                ("width_meters", C.c_float), ("height_meters", C.c_float), ("is_partially_occluded", C.c_bool), ("recognized_text", C.c_char_p),
+                ("attributes", C.c_char_p)]
+
+
+class VisionResult(C.Structure):
+    _fields_ = [("source_frame_timestamp_ns", C.c_uint64), ("valid_analyses_mask", C.c_uint32), ("object_count", C.c_size_t),
+                ("objects", C.POINTER(VisionObject)), ("text_block_count", C.c_size_t), ("text_blocks", C.c_void_p), ("depth_map", C.c_void_p),
+                ("serialized_scene_graph", C.c_char_p)]
+
+
+class VisionPipeline:
+    """tk_vision_pipeline_* (object-detection analysis)"""
+
+    def __init__(self, model="synthetic://yolov8n?seed=5&cls_bias=-0.45", conf=0.5, max_objects=0, device=0, backend=3):
+        lib().tk_path_create.restype = C.POINTER(_Path)
+        p = lib().tk_path_create(model.encode())
+        cfg = _PipelineConfig(backend, device, p, None, None, conf, max_objects, 500.0, 500.0)
+        self.h = C.c_void_p()
+        try:
+            check(lib().tk_vision_pipeline_create(C.byref(self.h), C.byref(cfg)))
+        finally:
+            lib().tk_path_destroy(C.byref(p))
+
+    def update(self, conf, iou, enable=True):
+        rc = _RuntimeConfig(conf, iou, enable, False)
+        check(lib().tk_vision_pipeline_update_config(self.h, C.byref(rc)))
+
+    def process(self, arr, flags=1, timestamp_ns=0):
+        f, keep = make_frame(arr)
+        res = C.POINTER(VisionResult)()
+        check(lib().tk_vision_pipeline_process_frame(self.h, C.byref(f), flags, None, C.c_uint64(timestamp_ns), C.byref(res)))
+        r = res.contents
+        objs = [(r.objects[i].class_id, r.objects[i].label, r.objects[i].confidence,
+                 (r.objects[i].bbox.x, r.objects[i].bbox.y, r.objects[i].bbox.w, r.objects[i].bbox.h), r.objects[i].attributes)
+                for i in range(r.object_count)]
+        out = (r.source_frame_timestamp_ns, r.valid_analyses_mask, objs)
+        lib().tk_vision_result_destroy(C.byref(res))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().tk_vision_pipeline_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
