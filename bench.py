@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--decode", type=int, default=128)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers => result marked invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sessions", type=int, default=2,
+    ap.add_argument("--sessions", type=int, default=3,
                     help="independent decode groups of --batch cycles run concurrently on their own HIP streams (fills the "
                          "launch/ramp bubbles of one group with another group's kernels); concurrent cycles = sessions * batch")
     ap.add_argument("--llm-only", action="store_true", help="configs[1] only: leave the detector / ASR / VAD streams out (marked in config)")
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the isolated per-shape timing of the dominant kernel (the roofline object); profile THIS command with "
                          "rocprofv3 --kernel-trace to compare its kernel durations with the HIP-event numbers (tools/roofline_check.py)")
-    ap.add_argument("--perception-batch", type=int, default=32, help="frames / utterances per detector / ASR call")
+    ap.add_argument("--perception-batch", type=int, default=64, help="frames / utterances per detector / ASR call")
     ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     args = ap.parse_args()
 
