@@ -6,10 +6,10 @@
  * inside a 256-block, float accumulation across blocks in ascending order, canonical
  * reduction trees elsewhere.  Results are bit-identical to the oracle.
  *
- * Roofline: every kernel here is HBM-bound.  The dominant one is tk_gemv_w4a8 (weights
- * streamed once per pass, 0.5625 / 0.8203 B per weight); MFMA is used for the int8
- * contraction [16 row slots x 32 k] x [32 k x 16 weight rows] so the same instruction stream
- * serves 1..16 concurrent sequences without touching the VALU budget.
+ * Roofline: the dominant kernels are k_gemv_w4a8 (passes of <= 32 rows) and k_gemm_w4a8 (33..128 rows): weights
+ * streamed once per pass, 0.5625 / 0.8203 B per weight; MFMA carries the int8 contraction
+ * [16 row slots x 64 k] x [64 k x 16 weight rows], so one weight pass serves up to 128 (sequence, position) rows.
+ * Measured fractions and where the time goes: DESIGN.md §6.
  */
 #include "tk_llm_kernels.h"
 
@@ -305,11 +305,11 @@ void tk_launch_rmsnorm_q8(float* x, const float* partial, int ks, int n_total_pa
 /* ------------------------------------------------------------------------------------------
  * W4A8 / W6A8 GEMV on MFMA:   out[ks][slot][n] = sum_{k in K-range ks} W[n][k] * a[slot][k]
  *
- * WG = 4 waves, wave w owns the 16-row tile 4*blockIdx.x + w and walks the K-range
- * blockIdx.y block by block; its weight stream is one contiguous run of tiles.  The int8
- * activations of the K-range (shared by the 4 waves) are staged once in LDS in MFMA
- * A-operand order.  Per 256-block and wave: 3 x 1 KiB coalesced non-temporal loads (Q4_K),
- * 8 MFMA 16x16x32 i8, scales applied in integer, two fp32 FMAs per (row, slot).
+ * One workgroup per CU (k_gemv_w4a8 below spells out the mapping): wave w owns one 16-row weight tile run and walks its K-range
+ * block by block; its weight stream is one contiguous run of tiles.  The int8 activations of the K-range (shared by the
+ * waves) are staged once in LDS in MFMA A-operand order.  Per 256-block and wave: 3 x 1 KiB coalesced non-temporal loads
+ * (Q4_K), the sub-block scales folded into the int8 B operand so the eight sub-blocks accumulate inside chained
+ * 16x16x64 i8 MFMAs (Q6_K: half-masked 16x16x32 MFMAs + 24-bit integer mads), two fp32 FMAs per (row, weight row).
  * Algorithmic bytes per launch = rows * K * (144 | 210) / 256.
  * ------------------------------------------------------------------------------------------ */
 struct FragQ4 { uint4 q0, q1, h; };
