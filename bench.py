@@ -295,6 +295,10 @@ def main():
         "decode_ms_per_step": round(dec_ms, 4), "prefill_s_per_cycle_batch": round(pre_s / args.steps, 4),
         "model_load_s": round(t_load, 2), "weight_bytes_per_decode_step": int(model.weight_bytes),
         "roofline": roofline,
+        # SURVEY.md 8d's whole-step view: (weights + B * 128 KiB * mean context of KV per row) per decode step over 8 TB/s, all groups in flight
+        "llm_decode_step_roofline": {"bytes_per_step": int(model.weight_bytes + B * 131072 * (P + N / 2.0)),
+                                     "steps_per_s": round(G * 1000.0 / dec_ms, 1),
+                                     "frac": round((model.weight_bytes + B * 131072 * (P + N / 2.0)) * (G * 1000.0 / dec_ms) / (HBM_PEAK_GBS * 1e9), 4)},
     }
     if roofline_16 is not None:
         out["roofline_16_rows"] = {k: roofline_16[k] for k in ("rows_per_pass", "achieved", "peak", "unit", "frac", "avg_launch_ms", "per_shape")}
