@@ -48,11 +48,14 @@ static void run(const char* name, int waves_per_simd) {
     printf("%-28s waves/SIMD=%d : %.2f ns per MFMA per SIMD  (= %.1f cycles @2.4 GHz)\n", name, waves_per_simd, per, per * 2.4);
 }
 int main() {
-    for (int w = 1; w <= 2; ++w) {
-        run<0>("x64 i8, 4 indep chains", w);
-        run<1>("x64 i8, 2 chains", w);
-        run<2>("x64 i8, 1 chain", w);
-        run<3>("x32 i8, 4 indep chains", w);
-    }
+    run<2>("(clock warm-up, ignore)", 2);
+    run<2>("(clock warm-up, ignore)", 2);
+    for (int rep = 0; rep < 2; ++rep)
+        for (int w = 1; w <= 2; ++w) {
+            run<2>("x64 i8, 1 chain", w);
+            run<1>("x64 i8, 2 chains", w);
+            run<0>("x64 i8, 4 indep chains", w);
+            run<3>("x32 i8, 4 indep chains", w);
+        }
     return 0;
 }
