@@ -583,11 +583,17 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
             if (TK_ABLATE & 4) break;
             /* the CUs of one XCD (blockIdx / 8 = index inside the XCD) all stage the same image from the same L2: each starts at
              * its own piece so they do not hammer one L2 channel in lock step */
-            const int rot = (int)((blockIdx.x >> 3) & 31) * npiece >> 5;
-            for (int c0 = wave; c0 < npiece; c0 += nw) {
-                const int c = c0 + rot < npiece ? c0 + rot : c0 + rot - npiece;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(lds_act + m * act_ts + c * 1024), 16, 0, 0);
+            /* pieces go in groups of four (npiece = Kr / 64 is a multiple of 4): one address and one LDS base per 4 KiB, immediate offsets */
+            const int ngroup = npiece >> 2;
+            const int rot = (int)((blockIdx.x >> 3) & 31) * ngroup >> 5;
+            for (int c0 = wave; c0 < ngroup; c0 += nw) {
+                const int c = c0 + rot < ngroup ? c0 + rot : c0 + rot - ngroup;
+                const auto gs = (const __attribute__((address_space(1))) void*)(src + (size_t)c * 4096 + lane * 16);
+                const auto ls = (__attribute__((address_space(3))) void*)(lds_act + m * act_ts + c * 4096);
+                __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
+                __builtin_amdgcn_global_load_lds(gs, ls, 16, 2048, 0);
+                __builtin_amdgcn_global_load_lds(gs, ls, 16, 3072, 0);
             }
         }
         /* block scales and sub-block sums: <= 5 x 16 B per thread and tile, loaded together, stored together */
@@ -875,28 +881,28 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[w][m][r] = 0.0f;
 
-    /* ring staging: 6 MT LDS-DMA pieces per block (4 x 1 KiB image, 256 B sums, 64 B scales per M-tile), dealt round-robin to the waves */
+    /* ring staging: whole M-tiles dealt round-robin to the waves; per tile one address computation and one LDS base feed four 1 KiB
+     * LDS-DMA instructions (immediate offsets) for the int8 image, then 256 B of sub-block sums and 64 B of scales.  (The device-side
+     * timestamp trace in profiles/r01_gemm_batched.txt had the issue of the staging at 16 % of a step when every 1 KiB piece carried its
+     * own address arithmetic and M0 write; dealing half-tiles for a better balance over 7 waves measured slower than this.) */
     auto stage = [&](int c, int slot) {
         uint8_t* dst = lds + slot * CH;
-        for (int p = wave; p < 6 * MT; p += nw) {
-            if (p < 4 * MT) {
-                const int m = p >> 2, q = p & 3;
-                const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)(blk0 + c) * 4096 + q * 1024 + lane * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + m * 4096 + q * 1024), 16, 0, 0);
-            } else if (p < 5 * MT) {
-                const int m = p - 4 * MT;
-                const uint8_t* src = (const uint8_t*)a.abs + m * a.abs_ts + (size_t)(blk0 + c) * 256 + lane * 16;
-                if (lane < 16)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(dst + OFF_AMN + m * 256), 16, 0, 0);
-            } else {
-                const int m = p - 5 * MT;
-                const uint8_t* src = (const uint8_t*)(a.ad + m * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS) + lane * 16;
-                if (lane < 4)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(dst + OFF_AD + m * 64), 16, 0, 0);
-            }
+        for (int m = wave; m < MT; m += nw) {
+            const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)(blk0 + c) * 4096 + lane * 16;
+            const auto gs = (const __attribute__((address_space(1))) void*)src;
+            const auto ls = (__attribute__((address_space(3))) void*)(dst + m * 4096);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 2048, 0);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 3072, 0);
+            const uint8_t* sm = (const uint8_t*)a.abs + m * a.abs_ts + (size_t)(blk0 + c) * 256 + lane * 16;
+            if (lane < 16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sm,
+                                                 (__attribute__((address_space(3))) void*)(dst + OFF_AMN + m * 256), 16, 0, 0);
+            const uint8_t* sd = (const uint8_t*)(a.ad + m * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS) + lane * 16;
+            if (lane < 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
+                                                 (__attribute__((address_space(3))) void*)(dst + OFF_AD + m * 64), 16, 0, 0);
         }
     };
 
