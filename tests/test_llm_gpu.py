@@ -132,15 +132,15 @@ def test_mistral_shaped_layer_bit_exact(gpu):
         assert np.array_equal(gam, wam)
 
 
-@pytest.mark.parametrize("nrows", [33, 48, 64, 65, 100, 128])
+@pytest.mark.parametrize("nrows", [33, 48, 64, 65, 100, 128, 129, 200, 256])
 def test_tiny_batched_pass_rows(gpu, nrows):
-    """passes of more than 32 rows take the K-streamed batched kernel (4 or 8 M-tiles per weight tile, folded Q6_K):
+    """passes of more than 32 rows take the K-streamed batched kernel (4, 8 or 16 M-tiles per weight tile, folded Q6_K):
     ragged rows over several sequences, then one decode row per sequence — bit-exact logits"""
     hp = gpu.TINY()
     model = gpu.LlmModel(hp).fill_synthetic(21)
     hp = model.hparams
     nseq = 7
-    sess = gpu.LlmSession(model, nseq, 64)
+    sess = gpu.LlmSession(model, nseq, 64)  # 256 rows over 7 sequences: up to 37 positions each
     orc = O.OracleLlm(oracle_cfg_from(hp, 64, nseq), seed=21)
     rng = np.random.default_rng(nrows)
     lens = np.full(nseq, nrows // nseq)
@@ -160,13 +160,14 @@ def test_tiny_batched_pass_rows(gpu, nrows):
 
 
 def test_mistral_shaped_layer_batched_bit_exact(gpu):
-    """the Mistral-7B-shaped layer again through the batched kernel: 40 rows (4 M-tiles) and 128 rows (8 M-tiles), Q4_K and Q6_K tensors"""
+    """the Mistral-7B-shaped layer again through the batched kernel: 40 rows (4 M-tiles), 128 rows (8) and 256 rows (16 M-tiles: the
+    mixed q / k / v matrix goes as one launch per tensor type), Q4_K and Q6_K tensors"""
     hp = gpu.MISTRAL_7B()
     hp.n_layer = 1
     model = gpu.LlmModel(hp).fill_synthetic(4)
     hp = model.hparams
     rng = np.random.default_rng(2)
-    for nrows in (40, 128):
+    for nrows in (40, 128, 256):
         sess = gpu.LlmSession(model, nrows, 8)
         orc = O.OracleLlm(oracle_cfg_from(hp, 8, nrows), seed=4)
         seq = np.arange(nrows, dtype=np.int32)

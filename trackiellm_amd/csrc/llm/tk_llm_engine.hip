@@ -312,7 +312,7 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
 
 bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
                            bool lm_head, const uint32_t* allow_mask) {
-    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,128]"; return false; }
+    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,256]"; return false; }
     for (int r = 0; r < nrows; ++r) {
         if (seq[r] < 0 || seq[r] >= max_seq || pos[r] < 0 || pos[r] >= max_ctx || tok[r] < 0 || tok[r] >= model->hp.vocab) {
             error = "row out of range (sequence id, position or token id)";
@@ -343,7 +343,7 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
 bool TkLlmSession::forward_stage(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, const float* x_in, float* x_out, bool x_on_host,
                                  int l0, int l1, bool head, int32_t* argmax_host) {
     const TkLlmHParams& h = model->hp;
-    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,128]"; return false; }
+    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,256]"; return false; }
     if (l0 < 0 || l1 < l0 || l1 > h.n_layer) { error = "bad layer range"; return false; }
     if ((tok == nullptr) == (x_in == nullptr)) { error = "a stage starts from tokens (first stage) or from a residual stream, not both"; return false; }
     if (head && l1 != h.n_layer) { error = "the head belongs to the stage that ends at the last layer"; return false; }
@@ -373,7 +373,7 @@ bool TkLlmSession::forward_stage(int nrows, const int32_t* seq, const int32_t* p
 }
 
 bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens_host) {
-    if (nseq <= 0 || nseq > TK_MAX_ROWS || nseq > max_seq) { error = "nseq must be in [1, min(128, max_seq)]"; return false; }
+    if (nseq <= 0 || nseq > TK_MAX_ROWS || nseq > max_seq) { error = "nseq must be in [1, min(256, max_seq)]"; return false; }
     if (n_prompt <= 0 || n_prompt >= max_ctx) { error = "prompt does not fit the context"; return false; }
     /* all but the last prompt token: 16 rows per pass, positions ascending so causality holds inside a pass */
     std::vector<int32_t> sq, ps, tk;
@@ -395,7 +395,7 @@ bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_
 }
 
 bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
-    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,128]"; return false; }
+    if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,256]"; return false; }
     if (n_steps <= 0 || n_steps > hist_cap) { error = "n_steps exceeds the session context"; return false; }
     HIPQ(hipSetDevice(model->device));
     /* positions must stay inside the cache for the whole loop */

@@ -22,7 +22,8 @@ struct TkGemvArgs {
     int nseg;
     int K;        /* reduction length, multiple of 256*ks */
     int ks;       /* K-split count: partial sums land in out[ks][16][n_total] */
-    int n_total;  /* sum of rows over segments */
+    int n_total;  /* row pitch of `out`: the sum of rows over all segments of the matrix */
+    int col0;     /* column of `out` where segment 0 starts (non-zero when a launch carries only some of the matrix's segments) */
     int nrows;    /* live rows (<= TK_MAX_ROWS); rows 16.. use the second M-tile */
     size_t aq_ts, ad_ts, abs_ts; /* M-tile strides of aq (bytes), ad (floats), abs (ints) */
     const int8_t* aq;

@@ -6,9 +6,9 @@
  * inside a 256-block, float accumulation across blocks in ascending order, canonical
  * reduction trees elsewhere.  Results are bit-identical to the oracle.
  *
- * Roofline: the dominant kernels are k_gemv_w4a8 (passes of <= 32 rows) and k_gemm_w4a8 (33..128 rows): weights
+ * Roofline: the dominant kernels are k_gemv_w4a8 (passes of <= 32 rows) and k_gemm_w4a8 (33..256 rows): weights
  * streamed once per pass, 0.5625 / 0.8203 B per weight; MFMA carries the int8 contraction
- * [16 row slots x 64 k] x [64 k x 16 weight rows], so one weight pass serves up to 128 (sequence, position) rows.
+ * [16 row slots x 64 k] x [64 k x 16 weight rows], so one weight pass serves up to 256 (sequence, position) rows.
  * Measured fractions and where the time goes: DESIGN.md §6.
  */
 #include "tk_llm_kernels.h"
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
         }
     }
 
-    const int n = row_base + rt * TK_TILE_ROWS + (lane & 15);
+    const int n = a.col0 + row_base + rt * TK_TILE_ROWS + (lane & 15);
     const int g = lane >> 4;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -676,8 +676,8 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
 }
 
 /* ------------------------------------------------------------------------------------------
- * Batched passes (33..128 rows: prefill chunks, wide decode batches): same work mapping and the same per-row arithmetic as
- * k_gemv_w4a8, but the weight tile is unpacked ONCE and multiplied against MT = 4 or 8 M-tiles, so the dequantisation VALU
+ * Batched passes (33..256 rows: prefill chunks, wide decode batches): same work mapping and the same per-row arithmetic as
+ * k_gemv_w4a8, but the weight tile is unpacked ONCE and multiplied against MT = 4, 8 or 16 M-tiles, so the dequantisation VALU
  * work and the HBM bytes per row drop by MT.  The K-range's activations no longer fit in LDS, so they stream through a
  * two-slot ring of 256-k blocks (MT x {4 KiB int8 image, 256 B sub-block sums, 64 B scales} each):
  *
@@ -770,7 +770,7 @@ struct PTile { v4i pl, ph, cl, ch; v4f da; };
 #define TK_GEMM_LDS_DEPTH 2
 #endif
 #ifndef TK_RING_BLOCKS
-#define TK_RING_BLOCKS 1 /* 256-k blocks per ring slot (per barrier): 2 slots x 1 block x 8 M-tiles = 69 KiB, two workgroups fit a CU */
+#define TK_RING_BLOCKS 1 /* 256-k blocks per ring slot (per barrier): 2 slots x 1 block x 16 M-tiles = 138 KiB of the 160 KiB LDS */
 #endif
 
 /* diagnostic builds: TK_ABLATE bit 32 = batched kernel without MFMAs (operands xor-ed so nothing is dead), 64 = without LDS operand reads,
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
     const int g = lane >> 4;
 #pragma unroll
     for (int w = 0; w < NT; ++w) {
-        const int n = row_base + (rt + w) * TK_TILE_ROWS + (lane & 15);
+        const int n = a.col0 + row_base + (rt + w) * TK_TILE_ROWS + (lane & 15);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -975,8 +975,22 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     while (waves > 8) { groups *= 2; waves = (row_tiles + groups - 1) / groups; } /* tall matrices: more than one WG per CU */
     int types = 0;
     for (int i = 0; i < a.nseg; ++i) types |= a.seg[i].type == TK_TYPE_Q4_K ? 1 : 2;
-    if (a.nrows > 2 * TK_ROW_SLOTS) { /* batched passes: K-streamed activations, 4 or 8 M-tiles per weight tile */
-        const int mtb = a.nrows > 4 * TK_ROW_SLOTS ? 8 : 4;
+    if (a.nrows > 8 * TK_ROW_SLOTS && types == 3) {
+        /* 16 M-tiles: the two-type kernel does not fit the register file; a mixed matrix (q, k Q4_K + v Q6_K) goes as two 8-M-tile launches
+         * over the first 128 rows and the rest (M-tile images and output rows are simply offset) */
+        TkGemvArgs lo = a, hi = a;
+        lo.nrows = 8 * TK_ROW_SLOTS;
+        hi.nrows = a.nrows - 8 * TK_ROW_SLOTS;
+        hi.aq = a.aq + 8 * a.aq_ts;
+        hi.ad = a.ad + 8 * a.ad_ts;
+        hi.abs = a.abs + 8 * a.abs_ts;
+        hi.out = a.out + (size_t)8 * TK_ROW_SLOTS * a.n_total;
+        tk_launch_gemv(lo, s);
+        tk_launch_gemv(hi, s);
+        return;
+    }
+    if (a.nrows > 2 * TK_ROW_SLOTS) { /* batched passes: K-streamed activations, 4, 8 or 16 M-tiles per weight tile */
+        const int mtb = a.nrows > 8 * TK_ROW_SLOTS ? 16 : a.nrows > 4 * TK_ROW_SLOTS ? 8 : 4;
         const size_t ldsb = (size_t)2 * TK_RING_BLOCKS * mtb * TK_RING_TILE_BYTES;
         /* weight tiles per wave: 1.  TK_GEMM_NT=2 selects two adjacent tiles per wave (tensor row counts are multiples of 64, so a
          * pair never straddles two tensors): it halves the LDS operand stream but leaves one wave per SIMD, and measured 25 % slower
@@ -1001,12 +1015,13 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
 #define TK_GEMM_LAUNCH(MTV, TYV, NTV)                                                                                              \
     do {                                                                                                                           \
         static bool opted = false;                                                                                                 \
-        if (!opted) { (void)hipFuncSetAttribute((const void*)k_gemm_w4a8<MTV, TYV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TK_RING_BLOCKS * 8 * TK_RING_TILE_BYTES); opted = true; } \
+        if (!opted) { (void)hipFuncSetAttribute((const void*)k_gemm_w4a8<MTV, TYV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TK_RING_BLOCKS * 16 * TK_RING_TILE_BYTES); opted = true; } \
         hipLaunchKernelGGL((k_gemm_w4a8<MTV, TYV, NTV>), dim3(groups * a.ks), dim3(64 * waves), ldsb, s, a, groups, row_tiles);     \
     } while (0)
 #define TK_GEMM_TY(MTV, NTV) do { if (types == 1) TK_GEMM_LAUNCH(MTV, 1, NTV); else if (types == 2) TK_GEMM_LAUNCH(MTV, 2, NTV); else TK_GEMM_LAUNCH(MTV, 3, NTV); } while (0)
         if (mtb == 4) { if (nt == 2) TK_GEMM_TY(4, 2); else TK_GEMM_TY(4, 1); }
-        else { if (nt == 2) TK_GEMM_TY(8, 2); else TK_GEMM_TY(8, 1); }
+        else if (mtb == 8) { if (nt == 2) TK_GEMM_TY(8, 2); else TK_GEMM_TY(8, 1); }
+        else TK_GEMM_TY(16, 1);
 #undef TK_GEMM_TY
 #undef TK_GEMM_LAUNCH
         return;

@@ -47,7 +47,7 @@
 #define TK_Q4K_TILE_BYTES 2304
 #define TK_Q6K_TILE_BYTES 3360
 #define TK_ROW_SLOTS 16  /* rows of one MFMA M-tile */
-#define TK_MAX_TILES 8   /* M-tiles per pass: a weight tile is unpacked once and multiplied against all of them */
+#define TK_MAX_TILES 16   /* M-tiles per pass: a weight tile is unpacked once and multiplied against all of them */
 #define TK_MAX_ROWS (TK_ROW_SLOTS * TK_MAX_TILES)
 
 /* per M-tile sizes; tile m of a buffer starts at m * (these) */
