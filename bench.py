@@ -316,7 +316,7 @@ def main():
                              "detections_last_batch": n_dets[0], "overlapped_with_llm": True, "dtype": "f32 (exact fp32 MFMA chain)"}
     if args.layers != 32:
         out["invalid"] = "debug run with fewer layers"
-    if not args.no_cpu_baseline and args.layers == 32:
+    if not args.no_cpu_baseline and args.layers == 32 and world == 1:  # the CPU baseline is a rank-0, N = 1 leg
         s_per_tok, t_synth, otoks, cores = cpu_baseline(hp)
         # parity spot-check on the same weights: 1 sequence, BOS then greedy
         chk = tk.LlmSession(model, 1, 16)
