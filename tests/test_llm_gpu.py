@@ -180,6 +180,33 @@ def test_mistral_shaped_layer_batched_bit_exact(gpu):
         sess.close()
 
 
+def test_full_7b_pass_width_invariance(gpu):
+    """size-independent property at BASELINE size (full 32-layer Mistral-7B Q4_K_M, synthetic weights): a row's logits do not depend on
+    how many other rows share its pass — 256 rows in one pass (16 M-tiles, batched kernel), the same rows as 2 x 128 and 16 x 16 passes
+    (8 M-tiles; one M-tile of the GEMV kernel) give bit-identical logits and ids.  (The 16-row path is the one pinned to the oracle.)"""
+    model = gpu.LlmModel(gpu.MISTRAL_7B()).fill_synthetic(4)
+    hp = model.hparams
+    rng = np.random.default_rng(8)
+    n = 256
+    seq = np.arange(n, dtype=np.int32)
+    pos = np.zeros(n, np.int32)
+    tok = rng.integers(3, hp.vocab, n).astype(np.int32)
+    tok2 = rng.integers(3, hp.vocab, n).astype(np.int32)
+    outs = []
+    for width in (256, 128, 16):
+        sess = gpu.LlmSession(model, n, 4)
+        lg = np.empty((2, n, hp.vocab), np.float32)
+        for i in range(0, n, width):
+            lg[0, i:i + width], _ = sess.forward(seq[i:i + width], pos[i:i + width], tok[i:i + width])
+        for i in range(0, n, width):                       # second position: the KV cache written by the first pass is read back
+            lg[1, i:i + width], _ = sess.forward(seq[i:i + width], pos[i:i + width] + 1, tok2[i:i + width])
+        outs.append(lg)
+        sess.close()
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
+    assert np.isfinite(outs[0]).all() and len(np.unique(outs[0].argmax(-1))) > 8
+
+
 def test_reference_runner_surface(gpu):
     """tk_model_loader_* + tk_llm_runner_* as the reference's Rust GgufRunner drives them"""
     loader = gpu.ModelLoader()

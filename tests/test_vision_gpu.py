@@ -54,6 +54,20 @@ def test_detector_head_maps_bit_exact(gpu):
         assert np.array_equal(boxes, wb)
 
 
+def test_detector_full_size_frame_bit_exact(gpu):
+    """BASELINE geometry: one 640x640 network input (8400 anchors): head maps and NMS survivors equal the oracle's, bit for bit"""
+    det = gpu.ObjectDetector(width=640, height=640, conf=0.05)
+    orc = O.OracleYolo(nc=80, seed=5, cls_bias=-4.0)
+    x = np.random.default_rng(33).standard_normal((1, 640, 640, 3)).astype(np.float32)
+    raw = det.forward_raw(x)
+    want = orc.forward(x)
+    assert raw.shape == (1, 8400, 144)
+    assert np.array_equal(raw, want), np.abs(raw - want).max()
+    boxes, cls, anc = det.last_boxes(0)
+    wb, wc, wa = orc.post(want[0], 640, 640, 0.05, 0.5)
+    assert np.array_equal(anc, wa) and np.array_equal(cls, wc) and np.array_equal(boxes, wb)
+
+
 def test_detector_weights_from_onnx_file(gpu, tmp_path):
     """an .onnx detector file (Conv initialisers in execution order + DFL conv, raw and packed float storage) goes in through
     tk_object_detector_create's model_path: head maps equal the oracle that owns the same weights"""
