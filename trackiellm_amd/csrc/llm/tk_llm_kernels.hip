@@ -1001,14 +1001,9 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
         for (int i = 0; i < a.nseg; ++i) even = even && a.seg[i].row_tiles % 2 == 0;
         const int nt = (force_nt == 2 && even) ? 2 : 1;
         /* waves per workgroup: with <= 4 (TK_GEMM_MAXWAVES) a CU holds two workgroups whose barrier phases drift apart */
-        static int maxw = -1, pack = -1;
+        static int maxw = -1;
         if (maxw < 0) { const char* e = getenv("TK_GEMM_MAXWAVES"); maxw = e ? atoi(e) : 8; if (maxw < 1 || maxw > 8) maxw = 8; }
-        if (pack < 0) { const char* e = getenv("TK_GEMM_PACK"); pack = e ? atoi(e) : 0; }
         while (waves > maxw) { groups *= 2; waves = (row_tiles + groups - 1) / groups; }
-        if (pack > 0) { /* experiment: `pack` waves per workgroup on fewer CUs (all four SIMDs evenly loaded, the other CUs left to concurrent launches) */
-            const int g2 = (row_tiles + pack - 1) / pack;
-            if (g2 < groups) { groups = g2; waves = (row_tiles + groups - 1) / groups; }
-        }
         if (nt == 2) {
             const int pairs = row_tiles / 2;
             groups = TK_NUM_CU / a.ks;
