@@ -171,19 +171,21 @@ bool TkLlmModel::ready() const {
 static bool alloc_act(TkActQ8* a, int K, std::string& error) {
     a->aq_ts = TK_AQ_BYTES(K); a->ad_ts = TK_AD_FLOATS(K); a->abs_ts = TK_ABS_BYTES(K);
     if (hipMalloc((void**)&a->aq, TK_MAX_TILES * a->aq_ts) != hipSuccess || hipMalloc((void**)&a->ad, TK_MAX_TILES * a->ad_ts * 4) != hipSuccess ||
-        hipMalloc((void**)&a->abs, TK_MAX_TILES * a->abs_ts) != hipSuccess) {
+        hipMalloc((void**)&a->abs, TK_MAX_TILES * a->abs_ts) != hipSuccess || hipMalloc((void**)&a->abs16, TK_MAX_TILES * a->abs_ts * 2) != hipSuccess) {
         error = "out of device memory (activation buffers)";
         return false;
     }
     (void)hipMemset(a->aq, 0, TK_MAX_TILES * a->aq_ts);
     (void)hipMemset(a->ad, 0, TK_MAX_TILES * a->ad_ts * 4);
     (void)hipMemset(a->abs, 0, TK_MAX_TILES * a->abs_ts);
+    (void)hipMemset(a->abs16, 0, TK_MAX_TILES * a->abs_ts * 2);
     return true;
 }
 static void free_act(TkActQ8* a) {
     if (a->aq) (void)hipFree(a->aq);
     if (a->ad) (void)hipFree(a->ad);
     if (a->abs) (void)hipFree(a->abs);
+    if (a->abs16) (void)hipFree(a->abs16);
     *a = TkActQ8{};
 }
 
@@ -255,7 +257,7 @@ bool TkLlmSession::reset() {
 }
 
 static void set_act(TkGemvArgs& a, const TkActQ8& q) {
-    a.aq = q.aq; a.ad = q.ad; a.abs = q.abs; a.aq_ts = q.aq_ts; a.ad_ts = q.ad_ts; a.abs_ts = q.abs_ts;
+    a.aq = q.aq; a.ad = q.ad; a.abs = q.abs; a.abs16 = q.abs16; a.aq_ts = q.aq_ts; a.ad_ts = q.ad_ts; a.abs_ts = q.abs_ts;
 }
 
 static TkGemvSeg seg_of(const TkDevTensor& t) { return TkGemvSeg{t.data, t.type, (int)(t.rows / TK_TILE_ROWS)}; }

@@ -29,6 +29,7 @@ struct TkGemvArgs {
     const int8_t* aq;
     const float* ad;
     const int8_t* abs; /* sub-block sums as (l, h) int8 images: [K/256][2][16][8] */
+    const uint16_t* abs16; /* the same sums as two f16 images (sum = 2 hh + ll): [K/256][2][16][8] halves, M-tile stride abs_ts halves */
     float* out;
 };
 
@@ -36,6 +37,7 @@ struct TkActQ8 { /* quantised-activation buffers for one K */
     int8_t* aq;
     float* ad;
     int8_t* abs; /* (l, h) images of the sub-block sums, 256 B per 256-block */
+    uint16_t* abs16; /* (hh, ll) f16 images of the same sums, 512 B per 256-block: the batched kernel's one-MFMA min term */
     size_t aq_ts, ad_ts, abs_ts; /* M-tile strides */
 };
 

@@ -191,6 +191,11 @@ __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot,
         int8_t* mb = out.abs + mt * out.abs_ts + (size_t)(c >> 5) * 256 + (size_t)sl * 8 + ((c >> 2) & 7);
         mb[0] = (int8_t)(sum & 63);
         mb[128] = (int8_t)(sum >> 6);
+        /* and as two f16 numbers, sum = 2 hh + ll (|hh| <= 2032 and ll in {0, 1} are exact in f16): the batched kernel contracts them with
+         * (2 m, m) in ONE f16 MFMA */
+        uint16_t* hb = out.abs16 + mt * out.abs_ts + (size_t)(c >> 5) * 256 + (size_t)sl * 8 + ((c >> 2) & 7);
+        hb[0] = tk_f32_to_f16((float)(sum >> 1));
+        hb[128] = tk_f32_to_f16((float)(sum & 1));
     }
     if ((c & 31) == 0) out.ad[mt * out.ad_ts + (size_t)(c >> 5) * TK_ROW_SLOTS + sl] = amax > 0.0f ? tk_divf(amax, 127.0f) : 0.0f;
 }
@@ -379,7 +384,8 @@ __device__ __forceinline__ uint32_t pk_scale(uint32_t q, unsigned short s) {
  */
 /* B operands of one Q4_K tile, ready for the matrix cores; the packed fragment is dead once this exists, so the
  * registers of the fragment can take the next tile's load while the MFMAs of this one run */
-struct OpsQ4 { v4i bl[4], bh[4]; long bm; float dw, dmin; };
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+struct OpsQ4 { v4i bl[4], bh[4]; long bm; v8h bm16; float dw, dmin; };
 
 __device__ __forceinline__ void unpack_q4(const FragQ4& f, int lane, OpsQ4& o) {
     const uint32_t qs[8] = {f.q0.x, f.q0.y, f.q0.z, f.q0.w, f.q1.x, f.q1.y, f.q1.z, f.q1.w};
@@ -403,6 +409,10 @@ __device__ __forceinline__ void unpack_q4(const FragQ4& f, int lane, OpsQ4& o) {
         o.bh[j >> 1][2 * e + 1] = (int)pk_scale(hi, shh);
     }
     o.bm = (lane >> 4) == 0 ? (long)(((unsigned long)mn_hi << 32) | mn_lo) : 0L;
+    /* f16 twin for the one-MFMA min term: k-slots 0..7 (lane group 0) pair 2 m_j with hh_j, k-slots 8..15 (group 1) pair m_j with ll_j */
+    const float wsc = (lane >> 4) == 0 ? 2.0f : ((lane >> 4) == 1 ? 1.0f : 0.0f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.bm16[e] = (_Float16)((float)(((e < 4 ? mn_lo : mn_hi) >> (8 * (e & 3))) & 0xFFu) * wsc);
     o.dw = f16bits_to_f32(f.h.x & 0xffffu);
     o.dmin = f16bits_to_f32(f.h.x >> 16);
 }
@@ -679,7 +689,7 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
  * Batched passes (33..256 rows: prefill chunks, wide decode batches): same work mapping and the same per-row arithmetic as
  * k_gemv_w4a8, but the weight tile is unpacked ONCE and multiplied against MT = 4, 8 or 16 M-tiles, so the dequantisation VALU
  * work and the HBM bytes per row drop by MT.  The K-range's activations no longer fit in LDS, so they stream through a
- * two-slot ring of 256-k blocks (MT x {4 KiB int8 image, 256 B sub-block sums, 64 B scales} each):
+ * two-slot ring of 256-k blocks (MT x {4 KiB int8 image, 512 B f16 sub-block sums, 64 B scales} each):
  *
  *   every TK_RING_BLOCKS blocks:  s_waitcnt vmcnt(0) -> my DMA pieces of this slot (and my weight tile) have landed
  *                                 barrier            -> everybody's pieces have; everybody is done with the other slot
@@ -742,30 +752,26 @@ __device__ __forceinline__ void unpack_q6_fold(const FragQ6& f, int lane, OpsQ4&
 }
 
 /* A-side operands of one M-tile of one ring block, read from LDS one tile AHEAD of the MFMAs that consume them */
-struct ATile { v4i a[4]; long ml, mh; v4f da; };
+struct ATile { v4i a[4]; v8h mn; v4f da; };
 template <bool MINS>
 __device__ __forceinline__ void lds_tile(ATile& t, const uint8_t* act, const uint8_t* amn, const uint8_t* ad, int lane) {
     const uint8_t* ap = act + lane * 16;
     if (TK_ABLATE & 64) {
         for (int j2 = 0; j2 < 4; ++j2) t.a[j2] = (v4i){lane, j2, lane + j2, 1};
-        t.ml = lane; t.mh = lane + 1; t.da = (v4f){1.0f, 2.0f, 3.0f, 4.0f};
+        t.da = (v4f){1.0f, 2.0f, 3.0f, 4.0f};
         return;
     }
 #pragma unroll
     for (int j2 = 0; j2 < 4; ++j2) {
         t.a[j2] = *(const v4i*)(ap + j2 * 1024);
     }
-    if (MINS) {
-        const uint8_t* mp = amn + (lane & 15) * 8;
-        t.ml = *(const long*)mp;
-        t.mh = *(const long*)(mp + 128);
-    }
+    if (MINS) t.mn = *(const v8h*)(amn + ((lane >> 4) & 1) * 256 + (lane & 15) * 16); /* groups 2, 3 re-read finite numbers: their B operand is 0 */
     t.da = *(const v4f*)(ad + 16 * (lane >> 4));
 }
 /* integer results of one M-tile, finished (two fp32 FMAs per row) while the next tile's MFMAs run */
-struct PTile { v4i pl, ph, cl, ch; v4f da; };
+struct PTile { v4i pl, ph; v4f cm, da; };
 
-#define TK_RING_TILE_BYTES (256 * TK_ROW_SLOTS + 256 + TK_ROW_SLOTS * 4) /* one M-tile of one 256-k block: image + sums + scales */
+#define TK_RING_TILE_BYTES (256 * TK_ROW_SLOTS + 512 + TK_ROW_SLOTS * 4) /* one M-tile of one 256-k block: image + f16 sums + scales */
 #ifndef TK_GEMM_LDS_DEPTH
 #define TK_GEMM_LDS_DEPTH 2
 #endif
@@ -787,7 +793,7 @@ __device__ __forceinline__ void finish_tile(const PTile& R, const OpsQ4& o, floa
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         acc[r] = tk_fmaf(o.dw * R.da[r], (float)((R.ph[r] << (Q4 ? 3 : 6)) + R.pl[r]), acc[r]);
-        if (Q4) acc[r] = tk_fmaf(-(o.dmin * R.da[r]), (float)((R.ch[r] << 6) + R.cl[r]), acc[r]);
+        if (Q4) acc[r] = tk_fmaf(-(o.dmin * R.da[r]), R.cm[r], acc[r]); /* cm = sum_j m_j bsum_j, an exact integer below 2^24 */
     }
 }
 
@@ -795,17 +801,17 @@ __device__ __forceinline__ void finish_tile(const PTile& R, const OpsQ4& o, floa
  * for all NT weight tiles) */
 template <int MT, int NT, bool Q4>
 __device__ __forceinline__ void gemm_block(const OpsQ4 (&o)[NT], const uint8_t* chunk, int lane, float (&acc)[NT][MT][4]) {
-    constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 256;
+    constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 512;
     const v4i zero = {0, 0, 0, 0};
     constexpr int AD = TK_GEMM_LDS_DEPTH; /* M-tiles of LDS operand reads in flight ahead of the MFMAs */
     ATile T[AD + 1];
     PTile R[NT];
 #pragma unroll
-    for (int m = 0; m < AD && m < MT; ++m) lds_tile<Q4>(T[m], chunk + m * 4096, chunk + OFF_AMN + m * 256, chunk + OFF_AD + m * 64, lane);
+    for (int m = 0; m < AD && m < MT; ++m) lds_tile<Q4>(T[m], chunk + m * 4096, chunk + OFF_AMN + m * 512, chunk + OFF_AD + m * 64, lane);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (m + AD < MT)
-            lds_tile<Q4>(T[(m + AD) % (AD + 1)], chunk + (m + AD) * 4096, chunk + OFF_AMN + (m + AD) * 256, chunk + OFF_AD + (m + AD) * 64, lane);
+            lds_tile<Q4>(T[(m + AD) % (AD + 1)], chunk + (m + AD) * 4096, chunk + OFF_AMN + (m + AD) * 512, chunk + OFF_AD + (m + AD) * 64, lane);
         __builtin_amdgcn_sched_barrier(0);
         const ATile& t = T[m % (AD + 1)];
         PTile c[NT];
@@ -823,10 +829,7 @@ __device__ __forceinline__ void gemm_block(const OpsQ4 (&o)[NT], const uint8_t* 
             }
 #pragma unroll
         for (int w = 0; w < NT; ++w) {
-            if (Q4) {
-                c[w].cl = TK_MFMA32(t.ml, o[w].bm, zero, 0, 0, 0);
-                c[w].ch = TK_MFMA32(t.mh, o[w].bm, zero, 0, 0, 0);
-            }
+            if (Q4) c[w].cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(t.mn, o[w].bm16, (v4f){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
             c[w].da = t.da;
         }
         if (m > 0) {
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int CH = MT * TK_RING_TILE_BYTES;   /* one block of the ring */
     constexpr int CB = TK_RING_BLOCKS;            /* blocks per ring slot = per barrier */
-    constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 256;
+    constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 512;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = blockDim.x >> 6;
@@ -882,7 +885,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
             for (int r = 0; r < 4; ++r) acc[w][m][r] = 0.0f;
 
     /* ring staging: whole M-tiles dealt round-robin to the waves; per tile one address computation and one LDS base feed four 1 KiB
-     * LDS-DMA instructions (immediate offsets) for the int8 image, then 256 B of sub-block sums and 64 B of scales.  (The device-side
+     * LDS-DMA instructions (immediate offsets) for the int8 image, then 512 B of f16 sub-block sums and 64 B of scales.  (The device-side
      * timestamp trace in profiles/r01_gemm_batched.txt had the issue of the staging at 16 % of a step when every 1 KiB piece carried its
      * own address arithmetic and M0 write; dealing half-tiles for a better balance over 7 waves measured slower than this.) */
     auto stage = [&](int c, int slot) {
@@ -895,10 +898,10 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
             __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
             __builtin_amdgcn_global_load_lds(gs, ls, 16, 2048, 0);
             __builtin_amdgcn_global_load_lds(gs, ls, 16, 3072, 0);
-            const uint8_t* sm = (const uint8_t*)a.abs + m * a.abs_ts + (size_t)(blk0 + c) * 256 + lane * 16;
-            if (lane < 16)
+            const uint8_t* sm = (const uint8_t*)(a.abs16 + m * a.abs_ts + (size_t)(blk0 + c) * 256) + lane * 16;
+            if (lane < 32)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sm,
-                                                 (__attribute__((address_space(3))) void*)(dst + OFF_AMN + m * 256), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst + OFF_AMN + m * 512), 16, 0, 0);
             const uint8_t* sd = (const uint8_t*)(a.ad + m * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS) + lane * 16;
             if (lane < 4)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
@@ -984,6 +987,7 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
         hi.aq = a.aq + 8 * a.aq_ts;
         hi.ad = a.ad + 8 * a.ad_ts;
         hi.abs = a.abs + 8 * a.abs_ts;
+        hi.abs16 = a.abs16 + 8 * a.abs_ts;
         hi.out = a.out + (size_t)8 * TK_ROW_SLOTS * a.n_total;
         tk_launch_gemv(lo, s);
         tk_launch_gemv(hi, s);

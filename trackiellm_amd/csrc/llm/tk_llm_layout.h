@@ -35,6 +35,8 @@
  *      abs : int8   [K/256][2][16][8]  per-sub-block sums of the int8 values (the Q4_K "min" term) split as
  *                                      sum = 64 h + l: image 0 holds l (0..63), image 1 holds h, byte j = sub-block j —
  *                                      the A operand of the MFMA that contracts them with the 6-bit mins
+ *      abs16: f16   [K/256][2][16][8]  the same sums as sum = 2 hh + ll (|hh| <= 2032, ll in {0, 1}: exact in f16) — the batched kernel
+ *                                      contracts them with (2 m_j, m_j) in ONE v_mfma_f32_16x16x32_f16 (exact: every partial sum < 2^24)
  *  "row slot" b < 16 is a (sequence, position) row of the current pass; a pass holds up to TK_MAX_TILES such
  *  16-row M-tiles (row r lives in tile r / 16, slot r % 16), each with its own aq / ad / abs image.
  */
