@@ -94,6 +94,9 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_transcribe_tokens(tk_asr_whisp
                                                                     int n_steps, int32_t* tokens_out, float* mel_out, float* enc_out,
                                                                     float* logits_out);
 TK_API void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_steps);
+/* the decoder prompt the next transcription starts from (English-only: <|sot|><|notimestamps|>; multilingual: + language and task
+ * tokens, whisper.cpp's whisper_full order); returns the count, -1 when the configured language has no token */
+TK_API int tk_mi355x_asr_prompt_tokens(tk_asr_whisper_context_t* ctx, int32_t* out, int cap);
 /* geometry of a created context (a whisper.cpp ggml checkpoint brings its own) */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_get_hparams(tk_asr_whisper_context_t* ctx, tk_mi355x_whisper_hparams_t* out);
 /* whisper.cpp "ggml" checkpoint (the file tk_asr_whisper_config_t.model_path names, src/audio/tk_asr_whisper.c:238): parse header,

@@ -365,11 +365,11 @@ class OracleWhisper:
                 assert a.shape == (r.value, c.value)
                 L.orc_whisper_set_tensor(self.h, i, ptr(a))
 
-    def transcribe(self, pcm, n_steps, want=("mel", "enc", "logits")):
+    def transcribe(self, pcm, n_steps, want=("mel", "enc", "logits"), prompt=None):
         pcm = np.ascontiguousarray(pcm, np.int16)
         B, n = pcm.shape
         hp = self.hp
-        prompt = whisper_prompt(hp)
+        prompt = whisper_prompt(hp) if prompt is None else np.ascontiguousarray(prompt, np.int32)
         toks = np.zeros((B, max(n_steps, 1)), np.int32)
         mel = np.empty((B, 2 * hp.n_audio_ctx, hp.n_mels), np.float32)
         enc = np.empty((B, hp.n_audio_ctx, hp.n_audio_state), np.float32)

@@ -121,3 +121,35 @@ def test_vad_probabilities_and_events(gpu):
     assert st.is_speech_active == bool(ws.active) and np.float32(st.speech_probability) == probs[-1]
     assert vad.set_threshold(1.5) == 1001 and vad.set_threshold(0.8) == 0
     assert abs(vad.probability(pcm[:480]) - probs[0]) == 0
+
+
+def test_asr_set_language_selects_the_decoder_prompt(gpu):
+    """tk_asr_whisper_set_language (src/audio/tk_asr_whisper.c:377-396): the language reaches the decoder the way whisper.cpp's
+    whisper_full uses it — multilingual vocabularies start from <|sot|><|lang|><|transcribe|><|notimestamps|>, English-only ones from
+    <|sot|><|notimestamps|> whatever the language; an unknown language fails the next decode, not the setter."""
+    ml = gpu.WhisperHP(80, 50, 64, 2, 2, 32, 64, 2, 2, 51865)          # small geometry, multilingual vocabulary size
+    asr = gpu.Asr(hp=ml, seed=11)
+    assert asr.prompt_tokens() == [50258, 50259, 50359, 50363]          # default: English, transcribe
+    assert asr.set_language("de") == 0
+    assert asr.prompt_tokens() == [50258, 50261, 50359, 50363]
+    rng = np.random.default_rng(4)
+    pcm = np.clip(rng.normal(0, 3000, (1, 16000)), -32768, 32767).astype(np.int16)
+    toks, mel, enc, lg = asr.transcribe_tokens(pcm, 4)
+    orc = O.OracleWhisper(O.WhisperHP(80, 50, 64, 2, 2, 32, 64, 2, 2, 51865), seed=11)
+    wt, wmel, wenc, wlg = orc.transcribe(pcm, 4, prompt=[50258, 50261, 50359, 50363])
+    assert np.array_equal(toks, wt) and np.array_equal(lg, wlg) and np.array_equal(enc, wenc)
+    assert asr.set_language("ja") == 0 and asr.prompt_tokens()[1] == 50258 + 1 + 7
+    tj, _, _, lj = asr.transcribe_tokens(pcm, 4)
+    wj, _, _, wlj = orc.transcribe(pcm, 4, prompt=[50258, 50266, 50359, 50363])
+    assert np.array_equal(tj, wj) and np.array_equal(lj, wlj)
+    assert not np.array_equal(lj, lg)                                   # the language token changes the logits
+    assert asr.set_language("xx") == 0                                  # stored like the reference stores it...
+    assert asr.prompt_tokens() is None
+    with pytest.raises(gpu.TkError) as e:                               # ...and the decode fails (whisper_full returns an error)
+        asr.transcribe_tokens(pcm, 2)
+    assert e.value.code == 4002 and "xx" in e.value.detail
+    assert asr.set_language(None) == 1001 and gpu.lib().tk_asr_whisper_set_language(None, b"en") == 1001
+    asr.close()
+    en = gpu.Asr(hp=gpu.WhisperHP(80, 50, 64, 2, 2, 32, 64, 2, 2, 51864), seed=11)
+    assert en.set_language("de") == 0 and en.prompt_tokens() == [50257, 50362]
+    en.close()

@@ -59,3 +59,53 @@ def test_sentencepiece_bpe_tokenizer(tmp_path):
     assert tok("hello", 0) == [263]
     assert tok("hé") == [1, 259, 267, 3 + 0xC3, 3 + 0xA9]          # "▁", "h", then <0xXX> byte fallback for the unknown character
     assert tok("") == [1, 259]                                     # llama adds the space prefix even to empty text
+
+
+def test_crafted_headers_are_rejected_not_crashed(tmp_path):
+    """64-bit fields of an untrusted file: a string-array count the file cannot hold, dims whose product wraps, an offset that wraps
+    the bounds test — each must come back as TK_ERROR_FILE_CORRUPT (3004), never an exception through the C-ABI or a wild pointer."""
+    import struct
+    G = gguf_util
+    kv = [("general.architecture", G.GGUF_STRING, "llama"), ("llama.block_count", G.GGUF_U32, 1), ("llama.embedding_length", G.GGUF_U32, 256),
+          ("llama.attention.head_count", G.GGUF_U32, 4), ("llama.feed_forward_length", G.GGUF_U32, 512)]
+    lacking = tmp_path / "lacking.gguf"   # no feed_forward_length: a load error, not a division by zero in the K-split planner
+    G.write_gguf(str(lacking), kv[:-1], [("token_embd.weight", [256, 512], 0, np.zeros(256 * 512, np.float32).tobytes())])
+    assert probe(str(lacking))[0] == 4000
+    good = tmp_path / "good.gguf"
+    G.write_gguf(str(good), kv, [("token_embd.weight", [256, 512], 0, np.zeros(256 * 512, np.float32).tobytes())])
+    assert probe(str(good))[0] == 0
+    raw = bytearray(good.read_bytes())
+
+    # (1) tokenizer string array whose count is 2^61: reserve() would throw / exhaust memory
+    huge = bytearray(b"GGUF" + struct.pack("<IQQ", 3, 0, 1))
+    huge += G._s("tokenizer.ggml.tokens") + struct.pack("<IIQ", G.GGUF_ARRAY, G.GGUF_STRING, 1 << 61)
+    p1 = tmp_path / "huge_array.gguf"
+    p1.write_bytes(bytes(huge) + b"\0" * 64)
+    assert probe(str(p1))[0] == 3004
+
+    # locate the tensor directory entry of the good file: name, n_dims, dims..., type, offset
+    name = G._s("token_embd.weight")
+    at = raw.index(name) + len(name)
+    assert struct.unpack_from("<I", raw, at)[0] == 2
+    dims_at, off_at = at + 4, at + 4 + 16 + 4
+
+    # (2) dims whose product wraps to a small number (2^63 * 2 * ... ): n *= d overflow
+    b2 = bytearray(raw)
+    struct.pack_into("<QQ", b2, dims_at, 1 << 63, 4)
+    p2 = tmp_path / "dims_wrap.gguf"
+    p2.write_bytes(bytes(b2))
+    assert probe(str(p2))[0] == 3004
+
+    # (3) offset close to 2^64: data0 + offset + nbytes wraps past the bounds test
+    b3 = bytearray(raw)
+    struct.pack_into("<Q", b3, off_at, (1 << 64) - 4096)
+    p3 = tmp_path / "offset_wrap.gguf"
+    p3.write_bytes(bytes(b3))
+    assert probe(str(p3))[0] == 3004
+
+    # (4) dims that do not wrap but describe more data than the file holds
+    b4 = bytearray(raw)
+    struct.pack_into("<QQ", b4, dims_at, 1 << 20, 1 << 20)
+    p4 = tmp_path / "too_big.gguf"
+    p4.write_bytes(bytes(b4))
+    assert probe(str(p4))[0] == 3004

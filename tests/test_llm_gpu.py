@@ -375,3 +375,99 @@ def test_gguf_checkpoint_end_to_end(gpu, tmp_path):
     loader.close()
     with pytest.raises(gpu.TkError):
         gpu.ModelLoader().load(str(tmp_path / "nope.gguf"))
+
+
+class _BorrowedModel:
+    """a tk_mi355x_llm_model_t* owned by a tk_model_loader (the handle tk_model_loader_load_model returns) seen as a LlmModel"""
+
+    def __init__(self, gpu, handle):
+        import ctypes as C
+        self.h = handle
+        self.hparams = gpu.LlmHParams()
+        gpu.lib().tk_mi355x_llm_model_get_hparams(handle, C.byref(self.hparams))
+
+
+def _ids_of(pieces):
+    """token ids of the synthetic byte vocabulary's display pieces (csrc/llm/tk_tokenizer.h)"""
+    return [3 + p[0] if len(p) == 1 else int(p.decode().strip()[1:]) for p in pieces]
+
+
+def test_7b_through_reference_runner_32_tokens(gpu):
+    """BASELINE configs[0] (tests/tk_cortex_test.cpp's model + token count) through the reference entry points only:
+    tk_model_loader_load_model -> tk_llm_runner_prepare_generation -> 32 x tk_llm_runner_generate_next_token on the full 32-layer
+    Mistral-7B Q4_K_M geometry; ids equal tk_mi355x_llm_forward (the entry the oracle pins) on the same weights."""
+    loader = gpu.ModelLoader()
+    h = loader.load("synthetic://mistral-7b?seed=4")
+    runner = gpu.LlmRunner(h, context_size=128)
+    prompt = "The user is in a room."
+    runner.prepare(prompt)
+    pieces = []
+    for _ in range(32):
+        p = runner.next_token()
+        assert p is not None and p != "<tool_call>"
+        pieces.append(p)
+    got = _ids_of(pieces)
+    model = _BorrowedModel(gpu, h)
+    assert model.hparams.n_layer == 32 and model.hparams.d_model == 4096
+    sess = gpu.LlmSession(model, 1, 128)
+    ids = [1] + [3 + b for b in prompt.encode()]
+    n = len(ids)
+    _, am = sess.forward(np.zeros(n, np.int32), np.arange(n, dtype=np.int32), ids, want_logits=False)
+    cur, want = int(am[-1]), []
+    for i in range(32):
+        want.append(cur)
+        _, am = sess.forward([0], [n + i], [cur], want_logits=False)
+        cur = int(am[0])
+    assert got == want
+    assert len(set(got)) > 1
+    sess.close()
+    runner.close()
+    loader.unload(h)
+    loader.close()
+
+
+def test_runner_add_tool_response_continues_the_context(gpu):
+    """tk_llm_runner_add_tool_response (src/ai_models/tk_runner_helpers.c:78-133): the formatted tool result is tokenised WITHOUT a
+    BOS and decoded into the KV cache at n_past; generation resumes from its last position.  Ids against the oracle fed the same
+    token stream."""
+    import ctypes as C
+    L = gpu.lib()
+    loader = gpu.ModelLoader()
+    h = loader.load("synthetic://tiny?seed=4")
+    model = _BorrowedModel(gpu, h)
+    runner = gpu.LlmRunner(h, context_size=192)
+    runner.prepare("go")
+    first = [runner.next_token() for _ in range(3)]
+    assert all(p is not None for p in first)
+    assert L.tk_llm_runner_add_tool_response(runner.h, b"get_time", b"{\"time\": \"12:00\"}") == 0
+    after = [runner.next_token() for _ in range(5)]
+    assert all(p is not None for p in after)
+    # oracle: prompt, 3 generated tokens, then the tool text, then 5 more
+    orc = O.OracleLlm(oracle_cfg_from(model.hparams, 192, 1), seed=4)
+    ids = [1, 3 + ord("g"), 3 + ord("o")]
+    _, am = orc.forward([0] * 3, [0, 1, 2], ids, want_logits=False)
+    cur, pos, want_first = int(am[-1]), 3, []
+    for _ in range(3):
+        want_first.append(cur)
+        _, am = orc.forward([0], [pos], [cur], want_logits=False)
+        cur, pos = int(am[0]), pos + 1
+    assert _ids_of(first) == want_first
+    # the token sampled after the third decode is still pending inside the runner: the reference discards it too (the tool text
+    # is decoded at n_past, sampling restarts from the logits of its last token)
+    tool = b"[TOOL_RESULT] name: \"get_time\", output: {\"time\": \"12:00\"} [/TOOL_RESULT]"
+    tids = [3 + b for b in tool]
+    _, am = orc.forward([0] * len(tids), list(range(pos, pos + len(tids))), tids, want_logits=False)
+    cur, pos, want_after = int(am[-1]), pos + len(tids), []
+    for _ in range(5):
+        want_after.append(cur)
+        _, am = orc.forward([0], [pos], [cur], want_logits=False)
+        cur, pos = int(am[0]), pos + 1
+    assert _ids_of(after) == want_after
+    # argument and state errors
+    assert L.tk_llm_runner_add_tool_response(runner.h, None, b"x") == 1001
+    assert L.tk_llm_runner_add_tool_response(None, b"a", b"x") == 1001
+    long_out = b"y" * 400  # does not fit what is left of the 192-token context
+    assert L.tk_llm_runner_add_tool_response(runner.h, b"a", long_out) != 0
+    runner.close()
+    loader.unload(h)
+    loader.close()

@@ -112,6 +112,15 @@ def test_detector_full_frame_path_and_batch(gpu):
         for (cid, label, confd, (x0, y0, w, h)), bb, cc in zip(res[b], wb, wc):
             assert cid == cc and label == gpu.COCO80[cc].encode() and np.float32(confd) == bb[4]
             assert (x0, y0, w, h) == (int(bb[0] * sx), int(bb[1] * sy), int((bb[2] - bb[0]) * sx), int((bb[3] - bb[1]) * sy))
+    # stride == 0 means tightly packed rows, as the reference's callers leave it (tk_object_detector.c:235 assumes width * 3)
+    import ctypes as C
+    from trackiellm_amd.vision import VideoFrame, DetectionResult
+    f0 = VideoFrame(200, 120, 0, 0, fr[1].ctypes.data)
+    rp, n = C.POINTER(DetectionResult)(), C.c_size_t(0)
+    assert gpu.lib().tk_object_detector_detect(det.h, C.byref(f0), C.byref(rp), C.byref(n)) == 0
+    assert [(rp[i].class_id, rp[i].bbox.x, rp[i].bbox.y, rp[i].bbox.w, rp[i].bbox.h) for i in range(n.value)] == \
+           [(c, r[0], r[1], r[2], r[3]) for c, _, _, r in one]
+    gpu.lib().tk_object_detector_free_results(C.byref(rp))
     det.set_thresholds(0.9999, 0.5)
     assert det.detect(fr[0]) == []                                            # empty result set
 

@@ -64,3 +64,24 @@ def test_rejections(small, tmp_path):
     G.write_ggml(bad, ohp, mf, vocab, wrong)                              # wrong element count
     assert probe(bad)[0] != 0
     assert probe(tmp_path / "nope.bin")[0] != 0
+
+
+def test_crafted_tensor_shape_cannot_wrap_the_bounds_check(small, tmp_path):
+    """ne values whose product overflows int64 (or exceeds the file) must be rejected, not wrapped past `offset + bytes > fsize`"""
+    import struct
+    import trackiellm_amd as tk
+    ohp, T, file_t, vocab = small
+    p = tmp_path / "ok.bin"
+    G.write_ggml(p, ohp, T["frontend.mel_filters"], vocab, file_t)
+    raw = bytearray(p.read_bytes())
+    name = file_t[0][0].encode()
+    at = raw.index(name)               # tensor header = n_dims, name_len, type, ne[n_dims], then the name
+    nd = file_t[0][1].ndim
+    ne_at = at - 4 * nd
+    for k in range(nd):
+        struct.pack_into("<i", raw, ne_at + 4 * k, 0x7FFFFFFF)
+    bad = tmp_path / "wrap.bin"
+    bad.write_bytes(bytes(raw))
+    hp = tk.WhisperHP()
+    rc = tk.lib().tk_mi355x_whisper_ggml_probe(str(bad).encode(), C.byref(hp), None, None)
+    assert rc == 4000  # TK_ERROR_MODEL_LOAD_FAILED

@@ -63,6 +63,14 @@ class Asr:
         check(lib().tk_mi355x_asr_transcribe_tokens(self.h, B, p(pcm), n, n_steps, p(toks), p(mel), p(enc), p(lg)))
         return toks, mel, enc, lg
 
+    def set_language(self, lang):
+        return lib().tk_asr_whisper_set_language(self.h, lang.encode() if lang is not None else None)
+
+    def prompt_tokens(self):
+        buf = (C.c_int32 * 8)()
+        n = lib().tk_mi355x_asr_prompt_tokens(self.h, buf, 8)
+        return None if n < 0 else list(buf[:n])
+
     def set_decode_steps(self, n):
         lib().tk_mi355x_asr_set_decode_steps(self.h, n)
 

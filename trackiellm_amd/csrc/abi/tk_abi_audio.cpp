@@ -36,8 +36,40 @@ struct tk_asr_whisper_context_s {
     std::string last_text, language;
     int decode_steps = 16;
     int32_t sot = 0, nots = 0, eot = 0;
+    bool multilingual = false, translate = false;
     std::vector<std::string> vocab; /* token id -> bytes, from a ggml checkpoint */
 };
+
+/* Whisper's language table in token order (<|en|> = sot + 1, <|zh|> = sot + 2, ...): the published tokenizer order, which
+ * whisper.cpp's g_lang follows (the reference hands `language` to whisper.cpp, src/audio/tk_asr_whisper.c:252,386) */
+static const char* const k_whisper_langs[] = {
+    "en", "zh", "de", "es", "ru", "ko", "fr", "ja", "pt", "tr", "pl", "ca", "nl", "ar", "sv", "it", "id", "hi", "fi", "vi", "he", "uk", "el", "ms", "cs",
+    "ro", "da", "hu", "ta", "no", "th", "ur", "hr", "bg", "lt", "la", "mi", "ml", "cy", "sk", "te", "fa", "lv", "bn", "sr", "az", "sl", "kn", "et", "mk",
+    "br", "eu", "is", "hy", "ne", "mn", "bs", "kk", "sq", "sw", "gl", "mr", "pa", "si", "km", "sn", "yo", "so", "af", "oc", "ka", "be", "tg", "sd", "gu",
+    "am", "yi", "lo", "uz", "fo", "ht", "ps", "tk", "nn", "mt", "sa", "lb", "my", "bo", "tl", "mg", "as", "tt", "haw", "ln", "ha", "ba", "jw", "su", "yue"};
+
+static int whisper_lang_id(const std::string& code) {
+    for (int i = 0; i < (int)(sizeof k_whisper_langs / sizeof k_whisper_langs[0]); ++i)
+        if (code == k_whisper_langs[i]) return i;
+    return -1;
+}
+
+/* decoder prompt, as whisper.cpp's whisper_full builds it: English-only vocabularies start from <|startoftranscript|> alone;
+ * multilingual ones add the language and task tokens; <|notimestamps|> closes both (the reference's wrapper concatenates segment
+ * texts only, tk_asr_whisper.c:160-181).  Returns false for a language the vocabulary has no token for. */
+static bool asr_prompt(const tk_asr_whisper_context_s* c, std::vector<int32_t>* out, std::string* why) {
+    out->clear();
+    out->push_back(c->sot);
+    if (c->multilingual) {
+        const int n_lang = c->model.hp.n_vocab - 51865 + 99; /* 99 languages at 51865 tokens, 100 (+ yue) at 51866 */
+        int id = whisper_lang_id(c->language.empty() || c->language == "auto" ? std::string("en") : c->language); /* no language detection pass: "auto" decodes as English */
+        if (id < 0 || id >= n_lang) { *why = "unknown language \"" + c->language + "\""; return false; }
+        out->push_back(c->sot + 1 + id);
+        out->push_back(c->sot + 1 + n_lang + (c->translate ? 0 : 1)); /* <|translate|>, <|transcribe|> follow the language block */
+    }
+    out->push_back(c->nots);
+    return true;
+}
 
 static bool have_gpu() {
     int n = 0;
@@ -70,6 +102,13 @@ static tk_error_code_t asr_new(tk_asr_whisper_context_t** out, const TkWhisperHP
     c->sot = 50257 + ml < v - 3 ? 50257 + ml : v - 3;
     c->nots = 50362 + ml < v - 1 ? 50362 + ml : v - 1;
     c->eot = 50256 + ml < v - 4 ? 50256 + ml : v - 4;
+    c->multilingual = ml != 0;
+    if (ml) { /* multilingual vocabulary (whisper.cpp's whisper_vocab): eot 50257, sot 50258, one token per language, then translate,
+               * transcribe, startoflm, startofprev, nospeech, notimestamps */
+        const int n_lang = v - 51865 + 99;
+        c->eot = 50257; c->sot = 50258;
+        c->nots = c->sot + 1 + n_lang + 5;
+    }
     *out = c.release();
     return TK_SUCCESS;
 }
@@ -82,6 +121,7 @@ tk_error_code_t tk_asr_whisper_create(tk_asr_whisper_context_t** out_context, co
     const std::string path = config->model_path->path_str;
     tk_error_code_t rc = asr_new(out_context, tk_whisper_tiny_en(), path, seed_of(path, 6), tk_mi355x_get_default_device(), 1);
     if (rc == TK_SUCCESS && config->language) (*out_context)->language = config->language;
+    if (rc == TK_SUCCESS) (*out_context)->translate = config->translate_to_en;
     return rc;
 }
 
@@ -134,9 +174,11 @@ void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_steps) 
 tk_error_code_t tk_mi355x_asr_transcribe_tokens(tk_asr_whisper_context_t* c, int batch, const int16_t* pcm, int n_samples, int n_steps,
                                                 int32_t* tokens_out, float* mel_out, float* enc_out, float* logits_out) {
     if (!c || (!pcm && n_samples > 0) || !tokens_out || n_steps <= 0) return TK_ERROR_INVALID_ARGUMENT;
-    const int32_t prompt[2] = {c->sot, c->nots};
+    std::vector<int32_t> prompt;
+    std::string why;
+    if (!asr_prompt(c, &prompt, &why)) return afail(TK_ERROR_INFERENCE_FAILED, why); /* whisper_full fails the same way at decode time */
     std::vector<float> mel, enc, lg;
-    if (!c->asr.transcribe(batch, pcm, n_samples, prompt, 2, n_steps, tokens_out, mel_out ? &mel : nullptr, enc_out ? &enc : nullptr,
+    if (!c->asr.transcribe(batch, pcm, n_samples, prompt.data(), (int)prompt.size(), n_steps, tokens_out, mel_out ? &mel : nullptr, enc_out ? &enc : nullptr,
                            logits_out ? &lg : nullptr))
         return afail(TK_ERROR_INFERENCE_FAILED, c->asr.error);
     if (mel_out) memcpy(mel_out, mel.data(), mel.size() * 4);
@@ -201,8 +243,17 @@ tk_error_code_t tk_asr_whisper_reset(tk_asr_whisper_context_t* c) {
 
 tk_error_code_t tk_asr_whisper_set_language(tk_asr_whisper_context_t* c, const char* language) {
     if (!c || !language) return TK_ERROR_INVALID_ARGUMENT;
-    c->language = language;
+    c->language = language; /* like the reference (tk_asr_whisper.c:377-396) any string is stored; a language the vocabulary lacks fails the next decode */
     return TK_SUCCESS;
+}
+
+int tk_mi355x_asr_prompt_tokens(tk_asr_whisper_context_t* c, int32_t* out, int cap) {
+    if (!c || !out || cap <= 0) return -1;
+    std::vector<int32_t> p;
+    std::string why;
+    if (!asr_prompt(c, &p, &why)) { tk_error_set_detail("%s", why.c_str()); return -1; }
+    for (size_t i = 0; i < p.size() && (int)i < cap; ++i) out[i] = p[i];
+    return (int)p.size();
 }
 
 /* ------------------------------------------------------------------ VAD ------------------ */

@@ -57,6 +57,7 @@ static TkLlmHParams to_hp(const tk_mi355x_llm_hparams_t& h) {
 /* K-split plan: at least one 64-row workgroup per CU (256) where the matrix allows it */
 static void default_plan(tk_mi355x_llm_hparams_t* h) {
     auto pick = [](int64_t rows, int64_t K) {
+        if (rows < 64 || K < 256) return 1; /* geometry the model rejects later (TkLlmModel::init): no plan to make */
         int nb = (int)(K / 256);
         int want = (int)((256 + rows / 64 - 1) / (rows / 64));
         int ks = 1;
@@ -142,7 +143,8 @@ tk_error_code_t tk_mi355x_gguf_probe(const char* path, tk_mi355x_llm_hparams_t* 
     h.rope_theta = (float)f.get(arch + ".rope.freq_base", 10000.0);
     const TkGgufTensor* te = f.find("token_embd.weight");
     h.vocab = te && te->dims.size() == 2 ? (int)te->dims[1] : (int)f.tokens.size();
-    if (h.n_layer <= 0 || h.d_model <= 0 || h.n_head <= 0 || h.vocab <= 0) return fail(TK_ERROR_MODEL_LOAD_FAILED, "GGUF lacks llama hyper-parameters");
+    if (h.n_layer <= 0 || h.d_model <= 0 || h.n_head <= 0 || h.vocab <= 0 || h.d_ff <= 0 || h.n_kv_head <= 0 || h.head_dim <= 0)
+        return fail(TK_ERROR_MODEL_LOAD_FAILED, "GGUF lacks llama hyper-parameters");
     default_plan(&h);
     *out = h;
     if (n_vocab_tokens) *n_vocab_tokens = (int32_t)f.tokens.size();

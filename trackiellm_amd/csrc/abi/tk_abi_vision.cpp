@@ -130,14 +130,18 @@ tk_error_code_t tk_mi355x_detector_detect_batch(tk_object_detector_t* d, int n, 
                                                 size_t* out_counts) {
     if (!d || !frames || !out_results || !out_counts || n <= 0) return TK_ERROR_INVALID_ARGUMENT;
     std::vector<const uint8_t*> ptrs(n);
+    /* stride 0 = tightly packed rows, as in the other entry points (the reference detector ignores `stride` and assumes width * 3,
+     * tk_object_detector.c:235, so callers that leave it unset must keep working) */
+    const uint32_t bpp = (uint32_t)bytes_per_pixel(&frames[0]);
+    auto pitch = [bpp](const tk_video_frame_t& f) { return f.stride ? f.stride : f.width * bpp; };
     for (int i = 0; i < n; ++i) {
         if (!frames[i].data) return TK_ERROR_INVALID_ARGUMENT;
-        if (frames[i].width != frames[0].width || frames[i].height != frames[0].height || frames[i].stride != frames[0].stride ||
-            frames[i].format != frames[0].format)
+        if (frames[i].width != frames[0].width || frames[i].height != frames[0].height || frames[i].format != frames[0].format ||
+            pitch(frames[i]) != pitch(frames[0]))
             return vfail(TK_ERROR_INVALID_ARGUMENT, "frames of one batch must share geometry");
         ptrs[i] = frames[i].data;
     }
-    if (!d->det->detect(n, ptrs.data(), frames[0].width, frames[0].height, frames[0].stride, (uint32_t)bytes_per_pixel(&frames[0]), &d->last))
+    if (!d->det->detect(n, ptrs.data(), frames[0].width, frames[0].height, pitch(frames[0]), bpp, &d->last))
         return vfail(TK_ERROR_INFERENCE_FAILED, d->det->error);
     for (int i = 0; i < n; ++i) {
         tk_error_code_t rc = to_results(d, d->last[i], &frames[i], &out_results[i], &out_counts[i]);

@@ -1,6 +1,8 @@
 /* tk_whisper_ggml.cpp — see tk_whisper_ggml.h */
 #include "tk_whisper_ggml.h"
 
+#include <stdexcept>
+
 #include <stdio.h>
 #include <string.h>
 
@@ -22,6 +24,15 @@ bool TkWhisperGgml::is_ggml(const char* path) {
 }
 
 bool TkWhisperGgml::open(const char* path) {
+    try { /* file contents are untrusted: nothing may throw through the extern "C" callers */
+        return open_checked(path);
+    } catch (const std::exception& e) {
+        error = std::string("corrupt whisper ggml file (") + e.what() + ")";
+        return false;
+    }
+}
+
+bool TkWhisperGgml::open_checked(const char* path) {
     path_ = path;
     tensors.clear();
     vocab.clear();
@@ -73,13 +84,14 @@ bool TkWhisperGgml::open(const char* path) {
             int32_t ne = 0;
             if (!fl.rd(&ne, 4) || ne <= 0) { error = "bad tensor shape"; return false; }
             t.ne[i] = ne;
+            if (t.count > (int64_t)fsize / ne) { error = "tensor element count exceeds the file size"; return false; } /* keeps count * ne from wrapping */
             t.count *= ne;
         }
         t.name.resize((size_t)d[1]);
         if (!fl.rd(&t.name[0], (size_t)d[1])) { error = "truncated tensor name"; return false; }
         t.offset = ftell(fl.f);
-        const int64_t bytes = t.count * (t.type == 1 ? 2 : 4);
-        if (t.offset + bytes > fsize) { error = "tensor " + t.name + " runs past the end of the file"; return false; }
+        const int64_t bytes = t.count * (t.type == 1 ? 2 : 4); /* count <= fsize: cannot wrap */
+        if (t.offset < 0 || t.offset > fsize || bytes > (int64_t)fsize - t.offset) { error = "tensor " + t.name + " runs past the end of the file"; return false; }
         pos = (long)(t.offset + bytes);
         tensors.push_back(t);
     }

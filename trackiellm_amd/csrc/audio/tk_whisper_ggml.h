@@ -43,6 +43,7 @@ public:
 
     static bool is_ggml(const char* path); /* magic check only */
     bool open(const char* path);           /* header, filters, vocabulary, tensor directory (data is not read) */
+    bool open_checked(const char* path);   /* open() without the exception barrier */
     /* tensor `idx` of `man` as fp32 rows x cols in this path's layout; frontend tables (hann / DFT) are not in the file -> false with found = false */
     bool read(const TkWhManifest& man, int idx, std::vector<float>* out, bool* found);
 

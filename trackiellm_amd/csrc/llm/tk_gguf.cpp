@@ -1,7 +1,9 @@
 #include "tk_gguf.h"
 
 #include <fcntl.h>
+#include <stdint.h>
 #include <string.h>
+#include <stdexcept>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -73,6 +75,16 @@ const TkGgufTensor* TkGgufFile::find(const std::string& name) const {
 }
 
 bool TkGgufFile::open(const char* path) {
+    /* file contents are untrusted: nothing below may throw through the extern "C" callers */
+    try {
+        return open_checked(path);
+    } catch (const std::exception& e) {
+        error = std::string("corrupt GGUF file (") + e.what() + ")";
+        return false;
+    }
+}
+
+bool TkGgufFile::open_checked(const char* path) {
     int fd = ::open(path, O_RDONLY);
     if (fd < 0) { error = std::string("cannot open ") + path; return false; }
     struct stat st;
@@ -99,6 +111,9 @@ bool TkGgufFile::open(const char* path) {
             uint64_t n = c.rd<uint64_t>();
             if (!c.ok) break;
             if (et == 8) {
+                /* every string costs at least its 8-byte length field: a count the remaining bytes cannot hold is corruption, not a
+                 * reason to reserve() whatever a crafted file asks for */
+                if (n > (uint64_t)(c.end - c.p) / 8) { c.ok = false; break; }
                 std::vector<std::string> v;
                 v.reserve((size_t)n);
                 for (uint64_t k = 0; k < n && c.ok; ++k) v.push_back(c.rds());
@@ -134,18 +149,27 @@ bool TkGgufFile::open(const char* path) {
     uint64_t align = (uint64_t)get("general.alignment", 32);
     if (align == 0) align = 32;
     uint64_t pos = (uint64_t)(c.p - (const uint8_t*)map_);
+    if (align > (1u << 20) || pos > map_len_ || align - 1 > map_len_ - pos) { error = "corrupt GGUF alignment"; return false; }
     uint64_t data0 = (pos + align - 1) / align * align;
+    if (data0 > map_len_) { error = "GGUF tensor data section is missing"; return false; }
+    const uint64_t data_len = map_len_ - data0;
     for (auto& t : tensors) {
         uint64_t n = 1;
-        for (auto d : t.dims) n *= d;
+        bool overflow = false;
+        for (auto d : t.dims) {
+            if (d != 0 && n > UINT64_MAX / d) { overflow = true; break; }
+            n *= d;
+        }
+        if (overflow) { error = "tensor element count overflows: " + t.name; return false; }
         size_t be = tk_type_block_elems((int)t.type), bb = tk_type_block_bytes((int)t.type);
         if (t.type != TK_TYPE_F32 && t.type != TK_TYPE_F16 && t.type != TK_TYPE_Q4_K && t.type != TK_TYPE_Q6_K) {
             t.nbytes = 0; /* unsupported type: reported when a consumer asks for this tensor */
             t.data = nullptr;
             continue;
         }
+        if (n / be > data_len / bb) { error = "tensor data runs past end of file: " + t.name; return false; } /* also rules out n / be * bb wrapping */
         t.nbytes = (size_t)(n / be * bb);
-        if (data0 + t.offset + t.nbytes > map_len_) { error = "tensor data runs past end of file: " + t.name; return false; }
+        if (t.offset > data_len || t.nbytes > data_len - t.offset) { error = "tensor data runs past end of file: " + t.name; return false; }
         t.data = (const uint8_t*)map_ + data0 + t.offset;
     }
     return true;

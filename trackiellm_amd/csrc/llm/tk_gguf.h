@@ -39,6 +39,7 @@ struct TkGgufFile {
     double get(const std::string& key, double dflt) const;
 
 private:
+    bool open_checked(const char* path);
     void* map_ = nullptr;
     size_t map_len_ = 0;
 };

@@ -234,7 +234,8 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     HIPQ(hipMalloc((void**)&rope_sin, sn.size() * 4));
     HIPQ(hipMemcpy(rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
     HIPQ(hipMemcpy(rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
-    /* kernels that want more than the default 64 KiB of dynamic LDS */
+    /* kernels that want more than the default 64 KiB of dynamic LDS: a per-device opt-in */
+    if (const char* e = tk_llm_prepare_device(m->device)) { error = std::string("LDS opt-in failed: ") + e; return false; }
     HIPQ(hipDeviceSynchronize());
     return true;
 }

@@ -521,11 +521,6 @@ size_t tk_gemv_lds_bytes(int K, int ks, int mtiles) {
  * staged once per CU, (c) all waves of a CU walk disjoint contiguous tile runs.
  */
 /* TYPES: bit 0 = the launch contains Q4_K tiles, bit 1 = Q6_K tiles; single-type launches keep only one fragment ring in registers */
-#ifndef TK_ABLATE
-#define TK_ABLATE 0
-#endif
-/* TK_ABLATE (diagnostic builds only, never shipped), bit mask: 1 = no weight loads inside the loop, 2 = no block math, 4 = no activation staging
- * (3 = launch + staging + epilogue only, 7 = launch + epilogue only), 8 = no epilogue stores, 16 = no prologue tile loads */
 template <int PF, int MT, int TYPES>
 __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int total_row_tiles) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -574,11 +569,11 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
     const bool is4 = HAS4 && (!HAS6 || type == TK_TYPE_Q4_K);
     FragQ4 f4[HAS4 ? PF : 1];
     FragQ6 f6[HAS6 ? PF : 1];
-    if (HAS4 && is4 && !(TK_ABLATE & 16)) {
+    if (HAS4 && is4) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) f4[HAS4 ? u : 0] = load_q4(tile + (size_t)u * tile_bytes, lane);
     }
-    if (HAS6 && !is4 && !(TK_ABLATE & 16)) {
+    if (HAS6 && !is4) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) f6[HAS6 ? u : 0] = load_q6(tile + (size_t)u * tile_bytes, lane);
     }
@@ -590,7 +585,6 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)blk0 * 256 * TK_ROW_SLOTS;
-            if (TK_ABLATE & 4) break;
             /* the CUs of one XCD (blockIdx / 8 = index inside the XCD) all stage the same image from the same L2: each starts at
              * its own piece so they do not hammer one L2 channel in lock step */
             /* pieces go in groups of four (npiece = Kr / 64 is a multiple of 4): one address and one LDS base per 4 KiB, immediate offsets */
@@ -633,13 +627,13 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
         for (int g = 0; g < ngrp - 1; ++g, tp += PF * tile_bytes) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if ((TK_ABLATE & 2)) { acc[0][0] += __builtin_bit_cast(float, f4[HAS4 ? u : 0].q0.x ^ f4[HAS4 ? u : 0].q1.y ^ f4[HAS4 ? u : 0].h.z); }
                 OpsQ4 o;
-                if (!(TK_ABLATE & 2)) { __builtin_amdgcn_sched_barrier(0); unpack_q4(f4[HAS4 ? u : 0], lane, o); }
                 __builtin_amdgcn_sched_barrier(0);
-                if ((TK_ABLATE & 1) == 0) f4[HAS4 ? u : 0] = load_q4(tp + u * tile_bytes, lane);
+                unpack_q4(f4[HAS4 ? u : 0], lane, o);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(TK_ABLATE & 2)) mma_q4<MT>(o, lds_act, lds_abs, lds_ad, act_ts, abs_ts, ad_ts, g * PF + u, lane, acc);
+                f4[HAS4 ? u : 0] = load_q4(tp + u * tile_bytes, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_q4<MT>(o, lds_act, lds_abs, lds_ad, act_ts, abs_ts, ad_ts, g * PF + u, lane, acc);
             }
         }
 #pragma unroll
@@ -656,13 +650,13 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
         for (int g = 0; g < ngrp - 1; ++g, tp += PF * tile_bytes) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if ((TK_ABLATE & 2)) { acc[0][0] += __builtin_bit_cast(float, f6[HAS6 ? u : 0].q0.x ^ f6[HAS6 ? u : 0].q1.y ^ f6[HAS6 ? u : 0].qh.z ^ f6[HAS6 ? u : 0].sc.w ^ f6[HAS6 ? u : 0].d); }
                 OpsQ6 o;
-                if (!(TK_ABLATE & 2)) { __builtin_amdgcn_sched_barrier(0); unpack_q6(f6[HAS6 ? u : 0], o); }
                 __builtin_amdgcn_sched_barrier(0);
-                if ((TK_ABLATE & 1) == 0) f6[HAS6 ? u : 0] = load_q6(tp + u * tile_bytes, lane);
+                unpack_q6(f6[HAS6 ? u : 0], o);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(TK_ABLATE & 2)) mma_q6<MT>(o, lds_act, lds_ad, act_ts, ad_ts, g * PF + u, lane, acc);
+                f6[HAS6 ? u : 0] = load_q6(tp + u * tile_bytes, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_q6<MT>(o, lds_act, lds_ad, act_ts, ad_ts, g * PF + u, lane, acc);
             }
         }
 #pragma unroll
@@ -681,7 +675,7 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m * TK_ROW_SLOTS + 4 * g + r;
-            if (row < a.nrows && (!(TK_ABLATE & 8) || (blockIdx.x == 0 && tid == 0))) __builtin_nontemporal_store(acc[m][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
+            if (row < a.nrows) __builtin_nontemporal_store(acc[m][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
         }
 }
 
@@ -756,11 +750,6 @@ struct ATile { v4i a[4]; v8h mn; v4f da; };
 template <bool MINS>
 __device__ __forceinline__ void lds_tile(ATile& t, const uint8_t* act, const uint8_t* amn, const uint8_t* ad, int lane) {
     const uint8_t* ap = act + lane * 16;
-    if (TK_ABLATE & 64) {
-        for (int j2 = 0; j2 < 4; ++j2) t.a[j2] = (v4i){lane, j2, lane + j2, 1};
-        t.da = (v4f){1.0f, 2.0f, 3.0f, 4.0f};
-        return;
-    }
 #pragma unroll
     for (int j2 = 0; j2 < 4; ++j2) {
         t.a[j2] = *(const v4i*)(ap + j2 * 1024);
@@ -779,15 +768,7 @@ struct PTile { v4i pl, ph; v4f cm, da; };
 #define TK_RING_BLOCKS 1 /* 256-k blocks per ring slot (per barrier): 2 slots x 1 block x 16 M-tiles = 138 KiB of the 160 KiB LDS */
 #endif
 
-/* diagnostic builds: TK_ABLATE bit 32 = batched kernel without MFMAs (operands xor-ed so nothing is dead), 64 = without LDS operand reads,
- * 128 = without the per-step barrier and ring refill (first block's activations reused) */
-#if TK_ABLATE & 32
-#define TK_MFMA64(a, b, c, x, y, z) ((c) ^ (a) ^ (b))
-#define TK_MFMA32(a, b, c, x, y, z) ((c) ^ (v4i){(int)(a), (int)((a) >> 32), (int)(b), (int)((b) >> 32)})
-#else
 #define TK_MFMA64 __builtin_amdgcn_mfma_i32_16x16x64_i8
-#define TK_MFMA32 __builtin_amdgcn_mfma_i32_16x16x32_i8
-#endif
 template <bool Q4>
 __device__ __forceinline__ void finish_tile(const PTile& R, const OpsQ4& o, float* acc) {
 #pragma unroll
@@ -922,14 +903,13 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
 
 #pragma unroll 1
     for (int b = 0; b < nb; ++b) {
-        if (b % CB == 0 && (!(TK_ABLATE & 128) || b == 0)) { /* chunk boundary: CB blocks per barrier */
+        if (b % CB == 0) { /* chunk boundary: CB blocks per barrier */
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            if (!(TK_ABLATE & 128))
-                for (int i = 0; i < CB && b + CB + i < nb; ++i) stage(b + CB + i, ((b / CB + 1) & 1) * CB + i);
+            for (int i = 0; i < CB && b + CB + i < nb; ++i) stage(b + CB + i, ((b / CB + 1) & 1) * CB + i);
         }
         if (!active) continue;
-        const uint8_t* chunk = lds + ((TK_ABLATE & 128) ? 0 : (((b / CB) & 1) * CB + b % CB)) * CH;
+        const uint8_t* chunk = lds + (((b / CB) & 1) * CB + b % CB) * CH;
         const uint8_t* next = tile + (size_t)(b + 1 < nb ? b + 1 : b) * tile_bytes; /* the last step re-requests its own tile: no branch around a load */
         OpsQ4 o[NT];
         if (HAS4 && is4) {
@@ -968,6 +948,16 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
 }
 
 #define TK_NUM_CU 256
+
+/* Dynamic LDS above 64 KiB is an opt-in that HIP keeps per (function, DEVICE): a process that drives several GPUs (the ABI takes a
+ * device ordinal per handle, SURVEY 8b "Threading") must raise it on each of them.  tk_llm_prepare_device() does that once per device
+ * for every instantiation, at session creation — outside any stream capture and before any host thread launches — so the launchers
+ * below never touch function attributes. */
+#define TK_MAX_DYN_LDS (160 * 1024)
+#include <mutex>
+template <typename F>
+static hipError_t opt_in_lds(F* fn) { return hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, TK_MAX_DYN_LDS); }
+
 void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     int row_tiles = 0;
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.seg[i].row_tiles;
@@ -996,68 +986,29 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     if (a.nrows > 2 * TK_ROW_SLOTS) { /* batched passes: K-streamed activations, 4, 8 or 16 M-tiles per weight tile */
         const int mtb = a.nrows > 8 * TK_ROW_SLOTS ? 16 : a.nrows > 4 * TK_ROW_SLOTS ? 8 : 4;
         const size_t ldsb = (size_t)2 * TK_RING_BLOCKS * mtb * TK_RING_TILE_BYTES;
-        /* weight tiles per wave: 1.  TK_GEMM_NT=2 selects two adjacent tiles per wave (tensor row counts are multiples of 64, so a
-         * pair never straddles two tensors): it halves the LDS operand stream but leaves one wave per SIMD, and measured 25 % slower
-         * on MI355X (profiles/r01_gemm_batched.txt) — kept as a tuning knob, parity-tested */
-        static int force_nt = -1;
-        if (force_nt < 0) { const char* e = getenv("TK_GEMM_NT"); force_nt = e ? atoi(e) : 0; }
-        bool even = true;
-        for (int i = 0; i < a.nseg; ++i) even = even && a.seg[i].row_tiles % 2 == 0;
-        const int nt = (force_nt == 2 && even) ? 2 : 1;
-        /* waves per workgroup: with <= 4 (TK_GEMM_MAXWAVES) a CU holds two workgroups whose barrier phases drift apart */
-        static int maxw = -1;
-        if (maxw < 0) { const char* e = getenv("TK_GEMM_MAXWAVES"); maxw = e ? atoi(e) : 8; if (maxw < 1 || maxw > 8) maxw = 8; }
-        while (waves > maxw) { groups *= 2; waves = (row_tiles + groups - 1) / groups; }
-        if (nt == 2) {
-            const int pairs = row_tiles / 2;
-            groups = TK_NUM_CU / a.ks;
-            if (groups < 1) groups = 1;
-            if (groups > pairs) groups = pairs;
-            waves = (pairs + groups - 1) / groups;
-            while (waves > 4) { groups *= 2; waves = (pairs + groups - 1) / groups; }
-        }
-#define TK_GEMM_LAUNCH(MTV, TYV, NTV)                                                                                              \
-    do {                                                                                                                           \
-        static bool opted = false;                                                                                                 \
-        if (!opted) { (void)hipFuncSetAttribute((const void*)k_gemm_w4a8<MTV, TYV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TK_RING_BLOCKS * 16 * TK_RING_TILE_BYTES); opted = true; } \
-        hipLaunchKernelGGL((k_gemm_w4a8<MTV, TYV, NTV>), dim3(groups * a.ks), dim3(64 * waves), ldsb, s, a, groups, row_tiles);     \
-    } while (0)
-#define TK_GEMM_TY(MTV, NTV) do { if (types == 1) TK_GEMM_LAUNCH(MTV, 1, NTV); else if (types == 2) TK_GEMM_LAUNCH(MTV, 2, NTV); else TK_GEMM_LAUNCH(MTV, 3, NTV); } while (0)
-        if (mtb == 4) { if (nt == 2) TK_GEMM_TY(4, 2); else TK_GEMM_TY(4, 1); }
-        else if (mtb == 8) { if (nt == 2) TK_GEMM_TY(8, 2); else TK_GEMM_TY(8, 1); }
-        else TK_GEMM_TY(16, 1);
+        /* one weight tile per wave (two adjacent tiles per wave halve the LDS operand stream but leave one wave per SIMD: 25 % slower on
+         * MI355X, profiles/r01_gemm_batched.txt) */
+#define TK_GEMM_LAUNCH(MTV, TYV) hipLaunchKernelGGL((k_gemm_w4a8<MTV, TYV, 1>), dim3(groups * a.ks), dim3(64 * waves), ldsb, s, a, groups, row_tiles)
+#define TK_GEMM_TY(MTV) do { if (types == 1) TK_GEMM_LAUNCH(MTV, 1); else if (types == 2) TK_GEMM_LAUNCH(MTV, 2); else TK_GEMM_LAUNCH(MTV, 3); } while (0)
+        if (mtb == 4) TK_GEMM_TY(4);
+        else if (mtb == 8) TK_GEMM_TY(8);
+        else TK_GEMM_TY(16);
 #undef TK_GEMM_TY
 #undef TK_GEMM_LAUNCH
         return;
     }
     const int mt = a.nrows > TK_ROW_SLOTS ? 2 : 1;
-    size_t lds = tk_gemv_lds_bytes(a.K, a.ks, mt);
+    const size_t lds = tk_gemv_lds_bytes(a.K, a.ks, mt);
     const int nb = a.K / a.ks / 256;
-    /* tiles in flight per wave: the largest depth the register file holds without spilling, per (M-tiles, tile types) variant —
-     * from the compiler's resource report and timings on MI355X (profiles/r01_gemv_variants.txt).
-     * Tuning overrides: TK_GEMV_CAPS="a,b,c,d,e,f" = depth caps for (1 M-tile: Q4, Q6, mixed; 2 M-tiles: Q4, Q6, mixed),
-     * TK_GEMV_MIXED=1 forces the two-type kernel. */
-    static int caps[2][3] = {{2, 2, 2}, {2, 2, 2}};
-    static int force_mixed = -1;
-    if (force_mixed < 0) {
-        const char* e1 = getenv("TK_GEMV_CAPS"); const char* e3 = getenv("TK_GEMV_MIXED");
-        if (e1) sscanf(e1, "%d,%d,%d,%d,%d,%d", &caps[0][0], &caps[0][1], &caps[0][2], &caps[1][0], &caps[1][1], &caps[1][2]);
-        force_mixed = e3 ? atoi(e3) : 0;
-    }
-    /* a Q6-only launch with two M-tiles spills as a single-type kernel at depth 2; the two-type kernel does not */
-    if (force_mixed > 0 || (mt == 2 && types == 2)) types = 3;
-    const int cap = caps[mt - 1][types - 1];
-    int pf = nb % 4 == 0 ? 4 : (nb % 2 == 0 ? 2 : 1);
-    while (pf > cap) pf /= 2;
-#define TK_GEMV_LAUNCH(PFV, MTV, TYV)                                                                                              \
-    do {                                                                                                                           \
-        static size_t cap = 0; /* >64 KiB of dynamic LDS must be opted into once per kernel */                                     \
-        if (lds > cap) { (void)hipFuncSetAttribute((const void*)k_gemv_w4a8<PFV, MTV, TYV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cap = lds; } \
-        hipLaunchKernelGGL((k_gemv_w4a8<PFV, MTV, TYV>), dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles);      \
-    } while (0)
+    /* weight tiles in flight per wave: 2, the largest depth every (M-tiles, tile types) variant holds without spilling (compiler resource
+     * report + timings on MI355X, profiles/r01_gemv_variants.txt).  A Q6-only launch with two M-tiles spills as a single-type kernel at that
+     * depth; the two-type kernel does not. */
+    if (mt == 2 && types == 2) types = 3;
+    const int pf = nb % 2 == 0 ? 2 : 1;
+#define TK_GEMV_LAUNCH(PFV, MTV, TYV) hipLaunchKernelGGL((k_gemv_w4a8<PFV, MTV, TYV>), dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles)
 #define TK_GEMV_TY(PFV, MTV) do { if (types == 1) TK_GEMV_LAUNCH(PFV, MTV, 1); else if (types == 2) TK_GEMV_LAUNCH(PFV, MTV, 2); else TK_GEMV_LAUNCH(PFV, MTV, 3); } while (0)
-    if (mt == 1) { if (pf == 4) TK_GEMV_TY(4, 1); else if (pf == 2) TK_GEMV_TY(2, 1); else TK_GEMV_TY(1, 1); }
-    else { if (pf == 4) TK_GEMV_TY(4, 2); else if (pf == 2) TK_GEMV_TY(2, 2); else TK_GEMV_TY(1, 2); }
+    if (mt == 1) { if (pf == 2) TK_GEMV_TY(2, 1); else TK_GEMV_TY(1, 1); }
+    else { if (pf == 2) TK_GEMV_TY(2, 2); else TK_GEMV_TY(1, 2); }
 #undef TK_GEMV_TY
 #undef TK_GEMV_LAUNCH
 }
@@ -1290,7 +1241,6 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
                   2 * (size_t)head_dim) * sizeof(float);
 #define TK_ATT_LAUNCH(G, F)                                                                                                          \
     do {                                                                                                                             \
-        (void)hipFuncSetAttribute((const void*)k_attention<G, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
         hipLaunchKernelGGL((k_attention<G, F>), dim3(nwg, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin,   \
                            kcache, vcache, seq, pos, n_head, n_kv_head, head_dim, layer, max_seq, max_ctx, out);                        \
     } while (0)
@@ -1363,4 +1313,31 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab,
 void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow, int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist,
                       int hist_stride, hipStream_t s) {
     hipLaunchKernelGGL(k_argmax, dim3(nrows), dim3(1024), 0, s, logits, vocab, allow, tok, pos, nsteps, hist, hist_stride);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * per-device opt-in to > 64 KiB of dynamic LDS for every kernel above (see the comment at TK_MAX_DYN_LDS)
+ * ------------------------------------------------------------------------------------------ */
+const char* tk_llm_prepare_device(int device) {
+    static std::mutex mu;
+    static bool done[64] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) return "device ordinal out of range";
+    if (done[device]) return nullptr;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) return "tk_llm_prepare_device: the calling thread's current device must be `device`";
+    hipError_t e = hipSuccess;
+#define TK_OPT(fn) do { if (e == hipSuccess) e = opt_in_lds(fn); } while (0)
+#define TK_OPT_GEMM(MTV) do { TK_OPT((k_gemm_w4a8<MTV, 1, 1>)); TK_OPT((k_gemm_w4a8<MTV, 2, 1>)); TK_OPT((k_gemm_w4a8<MTV, 3, 1>)); } while (0)
+    TK_OPT_GEMM(4); TK_OPT_GEMM(8); TK_OPT_GEMM(16);
+#define TK_OPT_GEMV(PFV, MTV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3>)); } while (0)
+    TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
+    TK_OPT((k_attention<1, true>)); TK_OPT((k_attention<2, true>)); TK_OPT((k_attention<4, true>));
+    TK_OPT((k_attention<1, false>)); TK_OPT((k_attention<2, false>)); TK_OPT((k_attention<4, false>));
+#undef TK_OPT_GEMV
+#undef TK_OPT_GEMM
+#undef TK_OPT
+    if (e != hipSuccess) return hipGetErrorString(e);
+    done[device] = true;
+    return nullptr;
 }

@@ -1,5 +1,8 @@
 #include "tk_nn_kernels.h"
 
+#include <atomic>
+#include <mutex>
+
 #include "../common/tk_exact_math.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -286,8 +289,17 @@ void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
     const int nz = g.batch > 0 ? g.batch : 1;
     if (g.M >= 256 && g.N >= 96) {
         const size_t lds = (size_t)2 * (LBM + LBN) * LDS_LD * sizeof(float);
-        static bool opted = false;
-        if (!opted) { (void)hipFuncSetAttribute((const void*)k_gemm_f32_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); opted = true; }
+        /* > 64 KiB of dynamic LDS is an opt-in HIP keeps per (function, device): one flag per device, set once under a lock (several host
+         * threads drive the detector / ASR / VAD streams, possibly on different GPUs) */
+        static std::atomic<bool> opted[64];
+        static std::mutex opt_mu;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !opted[dev].load(std::memory_order_acquire)) {
+            std::lock_guard<std::mutex> lk(opt_mu);
+            if (hipFuncSetAttribute((const void*)k_gemm_f32_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+                opted[dev].store(true, std::memory_order_release);
+        }
         dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
         hipLaunchKernelGGL(k_gemm_f32_big, grid, dim3(256), lds, s, g);
         return;
