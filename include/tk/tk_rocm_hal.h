@@ -72,6 +72,18 @@ TK_API TK_NODISCARD tk_error_code_t tk_kernels_preprocess_image_generic(const tk
 TK_API TK_NODISCARD tk_error_code_t tk_kernels_postprocess_depth_map(const tk_postprocess_depth_params_t* params, tk_hip_stream_t stream);
 TK_API TK_NODISCARD tk_error_code_t tk_kernels_depth_to_point_cloud(const tk_depth_to_points_params_t* params, tk_hip_stream_t stream);
 
+/* src/gpu/tk_gpu_helper.h:113-130 + src/gpu/cuda/tk_cuda_kernels.h:92 — row softmax of a [num_rows][num_cols] f32 tensor.  The reference
+ * ships it for CUDA only (tk_cuda_kernels.cu:312-393: power-of-two num_cols <= 1024); this one takes any num_cols and in-place calls
+ * (d_output_tensor == d_input_tensor).  It is the kernel the Whisper attention rows go through, and the one numeric known-answer test the
+ * reference holds (tests/tk_gpu_softmax_test.cpp) is replayed against it. */
+typedef struct {
+    const void* d_input_tensor;
+    void* d_output_tensor;
+    uint32_t num_rows;
+    uint32_t num_cols;
+} tk_softmax_params_t;
+TK_API TK_NODISCARD tk_error_code_t tk_kernels_softmax(const tk_softmax_params_t* params, tk_hip_stream_t stream);
+
 typedef struct tk_rocm_dispatcher_s tk_rocm_dispatcher_t;
 typedef struct tk_gpu_buffer_s* tk_gpu_buffer_t;
 typedef struct { int device_id; } tk_rocm_dispatcher_config_t;

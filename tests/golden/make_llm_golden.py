@@ -81,6 +81,39 @@ def main():
     agree = (logits.argmax(1) == hf_logits.argmax(1)).mean()
     print(f"max|oracle-hf| = {err:.4e}  (max|logit| = {scale:.3f}), argmax agreement = {agree:.3f}")
     assert err < 0.05 * scale, "oracle disagrees with HF Mistral beyond activation-quantisation noise"
+    # ---- decode with the KV cache: HF prefills 16 tokens, then takes 8 greedy single-token steps from its own cache; the oracle is
+    # teacher-forced with HF's ids (so a near-tie cannot fork the two sequences) and must reproduce every step's logits: pins cache
+    # indexing, position handling and the single-row path against an independent implementation (llm_tiny_decode.npz)
+    P, S = 16, 8
+    with torch.no_grad():
+        o = model(torch.from_numpy(tokens[:P].astype(np.int64))[None], use_cache=True)
+        past, step_logits, ids = o.past_key_values, [], []
+        nxt = int(o.logits[0, -1].argmax())
+        for i in range(S):
+            ids.append(nxt)
+            o = model(torch.tensor([[nxt]]), past_key_values=past, use_cache=True)
+            past = o.past_key_values
+            step_logits.append(o.logits[0, -1].numpy().astype(np.float32))
+            nxt = int(o.logits[0, -1].argmax())
+    ids, step_logits = np.array(ids, np.int32), np.stack(step_logits)
+    dec = {}
+    for mode in (1, 0):
+        O.lib().orc_set_fp32_activations(mode)
+        orc.reset()
+        pl, pam = orc.forward(np.zeros(P, np.int32), np.arange(P, dtype=np.int32), tokens[:P])
+        got = [orc.forward([0], [P + i], [ids[i]])[0][0] for i in range(S)]
+        dec[mode] = (pam[-1], np.stack(got))
+    O.lib().orc_set_fp32_activations(0)
+    e_dec = np.abs(dec[1][1] - step_logits).max()
+    print(f"decode, fp32-activation mode: first id {dec[1][0]} vs HF {ids[0]}, max|oracle-hf| over {S} cached steps = {e_dec:.3e}")
+    assert dec[1][0] == ids[0] and e_dec < 2e-3
+    assert np.array_equal(dec[1][1].argmax(1)[:-1], ids[1:]), "fp32-mode oracle must sample HF's ids step by step"
+    eq = np.abs(dec[0][1] - step_logits).max()
+    print(f"decode, int8-activation mode: max|oracle-hf| = {eq:.3e}")
+    assert eq < 0.05 * np.abs(step_logits).max()
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "llm_tiny_decode.npz"), tokens=tokens[:P], hf_ids=ids,
+                        hf_step_logits=step_logits, oracle_step_logits=dec[0][1], oracle_first_id=np.int32(dec[0][0]), seed=np.int64(4),
+                        fp32_mode_err=np.float32(e_dec))
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "llm_tiny.npz")
     np.savez_compressed(out, tokens=tokens, hf_logits=hf_logits.astype(np.float16), oracle_logits=logits,
                         oracle_argmax=am, seed=np.int64(4), fp32_mode_err=np.float32(e32))

@@ -110,6 +110,92 @@ def make_yolo():
     print("wrote yolo_tiny.npz")
 
 
+def torch_yolo_post(raw, H, W, nc, conf, iou, max_det=500, max_cand=2048):
+    """INDEPENDENT decode + NMS of a YOLOv8 head in the published Ultralytics / torchvision formulation (vectorised torch): DFL =
+    softmax over 16 bins . arange(16); dist2bbox(xyxy) on anchor centres (x + 0.5, y + 0.5) per stride; scores = sigmoid; class =
+    arg max; candidates score > conf ordered by score; class-aware NMS by the coordinate-offset trick of torchvision.ops.batched_nms
+    (boxes + cls * (max_coord + 1)) with a greedy loop over a vectorised IoU matrix.  Shares no code with csrc/common/tk_yolo_post.h."""
+    import torch
+    raw = torch.from_numpy(np.ascontiguousarray(raw, np.float32))
+    anchors, strides = [], []
+    for st in (8, 16, 32):
+        h, w = H // st, W // st
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5, torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
+        anchors.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], 1))
+        strides.append(torch.full((h * w,), float(st)))
+    anchors, strides = torch.cat(anchors), torch.cat(strides)
+    dist = (torch.softmax(raw[:, :64].reshape(-1, 4, 16), -1) * torch.arange(16, dtype=torch.float32)).sum(-1)
+    xyxy = torch.cat([anchors - dist[:, :2], anchors + dist[:, 2:]], 1) * strides[:, None]
+    scores, cls = torch.sigmoid(raw[:, 64:64 + nc]).max(1)
+    idx = torch.nonzero(scores > conf).reshape(-1)
+    order = torch.argsort(scores[idx], descending=True, stable=True)   # stable: equal scores keep ascending anchor order
+    idx = idx[order][:max_cand]
+    b, s, c = xyxy[idx], scores[idx], cls[idx]
+    off = b + (c.to(torch.float32) * (b.abs().max() + 1.0) if len(b) else 0.0)[:, None] if len(b) else b
+    area = (off[:, 2] - off[:, 0]) * (off[:, 3] - off[:, 1])
+    lt = torch.maximum(off[:, None, :2], off[None, :, :2])
+    rb = torch.minimum(off[:, None, 2:], off[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    ioum = inter / (area[:, None] + area[None, :] - inter)
+    keep, dead = [], torch.zeros(len(b), dtype=torch.bool)
+    for i in range(len(b)):
+        if dead[i]:
+            continue
+        keep.append(i)
+        dead |= ioum[i] > iou
+    keep = torch.tensor(keep[:max_det], dtype=torch.long)
+    return (torch.cat([b[keep], s[keep, None]], 1).numpy(), c[keep].numpy().astype(np.int32), idx[keep].numpy().astype(np.int32),
+            int(len(b)), ioum.numpy(), c.numpy())
+
+
+def make_yolo_dets():
+    """yolo_tiny_dets.npz — detections of the independent torch post-processor on the oracle's raw head maps (160 x 160 input)."""
+    orc = O.OracleYolo(nc=80, seed=5, cls_bias=-1.0)
+    rng = np.random.default_rng(19)
+    x = rng.standard_normal((1, 160, 160, 3)).astype(np.float32)
+    raw = orc.forward(x)[0]
+    conf = 0.3
+    # the IoU threshold of the fixture is the one (of a few) whose nearest same-class pair is farthest from it: decisions that sit on
+    # a rounding boundary would make the comparison of two float implementations a coin toss
+    _, _, _, _, ioum, candc = torch_yolo_post(raw, 160, 160, 80, conf, 0.5)
+    same = (candc[:, None] == candc[None, :]) & ~np.eye(len(candc), dtype=bool)
+    iou, margin = max(((t, float(np.abs(ioum[same] - t).min())) for t in (0.4, 0.45, 0.5, 0.55, 0.6, 0.65)), key=lambda p: p[1])
+    tb, tc, ta, ncand, ioum, candc = torch_yolo_post(raw, 160, 160, 80, conf, iou)
+    ob, oc, oa = orc.post(raw, 160, 160, conf, iou)
+    print(f"iou threshold {iou}: candidates {ncand}, kept by torch {len(ta)}, by the oracle {len(oa)}, closest same-class IoU to the threshold {margin:.2e}")
+    assert ncand - len(ta) >= 3, "fixture must exercise suppression"
+    assert margin > 2e-5
+    assert np.array_equal(ta, oa) and np.array_equal(tc, oc)
+    assert np.abs(tb - ob).max() < 1e-3
+    np.savez_compressed(os.path.join(HERE, "yolo_tiny_dets.npz"), x=x, conf=np.float32(conf), iou=np.float32(iou), torch_boxes=tb, torch_cls=tc,
+                        torch_anchors=ta, n_candidates=np.int32(ncand))
+    print("wrote yolo_tiny_dets.npz")
+
+
+def attribute_vector_frames():
+    """the two frames of the reference's tests/tk_attribute_classifier_test.c:21-54 (pure red) and :56-91 (gray with two black column bands)"""
+    red = np.zeros((100, 100, 3), np.uint8)
+    red[..., 0] = 255
+    door = np.full((100, 100, 3), 200, np.uint8)
+    door[:, 20:25] = 0
+    door[:, 70:75] = 0
+    return {"red_frame": (red, (10, 10, 80, 80)), "door_frame": (door, (0, 0, 100, 100))}
+
+
+def make_attribute_vectors():
+    """checks attribute_vectors.json against the compiled reference classifiers (the json is hand-written data + these outputs)"""
+    import json
+    assert O.have_ref()
+    j = json.load(open(os.path.join(HERE, "attribute_vectors.json")))
+    for name, (frame, box) in attribute_vector_frames().items():
+        color, door = O.ref_attributes(frame, box)
+        assert j[name]["compiled_reference"] == {"color": color, "door": door}, (name, color, door)
+        print(name, "->", color, door, "(reference test expects", j[name]["reference_test_expects"], ")")
+
+
 if __name__ == "__main__":
+    make_attribute_vectors()
     make_preprocess()
     make_yolo()
+    make_yolo_dets()

@@ -47,6 +47,43 @@ def test_hal_dispatcher_preprocess_and_depth(gpu):
     d.close()
 
 
+def test_softmax_known_answer_of_the_reference(gpu):
+    """replays tests/tk_gpu_softmax_test.cpp:24-69 — the only numeric known-answer test the reference holds: 4 x 256, input i % 256,
+    CPU softmax, |gpu - cpu| <= 1e-6 — through the same entry (tk_kernels_softmax(&params, stream)); the expected values are the
+    committed fixture tests/golden/softmax_4x256.npz (make_softmax_golden.py)."""
+    import os
+
+    class SoftmaxParams(C.Structure):
+        _fields_ = [("d_input_tensor", C.c_void_p), ("d_output_tensor", C.c_void_p), ("num_rows", C.c_uint32), ("num_cols", C.c_uint32)]
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "softmax_4x256.npz"))
+    x, want, tol = g["input"], g["expected"], float(g["tolerance"])
+    assert x.shape == (4, 256) and np.array_equal(x[2], np.arange(256, dtype=np.float32)) and tol == np.float32(1e-6)
+    d = gpu.RocmDispatcher(0)
+    a, b = d.malloc(x.nbytes), d.malloc(x.nbytes)
+    d.upload(a, x)
+    p = SoftmaxParams(d.ptr(a), d.ptr(b), 4, 256)
+    assert gpu.lib().tk_kernels_softmax(C.byref(p), d.stream()) == 0
+    got = d.download(b, (4, 256), np.float32)
+    assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
+    assert np.array_equal(d.download(a, (4, 256), np.float32), x)            # out of place: the input is untouched
+    # a width the reference's kernel cannot take (not a power of two, > 1024), in place: the Whisper score rows are 1500 wide
+    rng = np.random.default_rng(12)
+    y = rng.normal(0, 4, (3, 1500)).astype(np.float32)
+    c = d.malloc(y.nbytes)
+    d.upload(c, y)
+    q = SoftmaxParams(d.ptr(c), d.ptr(c), 3, 1500)
+    assert gpu.lib().tk_kernels_softmax(C.byref(q), d.stream()) == 0
+    e = np.exp(y.astype(np.float64) - y.max(1, keepdims=True))
+    assert np.abs(d.download(c, (3, 1500), np.float32) - e / e.sum(1, keepdims=True)).max() <= tol
+    assert gpu.lib().tk_kernels_softmax(None, None) == 1001
+    bad = SoftmaxParams(d.ptr(a), d.ptr(b), 0, 256)
+    assert gpu.lib().tk_kernels_softmax(C.byref(bad), d.stream()) == 1001
+    for buf in (a, b, c):
+        d.free(buf)
+    d.close()
+
+
 def test_cortex_cycle_like_reference_test(gpu):
     """reference tests/tk_cortex_test.cpp: one frame + 2 s of PCM, state-change callback must fire > 2 times"""
     cx = gpu.Cortex(llm="synthetic://tiny?seed=4", detector="synthetic://yolov8n?seed=5&cls_bias=0.5")

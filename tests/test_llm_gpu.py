@@ -471,3 +471,22 @@ def test_runner_add_tool_response_continues_the_context(gpu):
     runner.close()
     loader.unload(h)
     loader.close()
+
+
+def test_decode_with_kv_cache_matches_hf_fixture(gpu):
+    """the HIP path against the HF KV-cache decode fixture (llm_tiny_decode.npz): prefill 16 tokens in one pass, then 8 single-row passes
+    teacher-forced with HF's ids — step logits bit-identical to the committed oracle logits, within quantisation noise of HF's."""
+    import os
+    hp = gpu.TINY()
+    hp.ks_qkv = hp.ks_o = hp.ks_gateup = hp.ks_down = 1          # the fixture's K-split plan (oracle_lib.tiny_config defaults)
+    model = gpu.LlmModel(hp).fill_synthetic(4)
+    sess = gpu.LlmSession(model, 1, 64)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "llm_tiny_decode.npz"))
+    assert int(g["seed"]) == 4
+    toks, ids, hf = g["tokens"], g["hf_ids"], g["hf_step_logits"]
+    P = len(toks)
+    _, am = sess.forward(np.zeros(P, np.int32), np.arange(P, dtype=np.int32), toks)
+    assert int(am[-1]) == int(g["oracle_first_id"])
+    got = np.stack([sess.forward([0], [P + i], [ids[i]])[0][0] for i in range(len(ids))])
+    assert np.array_equal(got.view(np.uint32), g["oracle_step_logits"].view(np.uint32))
+    assert np.abs(got - hf).max() < 0.05 * np.abs(hf).max()

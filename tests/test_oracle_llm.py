@@ -23,6 +23,31 @@ def test_oracle_matches_hf_fixture():
     assert float(g["fp32_mode_err"]) < 2e-3
 
 
+def test_oracle_decode_matches_hf_kv_cache_fixture():
+    """llm_tiny_decode.npz: HF prefill of 16 tokens + 8 greedy single-token steps from HF's own KV cache; the oracle, teacher-forced with
+    HF's ids, reproduces the committed step logits bit for bit (determinism), stays within activation-quantisation noise of HF, and in
+    fp32-activation mode matches HF to 2e-3 with the same arg max at every step (cache indexing, positions, single-row path)."""
+    g = np.load(os.path.join(GOLD, "llm_tiny_decode.npz"))
+    toks, ids, hf = g["tokens"], g["hf_ids"], g["hf_step_logits"]
+    P, S = len(toks), len(ids)
+    orc = O.OracleLlm(O.tiny_config(), seed=int(g["seed"]))
+    _, am = orc.forward(np.zeros(P, np.int32), np.arange(P, dtype=np.int32), toks)
+    got = np.stack([orc.forward([0], [P + i], [ids[i]])[0][0] for i in range(S)])
+    assert int(am[-1]) == int(g["oracle_first_id"])
+    assert np.array_equal(got, g["oracle_step_logits"])
+    assert np.abs(got - hf).max() < 0.05 * np.abs(hf).max()
+    O.lib().orc_set_fp32_activations(1)
+    try:
+        orc.reset()
+        _, am = orc.forward(np.zeros(P, np.int32), np.arange(P, dtype=np.int32), toks)
+        g32 = np.stack([orc.forward([0], [P + i], [ids[i]])[0][0] for i in range(S)])
+    finally:
+        O.lib().orc_set_fp32_activations(0)
+    assert int(am[-1]) == int(ids[0])
+    assert np.abs(g32 - hf).max() < 2e-3 and float(g["fp32_mode_err"]) < 2e-3
+    assert np.array_equal(g32.argmax(1)[:-1], ids[1:])
+
+
 def test_prefill_equals_incremental_decode():
     orc = O.OracleLlm(O.tiny_config(), seed=7)
     toks = np.array([5, 17, 300, 42, 9, 260], dtype=np.int32)
@@ -79,6 +104,53 @@ def test_q4k_known_answer_block():
     y = O.dequant_rows(O.TYPE_Q4_K, blk, 1, 256)[0]
     want = np.array([sc[i // 32] * (i & 15) - mn[i // 32] for i in range(256)], np.float32)
     assert np.array_equal(y, want)
+
+
+def test_q6k_known_answer_block():
+    """Q6_K block (210 B: ql[128] low nibbles, qh[64] high 2 bits, 16 int8 group scales, f16 d) decoded by the PUBLISHED loop of
+    ggml's dequantize_row_q6_K, written out here in its own form (two 128-weight halves, four interleaved quarters per byte pair) —
+    independent of csrc/common/tk_ggml_blocks.h's per-index formula — on random bytes, a hand-set block and extreme scales."""
+    def published(blk):
+        ql, qh = blk[0:128].astype(np.int32), blk[128:192].astype(np.int32)
+        sc = blk[192:208].view(np.int8).astype(np.float32)
+        d = np.float32(blk[208:210].view(np.float16)[0])
+        y = np.zeros(256, np.float32)
+        for half in range(2):
+            qlh, qhh, sch, yo = ql[64 * half:], qh[32 * half:], sc[8 * half:], 128 * half
+            for l in range(32):
+                i_s = l // 16
+                q1 = ((qlh[l] & 0xF) | (((qhh[l] >> 0) & 3) << 4)) - 32
+                q2 = ((qlh[l + 32] & 0xF) | (((qhh[l] >> 2) & 3) << 4)) - 32
+                q3 = ((qlh[l] >> 4) | (((qhh[l] >> 4) & 3) << 4)) - 32
+                q4 = ((qlh[l + 32] >> 4) | (((qhh[l] >> 6) & 3) << 4)) - 32
+                y[yo + l] = np.float32(d * sch[i_s + 0]) * np.float32(q1)
+                y[yo + l + 32] = np.float32(d * sch[i_s + 2]) * np.float32(q2)
+                y[yo + l + 64] = np.float32(d * sch[i_s + 4]) * np.float32(q3)
+                y[yo + l + 96] = np.float32(d * sch[i_s + 6]) * np.float32(q4)
+        return y
+
+    rng = np.random.default_rng(66)
+    for trial in range(8):
+        blk = rng.integers(0, 256, 210, dtype=np.uint8)
+        blk[208:210] = np.frombuffer(np.float16([0.5, -0.03125, 1.0, 0.007, 2.0, 0.25, 1e-3, 3.0][trial]).tobytes(), np.uint8)
+        if trial == 7:
+            blk[192:208] = np.array([-128, 127, 0, 1, -1, 64, -64, 2] * 2, np.int8).view(np.uint8)
+        got = O.dequant_rows(O.TYPE_Q6_K, blk, 1, 256)[0]
+        assert np.array_equal(got.view(np.uint32), published(blk).view(np.uint32)), trial
+    # hand-set block: d = 1, scale k = k + 1, 6-bit value of weight i = i % 64  ->  y_i = (i // 16 + 1) * (i % 64 - 32)
+    blk = np.zeros(210, np.uint8)
+    blk[208:210] = np.frombuffer(np.float16(1.0).tobytes(), np.uint8)
+    blk[192:208] = np.arange(1, 17, dtype=np.int8).view(np.uint8)
+    for i in range(256):
+        q = i % 64
+        half, r = divmod(i, 128)
+        quarter, l = divmod(r, 32)
+        j = 64 * half + 32 * (quarter & 1) + l
+        blk[j] |= (q & 15) << (4 if quarter >= 2 else 0)
+        blk[128 + 32 * half + l] |= (q >> 4) << (2 * quarter)
+    want = np.array([(i // 16 + 1) * (i % 64 - 32) for i in range(256)], np.float32)
+    assert np.array_equal(published(blk), want)                         # the layout statement itself is self-consistent
+    assert np.array_equal(O.dequant_rows(O.TYPE_Q6_K, blk, 1, 256)[0], want)
 
 
 def test_q8k_quantize_properties():

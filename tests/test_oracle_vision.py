@@ -51,6 +51,28 @@ def test_yolo_oracle_matches_torch_fixture():
     assert len(orc.layers()) == 63 and sum(l["w"].size + l["b"].size for l in orc.layers()) > 3_000_000
 
 
+def test_yolo_post_matches_independent_torch_detections():
+    """DFL decode + class-aware NMS against an independent torch implementation (Ultralytics decode, torchvision-style batched NMS):
+    anchor indices and classes identical, boxes / scores within 1e-3 (SURVEY 8c's yolo_tiny_dets)."""
+    g = np.load(os.path.join(GOLD, "yolo_tiny_dets.npz"))
+    orc = O.OracleYolo(nc=80, seed=5, cls_bias=-1.0)
+    raw = orc.forward(g["x"])[0]
+    boxes, cls, anc = orc.post(raw, 160, 160, float(g["conf"]), float(g["iou"]))
+    assert int(g["n_candidates"]) - len(g["torch_anchors"]) >= 3          # the fixture does exercise suppression
+    assert np.array_equal(anc, g["torch_anchors"]) and np.array_equal(cls, g["torch_cls"])
+    assert np.abs(boxes - g["torch_boxes"]).max() < 1e-3
+
+
+@pytest.mark.skipif(not O.have_ref() or not os.path.exists(os.path.join(O.ROOT, "oracle", "_ref", "libtkref_attr.so")), reason="compiled reference not built")
+def test_attribute_vectors_fixture_is_what_the_compiled_reference_answers():
+    import json
+    from make_vision_golden import attribute_vector_frames
+    j = json.load(open(os.path.join(GOLD, "attribute_vectors.json")))
+    for name, (frame, box) in attribute_vector_frames().items():
+        color, door = O.ref_attributes(frame, box)
+        assert j[name]["compiled_reference"] == {"color": color, "door": door}
+
+
 def test_nms_properties():
     orc = O.OracleYolo(nc=80, seed=5, cls_bias=-2.0)
     rng = np.random.default_rng(3)

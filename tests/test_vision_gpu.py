@@ -94,6 +94,18 @@ def test_detector_weights_from_onnx_file(gpu, tmp_path):
     assert np.array_equal(det16.forward_raw(x), detf.forward_raw(x))
 
 
+def test_detector_detections_match_independent_torch_fixture(gpu):
+    """HIP decode / rank / NMS kernels against detections computed by an independent torch post-processor (yolo_tiny_dets.npz):
+    anchor indices and classes identical, boxes within 1e-3 px."""
+    g = np.load(os.path.join(GOLD, "yolo_tiny_dets.npz"))
+    det = gpu.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-1", width=160, height=160, conf=float(g["conf"]), iou=float(g["iou"]))
+    det.forward_raw(g["x"])
+    boxes, cls, anc = det.last_boxes()
+    assert np.array_equal(anc, g["torch_anchors"]) and np.array_equal(cls, g["torch_cls"])
+    assert np.abs(boxes - g["torch_boxes"]).max() < 1e-3
+    det.close()
+
+
 def test_detector_full_frame_path_and_batch(gpu):
     """u8 frame -> preprocess -> network -> NMS -> original-frame rects, 160x160 network input, 2 frames"""
     rng = np.random.default_rng(8)
@@ -154,6 +166,26 @@ def test_box_attributes_equal_the_compiled_reference(gpu):
         assert gpu.classify_attributes(prim, (8 * i, 0, 8, 40))[0] == name
     assert gpu.classify_attributes(stripes, (5, 5, 40, 40))[1] == "closed"
     assert gpu.classify_attributes(prim, (0, 0, 8, 40))[1] == "open"
+
+
+def test_reference_attribute_test_vectors(gpu):
+    """tests/tk_attribute_classifier_test.c replayed verbatim: the pure-red 100 x 100 frame with box (10, 10, 80, 80) is "red" (:21-54);
+    the door vector (:56-91) gets what the reference's IMPLEMENTATION answers — "open", not the "closed" its test asserts: the frame has
+    vertical bands only and tk_classify_door_state thresholds the difference between the rows above and below (ABI_NOTES.md).  Expected
+    values: tests/golden/attribute_vectors.json = outputs of the compiled reference."""
+    import json
+    from make_vision_golden import attribute_vector_frames
+    j = json.load(open(os.path.join(GOLD, "attribute_vectors.json")))
+    fr = attribute_vector_frames()
+    red, box = fr["red_frame"]
+    assert list(box) == j["red_frame"]["bbox"] and red.shape == (100, 100, 3) and (red[..., 0] == 255).all() and not red[..., 1:].any()
+    got = gpu.classify_attributes(red, box)
+    assert got[0] == j["red_frame"]["reference_test_expects"]["color"] == "red"
+    assert {"color": got[0], "door": got[1]} == j["red_frame"]["compiled_reference"]
+    door, box = fr["door_frame"]
+    got = gpu.classify_attributes(door, box)
+    assert {"color": got[0], "door": got[1]} == j["door_frame"]["compiled_reference"]
+    assert got[1] == "open" and j["door_frame"]["reference_test_expects"]["door"] == "closed"   # the recorded contradiction
 
 
 def test_vision_pipeline_object_detection(gpu):

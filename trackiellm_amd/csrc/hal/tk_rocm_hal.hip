@@ -7,6 +7,7 @@
 
 #include "../vision/tk_vision_engine.h"
 #include "tk/tk_rocm_hal.h"
+#include "../nn/tk_nn_kernels.h"
 
 struct tk_gpu_buffer_s {
     void* dptr;
@@ -96,6 +97,16 @@ tk_error_code_t tk_kernels_postprocess_depth_map(const tk_postprocess_depth_para
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_postprocess_depth, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    return launch_status();
+}
+
+tk_error_code_t tk_kernels_softmax(const tk_softmax_params_t* p, tk_hip_stream_t stream) {
+    if (!p || !p->d_input_tensor || !p->d_output_tensor || p->num_rows == 0 || p->num_cols == 0) return TK_ERROR_INVALID_ARGUMENT;
+    if (p->d_output_tensor != p->d_input_tensor &&
+        hipMemcpyAsync(p->d_output_tensor, p->d_input_tensor, (size_t)p->num_rows * p->num_cols * sizeof(float), hipMemcpyDeviceToDevice,
+                       (hipStream_t)stream) != hipSuccess)
+        return TK_ERROR_GPU_ROCM_ERROR;
+    tk_launch_softmax_rows((float*)p->d_output_tensor, (int)p->num_rows, (int)p->num_cols, (int)p->num_cols, (hipStream_t)stream);
     return launch_status();
 }
 
