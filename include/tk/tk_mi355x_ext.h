@@ -47,6 +47,14 @@ TK_API void tk_mi355x_llm_model_get_hparams(const tk_mi355x_llm_model_t* m, tk_m
 TK_API uint64_t tk_mi355x_llm_model_weight_bytes(const tk_mi355x_llm_model_t* m);
 TK_API void tk_mi355x_llm_model_destroy(tk_mi355x_llm_model_t** m);
 
+/* continuous batching behind tk_llm_runner_* (csrc/llm/tk_llm_batcher.h): the runners created on one model handle (what
+ * tk_model_loader_load_model returns) share decode sessions of `slots` sequences; their prepare_generation / generate_next_token rows
+ * are coalesced into passes by one scheduler thread per session.  Set before the first tk_llm_runner_create on the model (default:
+ * $TK_MI355X_RUNNER_SLOTS, else 16; at most tk_mi355x_llm_max_rows()).  KV memory = slots x context_size x 128 KiB for Mistral-7B. */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_set_runner_slots(void* model_handle, int slots);
+/* what the schedulers of a model have done so far: passes run, rows processed, the widest pass */
+TK_API void tk_mi355x_llm_model_batch_stats(void* model_handle, uint64_t* passes, uint64_t* rows, int32_t* max_rows_in_a_pass);
+
 /* sessions --------------------------------------------------------------------------------- */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_session_create(tk_mi355x_llm_session_t** out, tk_mi355x_llm_model_t* m, int max_seq,
                                                                  int max_ctx);
@@ -73,6 +81,11 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t
 /* HIP-event timing of one GEMV launch on the session stream: which = 0 gate+up, 1 down, 2 qkv, 3 lm_head, 4 o */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int layer, int which, int nrows, int iters, float* avg_ms,
                                                             double* algorithmic_bytes);
+
+/* HIP-event timing of the decode attention launch (k_attention) at nrows rows whose sequences hold ctx cached positions; kv_bytes =
+ * the K / V bytes one launch must read once */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_time_attention(tk_mi355x_llm_session_t* s, int nrows, int ctx, int iters, float* avg_ms,
+                                                                 double* kv_bytes);
 
 /* ---- tool-call grammar (GBNF) — the sampling constraint of tk_llm_runner_prepare_generation(..., use_tool_grammar = true)
  * (reference: src/ai_models/grammars/tool_call.gbnf via llama.cpp's grammar sampler, tk_runner_lifecycle.c:59,

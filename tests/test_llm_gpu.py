@@ -490,3 +490,66 @@ def test_decode_with_kv_cache_matches_hf_fixture(gpu):
     got = np.stack([sess.forward([0], [P + i], [ids[i]])[0][0] for i in range(len(ids))])
     assert np.array_equal(got.view(np.uint32), g["oracle_step_logits"].view(np.uint32))
     assert np.abs(got - hf).max() < 0.05 * np.abs(hf).max()
+
+
+def test_runners_on_one_model_share_decode_passes(gpu):
+    """continuous batching behind the reference ABI (csrc/llm/tk_llm_batcher.h): K tk_llm_runner_t handles driven from K host threads
+    through tk_llm_runner_* only.  Every runner gets exactly the tokens it gets when it runs alone (and the oracle's), while the
+    scheduler's counters show that their rows shared passes."""
+    import threading
+    K, NTOK = 8, 12
+    loader = gpu.ModelLoader()
+    h = loader.load("synthetic://tiny?seed=4")
+    gpu.ModelLoader.set_runner_slots(h, K)
+    model = _BorrowedModel(gpu, h)
+    prompts = ["p%d %s" % (i, "ab" * i) for i in range(K)]          # different lengths: prompt chunks and decode rows mix in passes
+
+    def generate(runner, prompt):
+        runner.prepare(prompt)
+        out = []
+        for _ in range(NTOK):
+            p = runner.next_token()
+            if p is None:
+                break
+            out.append(p)
+        return out
+
+    # alone, one after the other
+    solo = []
+    r0 = gpu.LlmRunner(h, context_size=96)
+    for pr in prompts:
+        solo.append(generate(r0, pr))
+    r0.close()
+    p_before, rows_before, _ = gpu.ModelLoader.batch_stats(h)
+    assert 0 < p_before < rows_before                               # prompt chunks are multi-row passes
+    # the oracle agrees with the first one
+    orc = O.OracleLlm(oracle_cfg_from(model.hparams, 96, 1), seed=4)
+    ids = [1] + [3 + b for b in prompts[0].encode()]
+    _, am = orc.forward([0] * len(ids), list(range(len(ids))), ids, want_logits=False)
+    cur, want = int(am[-1]), []
+    for i in range(NTOK):
+        want.append(cur)
+        _, am = orc.forward([0], [len(ids) + i], [cur], want_logits=False)
+        cur = int(am[0])
+    assert _ids_of(solo[0]) == want[:len(solo[0])]
+    # together: K runners, K threads, twice (slots are reused after prepare_generation restarts a sequence)
+    runners = [gpu.LlmRunner(h, context_size=96) for _ in range(K)]
+    for rnd in range(2):
+        got = [None] * K
+        th = [threading.Thread(target=lambda i=i: got.__setitem__(i, generate(runners[i], prompts[i]))) for i in range(K)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert got == solo, f"round {rnd}: a runner's tokens changed when other runners shared its passes"
+    p_after, rows_after, widest = gpu.ModelLoader.batch_stats(h)
+    assert rows_after - rows_before == 2 * (rows_before)            # the same rows were fed, twice
+    assert widest >= 2 and (p_after - p_before) < 2 * K * NTOK, (p_after - p_before, widest)   # decode rows of several runners per pass
+    # a ninth runner on a full session gets a session of its own (still correct, not batched with the others)
+    extra = gpu.LlmRunner(h, context_size=96)
+    assert generate(extra, prompts[3]) == solo[3]
+    extra.close()
+    for r in runners:
+        r.close()
+    loader.unload(h)
+    loader.close()

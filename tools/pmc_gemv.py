@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same command) to HBM bytes per launch of the
-W4A8 kernels, per GEMV shape.  Usage: tools/pmc_gemv.py <fetch counter_collection.csv> <write counter_collection.csv> <rows> <out.json>
+W4A8 kernels, per GEMV shape.  Usage: tools/pmc_gemv.py <fetch counter_collection.csv> <write counter_collection.csv> <rows> profiles/rNN_pmc_{gemm|gemv}_b<rows>.json
+The summary is stamped with the sha of the kernel source it was collected from (bench.py reports `traffic` only on a match).
 
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts 64 B per 128 B request for 16 B/lane streams
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section); the shapes are told apart by (grid size, workgroup size, LDS size).
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha  # noqa: E402  (bench.py refuses a summary whose stamp differs from the source it runs)
 
 
 def load(path, counter, family):
@@ -35,7 +40,7 @@ def main():
         tot_n += len(f)
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the same eager bench command; "
                    "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction for 16 B/lane streams)",
-           "rows_per_pass": rows, "kernel": family, "per_variant": per, "hbm_bytes_per_average_launch": round(tot_b / max(tot_n, 1)), "launches": tot_n}
+           "rows_per_pass": rows, "kernel": family, "kernel_source_sha": kernel_source_sha(), "per_variant": per, "hbm_bytes_per_average_launch": round(tot_b / max(tot_n, 1)), "launches": tot_n}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in per.items()}, indent=1))
     print("average per launch:", out["hbm_bytes_per_average_launch"])

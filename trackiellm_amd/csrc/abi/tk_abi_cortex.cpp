@@ -1,6 +1,12 @@
 /*
  * tk_abi_cortex.cpp — minimal cortex: event queue (128, src/cortex/tk_cortex_main.c:527), one loop thread
  * (:957-994), video ring of 4 (:542), VAD -> ASR -> LLM and detect -> LLM triggers (:1081, :1224-1237).
+ *
+ * The reference runs detect -> prompt -> whole LLM response serially on the loop thread (:1149-1237, :1323-1379).  Here the three
+ * model streams run concurrently, each on its own host thread and HIP stream: VAD + ASR on the thread that injects audio (the
+ * reference's audio worker, src/audio/tk_audio_pipeline.c:550-609), the detector on the loop thread (tk_cortex_run), the LLM on a
+ * response thread fed by a small prompt queue — so the detector already works on frame k + 1 while the LLM answers frame k, and the
+ * LLM rows of K cortex handles that share a model file are decoded together (csrc/llm/tk_llm_batcher.h).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -12,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "tk/tk_audio.h"
@@ -21,6 +28,7 @@
 
 #define TK_CORTEX_QUEUE_CAP 128
 #define TK_CORTEX_VIDEO_RING 4
+#define TK_CORTEX_PROMPT_QUEUE 8 /* prompts waiting for the response thread; the oldest scene prompt is dropped when full */
 
 static const char* kCoco[80] = {"person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light", "fire hydrant",
     "stop sign", "parking meter", "bench", "bird", "cat", "dog", "horse", "sheep", "cow", "elephant", "bear", "zebra", "giraffe", "backpack", "umbrella",
@@ -58,6 +66,13 @@ struct tk_cortex_s {
     tk_mi355x_cortex_stats_t stats{};
     std::string last_response;
     mutable std::mutex stat_mu;
+    /* response thread */
+    std::thread llm_thread;
+    std::mutex llm_mu;
+    std::condition_variable llm_cv;
+    struct Prompt { std::string text; bool from_speech; };
+    std::deque<Prompt> prompts;
+    bool llm_stop = false;
 };
 
 static void set_state(tk_cortex_s* c, tk_system_state_e s) {
@@ -84,6 +99,36 @@ static void run_llm(tk_cortex_s* c, const std::string& prompt) {
         c->last_response = resp;
     }
     set_state(c, TK_STATE_IDLE);
+}
+
+/* hand a prompt to the response thread; user speech is never dropped, stale scene descriptions are */
+static void post_prompt(tk_cortex_s* c, std::string text, bool from_speech) {
+    std::lock_guard<std::mutex> lk(c->llm_mu);
+    if (c->prompts.size() >= TK_CORTEX_PROMPT_QUEUE) {
+        for (auto it = c->prompts.begin(); it != c->prompts.end(); ++it)
+            if (!it->from_speech) {
+                c->prompts.erase(it);
+                std::lock_guard<std::mutex> sl(c->stat_mu);
+                c->stats.events_dropped++;
+                break;
+            }
+    }
+    c->prompts.push_back(tk_cortex_s::Prompt{std::move(text), from_speech});
+    c->llm_cv.notify_one();
+}
+
+static void llm_worker(tk_cortex_s* c) {
+    for (;;) {
+        tk_cortex_s::Prompt p;
+        {
+            std::unique_lock<std::mutex> lk(c->llm_mu);
+            c->llm_cv.wait(lk, [&] { return c->llm_stop || !c->prompts.empty(); });
+            if (c->llm_stop) return;
+            p = std::move(c->prompts.front());
+            c->prompts.pop_front();
+        }
+        run_llm(c, p.text);
+    }
 }
 
 extern "C" {
@@ -132,6 +177,7 @@ tk_error_code_t tk_cortex_create(tk_cortex_t** out_cortex, const tk_cortex_confi
     tk_llm_config_t rcfg{4096, NULL, 0}; /* n_ctx 4096: tk_runner_lifecycle.c:48 */
     if ((rc = tk_llm_runner_create(&c->runner, c->llm_model, &rcfg)) != TK_SUCCESS) return fail(rc);
 
+    c->llm_thread = std::thread(llm_worker, c.get());
     set_state(c.get(), TK_STATE_IDLE);
     *out_cortex = c.release();
     return TK_SUCCESS;
@@ -143,6 +189,12 @@ void tk_cortex_destroy(tk_cortex_t** cortex) {
     c->stop.store(true);
     c->cv.notify_all();
     set_state(c, TK_STATE_SHUTDOWN);
+    {
+        std::lock_guard<std::mutex> lk(c->llm_mu);
+        c->llm_stop = true;
+    }
+    c->llm_cv.notify_all();
+    if (c->llm_thread.joinable()) c->llm_thread.join(); /* run_llm leaves its token loop as soon as `stop` is set */
     if (c->runner) tk_llm_runner_destroy(&c->runner);
     if (c->loader) { if (c->llm_model) (void)tk_model_loader_unload_model(c->loader, &c->llm_model); tk_model_loader_destroy(&c->loader); }
     if (c->det) tk_object_detector_destroy(&c->det);
@@ -190,9 +242,9 @@ tk_error_code_t tk_cortex_run(tk_cortex_t* c) {
                 c->stats.frames_processed++;
                 if (n > 0) c->stats.frames_with_objects++;
             }
-            if (n > 0) run_llm(c, ctx); /* SIGNIFICANT_VISION_CHANGE: every frame with >= 1 detection (tk_cortex_main.c:1224-1237) */
+            if (n > 0) post_prompt(c, ctx, false); /* SIGNIFICANT_VISION_CHANGE: every frame with >= 1 detection (tk_cortex_main.c:1224-1237) */
         } else {
-            run_llm(c, "User said: " + ev.text);
+            post_prompt(c, "User said: " + ev.text, true);
         }
     }
     return TK_SUCCESS;

@@ -16,6 +16,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -23,6 +24,7 @@
 
 #include "../llm/tk_gguf.h"
 #include "../llm/tk_grammar.h"
+#include "../llm/tk_llm_batcher.h"
 #include "../llm/tk_llm_engine.h"
 #include "../llm/tk_tokenizer.h"
 #include "../common/tk_ggml_blocks.h"
@@ -35,6 +37,11 @@ struct tk_mi355x_llm_model_s {
     int context_length = 4096;
     std::string path;
     int refcount = 1;
+    /* continuous batching behind tk_llm_runner_*: the runners created on this model share decode sessions (declared after `model`:
+     * destroyed before it) */
+    std::mutex batch_mu;
+    std::vector<std::unique_ptr<TkLlmBatcher>> batchers;
+    int runner_slots = 0; /* sequences per shared session; 0 = $TK_MI355X_RUNNER_SLOTS or 16 */
 };
 
 struct tk_mi355x_llm_session_s {
@@ -251,6 +258,38 @@ tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int layer, i
     return TK_SUCCESS;
 }
 
+tk_error_code_t tk_mi355x_llm_time_attention(tk_mi355x_llm_session_t* s, int nrows, int ctx, int iters, float* avg_ms, double* kv_bytes) {
+    if (!s || !avg_ms || !kv_bytes) return TK_ERROR_INVALID_ARGUMENT;
+    if (!s->session.time_attention(nrows, ctx, iters, avg_ms, kv_bytes)) return fail(TK_ERROR_GPU_ROCM_ERROR, s->session.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_model_set_runner_slots(void* model_handle, int slots) {
+    if (!model_handle || slots < 1 || slots > TK_MAX_ROWS) return TK_ERROR_INVALID_ARGUMENT;
+    tk_mi355x_llm_model_t* m = (tk_mi355x_llm_model_t*)model_handle;
+    std::lock_guard<std::mutex> lk(m->batch_mu);
+    m->runner_slots = slots;
+    return TK_SUCCESS;
+}
+
+void tk_mi355x_llm_model_batch_stats(void* model_handle, uint64_t* passes, uint64_t* rows, int32_t* max_rows_in_a_pass) {
+    uint64_t p = 0, r = 0;
+    int mx = 0;
+    if (model_handle) {
+        tk_mi355x_llm_model_t* m = (tk_mi355x_llm_model_t*)model_handle;
+        std::lock_guard<std::mutex> lk(m->batch_mu);
+        for (auto& b : m->batchers) {
+            uint64_t bp, br;
+            int bm;
+            b->stats(&bp, &br, &bm);
+            p += bp; r += br; mx = bm > mx ? bm : mx;
+        }
+    }
+    if (passes) *passes = p;
+    if (rows) *rows = r;
+    if (max_rows_in_a_pass) *max_rows_in_a_pass = mx;
+}
+
 /* grammar engine entry points (no GPU involved): used by the CPU tests and by hosts that want the tool-call text */
 tk_error_code_t tk_mi355x_grammar_check(const char* gbnf, const char* text, int32_t* n_accepted, int32_t* complete) {
     if (!text || !n_accepted || !complete) return TK_ERROR_INVALID_ARGUMENT;
@@ -287,9 +326,32 @@ tk_error_code_t tk_mi355x_grammar_next_bytes(const char* gbnf, const char* prefi
 
 struct tk_model_loader_s {
     std::mutex mu;
-    std::vector<tk_mi355x_llm_model_t*> models;
+    std::vector<tk_mi355x_llm_model_t*> held; /* one entry per successful load_model: the references this loader owns */
     uint32_t max_models = 4;
 };
+
+/* Weights are immutable and 4.3 GB: a model file resident on a device is shared by every loader of the process (the reference caches
+ * per loader, src/ai_models/tk_model_loader.c:918-1083; K cortex handles — each with its own loader, tk_cortex_main.c:779-925 — would
+ * otherwise hold K copies and could not share decode passes).  force_reload loads a private copy. */
+static std::mutex g_models_mu;
+static std::vector<tk_mi355x_llm_model_t*> g_models;
+
+static void release_model(tk_mi355x_llm_model_t* m) { /* g_models_mu held */
+    if (--m->refcount > 0) return;
+    for (size_t i = 0; i < g_models.size(); ++i)
+        if (g_models[i] == m) { g_models.erase(g_models.begin() + i); break; }
+    tk_mi355x_llm_model_destroy(&m);
+}
+
+static size_t distinct_held(const tk_model_loader_s* l) {
+    size_t n = 0;
+    for (size_t i = 0; i < l->held.size(); ++i) {
+        bool seen = false;
+        for (size_t j = 0; j < i; ++j) seen = seen || l->held[j] == l->held[i];
+        n += seen ? 0 : 1;
+    }
+    return n;
+}
 
 tk_error_code_t tk_model_loader_create(tk_model_loader_t** out_loader, const tk_model_loader_config_t* config) {
     if (!out_loader || !config) return TK_ERROR_INVALID_ARGUMENT;
@@ -301,7 +363,10 @@ tk_error_code_t tk_model_loader_create(tk_model_loader_t** out_loader, const tk_
 
 void tk_model_loader_destroy(tk_model_loader_t** loader) {
     if (!loader || !*loader) return;
-    for (auto* m : (*loader)->models) tk_mi355x_llm_model_destroy(&m);
+    {
+        std::lock_guard<std::mutex> gl(g_models_mu);
+        for (auto* m : (*loader)->held) release_model(m);
+    }
     delete *loader;
     *loader = nullptr;
 }
@@ -325,11 +390,21 @@ tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_m
     if (params->lora_adapter) return fail(TK_ERROR_NOT_IMPLEMENTED, "LoRA adapters are out of scope of the MI355X path");
     if (params->model_type == TK_MODEL_FORMAT_ONNX) return fail(TK_ERROR_NOT_IMPLEMENTED, "ONNX graphs are not interpreted: the detector/ASR/VAD streams have dedicated entry points");
     std::lock_guard<std::mutex> lk(loader->mu);
+    std::lock_guard<std::mutex> gl(g_models_mu); /* also serialises loads: two threads asking for the same file get one copy */
     const std::string path = params->model_path->path_str;
+    const int device = tk_mi355x_get_default_device();
     if (!params->force_reload)
-        for (auto* m : loader->models)
-            if (m->path == path) { m->refcount++; *out_model_handle = m; return TK_SUCCESS; }
-    if (loader->models.size() >= loader->max_models) return fail(TK_ERROR_OUT_OF_MEMORY, "model cache full (max_models)");
+        for (auto* m : g_models)
+            if (m->path == path && m->model.device == device) {
+                bool mine = false;
+                for (auto* h : loader->held) mine = mine || h == m;
+                if (!mine && distinct_held(loader) >= loader->max_models) return fail(TK_ERROR_OUT_OF_MEMORY, "model cache full (max_models)");
+                m->refcount++;
+                loader->held.push_back(m);
+                *out_model_handle = m;
+                return TK_SUCCESS;
+            }
+    if (distinct_held(loader) >= loader->max_models) return fail(TK_ERROR_OUT_OF_MEMORY, "model cache full (max_models)");
     tk_mi355x_llm_model_t* m = nullptr;
     std::string name;
     uint64_t seed;
@@ -339,15 +414,16 @@ tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_m
         if (name == "mistral-7b") h = tk_mi355x_llm_hparams_t{32, 4096, 32, 8, 128, 14336, 32000, 1e-5f, 10000.0f, 0, 0, 0, 0, 1};
         else if (name == "tiny") h = tk_mi355x_llm_hparams_t{2, 256, 8, 2, 64, 512, 512, 1e-5f, 10000.0f, 0, 0, 0, 0, 1};
         else return fail(TK_ERROR_FILE_NOT_FOUND, "unknown synthetic model: " + name);
-        rc = tk_mi355x_llm_model_create(&m, &h, tk_mi355x_get_default_device());
+        rc = tk_mi355x_llm_model_create(&m, &h, device);
         if (rc == TK_SUCCESS) rc = tk_mi355x_llm_model_fill_synthetic(m, seed);
         if (rc != TK_SUCCESS) { tk_mi355x_llm_model_destroy(&m); return rc; }
         m->path = path;
     } else {
-        rc = tk_mi355x_llm_model_load_gguf(&m, path.c_str(), tk_mi355x_get_default_device());
+        rc = tk_mi355x_llm_model_load_gguf(&m, path.c_str(), device);
         if (rc != TK_SUCCESS) return rc;
     }
-    loader->models.push_back(m);
+    if (!params->force_reload) g_models.push_back(m); /* a force-reloaded copy stays private to its handle */
+    loader->held.push_back(m);
     *out_model_handle = m;
     return TK_SUCCESS;
 }
@@ -355,12 +431,11 @@ tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_m
 tk_error_code_t tk_model_loader_unload_model(tk_model_loader_t* loader, void** model_handle) {
     if (!loader || !model_handle || !*model_handle) return TK_ERROR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(loader->mu);
-    for (size_t i = 0; i < loader->models.size(); ++i)
-        if (loader->models[i] == *model_handle) {
-            if (--loader->models[i]->refcount <= 0) {
-                tk_mi355x_llm_model_destroy(&loader->models[i]);
-                loader->models.erase(loader->models.begin() + i);
-            }
+    std::lock_guard<std::mutex> gl(g_models_mu);
+    for (size_t i = 0; i < loader->held.size(); ++i)
+        if (loader->held[i] == *model_handle) {
+            loader->held.erase(loader->held.begin() + i);
+            release_model((tk_mi355x_llm_model_t*)*model_handle);
             *model_handle = nullptr;
             return TK_SUCCESS;
         }
@@ -369,7 +444,8 @@ tk_error_code_t tk_model_loader_unload_model(tk_model_loader_t* loader, void** m
 
 struct tk_llm_runner_s {
     tk_mi355x_llm_model_t* model = nullptr;
-    tk_mi355x_llm_session_t* session = nullptr;
+    TkLlmBatcher* batcher = nullptr; /* shared with the other runners of the model */
+    int slot = -1;                   /* this runner's sequence in the shared KV cache */
     int n_ctx = 0;
     int n_past = 0;
     int32_t pending = -1; /* token sampled from the last logits, not yet decoded */
@@ -425,8 +501,22 @@ tk_error_code_t tk_llm_runner_create(tk_llm_runner_t** out_runner, void* model_h
     r->model = (tk_mi355x_llm_model_t*)model_handle;
     r->n_ctx = config->context_size ? (int)config->context_size : 4096;
     if (config->system_prompt) r->system_prompt = config->system_prompt;
-    tk_error_code_t rc = tk_mi355x_llm_session_create(&r->session, r->model, 1, r->n_ctx);
-    if (rc != TK_SUCCESS) return rc;
+    {   /* a sequence slot in a shared session of this context size; a new session when every slot is taken */
+        std::lock_guard<std::mutex> lk(r->model->batch_mu);
+        for (auto& b : r->model->batchers)
+            if (b->n_ctx() == r->n_ctx && (r->slot = b->acquire_slot()) >= 0) { r->batcher = b.get(); break; }
+        if (!r->batcher) {
+            int slots = r->model->runner_slots;
+            if (slots <= 0) { const char* e = getenv("TK_MI355X_RUNNER_SLOTS"); slots = e ? atoi(e) : 0; }
+            if (slots <= 0) slots = 16;
+            std::unique_ptr<TkLlmBatcher> b(new TkLlmBatcher());
+            std::string err;
+            if (!b->init(&r->model->model, slots, r->n_ctx, &err)) return fail(TK_ERROR_GPU_MEMORY, err);
+            r->slot = b->acquire_slot();
+            r->batcher = b.get();
+            r->model->batchers.push_back(std::move(b));
+        }
+    }
     std::string gerr;
     r->has_grammar = r->grammar.parse(load_tool_grammar_text(), &gerr);
     if (!r->has_grammar) tk_error_set_detail("tool-call grammar rejected (%s): tool grammar disabled", gerr.c_str()); /* the reference logs and goes on */
@@ -436,25 +526,19 @@ tk_error_code_t tk_llm_runner_create(tk_llm_runner_t** out_runner, void* model_h
 
 void tk_llm_runner_destroy(tk_llm_runner_t** runner) {
     if (!runner || !*runner) return;
-    tk_mi355x_llm_session_destroy(&(*runner)->session);
+    if ((*runner)->batcher) (*runner)->batcher->release_slot((*runner)->slot); /* the shared session lives as long as the model */
     delete *runner;
     *runner = nullptr;
 }
 
-/* feed `toks` at positions n_past.. ; the last one is sampled */
+/* feed `toks` at positions n_past.. ; the last one is sampled.  The rows join whatever passes the model's scheduler is forming. */
 static tk_error_code_t feed(tk_llm_runner_s* r, const std::vector<int32_t>& toks) {
     if (toks.empty()) return TK_SUCCESS;
     if (r->n_past + (int)toks.size() >= r->n_ctx) return fail(TK_ERROR_INFERENCE_FAILED, "prompt exceeds the context window");
-    TkLlmSession& s = r->session->session;
-    std::vector<int32_t> sq, ps, tk;
-    size_t i = 0;
-    while (i + 1 < toks.size()) {
-        sq.clear(); ps.clear(); tk.clear();
-        while (i + 1 < toks.size() && sq.size() < TK_MAX_ROWS) { sq.push_back(0); ps.push_back(r->n_past++); tk.push_back(toks[i++]); }
-        if (!s.forward((int)sq.size(), sq.data(), ps.data(), tk.data(), nullptr, nullptr, false)) return fail(TK_ERROR_INFERENCE_FAILED, s.error);
-    }
-    int32_t z = 0, p = r->n_past++, t = toks.back(), am = -1;
-    if (!s.forward(1, &z, &p, &t, nullptr, &am, true, r->next_mask())) return fail(TK_ERROR_INFERENCE_FAILED, s.error);
+    int32_t am = -1;
+    std::string err;
+    if (!r->batcher->submit(r->slot, r->n_past, toks.data(), (int)toks.size(), r->next_mask(), &am, &err)) return fail(TK_ERROR_INFERENCE_FAILED, err);
+    r->n_past += (int)toks.size();
     r->pending = am;
     return TK_SUCCESS;
 }
@@ -496,9 +580,10 @@ const char* tk_llm_runner_generate_next_token(tk_llm_runner_t* runner) {
         }
     }
     if (runner->n_past + 1 >= runner->n_ctx) { runner->is_processing = false; return NULL; }
-    int32_t z = 0, p = runner->n_past, t = id, am = -1;
-    if (!runner->session->session.forward(1, &z, &p, &t, nullptr, &am, true, runner->next_mask())) {
-        tk_error_set_detail("%s", runner->session->session.error.c_str());
+    int32_t t = id, am = -1;
+    std::string err;
+    if (!runner->batcher->submit(runner->slot, runner->n_past, &t, 1, runner->next_mask(), &am, &err)) {
+        tk_error_set_detail("%s", err.c_str());
         runner->is_processing = false;
         return NULL;
     }

@@ -1,0 +1,64 @@
+/*
+ * tk_llm_batcher.h — continuous batching behind the reference's one-sequence-per-runner API.
+ *
+ * The reference gives every tk_llm_runner_t its own llama context and decodes one token per call on the caller's thread
+ * (src/ai_models/tk_runner_streaming.c:57-85, contract src/ai_models/tk_model_runner.h:164-181).  Behind the same calls, all runners
+ * created on one model share ONE decode session here: a runner owns a sequence slot of the session's KV cache; prepare_generation /
+ * generate_next_token / add_tool_response enqueue their (sequence, position, token) rows and block; one scheduler thread per model
+ * coalesces whatever is ready — prompt chunks and single decode rows of different runners alike — into passes of up to 256 rows, so
+ * K host threads that each drive "their" runner read the 4.3 GB of weights once per step instead of K times.
+ * A row's result does not depend on which other rows share its pass (bit-identical logits at any pass width:
+ * tests/test_llm_gpu.py::test_full_7b_pass_width_invariance), so a runner sees exactly the tokens it would see alone.
+ */
+#ifndef TK_LLM_BATCHER_H
+#define TK_LLM_BATCHER_H
+
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "tk_llm_engine.h"
+
+class TkLlmBatcher {
+public:
+    ~TkLlmBatcher();
+    /* one session with `slots` sequences of `n_ctx` positions on the model's device; starts the scheduler thread */
+    bool init(TkLlmModel* model, int slots, int n_ctx, std::string* err);
+    int acquire_slot();            /* -1 when every slot is taken */
+    void release_slot(int slot);
+    int n_ctx() const { return n_ctx_; }
+    int slots() const { return (int)slot_used_.size(); }
+    /* Blocking: feed `n` tokens of sequence `slot` at positions pos0, pos0 + 1, ...; *sampled = arg max after the last one (over the
+     * tokens `mask` allows, when given: (vocab + 31) / 32 words, bit t = token t).  Thread-safe; one outstanding call per slot. */
+    bool submit(int slot, int pos0, const int32_t* toks, int n, const uint32_t* mask, int32_t* sampled, std::string* err);
+    /* counters for tests and bench: passes run, rows processed, the widest pass so far */
+    void stats(uint64_t* passes, uint64_t* rows, int* max_rows);
+
+private:
+    struct Request {
+        int slot, pos0, n, done_rows = 0;
+        const int32_t* toks;
+        const uint32_t* mask;
+        int32_t sampled = -1;
+        bool finished = false, ok = true;
+        std::string error;
+        std::condition_variable cv;
+    };
+    void loop();
+    TkLlmSession session_;
+    int n_ctx_ = 0;
+    std::vector<char> slot_used_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Request*> queue_;
+    bool stop_ = false;
+    size_t expect_ = 0; /* requests finished by the last pass: their owners are about to submit the next token */
+    uint64_t passes_ = 0, rows_ = 0;
+    int max_rows_ = 0;
+    std::thread worker_;
+};
+
+#endif

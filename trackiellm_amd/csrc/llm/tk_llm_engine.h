@@ -95,6 +95,8 @@ public:
     float last_step_ms = 0.0f;
     /* stand-alone timing of the dominant GEMV (gate/up of layer 0) for bench.py's roofline leg */
     bool time_gemv(int layer, int which, int nrows, int iters, float* avg_ms, double* algo_bytes);
+    /* stand-alone timing of the decode attention launch at nrows rows x ctx cached positions, for bench.py's second roofline object */
+    bool time_attention(int nrows, int ctx, int iters, float* avg_ms, double* kv_bytes);
 
 private:
     void enqueue_pass(int nrows, bool lm_head, bool fused_attn);
@@ -106,7 +108,12 @@ private:
     uint32_t* d_mask = nullptr; /* allowed-token bits of the current pass, or unused */
     bool mask_on = false;
     int hist_cap = 0;
-    hipGraphExec_t graph_exec[TK_MAX_ROWS + 1] = {};
+    hipGraphExec_t graph_exec[TK_MAX_ROWS + 1] = {};    /* decode pass (head + sampling, fused attention), by row count */
+    hipGraphExec_t graph_prefill[TK_MAX_ROWS + 1] = {}; /* prompt pass (no head, rope/append as its own kernel), by row count */
+    hipGraphExec_t graph_head_nf[TK_MAX_ROWS + 1] = {}; /* sampling pass that holds several positions of one sequence (a prompt's last chunk) */
+    int32_t* d_tab = nullptr;                           /* prefill schedule: [3][total rows] = seq, pos, tok */
+    size_t tab_cap = 0;
+    bool capture_pass(hipGraphExec_t* slot, int nrows, bool lm_head, bool fused_attn);
 };
 
 #endif

@@ -244,7 +244,9 @@ TkLlmSession::~TkLlmSession() {
     if (model) (void)hipSetDevice(model->device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto& g : graph_exec) if (g) (void)hipGraphExecDestroy(g);
-    void* ptrs[] = {kcache, vcache, x, qbuf, partial, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask};
+    for (auto& g : graph_prefill) if (g) (void)hipGraphExecDestroy(g);
+    for (auto& g : graph_head_nf) if (g) (void)hipGraphExecDestroy(g);
+    void* ptrs[] = {kcache, vcache, x, qbuf, partial, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     free_act(&act_d); free_act(&act_qd); free_act(&act_ff);
     if (stream) (void)hipStreamDestroy(stream);
@@ -313,6 +315,28 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
     tk_launch_argmax(logits, h.vocab, nrows, mask_on ? d_mask : nullptr, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
 }
 
+static bool graphs_enabled() {
+    /* TK_MI355X_NO_GRAPH=1: eager launches, for profilers that cannot follow hipGraphLaunch (see DESIGN.md "Profiling") */
+    const char* ng = getenv("TK_MI355X_NO_GRAPH");
+    return !(ng && ng[0] == '1');
+}
+
+/* one capture at a time per process; relaxed mode: other host threads (detector / ASR / VAD streams) keep calling allocation and copy
+ * APIs while this stream records */
+static std::mutex g_capture_mu;
+
+bool TkLlmSession::capture_pass(hipGraphExec_t* slot, int nrows, bool lm_head, bool fused_attn) {
+    if (*slot) return true;
+    std::lock_guard<std::mutex> lk(g_capture_mu);
+    hipGraph_t g = nullptr;
+    HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+    enqueue_pass(nrows, lm_head, fused_attn);
+    HIPQ(hipStreamEndCapture(stream, &g));
+    HIPQ(hipGraphInstantiate(slot, g, nullptr, nullptr, 0));
+    HIPQ(hipGraphDestroy(g));
+    return true;
+}
+
 bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
                            bool lm_head, const uint32_t* allow_mask) {
     if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,256]"; return false; }
@@ -333,7 +357,16 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
             if (seq[a] == seq[b]) { distinct = false; break; }
     if (allow_mask && lm_head) HIPQ(hipMemcpyAsync(d_mask, allow_mask, ((size_t)model->hp.vocab + 31) / 32 * 4, hipMemcpyHostToDevice, stream));
     mask_on = allow_mask != nullptr && lm_head;
-    enqueue_pass(nrows, lm_head, distinct);
+    /* unmasked passes replay a captured pass (one graph per (row count, form)): a host that asks for one token at a time — the
+     * reference's runner API — pays one graph launch, not ~260 kernel launches, per token */
+    hipGraphExec_t* slot = mask_on || !graphs_enabled() ? nullptr
+                           : !lm_head ? &graph_prefill[nrows] : distinct ? &graph_exec[nrows] : &graph_head_nf[nrows];
+    if (slot) {
+        if (!capture_pass(slot, nrows, lm_head, lm_head && distinct)) { mask_on = false; return false; }
+        HIPQ(hipGraphLaunch(*slot, stream));
+    } else {
+        enqueue_pass(nrows, lm_head, distinct);
+    }
     mask_on = false;
     HIPQ(hipGetLastError());
     if (!lm_head) { HIPQ(hipStreamSynchronize(stream)); return true; }
@@ -375,25 +408,51 @@ bool TkLlmSession::forward_stage(int nrows, const int32_t* seq, const int32_t* p
     return true;
 }
 
+__global__ void k_stage_rows(const int32_t* __restrict__ tab, int n, int stride, int32_t* seq, int32_t* pos, int32_t* tok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { seq[i] = tab[i]; pos[i] = tab[stride + i]; tok[i] = tab[2 * stride + i]; }
+}
+
+/* Prompt rows that nobody samples from (all but the last token of every prompt): the whole schedule — (sequence, position, token) of
+ * every row of every pass — is uploaded once, each pass is one tiny staging launch + one replay of a captured pass (no lm_head,
+ * rope/append as its own kernel so a pass may hold several positions of one sequence), and the host synchronises once, in the final
+ * sampling pass.  Same kernels, same order, same arithmetic as forward(): bit-identical results. */
 bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens_host) {
     if (nseq <= 0 || nseq > TK_MAX_ROWS || nseq > max_seq) { error = "nseq must be in [1, min(256, max_seq)]"; return false; }
     if (n_prompt <= 0 || n_prompt >= max_ctx) { error = "prompt does not fit the context"; return false; }
-    /* all but the last prompt token: 16 rows per pass, positions ascending so causality holds inside a pass */
-    std::vector<int32_t> sq, ps, tk;
-    auto flush = [&]() -> bool {
-        if (sq.empty()) return true;
-        bool ok = forward((int)sq.size(), sq.data(), ps.data(), tk.data(), nullptr, nullptr, false);
-        sq.clear(); ps.clear(); tk.clear();
-        return ok;
-    };
-    for (int s = 0; s < nseq; ++s)
-        for (int p = 0; p + 1 < n_prompt; ++p) {
-            sq.push_back(s); ps.push_back(p); tk.push_back(tokens[(size_t)s * n_prompt + p]);
-            if ((int)sq.size() == TK_MAX_ROWS && !flush()) return false;
+    for (int64_t i = 0; i < (int64_t)nseq * n_prompt; ++i)
+        if (tokens[i] < 0 || tokens[i] >= model->hp.vocab) { error = "row out of range (sequence id, position or token id)"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    /* all but the last prompt token: up to 256 rows per pass, positions ascending inside a sequence so causality holds inside a pass */
+    const int64_t total = (int64_t)nseq * (n_prompt - 1);
+    if (total > 0) {
+        std::vector<int32_t> tab((size_t)3 * total);
+        int64_t k = 0;
+        for (int s = 0; s < nseq; ++s)
+            for (int p = 0; p + 1 < n_prompt; ++p, ++k) {
+                tab[k] = s; tab[total + k] = p; tab[2 * total + k] = tokens[(size_t)s * n_prompt + p];
+            }
+        if ((int64_t)tab_cap < 3 * total) {
+            if (d_tab) (void)hipFree(d_tab);
+            d_tab = nullptr;
+            HIPQ(hipMalloc((void**)&d_tab, (size_t)3 * total * 4));
+            tab_cap = (size_t)3 * total;
         }
-    if (!flush()) return false;
+        HIPQ(hipMemcpyAsync(d_tab, tab.data(), (size_t)3 * total * 4, hipMemcpyHostToDevice, stream));
+        HIPQ(hipStreamSynchronize(stream)); /* `tab` is pageable host memory that dies with this scope */
+        const bool use_graph = graphs_enabled();
+        for (int64_t off = 0; off < total; off += TK_MAX_ROWS) {
+            const int n = (int)std::min<int64_t>(TK_MAX_ROWS, total - off);
+            if (use_graph && !capture_pass(&graph_prefill[n], n, false, false)) return false;
+            hipLaunchKernelGGL(k_stage_rows, dim3((n + 255) / 256), dim3(256), 0, stream, d_tab + off, n, (int)total, d_seq, d_pos, d_tok);
+            if (use_graph) HIPQ(hipGraphLaunch(graph_prefill[n], stream));
+            else enqueue_pass(n, false, false);
+        }
+        HIPQ(hipGetLastError());
+    }
     /* last prompt token of every sequence: row r == sequence r, sampled -> decode() continues from here */
-    for (int s = 0; s < nseq; ++s) { sq.push_back(s); ps.push_back(n_prompt - 1); tk.push_back(tokens[(size_t)s * n_prompt + n_prompt - 1]); }
+    std::vector<int32_t> sq(nseq), ps(nseq), tk(nseq);
+    for (int s = 0; s < nseq; ++s) { sq[s] = s; ps[s] = n_prompt - 1; tk[s] = tokens[(size_t)s * n_prompt + n_prompt - 1]; }
     return forward(nseq, sq.data(), ps.data(), tk.data(), nullptr, first_tokens_host, true);
 }
 
@@ -407,21 +466,8 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     HIPQ(hipStreamSynchronize(stream));
     for (int r = 0; r < nrows; ++r)
         if (hpos[r] + n_steps > max_ctx) { error = "decode would run past max_ctx"; return false; }
-    /* TK_MI355X_NO_GRAPH=1: eager launches (rocprofv3's kernel trace crashes inside hipGraphLaunch on ROCm 7.2) */
-    const char* ng = getenv("TK_MI355X_NO_GRAPH");
-    const bool use_graph = !(ng && ng[0] == '1');
-    if (use_graph && !graph_exec[nrows]) {
-        /* one capture at a time per process; relaxed mode: other host threads (detector / ASR / VAD streams) keep calling
-         * allocation and copy APIs while this stream records */
-        static std::mutex capture_mu;
-        std::lock_guard<std::mutex> lk(capture_mu);
-        hipGraph_t g = nullptr;
-        HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-        enqueue_pass(nrows, true, true);
-        HIPQ(hipStreamEndCapture(stream, &g));
-        HIPQ(hipGraphInstantiate(&graph_exec[nrows], g, nullptr, nullptr, 0));
-        HIPQ(hipGraphDestroy(g));
-    }
+    const bool use_graph = graphs_enabled();
+    if (use_graph && !capture_pass(&graph_exec[nrows], nrows, true, true)) return false;
     HIPQ(hipMemsetAsync(d_nsteps, 0, TK_MAX_ROWS * 4, stream));
     hipEvent_t e0, e1;
     HIPQ(hipEventCreate(&e0));
@@ -495,12 +541,10 @@ bool TkLlmSession::time_gemv(int layer, int which, int nrows, int iters, float* 
     HIPQ(hipEventCreate(&e1));
     for (size_t i = 0; i < set.size(); ++i) tk_launch_gemv(set[i], stream);
     /* launched the way decode() launches them: as nodes of a hipGraph (unless TK_MI355X_NO_GRAPH=1, see decode()) */
-    const char* ng = getenv("TK_MI355X_NO_GRAPH");
-    const bool use_graph = !(ng && ng[0] == '1');
+    const bool use_graph = graphs_enabled();
     hipGraphExec_t ge = nullptr;
     if (use_graph) {
-        static std::mutex capture_mu;
-        std::lock_guard<std::mutex> lk(capture_mu);
+        std::lock_guard<std::mutex> lk(g_capture_mu);
         hipGraph_t g = nullptr;
         HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
         for (int i = 0; i < iters; ++i) tk_launch_gemv(set[(size_t)i % set.size()], stream);
@@ -512,6 +556,54 @@ bool TkLlmSession::time_gemv(int layer, int which, int nrows, int iters, float* 
     HIPQ(hipEventRecord(e0, stream));
     if (use_graph) HIPQ(hipGraphLaunch(ge, stream));
     else for (int i = 0; i < iters; ++i) tk_launch_gemv(set[(size_t)i % set.size()], stream);
+    HIPQ(hipEventRecord(e1, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    if (ge) (void)hipGraphExecDestroy(ge);
+    float ms = 0.0f;
+    HIPQ(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return true;
+}
+
+/* stand-alone timing of the decode attention launch (k_attention, fused rope/append form) at `nrows` rows whose sequences all sit at
+ * position ctx - 1: `iters` launches cycling through the layers (each layer's cache region is its own HBM range), launched as hipGraph
+ * nodes like decode().  kv_bytes = the K and V rows one launch must read once: nrows * ctx * n_kv_head * head_dim * 2 B * 2. */
+bool TkLlmSession::time_attention(int nrows, int ctx, int iters, float* avg_ms, double* kv_bytes) {
+    const TkLlmHParams& h = model->hp;
+    if (nrows < 1 || nrows > TK_MAX_ROWS || nrows > max_seq || ctx < 1 || ctx > max_ctx || iters < 1) { error = "bad nrows / ctx / iters"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    std::vector<int32_t> sq(nrows), ps(nrows, ctx - 1);
+    for (int r = 0; r < nrows; ++r) sq[r] = r;
+    HIPQ(hipMemcpyAsync(d_seq, sq.data(), nrows * 4, hipMemcpyHostToDevice, stream));
+    HIPQ(hipMemcpyAsync(d_pos, ps.data(), nrows * 4, hipMemcpyHostToDevice, stream));
+    HIPQ(hipStreamSynchronize(stream));
+    const int QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim;
+    auto launch = [&](int l) {
+        tk_launch_attention(qbuf, partial, h.ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
+                            h.head_dim, l % h.n_layer, max_seq, max_ctx, act_qd, true, stream);
+    };
+    *kv_bytes = (double)nrows * ctx * KVD * 2.0 * 2.0;
+    const bool use_graph = graphs_enabled();
+    hipGraphExec_t ge = nullptr;
+    launch(0);
+    if (use_graph) {
+        std::lock_guard<std::mutex> lk(g_capture_mu);
+        hipGraph_t g = nullptr;
+        HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+        for (int i = 0; i < iters; ++i) launch(i);
+        HIPQ(hipStreamEndCapture(stream, &g));
+        HIPQ(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HIPQ(hipGraphDestroy(g));
+        HIPQ(hipGraphLaunch(ge, stream)); /* warm */
+    }
+    hipEvent_t e0, e1;
+    HIPQ(hipEventCreate(&e0));
+    HIPQ(hipEventCreate(&e1));
+    HIPQ(hipEventRecord(e0, stream));
+    if (use_graph) HIPQ(hipGraphLaunch(ge, stream));
+    else for (int i = 0; i < iters; ++i) launch(i);
     HIPQ(hipEventRecord(e1, stream));
     HIPQ(hipStreamSynchronize(stream));
     if (ge) (void)hipGraphExecDestroy(ge);

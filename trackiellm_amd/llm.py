@@ -116,6 +116,12 @@ class LlmSession:
         check(lib().tk_mi355x_llm_time_gemv(self.h, layer, which, nrows, iters, C.byref(ms), C.byref(nbytes)))
         return ms.value, nbytes.value
 
+    def time_attention(self, nrows, ctx, iters):
+        ms = C.c_float(0)
+        nbytes = C.c_double(0)
+        check(lib().tk_mi355x_llm_time_attention(self.h, nrows, ctx, iters, C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value
+
     def close(self):
         if self.h:
             lib().tk_mi355x_llm_session_destroy(C.byref(self.h))
@@ -167,6 +173,18 @@ class ModelLoader:
 
     def unload(self, handle):
         check(lib().tk_model_loader_unload_model(self.h, C.byref(handle)))
+
+    @staticmethod
+    def set_runner_slots(handle, slots):
+        """sequences per shared decode session of the runners created on this model handle (before the first tk_llm_runner_create)"""
+        check(lib().tk_mi355x_llm_model_set_runner_slots(handle, slots))
+
+    @staticmethod
+    def batch_stats(handle):
+        """(passes, rows, widest pass) of the continuous-batching schedulers of this model"""
+        p, r, m = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        lib().tk_mi355x_llm_model_batch_stats(handle, C.byref(p), C.byref(r), C.byref(m))
+        return p.value, r.value, m.value
 
     def close(self):
         if self.h:
