@@ -69,7 +69,7 @@ static void default_plan(tk_mi355x_llm_hparams_t* h) {
         int want = (int)((256 + rows / 64 - 1) / (rows / 64));
         int ks = 1;
         /* prefer K-ranges of a multiple of 4 blocks: the GEMV keeps 4 weight tiles in flight per wave */
-        for (int c = 1; c <= nb; ++c)
+        for (int c = 1; c <= nb && c <= 8; ++c) /* at most 8 K-ranges: the consumers keep every partial slab of a row in flight at once */
             if (nb % c == 0 && ((nb / c) % 4 == 0 || nb < 4 * want)) { ks = c; if (c >= want) break; }
         if (K / ks > 4096) { /* LDS image of the K-range must fit: 16 B per k */
             for (int c = ks; c <= nb; ++c) if (nb % c == 0 && K / c <= 4096) { ks = c; break; }

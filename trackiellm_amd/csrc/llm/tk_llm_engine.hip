@@ -74,7 +74,7 @@ bool TkLlmModel::init(const TkLlmHParams& h, int dev) {
     const int ksv[4] = {h.ks_qkv, h.ks_o, h.ks_gateup, h.ks_down};
     const int64_t kk[4] = {h.d_model, qd, h.d_model, h.d_ff};
     for (int i = 0; i < 4; ++i)
-        if (ksv[i] <= 0 || (kk[i] / 256) % ksv[i]) return bad("K-split must divide K/256");
+        if (ksv[i] <= 0 || ksv[i] > 8 || (kk[i] / 256) % ksv[i]) return bad("K-split must be in [1, 8] and divide K/256");
     HIPQ(hipSetDevice(device));
     layers.assign(h.n_layer, TkLlmLayer());
     return true;
@@ -196,6 +196,10 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     if (!m || !m->ready()) { error = "model has missing tensors"; return false; }
     if (mseq <= 0 || mctx <= 0) { error = "max_seq and max_ctx must be positive"; return false; }
     const TkLlmHParams& h = m->hp;
+    if (tk_attention_lds_bytes(h.n_head / h.n_kv_head, h.head_dim, mctx) > 160 * 1024) {
+        error = "max_ctx too large: the attention kernel keeps one score row per query head of a KV group in LDS (about 9000 positions for 4 x 128)";
+        return false;
+    }
     HIPQ(hipSetDevice(m->device));
     HIPQ(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     const int QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim, half = h.head_dim / 2;

@@ -202,87 +202,70 @@ __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot,
 
 /* ------------------------------------------------------------------------------------------
  * residual add (sum of K-split partials, ascending) + RMSNorm + Q8 quantise.  One WG per row.
+ *
+ * A row is 16 KB of residual stream plus up to 8 K-split slabs of 16 KB pulled through one CU, and at 16 rows per pass only 16 CUs
+ * take part: the kernel is pure memory latency.  So the workgroup is as wide as the row has 16-byte groups (1024 threads for
+ * d_model 4096) and every thread requests its residual group and ALL its slab groups before it adds the first: one round trip
+ * instead of one per slab.  The arithmetic keeps the oracle's order (orc_rmsnorm): slabs added in ascending order, then the sum of
+ * squares as 256 chains — chain t runs over the groups t, t + 256, ... element by element — joined by the canonical 256-sum; the
+ * chains read the finished row back from LDS, so how many threads loaded it does not enter the result.
  * ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(256) void k_rmsnorm_q8(float* __restrict__ x, const float* __restrict__ partial, int ks, int n_total,
-                                                     const float* __restrict__ w, float eps, int D, TkActQ8 out) {
+#define TK_RMS_MAX_KS 8
+__global__ __launch_bounds__(1024) void k_rmsnorm_q8(float* __restrict__ x, const float* __restrict__ partial, int ks, int n_total,
+                                                      const float* __restrict__ w, float eps, int D, TkActQ8 out) {
     extern __shared__ float sh[]; /* D floats + 4 */
     float* hbuf = sh;
     float* red = sh + D;
-    const int r = blockIdx.x, t = threadIdx.x;
+    const int r = blockIdx.x, t = threadIdx.x, nthr = blockDim.x;
     float* xr = x + (int64_t)r * D;
-    float ss = 0.0f;
-    /* Canonical order (oracle: orc_rmsnorm): thread t owns the float4 groups g = t, t + 256, ... of the row and
-     * accumulates x^2 over them element by element; 16-byte loads, 4 groups per pass, every load of a pass issued before
-     * its first use — the K-split partials of one row are up to 128 KB pulled through a single CU. */
     const int ngrp = D / 4;
-    for (int g0 = 0; g0 < ngrp; g0 += 256 * 4) {
-        v4f v[4], o[4];
-        bool live[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int g = g0 + t + 256 * e;
-            live[e] = g < ngrp;
-            v[e] = live[e] ? *(const v4f*)(xr + 4 * g) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
-        }
+    for (int g = t; g < ngrp; g += nthr) {
+        v4f v = *(const v4f*)(xr + 4 * g);
         if (partial) {
+            v4f p[TK_RMS_MAX_KS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int g = g0 + t + 256 * e;
-                o[e] = live[e] ? *(const v4f*)(partial + (int64_t)r * n_total + 4 * g) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
-            }
-            for (int s = 1; s < ks; ++s) {
-                v4f p[4];
+            for (int s = 0; s < TK_RMS_MAX_KS; ++s)
+                if (s < ks) p[s] = *(const v4f*)(partial + ((int64_t)s * TK_MAX_ROWS + r) * n_total + 4 * g);
+            v4f o = p[0];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int g = g0 + t + 256 * e;
-                    p[e] = live[e] ? *(const v4f*)(partial + ((int64_t)s * TK_MAX_ROWS + r) * n_total + 4 * g) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = o[e] + p[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] + o[e];
+            for (int s = 1; s < TK_RMS_MAX_KS; ++s)
+                if (s < ks) o = o + p[s];
+            v = v + o;
+            *(v4f*)(xr + 4 * g) = v;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int g = g0 + t + 256 * e;
-            if (live[e]) {
-                if (partial) *(v4f*)(xr + 4 * g) = v[e];
-                *(v4f*)(hbuf + 4 * g) = v[e];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ss = tk_fmaf(v[e][i], v[e][i], ss);
-            }
-        }
+        *(v4f*)(hbuf + 4 * g) = v;
     }
-    /* norm weights of this thread's first two chunks are requested before the reduction so their latency hides under it */
+    /* norm weights of this thread's first chunk are requested before the reductions so their latency hides under them */
     const int nchunk = D / 8;
-    v4f wa[2][2];
+    v4f wa[2];
+    if (t < nchunk) { wa[0] = *(const v4f*)(w + 8 * t); wa[1] = *(const v4f*)(w + 8 * t + 4); }
+    __syncthreads();
+    float ss = 0.0f;
+    if (t < 256)
+        for (int g = t; g < ngrp; g += 256) {
+            const v4f v = *(const v4f*)(hbuf + 4 * g);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int c = t + 256 * u;
-        if (c < nchunk) { wa[u][0] = *(const v4f*)(w + 8 * c); wa[u][1] = *(const v4f*)(w + 8 * c + 4); }
-    }
-    float tot = block_sum256(ss, red);
-    float mean = tk_divf(tot, (float)D);
-    float scale = tk_divf(1.0f, tk_sqrtf(mean + eps));
-    for (int c0 = t; c0 < nchunk; c0 += 512) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = c0 + 256 * u;
-            if (c < nchunk) { /* nchunk is a multiple of 32: half-waves enter together, as quantize_chunk8 needs */
-                v4f w0, w1;
-                if (c0 == t) { w0 = wa[u][0]; w1 = wa[u][1]; }
-                else { w0 = *(const v4f*)(w + 8 * c); w1 = *(const v4f*)(w + 8 * c + 4); }
-                const v4f h0 = *(const v4f*)(hbuf + 8 * c), h1 = *(const v4f*)(hbuf + 8 * c + 4);
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = (h0[i] * scale) * w0[i];
-                    v[4 + i] = (h1[i] * scale) * w1[i];
-                }
-                quantize_chunk8(v, c, r, out);
-            }
+            for (int i = 0; i < 4; ++i) ss = tk_fmaf(v[i], v[i], ss);
         }
+    /* canonical sum of the 256 chains (block_sum256's arithmetic, carried by the first four waves of a wider workgroup) */
+    for (int s = 32; s >= 1; s >>= 1) ss = ss + wave_xor_f(ss, s);
+    if (t < 256 && (t & 63) == 0) red[t >> 6] = ss;
+    __syncthreads();
+    const float tot = ((red[0] + red[1]) + red[2]) + red[3];
+    const float mean = tk_divf(tot, (float)D);
+    const float scale = tk_divf(1.0f, tk_sqrtf(mean + eps));
+    for (int c = t; c < nchunk; c += nthr) { /* nchunk and nthr are multiples of 32: half-waves enter together, as quantize_chunk8 needs */
+        v4f w0, w1;
+        if (c == t) { w0 = wa[0]; w1 = wa[1]; }
+        else { w0 = *(const v4f*)(w + 8 * c); w1 = *(const v4f*)(w + 8 * c + 4); }
+        const v4f h0 = *(const v4f*)(hbuf + 8 * c), h1 = *(const v4f*)(hbuf + 8 * c + 4);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = (h0[i] * scale) * w0[i];
+            v[4 + i] = (h1[i] * scale) * w1[i];
+        }
+        quantize_chunk8(v, c, r, out);
     }
 }
 
@@ -304,7 +287,9 @@ void tk_launch_residual_fold(float* x, const float* partial, int ks, int n_total
 
 void tk_launch_rmsnorm_q8(float* x, const float* partial, int ks, int n_total_partial, const float* w, float eps, int D, int nrows,
                           TkActQ8 out, hipStream_t s) {
-    hipLaunchKernelGGL(k_rmsnorm_q8, dim3(nrows), dim3(256), (D + 4) * sizeof(float), s, x, partial, ks, n_total_partial, w, eps, D, out);
+    int nthr = D / 4; /* one thread per 16-byte group of the row, 256 .. 1024 */
+    nthr = nthr < 256 ? 256 : nthr > 1024 ? 1024 : (nthr + 255) / 256 * 256;
+    hipLaunchKernelGGL(k_rmsnorm_q8, dim3(nrows), dim3(nthr), (D + 4) * sizeof(float), s, x, partial, ks, n_total_partial, w, eps, D, out);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1032,7 +1017,7 @@ __global__ void k_qkv_rope_append(const float* partial, int ks, int n_total, int
     const int p = pos[r], sq = seq[r];
     const float* cs = rope_cos + (int64_t)p * half;
     const float* sn = rope_sin + (int64_t)p * half;
-    const int64_t cbase = ((((int64_t)layer * max_seq + sq) * max_ctx + p) * n_kv_head + kvh) * head_dim;
+    const int64_t cbase = ((((int64_t)layer * max_seq + sq) * n_kv_head + kvh) * max_ctx + p) * head_dim; /* [layer][seq][kv head][ctx][dim] */
     for (int idx = threadIdx.x; idx < (grp + 1) * half; idx += blockDim.x) {
         const int hsel = idx / half, i = idx % half;
         if (hsel < grp) {
@@ -1062,193 +1047,301 @@ void tk_launch_qkv_rope_append(const float* partial, int ks, int n_total, int n_
 }
 
 /* ------------------------------------------------------------------------------------------
- * causal GQA attention for one (row, kv head): scores (sequential fma over head_dim),
- * max, exp, PV and the softmax denominator accumulated in ascending position order —
- * the oracle's order — then the Q8 quantisation the o-projection consumes.
- * Requires head_dim * (n_head / n_kv_head) == 512 or less and a multiple of 256.
+ * causal GQA attention.  One workgroup per (row, KV head): it serves all GQ = n_head / n_kv_head query heads that share the KV head, so
+ * the head's K and V rows are read ONCE per row, and they are read as what they are in the cache layout
+ * [layer][sequence][kv head][position][dim]: one contiguous run, streamed through a two-slot LDS ring by LDS-DMA in chunks of 64
+ * positions (16 KiB), the next chunk in flight under the current chunk's arithmetic.  Algorithmic bytes per launch = rows x cached
+ * positions x n_kv_head x head_dim x 2 B x 2 (bench.py: roofline_attention).
+ *
+ * Arithmetic = the oracle's order: a score is one fma chain over head_dim (thread = one position of one head, its key row read from
+ * LDS); max; exp; PV and the softmax denominator as 4 interleaved partial sums over positions (t mod 4, wave j = partial j), each in
+ * ascending position order, combined in j order; then the Q8 quantisation the o-projection consumes (GQ * head_dim is a multiple of
+ * 256: whole Q8 blocks).  The key rows sit in LDS with their 16-byte pieces XOR-swizzled by the row number — the swizzle is applied to
+ * the per-lane SOURCE address of the DMA — so 16 lanes that read piece i of 16 consecutive rows hit 16 different bank groups.
+ * FUSED (decode passes: every sequence appears once): the workgroup first finishes its own q / k / v — K-split partial sums, RoPE,
+ * f16 rounding, cache append — and patches its own position into the ring from LDS instead of reading its store back.
+ * Non-fused (passes that hold several positions of one sequence): the cache was appended by k_qkv_rope_append before.
  * ------------------------------------------------------------------------------------------ */
 #define TK_ATT_MAX_GRP 4
 #define TK_ATT_TSPLIT 4 /* canonical: 4 interleaved partial sums over positions (t mod 4), added in order */
-/*
- * One workgroup per (row, group of GRP query heads that share a KV head).  GRP * head_dim must be a multiple of 256
- * so the workgroup's outputs are whole Q8 blocks of the o-projection input.
- * FUSED (decode passes: every sequence appears once): the workgroup first finishes its own q / k / v — K-split partial
- * sums, RoPE, f16 rounding, cache append — and attends to its own position from LDS, which removes the separate
- * k_qkv_rope_append launch.  Non-fused (prefill passes with several rows per sequence): the cache was appended before.
- */
-template <int GRP, bool FUSED>
+#define TK_ATT_CHUNK 64 /* positions per ring slot */
+#define TK_ATT_SLOTS 2  /* ring slots: the next chunk lands while the current one is used.  Measured on MI355X (256 rows x 128 cached
+                         * positions, profiles/r02_attention_variants.txt): 2 x 64 rows 53.5 us, 8 x 32 rows 86 us — a workgroup's life is a
+                         * chain of short dependent phases, so what pays is workgroups per CU (LDS footprint), not bytes in flight per workgroup */
+
+__device__ __forceinline__ float sum_partials_wide(const float* partial, int ks, int n_total, int row, int col) {
+    float p[TK_RMS_MAX_KS];
+#pragma unroll
+    for (int s = 0; s < TK_RMS_MAX_KS; ++s)
+        if (s < ks) p[s] = partial[((int64_t)s * TK_MAX_ROWS + row) * n_total + col];
+    float o = p[0];
+#pragma unroll
+    for (int s = 1; s < TK_RMS_MAX_KS; ++s)
+        if (s < ks) o = o + p[s];
+    return o;
+}
+
+/* s_waitcnt vmcnt(n) alone (expcnt / lgkmcnt untouched): until all but this wave's n youngest vector-memory operations are done.  The
+ * LDS-DMA pieces of a chunk are invisible to the compiler's own wait insertion, so the ring is guarded by hand. */
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define TK_VMW(k) case k: __builtin_amdgcn_s_waitcnt(0x0F70 | ((k) & 15) | (((k) >> 4) << 14)); break;
+    switch (n) {
+        TK_VMW(0) TK_VMW(1) TK_VMW(2) TK_VMW(3) TK_VMW(4) TK_VMW(5) TK_VMW(6) TK_VMW(7) TK_VMW(8) TK_VMW(9) TK_VMW(10) TK_VMW(11) TK_VMW(12)
+        TK_VMW(13) TK_VMW(14) TK_VMW(15) TK_VMW(16) TK_VMW(17) TK_VMW(18) TK_VMW(19) TK_VMW(20) TK_VMW(21) TK_VMW(22) TK_VMW(23) TK_VMW(24)
+        TK_VMW(25) TK_VMW(26) TK_VMW(27) TK_VMW(28)
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+#undef TK_VMW
+}
+
+/* stage rows [row0, row0 + 32) of one (sequence, kv head) cache run into an LDS slot; rows past `last_row` are clamped (their
+ * content is never used).  swz: XOR-swizzle the 16-byte pieces of a row by the row number (K); plain copy otherwise (V).
+ * Every wave issues exactly chunk_bytes / 4096 one-KiB pieces: the counted waits rely on it. */
+__device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int last_row, int rb /* row bytes */, uint8_t* slot, bool swz, int wave, int lane) {
+    const int pieces = TK_ATT_CHUNK * rb / 1024, ppr = rb / 16; /* 1 KiB pieces per chunk; 16-byte pieces per row */
+    for (int pc = wave; pc < pieces; pc += 4) {
+        const int idx = pc * 64 + lane;           /* 16-byte piece index inside the chunk */
+        const int r = idx / ppr, cs = idx % ppr;  /* row inside the chunk, piece slot inside the row */
+        int gr = row0 + r;
+        gr = gr < last_row ? gr : last_row;
+        const int src = swz ? (cs ^ (r & (ppr - 1))) : cs;
+        const auto gs = (const __attribute__((address_space(1))) void*)((const uint8_t*)run + (int64_t)gr * rb + src * 16);
+        const auto ls = (__attribute__((address_space(3))) void*)(slot + pc * 1024);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
+    }
+}
+
+template <int GQ, bool FUSED, int HD /* head_dim when it is 64 or 128 (loops unroll, LDS reads batch), 0 = any */>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbuf, const float* __restrict__ partial, int ks, int n_total,
                                                     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                                     uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache, const int32_t* __restrict__ seq,
-                                                    const int32_t* __restrict__ pos, int n_head, int n_kv_head, int head_dim, int layer, int max_seq,
+                                                    const int32_t* __restrict__ pos, int n_head, int n_kv_head, int head_dim_rt, int layer, int max_seq,
                                                     int max_ctx, TkActQ8 out) {
-    extern __shared__ float sh[];
-    const int vh = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
-    constexpr int grp = GRP;
-    const int kvh = vh / ((n_head / n_kv_head) / grp); /* several workgroups may share a KV head */
+    extern __shared__ __attribute__((aligned(16))) uint8_t att_lds[];
+    const int head_dim = HD ? HD : head_dim_rt;
+    /* blockIdx.x = block of GQ consecutive query heads; GQ is the whole KV group (its K / V rows are read once per row), or half of it
+     * in passes with few rows, where more, shorter workgroups beat the second read (the launcher decides) */
+    const int hb = blockIdx.x, r = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int kvh = hb * GQ / (n_head / n_kv_head);
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int p = pos[r], T = p + 1, sq = seq[r];
-    const int W = grp * head_dim;              /* outputs of this WG */
-    float* qs = sh;                            /* [grp][head_dim] */
-    float* sc = qs + W;                        /* [grp][max_ctx] */
-    float* red = sc + (size_t)grp * max_ctx;   /* [4 waves][grp] */
-    float* part = red + 4 * TK_ATT_MAX_GRP;    /* [TSPLIT][W] partial outputs */
-    float* lpart = part + TK_ATT_TSPLIT * W;   /* [TSPLIT][grp] partial denominators */
+    const int W = GQ * head_dim;               /* outputs of this WG */
+    const int rb = head_dim * 2;               /* bytes of one cache row */
+    const int half = head_dim / 2, QD = n_head * head_dim, KVD = n_kv_head * head_dim;
+    const int slot_bytes = TK_ATT_CHUNK * rb;
+    /* LDS: the ring (K chunks, then V chunks: one stream), then the float arrays */
+    uint8_t* ring = att_lds;
+    float* qs = (float*)(att_lds + TK_ATT_SLOTS * slot_bytes); /* [GQ][head_dim] */
+    float* sc = qs + W;                                   /* [GQ][max_ctx] */
+    float* red = sc + (size_t)GQ * max_ctx;               /* [4 waves][GQ] */
+    float* part = red + 4 * TK_ATT_MAX_GRP;               /* [TSPLIT][W] partial outputs */
+    float* lpart = part + TK_ATT_TSPLIT * W;              /* [TSPLIT][GQ] partial denominators */
     float* obuf = lpart + TK_ATT_TSPLIT * TK_ATT_MAX_GRP; /* [W] */
-    const int QD = n_head * head_dim, KVD = n_kv_head * head_dim, half = head_dim / 2;
-    const int64_t rowstride = (int64_t)n_kv_head * head_dim;
-    const int64_t sbase = (((int64_t)layer * max_seq + sq) * max_ctx) * rowstride + (int64_t)kvh * head_dim;
+    uint16_t* own = (uint16_t*)(obuf + W);                /* [2][head_dim]: this row's own K and V (FUSED) */
+    const int64_t run0 = (((int64_t)layer * max_seq + sq) * n_kv_head + kvh) * (int64_t)max_ctx * head_dim;
+    const uint16_t* krun = kcache + run0;
+    const uint16_t* vrun = vcache + run0;
+    const int nchunk = (T + TK_ATT_CHUNK - 1) / TK_ATT_CHUNK;
+    const int total = 2 * nchunk;              /* the stream: K chunks 0 .. nchunk - 1, then V chunks 0 .. nchunk - 1 */
+    const int last_row = max_ctx - 1;
+    const int ppw = slot_bytes / 4096;         /* DMA pieces per wave and chunk */
+    const int ppr = rb / 16;
+    auto issue = [&](int j) { /* chunk j of the stream into slot j % SLOTS; always issued (a chunk with nothing cached yet re-reads clamped rows) */
+        const bool is_k = j < nchunk;
+        const int c = is_k ? j : j - nchunk;
+        att_stage(is_k ? krun : vrun, c * TK_ATT_CHUNK, last_row, rb, ring + (j % TK_ATT_SLOTS) * slot_bytes, is_k, wave, lane);
+    };
+    /* before touching chunk j: all but the chunks issued after it have landed; everybody is done with chunk j - 1, whose slot takes
+     * chunk j + SLOTS - 1 */
+    auto acquire = [&](int j) {
+        const int ahead = total - 1 - j < TK_ATT_SLOTS - 2 ? total - 1 - j : TK_ATT_SLOTS - 2;
+        wait_vmcnt(ahead * ppw);
+        __syncthreads();
+        if (j + TK_ATT_SLOTS - 1 < total) issue(j + TK_ATT_SLOTS - 1);
+    };
+
+    for (int j = 0; j < TK_ATT_SLOTS - 1 && j < total; ++j) issue(j); /* in flight under the q / k / v prologue */
     if (FUSED) {
         const float* cs = rope_cos + (int64_t)p * half;
         const float* sn = rope_sin + (int64_t)p * half;
-        for (int idx = t; idx < (grp + 2) * half; idx += 256) {
+        for (int idx = t; idx < (GQ + 2) * half; idx += 256) {
             const int hsel = idx / half, i = idx % half;
-            if (hsel < grp) {
-                const int col = vh * W + hsel * head_dim + 2 * i;
-                const float a = sum_partials(partial, ks, n_total, r, col), b = sum_partials(partial, ks, n_total, r, col + 1);
+            if (hsel < GQ) {
+                const int col = (hb * GQ + hsel) * head_dim + 2 * i;
+                const float a = sum_partials_wide(partial, ks, n_total, r, col), b = sum_partials_wide(partial, ks, n_total, r, col + 1);
                 qs[hsel * head_dim + 2 * i] = tk_fmaf(-b, sn[i], a * cs[i]);
                 qs[hsel * head_dim + 2 * i + 1] = tk_fmaf(a, sn[i], b * cs[i]);
-            } else if (hsel == grp) {
+            } else if (hsel == GQ) {
                 const int col = QD + kvh * head_dim + 2 * i;
-                const float a = sum_partials(partial, ks, n_total, r, col), b = sum_partials(partial, ks, n_total, r, col + 1);
+                const float a = sum_partials_wide(partial, ks, n_total, r, col), b = sum_partials_wide(partial, ks, n_total, r, col + 1);
                 const uint16_t k0 = tk_f32_to_f16(tk_fmaf(-b, sn[i], a * cs[i])), k1 = tk_f32_to_f16(tk_fmaf(a, sn[i], b * cs[i]));
-                /* every workgroup of the KV group stores the (identical) row: it re-reads its own store after the barrier */
-                *(uint32_t*)(kcache + sbase + (int64_t)p * rowstride + 2 * i) = (uint32_t)k0 | ((uint32_t)k1 << 16);
+                const uint32_t kk = (uint32_t)k0 | ((uint32_t)k1 << 16);
+                *(uint32_t*)(kcache + run0 + (int64_t)p * head_dim + 2 * i) = kk;
+                *(uint32_t*)(own + 2 * i) = kk;
             } else {
                 const int col = QD + KVD + kvh * head_dim + 2 * i;
-                const uint16_t v0 = tk_f32_to_f16(sum_partials(partial, ks, n_total, r, col)), v1 = tk_f32_to_f16(sum_partials(partial, ks, n_total, r, col + 1));
-                *(uint32_t*)(vcache + sbase + (int64_t)p * rowstride + 2 * i) = (uint32_t)v0 | ((uint32_t)v1 << 16);
+                const uint16_t v0 = tk_f32_to_f16(sum_partials_wide(partial, ks, n_total, r, col)), v1 = tk_f32_to_f16(sum_partials_wide(partial, ks, n_total, r, col + 1));
+                const uint32_t vv = (uint32_t)v0 | ((uint32_t)v1 << 16);
+                *(uint32_t*)(vcache + run0 + (int64_t)p * head_dim + 2 * i) = vv;
+                *(uint32_t*)(own + head_dim + 2 * i) = vv;
             }
         }
     } else {
-        for (int i = t; i < W; i += 256) qs[i] = qbuf[(int64_t)r * QD + vh * W + i];
+        for (int i = t; i < W; i += 256) qs[i] = qbuf[(int64_t)r * QD + hb * W + i];
     }
-    __syncthreads();
     const float att_scale = tk_divf(1.0f, tk_sqrtf((float)head_dim));
-    const int Tc = T; /* every position, the row's own included, is served by the cache (global stores are visible after the barrier) */
-    float mx[GRP];
+
+    /* ---- scores: thread = (head, position of the chunk); GQ * CHUNK threads work, one fma chain over head_dim each ---- */
+    float mx = -INFINITY;
+    for (int c = 0; c < nchunk; ++c) {
+        acquire(c); /* the first barrier also publishes qs and own */
+        uint8_t* slot = ring + (c % TK_ATT_SLOTS) * slot_bytes;
+        if (FUSED && c == nchunk - 1) { /* the row's own key (position p, always in the last chunk) comes from LDS, swizzled like the rest */
+            const int rr = p - c * TK_ATT_CHUNK;
+            if (t < ppr) *(uint4*)(slot + rr * rb + ((t ^ (rr & (ppr - 1))) * 16)) = *(const uint4*)((const uint8_t*)own + t * 16);
+            __syncthreads();
+        }
+        for (int idx = t; idx < GQ * TK_ATT_CHUNK; idx += 256) {
+            const int h = idx / TK_ATT_CHUNK, rr = idx % TK_ATT_CHUNK, tt = c * TK_ATT_CHUNK + rr;
+            if (tt < T) {
+                const uint8_t* kr = slot + rr * rb;
+                const float* qh = qs + h * head_dim;
+                float a = 0.0f;
+                constexpr int KB = HD ? HD / 8 : 1; /* key pieces read per batch: the whole row when head_dim is known */
+                for (int i0 = 0; i0 < ppr; i0 += KB) {
+                    uint4 kv[KB];
 #pragma unroll
-    for (int h = 0; h < grp; ++h) mx[h] = -INFINITY;
-    for (int tt = t; tt < T; tt += 256) {
-        float a[GRP];
+                    for (int u = 0; u < KB; ++u) kv[u] = *(const uint4*)(kr + (((i0 + u) ^ (rr & (ppr - 1))) * 16));
 #pragma unroll
-        for (int h = 0; h < grp; ++h) a[h] = 0.0f;
-        {
-            const uint16_t* kr = kcache + sbase + (int64_t)tt * rowstride;
-            for (int i0 = 0; i0 < head_dim; i0 += 64) { /* 8 x 16 B of the key row in flight per pass */
-                uint4 kv[8];
+                    for (int u = 0; u < KB; ++u) {
+                        const v4f q0 = *(const v4f*)(qh + 8 * (i0 + u)), q1 = *(const v4f*)(qh + 8 * (i0 + u) + 4);
+                        const uint32_t kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
 #pragma unroll
-                for (int u = 0; u < 8; ++u) kv[u] = *(const uint4*)(kr + i0 + 8 * u);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint32_t kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float kf = f16bits_to_f32((kw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
-#pragma unroll
-                        for (int h = 0; h < grp; ++h) a[h] = tk_fmaf(qs[h * head_dim + i0 + 8 * u + e], kf, a[h]);
+                        for (int e = 0; e < 8; ++e) {
+                            const float kf = f16bits_to_f32((kw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                            a = tk_fmaf(e < 4 ? q0[e] : q1[e - 4], kf, a);
+                        }
                     }
                 }
+                const float s = a * att_scale;
+                sc[(size_t)h * max_ctx + tt] = s;
+                mx = tk_fmaxf(mx, s);
             }
         }
-#pragma unroll
-        for (int h = 0; h < grp; ++h) {
-            const float s = a[h] * att_scale;
-            sc[(size_t)h * max_ctx + tt] = s;
-            mx[h] = tk_fmaxf(mx[h], s);
-        }
     }
-#pragma unroll
-    for (int h = 0; h < grp; ++h) {
-        float m = mx[h];
-        for (int s = 32; s >= 1; s >>= 1) m = tk_fmaxf(m, wave_xor_f(m, s));
-        if ((t & 63) == 0) red[(t >> 6) * TK_ATT_MAX_GRP + h] = m;
+    /* row maximum per head: thread idx = h * CHUNK + rr served head h in every chunk (GQ * CHUNK <= 256 threads: one idx per thread) */
+    {
+        float m = mx;
+        for (int s = TK_ATT_CHUNK / 2; s >= 1; s >>= 1) m = tk_fmaxf(m, wave_xor_f(m, s)); /* over the CHUNK lanes of one head */
+        if ((lane & (TK_ATT_CHUNK - 1)) == 0 && t < GQ * TK_ATT_CHUNK) red[t / TK_ATT_CHUNK] = m;
     }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < grp; ++h) {
-        const float m = tk_fmaxf(tk_fmaxf(red[h], red[TK_ATT_MAX_GRP + h]), tk_fmaxf(red[2 * TK_ATT_MAX_GRP + h], red[3 * TK_ATT_MAX_GRP + h]));
+    __syncthreads(); /* every score is written */
+    for (int h = 0; h < GQ; ++h) {
+        const float m = red[h];
         for (int tt = t; tt < T; tt += 256) sc[(size_t)h * max_ctx + tt] = tk_expf(sc[(size_t)h * max_ctx + tt] - m);
     }
-    __syncthreads();
-    /* PV: wave j takes positions t = j (mod 4); lane owns dims (2*lane, 2*lane+1) [+128k] of every head, so one
-     * 4-byte V load feeds GRP heads; 16 loads in flight per lane.  Partials are combined in j order afterwards. */
-    {
-        const int j = t >> 6, lane = t & 63;
-        for (int d0 = 2 * lane; d0 < head_dim; d0 += 128) {
-            float acc[GRP][2], l[GRP];
+    /* ---- PV: wave j takes positions t = j (mod 4); lane owns dims (2 lane, 2 lane + 1) [+ 128 k] of every head ---- */
+    float acc[GQ][2][2], l[GQ]; /* [head][dim block of 128][pair] */
 #pragma unroll
-            for (int h = 0; h < grp; ++h) { acc[h][0] = 0.0f; acc[h][1] = 0.0f; l[h] = 0.0f; }
-            const uint16_t* vc = vcache + sbase + d0;
-            /* 16 positions per batch, all loads issued together.  Out-of-range slots read a clamped address and enter
-             * with probability 0: fma(0, v, acc) == acc and l + 0 == l exactly, so the canonical order is untouched while
-             * the tail costs one memory round trip instead of one per position. */
-            for (int tt = j; tt < T; tt += 16 * TK_ATT_TSPLIT) {
-                uint32_t vv[16];
+    for (int h = 0; h < GQ; ++h) { l[h] = 0.0f; acc[h][0][0] = acc[h][0][1] = acc[h][1][0] = acc[h][1][1] = 0.0f; }
+    for (int c = 0; c < nchunk; ++c) {
+        acquire(nchunk + c); /* the first barrier also publishes the probabilities */
+        uint8_t* slot = ring + ((nchunk + c) % TK_ATT_SLOTS) * slot_bytes;
+        if (FUSED && c == nchunk - 1) {
+            const int rr = p - c * TK_ATT_CHUNK;
+            if (t < ppr) *(uint4*)(slot + rr * rb + t * 16) = *(const uint4*)((const uint8_t*)(own + head_dim) + t * 16);
+            __syncthreads();
+        }
+        const int t_end = T - c * TK_ATT_CHUNK < TK_ATT_CHUNK ? T - c * TK_ATT_CHUNK : TK_ATT_CHUNK;
+        /* positions in batches of PB: every LDS read of a batch is issued before its first fma (out-of-range slots of the last batch
+         * read a clamped row and enter with probability 0: fma(0, v, acc) == acc and l + 0 == l exactly, the canonical order is untouched) */
+        constexpr int PB = 4;
+        for (int rr0 = wave; rr0 < t_end; rr0 += PB * TK_ATT_TSPLIT) {
+            float pr[PB][GQ];
+            uint32_t vv[PB][2];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    int pu = tt + u * TK_ATT_TSPLIT;
-                    pu = pu < Tc ? pu : (Tc > 0 ? Tc - 1 : 0);
-                    vv[u] = Tc > 0 ? *(const uint32_t*)(vc + (int64_t)pu * rowstride) : 0u;
+            for (int u = 0; u < PB; ++u) {
+                const int rr = rr0 + u * TK_ATT_TSPLIT;
+                const bool live = rr < t_end;
+                const int rc = live ? rr : t_end - 1;
+#pragma unroll
+                for (int h = 0; h < GQ; ++h) pr[u][h] = live ? sc[(size_t)h * max_ctx + c * TK_ATT_CHUNK + rc] : 0.0f;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int d0 = 2 * lane + 128 * db;
+                    vv[u][db] = d0 < head_dim ? *(const uint32_t*)(slot + rc * rb + d0 * 2) : 0u;
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int pu = tt + u * TK_ATT_TSPLIT;
-                    float v0 = f16bits_to_f32(vv[u] & 0xffffu), v1 = f16bits_to_f32(vv[u] >> 16);
-                    const bool live = pu < T;
+            for (int u = 0; u < PB; ++u) {
 #pragma unroll
-                    for (int h = 0; h < grp; ++h) {
-                        const float pr = live ? sc[(size_t)h * max_ctx + pu] : 0.0f;
-                        acc[h][0] = tk_fmaf(pr, v0, acc[h][0]);
-                        acc[h][1] = tk_fmaf(pr, v1, acc[h][1]);
-                        l[h] = l[h] + pr;
+                for (int db = 0; db < 2; ++db) {
+                    if (2 * lane + 128 * db < head_dim) {
+                        const float v0 = f16bits_to_f32(vv[u][db] & 0xffffu), v1 = f16bits_to_f32(vv[u][db] >> 16);
+#pragma unroll
+                        for (int h = 0; h < GQ; ++h) {
+                            acc[h][db][0] = tk_fmaf(pr[u][h], v0, acc[h][db][0]);
+                            acc[h][db][1] = tk_fmaf(pr[u][h], v1, acc[h][db][1]);
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int h = 0; h < grp; ++h) {
-                part[j * W + h * head_dim + d0] = acc[h][0];
-                part[j * W + h * head_dim + d0 + 1] = acc[h][1];
-                if (lane == 0 && d0 == 0) lpart[j * TK_ATT_MAX_GRP + h] = l[h];
+                for (int h = 0; h < GQ; ++h) l[h] = l[h] + pr[u][h];
             }
         }
+    }
+#pragma unroll
+    for (int h = 0; h < GQ; ++h) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int d0 = 2 * lane + 128 * db;
+            if (d0 < head_dim) {
+                part[wave * W + h * head_dim + d0] = acc[h][db][0];
+                part[wave * W + h * head_dim + d0 + 1] = acc[h][db][1];
+            }
+        }
+        if (lane == 0) lpart[wave * TK_ATT_MAX_GRP + h] = l[h];
     }
     __syncthreads();
     for (int i = t; i < W; i += 256) {
         const int h = i / head_dim;
         const float a = ((part[i] + part[W + i]) + part[2 * W + i]) + part[3 * W + i];
-        const float l = ((lpart[h] + lpart[TK_ATT_MAX_GRP + h]) + lpart[2 * TK_ATT_MAX_GRP + h]) + lpart[3 * TK_ATT_MAX_GRP + h];
-        obuf[i] = tk_divf(a, l);
+        const float ll = ((lpart[h] + lpart[TK_ATT_MAX_GRP + h]) + lpart[2 * TK_ATT_MAX_GRP + h]) + lpart[3 * TK_ATT_MAX_GRP + h];
+        obuf[i] = tk_divf(a, ll);
     }
     __syncthreads();
     for (int c = t; c < W / 8; c += 256) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = obuf[8 * c + i];
-        quantize_chunk8(v, vh * (W / 8) + c, r, out);
+        quantize_chunk8(v, hb * (W / 8) + c, r, out);
     }
+}
+
+size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx) {
+    const size_t W = (size_t)gq * head_dim;
+    return (size_t)TK_ATT_SLOTS * TK_ATT_CHUNK * head_dim * 2 +
+           (W + (size_t)gq * max_ctx + 4 * TK_ATT_MAX_GRP + (size_t)TK_ATT_TSPLIT * W + TK_ATT_TSPLIT * TK_ATT_MAX_GRP + W) * sizeof(float) + (size_t)2 * head_dim * 2;
 }
 
 void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_total, const float* rope_cos, const float* rope_sin,
                          uint16_t* kcache, uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows, int n_head, int n_kv_head,
                          int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, bool fused, hipStream_t s) {
-    const int grp_real = n_head / n_kv_head;
-    /* smallest head group whose outputs are whole 256-wide Q8 blocks: more, shorter workgroups */
-    int grp = 1;
-    while ((grp * head_dim) % 256 && grp < grp_real) grp *= 2;
-    const int W = grp * head_dim;
-    const int nwg = n_head / grp;
-    size_t lds = ((size_t)W + (size_t)grp * max_ctx + 4 * TK_ATT_MAX_GRP + (size_t)TK_ATT_TSPLIT * W + TK_ATT_TSPLIT * TK_ATT_MAX_GRP + W +
-                  2 * (size_t)head_dim) * sizeof(float);
-#define TK_ATT_LAUNCH(G, F)                                                                                                          \
-    do {                                                                                                                             \
-        hipLaunchKernelGGL((k_attention<G, F>), dim3(nwg, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin,   \
-                           kcache, vcache, seq, pos, n_head, n_kv_head, head_dim, layer, max_seq, max_ctx, out);                        \
-    } while (0)
+    int gq = n_head / n_kv_head; /* 1, 2 or 4 (TkLlmModel::init) */
+    /* few rows: two workgroups per KV head (two query heads each) — twice the workgroups, half the dependent work in each; K / V are then
+     * read twice, which costs nothing while the launch is latency-bound (16 rows: 15.9 -> see profiles/r02_attention_variants.txt) */
+    if (gq == 4 && (2 * head_dim) % 256 == 0 && nrows * n_kv_head < 2 * TK_NUM_CU) gq = 2;
+    const size_t lds = tk_attention_lds_bytes(gq, head_dim, max_ctx);
+#define TK_ATT_LAUNCH_HD(G, F, H)                                                                                                             \
+    hipLaunchKernelGGL((k_attention<G, F, H>), dim3(n_head / gq, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin, kcache, \
+                       vcache, seq, pos, n_head, n_kv_head, head_dim, layer, max_seq, max_ctx, out)
+#define TK_ATT_LAUNCH(G, F) do { if (head_dim == 128) TK_ATT_LAUNCH_HD(G, F, 128); else if (head_dim == 64) TK_ATT_LAUNCH_HD(G, F, 64); else TK_ATT_LAUNCH_HD(G, F, 0); } while (0)
     if (fused) {
-        if (grp == 4) TK_ATT_LAUNCH(4, true); else if (grp == 2) TK_ATT_LAUNCH(2, true); else TK_ATT_LAUNCH(1, true);
+        if (gq == 4) TK_ATT_LAUNCH(4, true); else if (gq == 2) TK_ATT_LAUNCH(2, true); else TK_ATT_LAUNCH(1, true);
     } else {
-        if (grp == 4) TK_ATT_LAUNCH(4, false); else if (grp == 2) TK_ATT_LAUNCH(2, false); else TK_ATT_LAUNCH(1, false);
+        if (gq == 4) TK_ATT_LAUNCH(4, false); else if (gq == 2) TK_ATT_LAUNCH(2, false); else TK_ATT_LAUNCH(1, false);
     }
+#undef TK_ATT_LAUNCH_HD
 #undef TK_ATT_LAUNCH
 }
 
@@ -1332,8 +1425,10 @@ const char* tk_llm_prepare_device(int device) {
     TK_OPT_GEMM(4); TK_OPT_GEMM(8); TK_OPT_GEMM(16);
 #define TK_OPT_GEMV(PFV, MTV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3>)); } while (0)
     TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
-    TK_OPT((k_attention<1, true>)); TK_OPT((k_attention<2, true>)); TK_OPT((k_attention<4, true>));
-    TK_OPT((k_attention<1, false>)); TK_OPT((k_attention<2, false>)); TK_OPT((k_attention<4, false>));
+#define TK_OPT_ATT(H) do { TK_OPT((k_attention<1, true, H>)); TK_OPT((k_attention<2, true, H>)); TK_OPT((k_attention<4, true, H>)); \
+                         TK_OPT((k_attention<1, false, H>)); TK_OPT((k_attention<2, false, H>)); TK_OPT((k_attention<4, false, H>)); } while (0)
+    TK_OPT_ATT(0); TK_OPT_ATT(64); TK_OPT_ATT(128);
+#undef TK_OPT_ATT
 #undef TK_OPT_GEMV
 #undef TK_OPT_GEMM
 #undef TK_OPT
