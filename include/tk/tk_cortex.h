@@ -72,10 +72,13 @@ TK_API TK_NODISCARD tk_error_code_t tk_cortex_get_state(const tk_cortex_t* corte
 /* ---- extensions ---- */
 typedef struct {
     uint64_t frames_processed, frames_with_objects, speech_segments, llm_responses, llm_tokens, events_dropped;
+    uint64_t responses_parsed, actions_parsed; /* LLM responses that were the decision engine's JSON schema, and the actions they carried */
 } tk_mi355x_cortex_stats_t;
 TK_API void tk_mi355x_cortex_get_stats(const tk_cortex_t* cortex, tk_mi355x_cortex_stats_t* out);
 /* text of the most recent LLM response (copied into buf, NUL terminated); returns its length */
 TK_API size_t tk_mi355x_cortex_last_response(const tk_cortex_t* cortex, char* buf, size_t cap);
+/* the prompt of the most recent LLM turn: the contextual reasoner's context string (src/cortex/tk_contextual_reasoner.c:681-743) */
+TK_API size_t tk_mi355x_cortex_last_prompt(const tk_cortex_t* cortex, char* buf, size_t cap);
 TK_API void tk_mi355x_cortex_set_max_response_tokens(tk_cortex_t* cortex, int n);
 
 #ifdef __cplusplus

@@ -71,6 +71,10 @@ typedef enum tk_error_code_t {
     TK_ERROR_CODE_COUNT
 } tk_error_code_t;
 
+/* TK_ERROR_INVALID_FORMAT is returned by the reference's LLM-response parser (src/cortex/tk_decision_engine.c:1644,1706,...) and declared
+ * nowhere: it maps to the declared parse-failure code */
+#define TK_ERROR_INVALID_FORMAT TK_ERROR_CONFIG_PARSE_FAILED
+
 #ifdef __cplusplus
 extern "C" {
 #endif

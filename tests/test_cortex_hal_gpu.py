@@ -117,5 +117,10 @@ def test_cortex_cycle_like_reference_test(gpu):
     assert len(cx.states) > 2                                    # the reference's pass criterion (tk_cortex_test.cpp:111-116)
     assert 4 in cx.states and 5 in cx.states                     # PROCESSING and RESPONDING were reported
     assert len(cx.last_response()) > 0
+    # the prompt is the contextual reasoner's context string (tk_contextual_reasoner.c:681-743): objects, navigation, conversation
+    pr = cx.last_prompt().decode()
+    assert "(0.0m, " in pr and "% confidence)" in pr and "No clear path. 0 hazards detected." in pr
+    assert pr.endswith("No recent conversation") or 'User: "' in pr or 'System: "' in pr
+    assert s.responses_parsed == 0 and s.actions_parsed == 0   # a random-weight model does not speak the decision engine's JSON
     assert gpu.lib().tk_cortex_inject_video_frame(cx.h, None) == 1001
     cx.close()

@@ -27,7 +27,8 @@ class _Callbacks(C.Structure):
 
 
 class CortexStats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("frames_processed", "frames_with_objects", "speech_segments", "llm_responses", "llm_tokens", "events_dropped")]
+    _fields_ = [(n, C.c_uint64) for n in ("frames_processed", "frames_with_objects", "speech_segments", "llm_responses", "llm_tokens", "events_dropped",
+                                          "responses_parsed", "actions_parsed")]
 
 
 class Cortex:
@@ -72,6 +73,12 @@ class Cortex:
         buf = C.create_string_buffer(4096)
         lib().tk_mi355x_cortex_last_response.restype = C.c_size_t
         lib().tk_mi355x_cortex_last_response(self.h, buf, 4096)
+        return buf.value
+
+    def last_prompt(self):
+        buf = C.create_string_buffer(16384)
+        lib().tk_mi355x_cortex_last_prompt.restype = C.c_size_t
+        lib().tk_mi355x_cortex_last_prompt(self.h, buf, 16384)
         return buf.value
 
     def set_max_tokens(self, n):

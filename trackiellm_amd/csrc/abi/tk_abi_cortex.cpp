@@ -24,6 +24,7 @@
 #include "tk/tk_audio.h"
 #include "tk/tk_cortex.h"
 #include "tk/tk_model_runner.h"
+#include "tk/tk_reasoner.h"
 #include "tk/tk_vision.h"
 
 #define TK_CORTEX_QUEUE_CAP 128
@@ -59,18 +60,19 @@ struct tk_cortex_s {
     tk_model_loader_t* loader = nullptr;
     void* llm_model = nullptr;
     tk_llm_runner_t* runner = nullptr;
+    tk_contextual_reasoner_t* reasoner = nullptr; /* scene / conversation memory the prompt is assembled from (tk_cortex_main.c:1323-1340) */
     std::mutex audio_mu;     /* VAD + speech accumulation happen on the injecting thread, like the reference's audio worker */
     std::vector<int16_t> speech;
     bool in_speech = false;
     int max_tokens = 32;
     tk_mi355x_cortex_stats_t stats{};
-    std::string last_response;
+    std::string last_response, last_prompt;
     mutable std::mutex stat_mu;
     /* response thread */
     std::thread llm_thread;
     std::mutex llm_mu;
     std::condition_variable llm_cv;
-    struct Prompt { std::string text; bool from_speech; };
+    struct Prompt { bool from_speech; };
     std::deque<Prompt> prompts;
     bool llm_stop = false;
 };
@@ -81,8 +83,15 @@ static void set_state(tk_cortex_s* c, tk_system_state_e s) {
 
 static tk_error_code_t mkpath(const char* s, const char* dflt, tk_path_t** out) { return tk_path_create_from_string(out, s ? s : dflt); }
 
-static void run_llm(tk_cortex_s* c, const std::string& prompt) {
+/* one LLM turn as cortex_run_llm_inference does it (tk_cortex_main.c:1323-1379): the prompt is the reasoner's context string under a
+ * 2048-token budget; the response text is parsed into actions (tk_decision_engine.c:1632) — executing them (TTS, navigation) is outside
+ * the hot path, they are counted — and remembered as the system's conversation turn */
+static void run_llm(tk_cortex_s* c) {
     set_state(c, TK_STATE_PROCESSING);
+    char* ctx = nullptr;
+    if (tk_contextual_reasoner_generate_context_string(c->reasoner, &ctx, 2048) != TK_SUCCESS || !ctx) { set_state(c, TK_STATE_IDLE); return; }
+    const std::string prompt = ctx;
+    (void)tk_contextual_reasoner_free_context_string(ctx);
     if (tk_llm_runner_prepare_generation(c->runner, prompt.c_str(), false) != TK_SUCCESS) { set_state(c, TK_STATE_IDLE); return; }
     set_state(c, TK_STATE_RESPONDING);
     std::string resp;
@@ -92,17 +101,25 @@ static void run_llm(tk_cortex_s* c, const std::string& prompt) {
         if (!p || p == TK_TOOL_CALL_TOKEN) break;
         resp += p;
     }
+    tk_llm_response_t* parsed = nullptr;
+    const bool ok = tk_decision_engine_parse_llm_response_text(resp.c_str(), &parsed) == TK_SUCCESS;
+    const uint64_t n_actions = ok && parsed ? parsed->action_count : 0;
+    tk_decision_engine_free_response(&parsed);
+    (void)tk_contextual_reasoner_add_conversation_turn(c->reasoner, false, resp.c_str(), 1.0f);
     {
         std::lock_guard<std::mutex> lk(c->stat_mu);
         c->stats.llm_responses++;
         c->stats.llm_tokens += (uint64_t)n;
+        c->stats.responses_parsed += ok ? 1 : 0;
+        c->stats.actions_parsed += n_actions;
         c->last_response = resp;
+        c->last_prompt = prompt;
     }
     set_state(c, TK_STATE_IDLE);
 }
 
 /* hand a prompt to the response thread; user speech is never dropped, stale scene descriptions are */
-static void post_prompt(tk_cortex_s* c, std::string text, bool from_speech) {
+static void post_prompt(tk_cortex_s* c, bool from_speech) {
     std::lock_guard<std::mutex> lk(c->llm_mu);
     if (c->prompts.size() >= TK_CORTEX_PROMPT_QUEUE) {
         for (auto it = c->prompts.begin(); it != c->prompts.end(); ++it)
@@ -113,7 +130,7 @@ static void post_prompt(tk_cortex_s* c, std::string text, bool from_speech) {
                 break;
             }
     }
-    c->prompts.push_back(tk_cortex_s::Prompt{std::move(text), from_speech});
+    c->prompts.push_back(tk_cortex_s::Prompt{from_speech});
     c->llm_cv.notify_one();
 }
 
@@ -124,10 +141,10 @@ static void llm_worker(tk_cortex_s* c) {
             std::unique_lock<std::mutex> lk(c->llm_mu);
             c->llm_cv.wait(lk, [&] { return c->llm_stop || !c->prompts.empty(); });
             if (c->llm_stop) return;
-            p = std::move(c->prompts.front());
+            p = c->prompts.front();
             c->prompts.pop_front();
         }
-        run_llm(c, p.text);
+        run_llm(c);
     }
 }
 
@@ -176,6 +193,8 @@ tk_error_code_t tk_cortex_create(tk_cortex_t** out_cortex, const tk_cortex_confi
     if (rc != TK_SUCCESS) return fail(rc);
     tk_llm_config_t rcfg{4096, NULL, 0}; /* n_ctx 4096: tk_runner_lifecycle.c:48 */
     if ((rc = tk_llm_runner_create(&c->runner, c->llm_model, &rcfg)) != TK_SUCCESS) return fail(rc);
+    tk_context_config_t cc{100, 20, 0.3f, 0.95f, 100}; /* tk_cortex_main.c:835-841 */
+    if ((rc = tk_contextual_reasoner_create(&c->reasoner, &cc)) != TK_SUCCESS) return fail(rc);
 
     c->llm_thread = std::thread(llm_worker, c.get());
     set_state(c.get(), TK_STATE_IDLE);
@@ -196,6 +215,7 @@ void tk_cortex_destroy(tk_cortex_t** cortex) {
     c->llm_cv.notify_all();
     if (c->llm_thread.joinable()) c->llm_thread.join(); /* run_llm leaves its token loop as soon as `stop` is set */
     if (c->runner) tk_llm_runner_destroy(&c->runner);
+    if (c->reasoner) tk_contextual_reasoner_destroy(&c->reasoner);
     if (c->loader) { if (c->llm_model) (void)tk_model_loader_unload_model(c->loader, &c->llm_model); tk_model_loader_destroy(&c->loader); }
     if (c->det) tk_object_detector_destroy(&c->det);
     if (c->asr) tk_asr_whisper_destroy(&c->asr);
@@ -228,23 +248,26 @@ tk_error_code_t tk_cortex_run(tk_cortex_t* c) {
             tk_detection_result_t* res = nullptr;
             size_t n = 0;
             if (tk_object_detector_detect(c->det, &f, &res, &n) != TK_SUCCESS) continue;
-            std::string ctx = "Scene:";
+            /* detections -> the reasoner's environmental snapshot (cortex_process_vision_input, tk_cortex_main.c:1198-1222) */
             const size_t shown = n < 20 ? n : 20; /* max_detected_objects 20: tk_cortex_main.c:781 */
+            std::vector<tk_vision_object_t> objs(shown);
             for (size_t i = 0; i < shown; ++i) {
-                char b[160];
-                snprintf(b, sizeof b, " %s (%.2f) at [%d,%d,%d,%d];", res[i].label ? res[i].label : "object", res[i].confidence, res[i].bbox.x, res[i].bbox.y,
-                         res[i].bbox.w, res[i].bbox.h);
-                ctx += b;
+                objs[i] = tk_vision_object_t{};
+                objs[i].class_id = res[i].class_id; objs[i].label = res[i].label; objs[i].confidence = res[i].confidence; objs[i].bbox = res[i].bbox;
             }
+            tk_vision_result_t vr{};
+            vr.valid_analyses_mask = TK_VISION_RESULT_OBJECT_DETECTION; vr.object_count = shown; vr.objects = objs.data();
+            (void)tk_contextual_reasoner_update_vision_context(c->reasoner, &vr);
             tk_object_detector_free_results(&res);
             {
                 std::lock_guard<std::mutex> lk(c->stat_mu);
                 c->stats.frames_processed++;
                 if (n > 0) c->stats.frames_with_objects++;
             }
-            if (n > 0) post_prompt(c, ctx, false); /* SIGNIFICANT_VISION_CHANGE: every frame with >= 1 detection (tk_cortex_main.c:1224-1237) */
+            if (n > 0) post_prompt(c, false); /* SIGNIFICANT_VISION_CHANGE: every frame with >= 1 detection (tk_cortex_main.c:1224-1237) */
         } else {
-            post_prompt(c, "User said: " + ev.text, true);
+            (void)tk_contextual_reasoner_add_conversation_turn(c->reasoner, true, ev.text.c_str(), 0.9f); /* final transcription (:1081) */
+            post_prompt(c, true);
         }
     }
     return TK_SUCCESS;
@@ -349,6 +372,17 @@ size_t tk_mi355x_cortex_last_response(const tk_cortex_t* c, char* buf, size_t ca
         buf[n] = 0;
     }
     return c->last_response.size();
+}
+
+size_t tk_mi355x_cortex_last_prompt(const tk_cortex_t* c, char* buf, size_t cap) {
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->stat_mu);
+    if (buf && cap) {
+        size_t n = c->last_prompt.size() < cap - 1 ? c->last_prompt.size() : cap - 1;
+        memcpy(buf, c->last_prompt.data(), n);
+        buf[n] = 0;
+    }
+    return c->last_prompt.size();
 }
 
 void tk_mi355x_cortex_set_max_response_tokens(tk_cortex_t* c, int n) {
