@@ -765,19 +765,27 @@ __device__ __forceinline__ void finish_tile(const PTile& R, const OpsQ4& o, floa
 
 /* one 256-k block: NT weight tiles (operands in registers) x MT M-tiles (operands streamed from the LDS ring, each read once
  * for all NT weight tiles) */
+/* rot (0 or MT / 2, wave-uniform): register slot m of this wave works on M-tile m ^ rot.  The second half of a workgroup's waves (the
+ * SIMD partners of the first half) walk the M-tiles from the middle, so the two waves of a SIMD never want the same LDS rows and the
+ * matrix pipe at the same moment (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  M-tiles are independent accumulators: the order
+ * does not enter the result; the epilogue stores slot m to rows of tile m ^ rot. */
 template <int MT, int NT, bool Q4>
-__device__ __forceinline__ void gemm_block(const OpsQ4 (&o)[NT], const uint8_t* chunk, int lane, float (&acc)[NT][MT][4]) {
+__device__ __forceinline__ void gemm_block(const OpsQ4 (&o)[NT], const uint8_t* chunk, int rot, int lane, float (&acc)[NT][MT][4]) {
     constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 512;
     const v4i zero = {0, 0, 0, 0};
     constexpr int AD = TK_GEMM_LDS_DEPTH; /* M-tiles of LDS operand reads in flight ahead of the MFMAs */
     ATile T[AD + 1];
     PTile R[NT];
+    /* (m ^ rot) * S = m * S + rot * S for the lower half of the slots, m * S - rot * S for the upper half: two bases, static offsets */
+    const uint8_t* act[2] = {chunk + rot * 4096, chunk - rot * 4096};
+    const uint8_t* amn[2] = {chunk + OFF_AMN + rot * 512, chunk + OFF_AMN - rot * 512};
+    const uint8_t* adp[2] = {chunk + OFF_AD + rot * 64, chunk + OFF_AD - rot * 64};
+#define TK_LDS_TILE(slot, m) lds_tile<Q4>(T[slot], act[(m) >= MT / 2] + (m) * 4096, amn[(m) >= MT / 2] + (m) * 512, adp[(m) >= MT / 2] + (m) * 64, lane)
 #pragma unroll
-    for (int m = 0; m < AD && m < MT; ++m) lds_tile<Q4>(T[m], chunk + m * 4096, chunk + OFF_AMN + m * 512, chunk + OFF_AD + m * 64, lane);
+    for (int m = 0; m < AD && m < MT; ++m) TK_LDS_TILE(m, m);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        if (m + AD < MT)
-            lds_tile<Q4>(T[(m + AD) % (AD + 1)], chunk + (m + AD) * 4096, chunk + OFF_AMN + (m + AD) * 512, chunk + OFF_AD + (m + AD) * 64, lane);
+        if (m + AD < MT) TK_LDS_TILE((m + AD) % (AD + 1), m + AD);
         __builtin_amdgcn_sched_barrier(0);
         const ATile& t = T[m % (AD + 1)];
         PTile c[NT];
@@ -808,6 +816,7 @@ __device__ __forceinline__ void gemm_block(const OpsQ4 (&o)[NT], const uint8_t* 
     }
 #pragma unroll
     for (int w = 0; w < NT; ++w) finish_tile<Q4>(R[w], o[w], acc[w][MT - 1]);
+#undef TK_LDS_TILE
 }
 
 /* NT = weight tiles per wave: 2 (adjacent row tiles, same tensor) when a CU owns enough tiles to keep four such waves busy —
@@ -825,6 +834,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
     const int nblk_total = a.K / 256;
     const int ksi = blockIdx.x % a.ks;
     const int blk0 = ksi * nb;
+    const int rot = wave >= 4 ? MT / 2 : 0; /* waves 4..7 share their SIMDs with waves 0..3: they start from the middle M-tile (gemm_block) */
 
     int rt = NT * (blockIdx.x / a.ks + wave * groups); /* first of this wave's NT adjacent row tiles */
     const bool active = rt < total_row_tiles;
@@ -904,7 +914,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
 #pragma unroll
             for (int w = 0; w < NT; ++w) f4[HAS4 ? w : 0] = load_q4(next + w * tile_pitch, lane);
             __builtin_amdgcn_sched_barrier(0);
-            gemm_block<MT, NT, true>(o, chunk, lane, acc);
+            gemm_block<MT, NT, true>(o, chunk, rot, lane, acc);
         }
         if (HAS6 && !is4) {
 #pragma unroll
@@ -913,7 +923,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
 #pragma unroll
             for (int w = 0; w < NT; ++w) f6[HAS6 ? w : 0] = load_q6(next + w * tile_pitch, lane);
             __builtin_amdgcn_sched_barrier(0);
-            gemm_block<MT, NT, false>(o, chunk, lane, acc);
+            gemm_block<MT, NT, false>(o, chunk, rot, lane, acc);
         }
     }
     if (!active) return;
@@ -926,7 +936,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m * TK_ROW_SLOTS + 4 * g + r;
+                const int row = (m ^ rot) * TK_ROW_SLOTS + 4 * g + r; /* register slot m holds M-tile m ^ rot */
                 if (row < a.nrows) __builtin_nontemporal_store(acc[w][m][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
             }
     }
