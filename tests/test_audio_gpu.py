@@ -153,3 +153,109 @@ def test_asr_set_language_selects_the_decoder_prompt(gpu):
     en = gpu.Asr(hp=gpu.WhisperHP(80, 50, 64, 2, 2, 32, 64, 2, 2, 51864), seed=11)
     assert en.set_language("de") == 0 and en.prompt_tokens() == [50257, 50362]
     en.close()
+
+
+def test_audio_pipeline_vad_asr_flow_matches_the_direct_calls(gpu):
+    """tk_audio_pipeline_* (src/audio/tk_audio_pipeline.c:550-803): chunks -> ring -> 32 ms VAD frames -> events -> speech segment -> final
+    transcription -> back to AWAITING_WAKE_WORD.  The segment boundaries, events and text equal the same VAD / ASR entry points driven by
+    hand on the same frames (process_vad's order: events first, then the frame joins the segment while speech is active)."""
+    rng = np.random.default_rng(2)
+    loud = np.clip(rng.normal(0, 9000, 16000), -32768, 32767).astype(np.int16)
+    sig = np.concatenate([loud, np.zeros(24000, np.int16)])
+    ap = gpu.AudioPipeline(threshold=0.8, silence_ms=500.0)                 # no wake-word model: always awake
+    assert ap.state() in (1, 2)
+    for chunk in np.split(sig, 25):                                          # 100 ms chunks, like the reference's mock microphone
+        assert ap.feed(chunk) == 0
+        assert ap.drain() == 0
+    # by hand
+    vad, asr = gpu.Vad(threshold=0.8, min_silence_ms=500.0), gpu.Asr()
+    seg, want_events, want_text = [], [], []
+    frames = [ch[k:k + 512] for ch in np.split(sig, 25) for k in range(0, len(ch), 512)]   # a drained ring hands out 512, 512, 512, 64 per chunk
+    for fr in frames:
+        ev = vad.process_with_events(fr)
+        want_events += ev
+        if 1 in ev and seg:
+            text, _, conf, partial = asr.process_audio(np.concatenate(seg), True)
+            want_text.append((text, True, conf))
+            seg = []
+        if vad.state().is_speech_active:
+            seg.append(fr)
+    assert want_events.count(0) >= 1 and want_events.count(1) >= 1 and len(want_text) >= 1
+    assert ap.vad_events == want_events
+    assert [(t, f) for t, f, _ in ap.transcriptions] == [(t, f) for t, f, _ in want_text]
+    assert all(abs(c - 0.9) < 1e-7 for _, _, c in ap.transcriptions)
+    assert ap.state() in (1, 2) and ap.force_end() == 0
+    assert ap.feed(np.zeros(20000, np.int16)) == 1004                        # TK_ERROR_BUFFER_TOO_SMALL: larger than the 16384-sample ring
+    assert gpu.lib().tk_audio_pipeline_process_chunk(None, None, 0) == 1001
+    ap.close()
+    # with a wake-word model configured, audio before the detector's hit goes to the detector only
+    ap = gpu.AudioPipeline(wake_word="porcupine.pv", threshold=0.8, silence_ms=500.0)
+    assert ap.state() == 1
+    for chunk in np.split(sig[:16000], 10):
+        assert ap.feed(chunk) == 0
+    assert ap.drain() == 0 and ap.vad_events == [] and ap.transcriptions == []
+    assert ap.wake() == 0 and ap.state() == 2 and ap.wake() == 1002          # TK_ERROR_INVALID_STATE: already listening
+    for chunk in np.split(sig, 25):
+        assert ap.feed(chunk) == 0
+        assert ap.drain() == 0
+    assert ap.vad_events == want_events and [(t, f) for t, f, _ in ap.transcriptions] == [(t, f) for t, f, _ in want_text]
+    assert ap.state() == 1                                                   # back to waiting for the wake word after the transcription
+    ap.close()
+
+
+def test_audio_pipeline_tts_priority_queue_and_interruption(gpu):
+    """the TTS hand-off (tk_audio_pipeline.c:837-1010): requests leave the queue by priority (FIFO inside one), a more urgent request
+    interrupts a LOW / NORMAL one that is being spoken (on_tts_interrupt, its remaining audio dropped), never a HIGH one; 16 entries at most."""
+    import threading
+    import time
+    LOW, NORMAL, HIGH, CRITICAL = 3, 2, 1, 0
+    ap = gpu.AudioPipeline()
+    spoken, gate = [], threading.Event()
+
+    def synth(text, emit):
+        spoken.append(text)
+        emit(np.full(100, 1, np.int16))
+        if text == b"first":
+            gate.wait(10)
+        emit(np.full(100, 2, np.int16))
+        return 0
+
+    ap.set_synthesizer(synth)
+    assert ap.say("first", LOW) == 0
+    t0 = time.time()
+    while not spoken and time.time() - t0 < 10:
+        time.sleep(0.005)
+    assert spoken == [b"first"] and ap.state() == 4                          # SYNTHESIZING
+    for text, pr in (("n1", NORMAL), ("low", LOW), ("h1", HIGH), ("n2", NORMAL), ("crit", CRITICAL), ("h2", HIGH)):
+        assert ap.say(text, pr) == 0
+    assert ap.interrupts >= 1                                                # NORMAL / HIGH / CRITICAL arrived while a LOW one was speaking
+    gate.set()
+    assert ap.drain() == 0
+    assert spoken == [b"first", b"crit", b"h1", b"h2", b"n1", b"n2", b"low"]
+    first_chunks = [a for a, sr in ap.tts_audio[:2]]
+    assert first_chunks[0][0] == 1                                           # "first": the chunk before the interruption was delivered ...
+    assert sum(1 for a, _ in ap.tts_audio if a[0] == 2) == 6                 # ... its second chunk was dropped; the six others were complete
+    # a HIGH request being spoken is not interrupted by a CRITICAL one
+    n_int = ap.interrupts
+    gate.clear()
+    spoken.clear()
+
+    def synth2(text, emit):
+        spoken.append(text)
+        if text == b"urgent":
+            gate.wait(10)
+        emit(np.full(10, 7, np.int16))
+        return 0
+
+    ap.set_synthesizer(synth2)
+    assert ap.say("urgent", HIGH) == 0
+    t0 = time.time()
+    while not spoken and time.time() - t0 < 10:
+        time.sleep(0.005)
+    assert ap.say("fire", CRITICAL) == 0 and ap.interrupts == n_int
+    for i in range(15):
+        assert ap.say("x%d" % i, LOW) == (0 if i < 14 else 1004)             # 16 entries: urgent + fire + 14
+    gate.set()
+    assert ap.drain() == 0 and spoken[:2] == [b"urgent", b"fire"] and len(spoken) == 16
+    assert gpu.lib().tk_audio_pipeline_synthesize_text(ap.h, None, 0) == 1001
+    ap.close()

@@ -1,0 +1,109 @@
+"""CPU: the audio pipeline's host logic (ring, worker thread, wake-word / listening / transcribing states, TTS priority queue and
+interruption — csrc/abi/tk_abi_audio_pipeline.cpp restating src/audio/tk_audio_pipeline.c:387-1010) against stub VAD / ASR engines
+(tests/stubs/audio_engine_stub.cpp: amplitude threshold, "seg<N>" transcriptions).  The same flows run against the GPU engines in
+tests/test_audio_gpu.py."""
+import ctypes as C
+import os
+import subprocess
+import threading
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOW, NORMAL, HIGH, CRITICAL = 3, 2, 1, 0
+
+
+@pytest.fixture(scope="module")
+def stub_lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("stub") / "libtk_audio_pipeline_stub.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "stubs", "audio_engine_stub.cpp"),
+                           os.path.join(ROOT, "trackiellm_amd", "csrc", "abi", "tk_abi_audio_pipeline.cpp"), "-o", out, "-lpthread", "-Wl,-Bsymbolic"])  # -Bsymbolic: bind to the stubs even when the product library is loaded RTLD_GLOBAL
+    return C.CDLL(out)
+
+
+def make(stub_lib, **kw):
+    from trackiellm_amd.audio import AudioPipeline
+    return AudioPipeline(library=stub_lib, **kw)
+
+
+SIG = np.concatenate([np.full(16000, 5000, np.int16), np.zeros(24000, np.int16)])
+
+
+def test_always_awake_flow(stub_lib):
+    ap = make(stub_lib)
+    for chunk in np.split(SIG, 25):
+        assert ap.feed(chunk) == 0 and ap.drain() == 0
+    # the stub VAD starts with the first loud frame and ends with the first silent one: the segment is the loud second
+    assert ap.vad_events == [0, 1] and ap.transcriptions == [("seg16000", True, pytest.approx(0.9))]
+    assert ap.state() in (1, 2)
+    assert ap.feed(np.zeros(16384, np.int16)) == 1004          # the ring keeps one slot free
+    assert ap.feed(np.zeros(16383, np.int16)) == 0 and ap.drain() == 0
+    ap.close()
+
+
+def test_wake_word_gate_and_partial_frames_do_not_spin(stub_lib):
+    """1600-sample chunks leave 64 samples (less than a wake-word frame) in the ring: the worker must sleep on them, not spin with the
+    mutex held (a regression this test pins: feed() starved forever)."""
+    ap = make(stub_lib, wake_word="porcupine.pv")
+    assert ap.state() == 1
+    for chunk in np.split(SIG[:16000], 10):
+        assert ap.feed(chunk) == 0
+    assert ap.drain() == 0 and ap.vad_events == [] and ap.transcriptions == []
+    assert ap.wake() == 0 and ap.state() == 2 and ap.wake() == 1002
+    for chunk in np.split(SIG, 25):
+        assert ap.feed(chunk) == 0 and ap.drain() == 0
+    assert ap.vad_events == [0, 1] and len(ap.transcriptions) == 1 and ap.transcriptions[0][1]
+    assert ap.state() == 1                                     # back to waiting for the wake word after the final transcription
+    ap.close()
+
+
+def test_tts_priority_queue_and_interruption(stub_lib):
+    ap = make(stub_lib)
+    spoken, gate = [], threading.Event()
+
+    def synth(text, emit):
+        spoken.append(text)
+        emit(np.full(100, 1, np.int16))
+        if text == b"first":
+            gate.wait(10)
+        emit(np.full(100, 2, np.int16))
+        return 0
+
+    ap.set_synthesizer(synth)
+    assert ap.say("first", LOW) == 0
+    t0 = time.time()
+    while not spoken and time.time() - t0 < 10:
+        time.sleep(0.005)
+    assert spoken == [b"first"] and ap.state() == 4
+    for text, pr in (("n1", NORMAL), ("low", LOW), ("h1", HIGH), ("n2", NORMAL), ("crit", CRITICAL), ("h2", HIGH)):
+        assert ap.say(text, pr) == 0
+    assert ap.interrupts >= 1
+    gate.set()
+    assert ap.drain() == 0
+    assert spoken == [b"first", b"crit", b"h1", b"h2", b"n1", b"n2", b"low"]
+    assert sum(1 for a, _ in ap.tts_audio if a[0] == 2) == 6   # the interrupted request's second chunk was dropped
+    n_int = ap.interrupts
+    gate.clear()
+    spoken.clear()
+
+    def synth2(text, emit):
+        spoken.append(text)
+        if text == b"urgent":
+            gate.wait(10)
+        emit(np.full(10, 7, np.int16))
+        return 0
+
+    ap.set_synthesizer(synth2)
+    assert ap.say("urgent", HIGH) == 0
+    t0 = time.time()
+    while not spoken and time.time() - t0 < 10:
+        time.sleep(0.005)
+    assert ap.say("fire", CRITICAL) == 0 and ap.interrupts == n_int      # a HIGH request is never interrupted
+    for i in range(15):
+        assert ap.say("x%d" % i, LOW) == (0 if i < 14 else 1004)         # 16 entries at most
+    gate.set()
+    assert ap.drain() == 0 and spoken[:2] == [b"urgent", b"fire"] and len(spoken) == 16
+    ap.close()

@@ -118,7 +118,7 @@ def test_cortex_cycle_like_reference_test(gpu):
     assert 4 in cx.states and 5 in cx.states                     # PROCESSING and RESPONDING were reported
     assert len(cx.last_response()) > 0
     # the prompt is the contextual reasoner's context string (tk_contextual_reasoner.c:681-743): objects, navigation, conversation
-    pr = cx.last_prompt().decode()
+    pr = cx.last_prompt().decode("utf-8", "replace")   # a System turn carries raw bytes of the random model's tokens
     assert "(0.0m, " in pr and "% confidence)" in pr and "No clear path. 0 hazards detected." in pr
     assert pr.endswith("No recent conversation") or 'User: "' in pr or 'System: "' in pr
     assert s.responses_parsed == 0 and s.actions_parsed == 0   # a random-weight model does not speak the decision engine's JSON

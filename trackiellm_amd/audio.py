@@ -156,3 +156,95 @@ class Vad:
             self.close()
         except Exception:
             pass
+
+
+# ---- audio pipeline state machine (tk_audio_pipeline_*) ----
+
+class _AudioParams(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("channels", C.c_uint32)]
+
+
+class _PipelineConfig(C.Structure):
+    _fields_ = [("input_audio_params", _AudioParams), ("user_language", C.c_char_p), ("user_data", C.c_void_p), ("asr_model_path", C.POINTER(_Path)),
+                ("vad_model_path", C.POINTER(_Path)), ("tts_model_path", C.POINTER(_Path)), ("tts_config_path", C.POINTER(_Path)),
+                ("ww_model_path", C.POINTER(_Path)), ("ww_keyword_path", C.POINTER(_Path)), ("ww_sensitivity", C.c_float),
+                ("sc_model_path", C.POINTER(_Path)), ("vad_silence_threshold_ms", C.c_float), ("vad_speech_probability_threshold", C.c_float)]
+
+
+class Transcription(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("is_final", C.c_bool), ("confidence", C.c_float)]
+
+
+_TRANS_CB = C.CFUNCTYPE(None, C.POINTER(Transcription), C.c_void_p)
+_TTS_AUDIO_CB = C.CFUNCTYPE(None, C.POINTER(C.c_int16), C.c_size_t, C.c_uint32, C.c_void_p)
+_TTS_INT_CB = C.CFUNCTYPE(None, C.c_void_p)
+_AMBIENT_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_EMIT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_int16), C.c_size_t, C.c_uint32, C.c_void_p)
+_SYNTH_FN = C.CFUNCTYPE(C.c_int, C.c_char_p, _EMIT_FN, C.c_void_p, C.c_void_p)
+
+
+class _AudioCallbacks(C.Structure):
+    _fields_ = [("on_vad_event", _VAD_CB), ("on_transcription", _TRANS_CB), ("on_tts_audio_ready", _TTS_AUDIO_CB), ("on_tts_interrupt", _TTS_INT_CB),
+                ("on_ambient_sound_detected", _AMBIENT_CB)]
+
+
+class AudioPipeline:
+    """tk_audio_pipeline_*: ring -> (wake word) -> VAD -> ASR -> transcription callback; priority TTS queue in front of a pluggable synthesiser."""
+
+    def __init__(self, asr="synthetic://whisper-tiny.en?seed=6", vad="synthetic://vad?seed=7", wake_word=None, threshold=0.8, silence_ms=500.0,
+                 sample_rate=16000, library=None):
+        self._lib = library if library is not None else lib()   # tests drive the host state machine against a stub-engine build
+        self.vad_events, self.transcriptions, self.tts_audio, self.interrupts = [], [], [], 0
+        self._cbs = _AudioCallbacks(
+            _VAD_CB(lambda e, u: self.vad_events.append(e)),
+            _TRANS_CB(lambda t, u: self.transcriptions.append((t.contents.text.decode(), t.contents.is_final, t.contents.confidence))),
+            _TTS_AUDIO_CB(lambda a, n, sr, u: self.tts_audio.append((np.ctypeslib.as_array(a, (n,)).copy(), sr))),
+            _TTS_INT_CB(lambda u: setattr(self, "interrupts", self.interrupts + 1)),
+            _AMBIENT_CB(lambda r, u: None))
+        self._lib.tk_path_create.restype = C.POINTER(_Path)
+        paths = [self._lib.tk_path_create(s.encode()) if s else None for s in (asr, vad, wake_word)]
+        cfg = _PipelineConfig(_AudioParams(sample_rate, 1), b"en", None, paths[0], paths[1], None, None, paths[2], None, 0.5, None, silence_ms, threshold)
+        self.h = C.c_void_p()
+        try:
+            rc = self._lib.tk_audio_pipeline_create(C.byref(self.h), C.byref(cfg), self._cbs)
+            if rc != 0:
+                raise RuntimeError("tk_audio_pipeline_create failed: %d" % rc)
+        finally:
+            for p in paths:
+                if p:
+                    self._lib.tk_path_destroy(C.byref(p))
+        self._synth = None
+
+    def feed(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        return self._lib.tk_audio_pipeline_process_chunk(self.h, pcm.ctypes.data_as(C.c_void_p), C.c_size_t(pcm.size))
+
+    def say(self, text, priority):
+        return self._lib.tk_audio_pipeline_synthesize_text(self.h, text.encode(), priority)
+
+    def set_synthesizer(self, fn):
+        """fn(text: bytes, emit(pcm int16 array, sample_rate)) -> int error code, called on the pipeline's worker thread"""
+        def tramp(text, emit, ctx, user):
+            def e(pcm, sr=22050):
+                pcm = np.ascontiguousarray(pcm, np.int16)
+                emit(pcm.ctypes.data_as(C.POINTER(C.c_int16)), pcm.size, sr, ctx)
+            return fn(text, e) or 0
+        self._synth = _SYNTH_FN(tramp)
+        assert self._lib.tk_mi355x_audio_pipeline_set_synthesizer(self.h, self._synth, None) == 0
+
+    def wake(self):
+        return self._lib.tk_mi355x_audio_pipeline_trigger_wake_word(self.h)
+
+    def drain(self, timeout_ms=30000):
+        return self._lib.tk_mi355x_audio_pipeline_drain(self.h, timeout_ms)
+
+    def force_end(self):
+        return self._lib.tk_audio_pipeline_force_transcription_end(self.h)
+
+    def state(self):
+        return self._lib.tk_audio_pipeline_get_state(self.h)
+
+    def close(self):
+        if self.h:
+            self._lib.tk_audio_pipeline_destroy(C.byref(self.h))
+            self.h = C.c_void_p()

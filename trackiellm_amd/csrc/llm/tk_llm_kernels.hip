@@ -1362,13 +1362,25 @@ __global__ __launch_bounds__(256) void k_swiglu_q8(const float* partial, int ks,
     const int r = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= FF / 8) return; /* FF/8 is a multiple of 32: whole half-waves drop out together */
+    /* 8 gate and 8 up values as 16-byte loads, every K-split slab requested before the first add (slabs added in ascending order) */
+    v4f g[2], u[2];
+    {
+        v4f pg[TK_RMS_MAX_KS][2], pu[TK_RMS_MAX_KS][2];
+#pragma unroll
+        for (int s = 0; s < TK_RMS_MAX_KS; ++s)
+            if (s < ks) {
+                const float* row = partial + ((int64_t)s * TK_MAX_ROWS + r) * (2 * (int64_t)FF);
+                pg[s][0] = *(const v4f*)(row + 8 * c); pg[s][1] = *(const v4f*)(row + 8 * c + 4);
+                pu[s][0] = *(const v4f*)(row + FF + 8 * c); pu[s][1] = *(const v4f*)(row + FF + 8 * c + 4);
+            }
+        g[0] = pg[0][0]; g[1] = pg[0][1]; u[0] = pu[0][0]; u[1] = pu[0][1];
+#pragma unroll
+        for (int s = 1; s < TK_RMS_MAX_KS; ++s)
+            if (s < ks) { g[0] = g[0] + pg[s][0]; g[1] = g[1] + pg[s][1]; u[0] = u[0] + pu[s][0]; u[1] = u[1] + pu[s][1]; }
+    }
     float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float g = sum_partials(partial, ks, 2 * FF, r, 8 * c + i);
-        const float u = sum_partials(partial, ks, 2 * FF, r, FF + 8 * c + i);
-        v[i] = tk_siluf(g) * u;
-    }
+    for (int i = 0; i < 8; ++i) v[i] = tk_siluf(g[i >> 2][i & 3]) * u[i >> 2][i & 3];
     quantize_chunk8(v, c, r, out);
 }
 
