@@ -104,6 +104,9 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_get_hparams(tk_asr_whisper_con
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_whisper_ggml_probe(const char* path, tk_mi355x_whisper_hparams_t* out, int32_t* n_tokens,
                                                                  int32_t* n_tensors);
 /* feed one window probability straight into the VAD state machine (30 ms step); returns -1 none, 0 started, 1 ended */
+/* a VAD .onnx file (tk_vad_silero_config_t.model_path, src/sensors/tk_vad_silero.c:110-150): parse the graph (no ONNX Runtime, no GPU) and
+ * check that every node is an op the GPU executor runs (csrc/audio/tk_vad_graph.h); counts optional */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_vad_onnx_probe(const char* path, int32_t* n_nodes, int32_t* n_initialisers, int32_t* n_state_inputs);
 TK_API int tk_mi355x_vad_step(tk_vad_silero_context_t* ctx, float probability);
 /* probabilities of n consecutive float windows of the model's window length */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_vad_probabilities(tk_vad_silero_context_t* ctx, const float* windows, int n, float* out);

@@ -259,3 +259,42 @@ def test_audio_pipeline_tts_priority_queue_and_interruption(gpu):
     assert ap.drain() == 0 and spoken[:2] == [b"urgent", b"fire"] and len(spoken) == 16
     assert gpu.lib().tk_audio_pipeline_synthesize_text(ap.h, None, 0) == 1001
     ap.close()
+
+
+def test_vad_onnx_graph_on_the_gpu_matches_torch(gpu, tmp_path):
+    """tk_vad_silero_create on an .onnx model_path (src/sensors/tk_vad_silero.c:110-280): the graph itself — reflect pad, STFT conv,
+    magnitude, conv / ReLU encoder, LSTM with recurrent state, 1x1 conv, sigmoid, mean — runs node by node on the GPU
+    (csrc/audio/tk_vad_graph.hip).  Probabilities of eight consecutive windows against an independent torch implementation
+    (tests/golden/vad_graph.npz), state handling, and the failure mode for an op outside the supported class."""
+    import onnx_util
+    g = np.load(os.path.join(GOLD, "vad_graph.npz"))
+    W = onnx_util.vad_weights(int(g["seed"]))
+    path = tmp_path / "silero_class_vad.onnx"
+    path.write_bytes(onnx_util.vad_model(W))
+    vad = gpu.Vad(model=str(path))
+    wins, want = g["windows"], g["torch_probs"]
+    got = vad.probabilities(wins)
+    assert np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
+    # the recurrent state is carried from window to window and from call to call; reset() clears it
+    vad.reset()
+    again = np.concatenate([vad.probabilities(wins[:3]), vad.probabilities(wins[3:])])
+    assert np.array_equal(again, got)
+    cont = vad.probabilities(wins[:2])
+    assert not np.array_equal(cont, got[:2])
+    vad.reset()
+    assert np.array_equal(vad.probabilities(wins[:2]), got[:2])
+    # the streaming entry drives the same graph: 1 s of the fixture's tone, events from the reference state machine on the graph's output
+    pcm = np.clip(np.tile(wins.reshape(-1), 5)[:16000] * 32768.0, -32768, 32767).astype(np.int16)
+    vad.reset()
+    ev = vad.process_with_events(pcm)
+    st = vad.state()
+    assert 0.0 < st.speech_probability < 1.0 and all(e in (0, 1) for e in ev)
+    # the stand-alone single-window query answers from a cleared state, twice the same
+    a, b = vad.probability(pcm[:480]), vad.probability(pcm[:480])
+    assert a == b and abs(a - got[0]) < 1e-3     # the same first window, up to the int16 round trip
+    vad.close()
+    bad = tmp_path / "vad_if.onnx"
+    bad.write_bytes(onnx_util.vad_model(W, extra_op="If"))
+    with pytest.raises(gpu.TkError) as e:
+        gpu.Vad(model=str(bad))
+    assert e.value.code == 4000 and "If" in e.value.detail

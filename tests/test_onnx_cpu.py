@@ -48,3 +48,22 @@ def test_rejections(layers, tmp_path):
     # a Conv without a bias input is legal ONNX: the bias reads as zeros
     p.write_bytes(X.yolo_model(layers, drop_bias_of=5))
     assert probe(p)[0] == 0
+
+
+def test_vad_graph_probe_accepts_the_silero_class_and_names_unsupported_ops(tmp_path):
+    """general ONNX graph reader (csrc/nn/tk_onnx_graph.cpp): nodes, attributes, float / int64 initialisers, declared inputs; the VAD
+    executor's op check runs without a GPU"""
+    W = X.vad_weights(21)
+    ok = tmp_path / "vad.onnx"
+    ok.write_bytes(X.vad_model(W))
+    n, ni, ns = C.c_int32(), C.c_int32(), C.c_int32()
+    assert tk.lib().tk_mi355x_vad_onnx_probe(str(ok).encode(), C.byref(n), C.byref(ni), C.byref(ns)) == 0
+    assert n.value == 24 and ni.value == len(W) + 5 and ns.value == 2          # h and c are recurrent inputs
+    bad = tmp_path / "vad_if.onnx"
+    bad.write_bytes(X.vad_model(W, extra_op="If"))
+    assert tk.lib().tk_mi355x_vad_onnx_probe(str(bad).encode(), None, None, None) == 4001   # TK_ERROR_MODEL_VERIFICATION_FAILED
+    assert b"'If'" in tk.lib().tk_error_get_detail()
+    assert tk.lib().tk_mi355x_vad_onnx_probe(str(tmp_path / "none.onnx").encode(), None, None, None) == 3001
+    junk = tmp_path / "junk.onnx"
+    junk.write_bytes(b"\x3a\xff\xff\xff\xff\x0f" + b"\0" * 16)                   # a graph field longer than the file
+    assert tk.lib().tk_mi355x_vad_onnx_probe(str(junk).encode(), None, None, None) == 3004

@@ -5,12 +5,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <memory>
 #include <string>
 #include <vector>
 
 #include "../audio/tk_audio_engine.h"
+#include "../audio/tk_vad_graph.h"
 #include "../audio/tk_whisper_ggml.h"
 #include "tk/tk_audio.h"
 #include "tk/tk_mi355x_ext.h"
@@ -262,7 +264,8 @@ int tk_mi355x_asr_prompt_tokens(tk_asr_whisper_context_t* c, int32_t* out, int c
 
 struct tk_vad_silero_context_s {
     tk_vad_silero_config_t config;
-    TkVadModel model;
+    TkVadModel model;                  /* synthetic://vad: the stand-in MLP */
+    std::unique_ptr<TkVadGraph> graph; /* an .onnx model_path: the graph itself, node by node (csrc/audio/tk_vad_graph.h) */
     tk_vad_silero_state_t state;
     float last_probability = 0.0f, time_since_last_event_ms = 0.0f;
     bool triggered_speech_start = false;
@@ -313,8 +316,13 @@ tk_error_code_t tk_vad_silero_create(tk_vad_silero_context_t** out_context, cons
     c->window = (size_t)c->sample_rate * 30 / 1000;
     c->step = (size_t)c->sample_rate * 10 / 1000;
     const std::string path = config->model_path->path_str ? config->model_path->path_str : "";
-    if (path.compare(0, 12, "synthetic://") != 0) return afail(TK_ERROR_MODEL_LOAD_FAILED, "only synthetic://vad is available: ONNX graphs are not interpreted");
-    if (!c->model.init(tk_mi355x_get_default_device(), (int)c->window, 64) || !c->model.fill_synthetic(seed_of(path, 7))) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+    if (path.compare(0, 12, "synthetic://") == 0) {
+        if (!c->model.init(tk_mi355x_get_default_device(), (int)c->window, 64) || !c->model.fill_synthetic(seed_of(path, 7))) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->model.error);
+    } else {
+        /* the reference's OrtCreateSession on config->model_path (src/sensors/tk_vad_silero.c:110-150) */
+        c->graph.reset(new TkVadGraph());
+        if (!c->graph->load(path.c_str(), tk_mi355x_get_default_device(), (int)c->window, (int)c->sample_rate)) return afail(TK_ERROR_MODEL_LOAD_FAILED, c->graph->error);
+    }
     *out_context = c.release();
     return TK_SUCCESS;
 }
@@ -327,6 +335,7 @@ void tk_vad_silero_destroy(tk_vad_silero_context_t** context) {
 
 tk_error_code_t tk_mi355x_vad_probabilities(tk_vad_silero_context_t* c, const float* windows, int n, float* out) {
     if (!c || !windows || !out || n < 0) return TK_ERROR_INVALID_ARGUMENT;
+    if (c->graph) { if (!c->graph->infer(windows, n, out)) return afail(TK_ERROR_INFERENCE_FAILED, c->graph->error); return TK_SUCCESS; }
     if (!c->model.infer(windows, n, out)) return afail(TK_ERROR_INFERENCE_FAILED, c->model.error);
     return TK_SUCCESS;
 }
@@ -337,7 +346,26 @@ tk_error_code_t tk_vad_silero_process_audio(tk_vad_silero_context_t* c, const in
     /* stateless single-window probability: the model window is fixed, shorter input is zero padded, longer truncated */
     std::vector<float> w(c->window, 0.0f);
     for (size_t i = 0; i < frame_count && i < c->window; ++i) w[i] = (float)audio_data[i] / 32768.0f;
-    return tk_mi355x_vad_probabilities(c, w.data(), 1, out_probability);
+    /* a recurrent graph answers this stand-alone query from a cleared state and leaves a cleared state behind (the reference never feeds
+     * state at all: one input, src/sensors/tk_vad_silero.c:225-245) */
+    if (c->graph && c->graph->stateful() && !c->graph->reset()) return afail(TK_ERROR_INFERENCE_FAILED, c->graph->error);
+    tk_error_code_t rc = tk_mi355x_vad_probabilities(c, w.data(), 1, out_probability);
+    if (rc == TK_SUCCESS && c->graph && c->graph->stateful() && !c->graph->reset()) return afail(TK_ERROR_INFERENCE_FAILED, c->graph->error);
+    return rc;
+}
+
+tk_error_code_t tk_mi355x_vad_onnx_probe(const char* path, int32_t* n_nodes, int32_t* n_initialisers, int32_t* n_state_inputs) {
+    if (!path) return TK_ERROR_INVALID_ARGUMENT;
+    TkOnnxGraph g;
+    if (!g.load(path)) return afail(access(path, 0) == 0 ? TK_ERROR_FILE_CORRUPT : TK_ERROR_FILE_NOT_FOUND, g.error);
+    std::string err;
+    if (!TkVadGraph::check_supported(g, &err)) return afail(TK_ERROR_MODEL_VERIFICATION_FAILED, err);
+    int st = 0, fl = 0;
+    for (const auto& vi : g.inputs) { if (vi.elem_type == 1 || vi.elem_type == 0) { if (fl++) ++st; } }
+    if (n_nodes) *n_nodes = (int32_t)g.nodes.size();
+    if (n_initialisers) *n_initialisers = (int32_t)g.init.size();
+    if (n_state_inputs) *n_state_inputs = st;
+    return TK_SUCCESS;
 }
 
 int tk_mi355x_vad_step(tk_vad_silero_context_t* c, float probability) {
@@ -397,6 +425,7 @@ tk_error_code_t tk_vad_silero_reset(tk_vad_silero_context_t* c) {
     c->time_since_last_event_ms = 0.0f;
     c->triggered_speech_start = false;
     c->audio_size = 0;
+    if (c->graph && !c->graph->reset()) return afail(TK_ERROR_INFERENCE_FAILED, c->graph->error);
     return TK_SUCCESS;
 }
 
