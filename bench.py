@@ -422,6 +422,9 @@ def main():
     ap.add_argument("--perception-batch", type=int, default=64, help="frames / utterances per detector / ASR call")
     ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     ap.add_argument("--ns-steps", type=int, default=4, help="timed steps of the north_star_point run")
+    ap.add_argument("--weights", choices=["q4_k_m", "f16"], default="q4_k_m",
+                    help="f16: BASELINE configs[4]'s fp16 checkpoint (14.2 GB of weights per decode step) on the exact fp32 MFMA GEMM; LLM stream only, "
+                         "no W4A8 roofline object (other kernels)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -452,9 +455,12 @@ def main():
         return run_model_per_gpu(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N)
 
     t0 = time.time()
-    model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4)
+    f16 = args.weights == "f16"
+    model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4, f16=f16)
     hp = model.hparams
     t_load = time.time() - t0
+    if f16:
+        args.llm_only, args.no_extras = True, True
     if args.roofline_only:
         args.llm_only, args.steps, args.warmup = True, 0, 0
     fused = not args.llm_only
@@ -470,6 +476,22 @@ def main():
         return
 
     sess = cb.sessions[0]
+    if f16:  # other kernels (k_gemm_f32 on f16 weights): the whole-step view is the roofline statement of this run
+        value = D.aggregate_throughput(G * B, args.steps, world, elapsed)
+        dec_ms = r["decode_ms_per_step"]
+        print(json.dumps({"metric": METRIC, "value": round(value, 3), "unit": "cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f16 weights x f16-rounded f32 activations, fp32 MFMA chain", "data": "synthetic",
+                          "config": {"workload": "configs[4] weights on one GPU: Mistral-7B fp16, 64-token prefill + 128-token greedy decode per cycle (LLM stream only)",
+                                     "concurrent_cycles_per_gpu": G * B, "decode_groups": G, "rows_per_llm_pass": B, "parallelism": f"replicas x{world}"},
+                          "llm_tok_per_s": round(G * B * world * N / r["decode_s"], 1), "decode_ms_per_step": round(dec_ms, 4),
+                          "weight_bytes_per_decode_step": int(model.weight_bytes),
+                          "llm_decode_step_roofline": {"bytes_per_step": int(model.weight_bytes), "steps_per_s": round(G * 1000.0 / dec_ms, 1),
+                                                       "frac": round(model.weight_bytes * (G * 1000.0 / dec_ms) / (HBM_PEAK_GBS * 1e9), 4)}}))
+        cb.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     roofline = gemv_roofline(sess, hp, B, model.weight_bytes)
     roofline_att = attention_roofline(sess, hp, B, min(P + N // 2, P + N))
     if args.roofline_only:
@@ -573,6 +595,15 @@ def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N):
     dist.destroy_process_group()
 
 
+def model_per_gpu_roles(world):
+    """rank 0 = the LLM; with 2 GPUs rank 1 runs detector + VAD + ASR; with more, the odd ranks run the detector and the
+    even ranks (> 0) VAD + ASR.  Returns (vision ranks, audio ranks)."""
+    per = list(range(1, world))
+    if world <= 2:
+        return per, per
+    return [r for r in per if r % 2 == 1], [r for r in per if r % 2 == 0]
+
+
 def run_model_per_gpu(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N):
     """SURVEY.md §8e rows "2" / "4" / "8": rank 0's GPU holds the LLM and decodes ALL cycles of the job; ranks 1.. run the detector
     (odd ranks) and VAD + ASR (even ranks, all of them when world == 2) for those cycles.  One step = G x B cycles through every
@@ -580,9 +611,7 @@ def run_model_per_gpu(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N
     and a text string per cycle (bytes, through the host): the bench hands nothing over inside the timed region — the software
     pipeline of CycleBench (the LLM of batch k next to the perception of batch k + 1) is what the placement preserves."""
     cycles = G * B
-    per = [r for r in range(1, world)]
-    vis = [r for r in per if r % 2 == 1] if world > 2 else per
-    aud = [r for r in per if r % 2 == 0] if world > 2 else per
+    vis, aud = model_per_gpu_roles(world)
 
     def barrier():
         D.barrier(dist, cuda=True)

@@ -34,8 +34,12 @@ TK_API int tk_mi355x_get_default_device(void);
 /* models ----------------------------------------------------------------------------------- */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_create(tk_mi355x_llm_model_t** out, const tk_mi355x_llm_hparams_t* hp, int device);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_fill_synthetic(tk_mi355x_llm_model_t* m, uint64_t seed);
+/* the fp16 checkpoint recipe (BASELINE configs[4]): every matrix and the token embedding IEEE f16 (GGUF type 1), norms f32.  f16 matrices run
+ * on the exact fp32 MFMA GEMM over f16-rounded activations (one k-ordered chain per output, no K-split): results stay bit-identical to
+ * the oracle.  Loader name: synthetic://mistral-7b-f16, synthetic://tiny-f16; GGUF files with F16 tensors load the same way. */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_fill_synthetic_f16(tk_mi355x_llm_model_t* m, uint64_t seed);
 /* tensor in GGUF block layout; layer = -1 for {0 token_embd, 1 output_norm, 2 output}, else
- * {0 attn_norm,1 q,2 k,3 v,4 o,5 ffn_norm,6 gate,7 up,8 down}; type = ggml type id (0 F32, 12 Q4_K, 14 Q6_K) */
+ * {0 attn_norm,1 q,2 k,3 v,4 o,5 ffn_norm,6 gate,7 up,8 down}; type = ggml type id (0 F32, 1 F16, 12 Q4_K, 14 Q6_K) */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_set_tensor(tk_mi355x_llm_model_t* m, int layer, int which, int type, const void* data,
                                                                    size_t nbytes);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_load_gguf(tk_mi355x_llm_model_t** out, const char* path, int device);

@@ -254,6 +254,13 @@ static void synth_tensor(orc_tensor* t, uint64_t seed, uint64_t tid, int type, i
         for (int64_t i = 0; i < n; ++i) f[i] = 1.0f + 0.1f * tk_synth_normal(seed, tid, (uint64_t)i);
         return;
     }
+    if (type == TK_TYPE_F16) {
+        t->data.resize(n * 2);
+        uint16_t* hp = (uint16_t*)t->data.data();
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) hp[i] = tk_f32_to_f16(0.02f * tk_synth_normal(seed, tid, (uint64_t)i));
+        return;
+    }
     int64_t nb = n / 256;
     t->data.resize(nb * tk_type_block_bytes(type));
 #pragma omp parallel for schedule(static)
@@ -287,20 +294,32 @@ orc_llm* orc_llm_create(const orc_llm_config_t* cfg) {
 
 void orc_llm_destroy(orc_llm* m) { delete m; }
 
+static int g_synth_f16 = 0; /* orc_llm_synth_f16: every matrix and the embedding as IEEE f16 (the fp16 checkpoint recipe), norms f32 */
+static int synth_type(const orc_llm_config_t* c, int layer, int which) {
+    const int t = orc_llm_tensor_type(c, layer, which);
+    return (g_synth_f16 && t != TK_TYPE_F32) ? (int)TK_TYPE_F16 : t;
+}
+
 void orc_llm_synth(orc_llm* m, uint64_t seed) {
     const orc_llm_config_t* c = &m->cfg;
     int64_t r, k;
     tensor_shape(c, -1, ORC_T_TOKEN_EMBD, &r, &k);
-    synth_tensor(&m->token_embd, seed, tensor_id(-1, ORC_T_TOKEN_EMBD), orc_llm_tensor_type(c, -1, ORC_T_TOKEN_EMBD), r, k);
+    synth_tensor(&m->token_embd, seed, tensor_id(-1, ORC_T_TOKEN_EMBD), synth_type(c, -1, ORC_T_TOKEN_EMBD), r, k);
     tensor_shape(c, -1, ORC_T_OUT_NORM, &r, &k);
     synth_tensor(&m->out_norm, seed, tensor_id(-1, ORC_T_OUT_NORM), TK_TYPE_F32, r, k);
     tensor_shape(c, -1, ORC_T_OUTPUT, &r, &k);
-    synth_tensor(&m->output, seed, tensor_id(-1, ORC_T_OUTPUT), orc_llm_tensor_type(c, -1, ORC_T_OUTPUT), r, k);
+    synth_tensor(&m->output, seed, tensor_id(-1, ORC_T_OUTPUT), synth_type(c, -1, ORC_T_OUTPUT), r, k);
     for (int l = 0; l < c->n_layer; ++l)
         for (int w = 0; w < ORC_L_COUNT; ++w) {
             tensor_shape(c, l, w, &r, &k);
-            synth_tensor(&m->layers[(size_t)l * ORC_L_COUNT + w], seed, tensor_id(l, w), orc_llm_tensor_type(c, l, w), r, k);
+            synth_tensor(&m->layers[(size_t)l * ORC_L_COUNT + w], seed, tensor_id(l, w), synth_type(c, l, w), r, k);
         }
+}
+
+void orc_llm_synth_f16(orc_llm* m, uint64_t seed) {
+    g_synth_f16 = 1;
+    orc_llm_synth(m, seed);
+    g_synth_f16 = 0;
 }
 
 /* load one tensor in GGUF block layout (layer = -1 for the three global tensors) */
@@ -341,9 +360,32 @@ static void gemv_f32(const orc_tensor& t, const float* h, float* y) {
     }
 }
 
+/* f16 weight matrix (fp16 checkpoints): the activation row is rounded through f16 — what a CPU engine's f16 matmul does to its f32 input
+ * (ggml converts src1 to f16, then dots in f32) — and each output is ONE fp32 fma chain over k ascending (no K-split: a single slab) */
+static void gemv_f16(const orc_tensor& t, const float* h, float* y) {
+    const int K = (int)t.cols;
+    std::vector<float> a(K);
+    for (int i = 0; i < K; ++i) a[i] = tk_f16_to_f32(tk_f32_to_f16(h[i]));
+    const uint16_t* w = (const uint16_t*)t.data.data();
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < t.rows; ++r) {
+        float acc = 0.0f;
+        for (int i = 0; i < K; ++i) acc = tk_fmaf(a[i], tk_f16_to_f32(w[r * K + i]), acc);
+        y[r] = acc;
+    }
+}
+
+/* a matmul on an already quantised row (q / d / bs) or, for f16 tensors, on the f32 row itself */
+static void mat(const orc_tensor& t, int ks, const float* h, const int8_t* q, const float* d, const int32_t* bs, float* y) {
+    if (g_fp32_activations) { gemv_f32(t, h, y); return; }
+    if (t.type == TK_TYPE_F16) { gemv_f16(t, h, y); return; }
+    orc_gemv_q8(t.type, t.data.data(), t.rows, (int)t.cols, ks, q, d, bs, y);
+}
+
 static void matvec(const orc_tensor& t, int ks, const float* h, float* y, std::vector<int8_t>& q, std::vector<float>& d,
                    std::vector<int32_t>& bs) {
     if (g_fp32_activations) { gemv_f32(t, h, y); return; }
+    if (t.type == TK_TYPE_F16) { gemv_f16(t, h, y); return; }
     int K = (int)t.cols;
     q.resize(K); d.resize(K / 256); bs.resize(K / 32);
     orc_q8k_quantize(h, K, q.data(), d.data(), bs.data());
@@ -376,13 +418,9 @@ void orc_llm_forward(orc_llm* m, int n_rows, const int32_t* seq, const int32_t* 
             q8.resize(D); qd.resize(D / 256); qb.resize(D / 32);
             orc_q8k_quantize(h.data(), D, q8.data(), qd.data(), qb.data());
             float* qr = &qv[(size_t)r * QD];
-            if (g_fp32_activations) {
-                gemv_f32(L[ORC_L_Q], h.data(), qr); gemv_f32(L[ORC_L_K], h.data(), kv.data()); gemv_f32(L[ORC_L_V], h.data(), vv.data());
-            } else {
-                orc_gemv_q8(L[ORC_L_Q].type, L[ORC_L_Q].data.data(), QD, D, c.ks_qkv, q8.data(), qd.data(), qb.data(), qr);
-                orc_gemv_q8(L[ORC_L_K].type, L[ORC_L_K].data.data(), KVD, D, c.ks_qkv, q8.data(), qd.data(), qb.data(), kv.data());
-                orc_gemv_q8(L[ORC_L_V].type, L[ORC_L_V].data.data(), KVD, D, c.ks_qkv, q8.data(), qd.data(), qb.data(), vv.data());
-            }
+            mat(L[ORC_L_Q], c.ks_qkv, h.data(), q8.data(), qd.data(), qb.data(), qr);
+            mat(L[ORC_L_K], c.ks_qkv, h.data(), q8.data(), qd.data(), qb.data(), kv.data());
+            mat(L[ORC_L_V], c.ks_qkv, h.data(), q8.data(), qd.data(), qb.data(), vv.data());
             const float* cs = &m->rope_cos[(size_t)pos[r] * half];
             const float* sn = &m->rope_sin[(size_t)pos[r] * half];
             for (int hh = 0; hh < NH; ++hh)
@@ -433,12 +471,8 @@ void orc_llm_forward(orc_llm* m, int n_rows, const int32_t* seq, const int32_t* 
             orc_rmsnorm(xr, (const float*)L[ORC_L_FFN_NORM].data.data(), D, c.rms_eps, h.data());
             q8.resize(D); qd.resize(D / 256); qb.resize(D / 32);
             orc_q8k_quantize(h.data(), D, q8.data(), qd.data(), qb.data());
-            if (g_fp32_activations) {
-                gemv_f32(L[ORC_L_GATE], h.data(), gate.data()); gemv_f32(L[ORC_L_UP], h.data(), up.data());
-            } else {
-                orc_gemv_q8(L[ORC_L_GATE].type, L[ORC_L_GATE].data.data(), FF, D, c.ks_gateup, q8.data(), qd.data(), qb.data(), gate.data());
-                orc_gemv_q8(L[ORC_L_UP].type, L[ORC_L_UP].data.data(), FF, D, c.ks_gateup, q8.data(), qd.data(), qb.data(), up.data());
-            }
+            mat(L[ORC_L_GATE], c.ks_gateup, h.data(), q8.data(), qd.data(), qb.data(), gate.data());
+            mat(L[ORC_L_UP], c.ks_gateup, h.data(), q8.data(), qd.data(), qb.data(), up.data());
             for (int i = 0; i < FF; ++i) act[i] = tk_siluf(gate[i]) * up[i];
             matvec(L[ORC_L_DOWN], c.ks_down, act.data(), o.data(), q8, qd, qb);
             for (int i = 0; i < D; ++i) xr[i] = xr[i] + o[i];

@@ -48,6 +48,7 @@ def lib():
         L.orc_llm_create.argtypes = [C.POINTER(LlmConfig)]
         L.orc_llm_destroy.argtypes = [C.c_void_p]
         L.orc_llm_synth.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_llm_synth_f16.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_llm_reset.argtypes = [C.c_void_p]
         L.orc_llm_set_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
         L.orc_llm_get_tensor.restype = C.c_int64
@@ -75,11 +76,11 @@ def ptr(a):
 
 
 class OracleLlm:
-    def __init__(self, cfg, seed=None):
+    def __init__(self, cfg, seed=None, f16=False):
         self.cfg = cfg
         self.h = lib().orc_llm_create(C.byref(cfg))
         if seed is not None:
-            lib().orc_llm_synth(self.h, seed)
+            (lib().orc_llm_synth_f16 if f16 else lib().orc_llm_synth)(self.h, seed)
 
     def close(self):
         if self.h:

@@ -37,3 +37,13 @@ def test_two_rank_gloo_aggregation():
     assert out[0][1] == out[1][1] == 1.5                          # MAX over ranks, seen by both
     assert set(out[0][2]).isdisjoint(out[1][2]) and len(out[0][2]) + len(out[1][2]) == 32
     assert out[0][3] == pytest.approx(16 * 3 * 2 / 1.5)           # whole-job aggregate, not per GPU
+
+
+def test_model_per_gpu_roles_cover_every_stream():
+    """bench.py --placement model-per-gpu: rank 0 is the LLM, every other rank has a perception role, both
+    perception streams are served at every size"""
+    import bench
+    assert bench.model_per_gpu_roles(2) == ([1], [1])
+    assert bench.model_per_gpu_roles(4) == ([1, 3], [2])
+    vis, aud = bench.model_per_gpu_roles(8)
+    assert vis == [1, 3, 5, 7] and aud == [2, 4, 6] and 0 not in vis + aud and sorted(vis + aud) == list(range(1, 8))

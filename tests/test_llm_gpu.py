@@ -1,4 +1,6 @@
 """GPU parity: the HIP LLM path (through the C-ABI) against the oracle — bit-exact logits and token ids."""
+import os
+
 import numpy as np
 import pytest
 
@@ -553,3 +555,51 @@ def test_runners_on_one_model_share_decode_passes(gpu):
         r.close()
     loader.unload(h)
     loader.close()
+
+
+def test_f16_weights_bit_exact_and_pipeline_split(gpu):
+    """fp16 checkpoints (BASELINE configs[4]): every matrix IEEE f16, run on the exact fp32 MFMA GEMM over f16-rounded activations.
+    Logits bit-identical to the oracle (one fma chain per output over k ascending); a decode loop through the captured graphs; the
+    layer-sharded split of configs[4] (forward_stage over two stages) bit-identical to the unsplit pass."""
+    model = gpu.LlmModel(gpu.TINY()).fill_synthetic(12, f16=True)
+    hp = model.hparams
+    sess = gpu.LlmSession(model, 4, 64)
+    orc = O.OracleLlm(oracle_cfg_from(hp, 64, 4), seed=12, f16=True)
+    assert orc.get_tensor(0, 1)[0] == 1 and orc.get_tensor(-1, 0)[0] == 1          # ggml type F16 for matrices and the embedding
+    rng = np.random.default_rng(31)
+    seq = np.array([0] * 9 + [2] * 7 + [3] * 4, np.int32)
+    pos = np.concatenate([np.arange(9), np.arange(7), np.arange(4)]).astype(np.int32)
+    tok = rng.integers(3, hp.vocab, 20).astype(np.int32)
+    want, wam = orc.forward(seq, pos, tok)
+    got, gam = sess.forward(seq, pos, tok)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.array_equal(gam, wam)
+    # greedy decode, graph replay: ids equal the oracle's
+    s2, p2, cur = np.array([0, 2, 3], np.int32), np.array([9, 7, 4], np.int32), np.array(gam[[8, 15, 19]], np.int32)
+    _, gcur = sess.forward(s2, p2, cur, want_logits=False)
+    _, wcur = orc.forward(s2, p2, cur, want_logits=False)
+    assert np.array_equal(gcur, wcur)
+    # the same weights loaded tensor by tensor (the GGUF path's entry) give the same bits
+    m2 = gpu.LlmModel(gpu.TINY())
+    copy_oracle_weights(orc, m2, hp.n_layer)
+    se2 = gpu.LlmSession(m2, 4, 64)
+    g2, _ = se2.forward(seq, pos, tok)
+    assert np.array_equal(g2.view(np.uint32), want.view(np.uint32))
+    # ... and so does a GGUF file whose tensors are F16 (what a real fp16 checkpoint is)
+    import gguf_util, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "tiny-f16.gguf")
+        gguf_util.write_llama_gguf(path, orc, O.tiny_config())
+        m3 = gpu.LlmModel(gguf=path)
+        se3 = gpu.LlmSession(m3, 4, 64)
+        g3, _ = se3.forward(seq, pos, tok)
+        assert np.array_equal(g3.view(np.uint32), want.view(np.uint32))
+        se3.close()
+    # layer-sharded: stage 0 = layer 0, stage 1 = layer 1 + head, the residual stream crosses as fp32
+    a, b = gpu.LlmSession(model, 4, 64), gpu.LlmSession(model, 4, 64)
+    x01 = np.empty((20, hp.d_model), np.float32)
+    a.forward_stage(seq, pos, 0, 1, tok=tok, x_out=x01)
+    am = b.forward_stage(seq, pos, 1, 2, x_in=x01, head=True)
+    assert np.array_equal(am, wam)
+    for s in (sess, se2, a, b):
+        s.close()

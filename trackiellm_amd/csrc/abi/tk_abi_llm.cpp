@@ -106,6 +106,12 @@ tk_error_code_t tk_mi355x_llm_model_fill_synthetic(tk_mi355x_llm_model_t* m, uin
     return TK_SUCCESS;
 }
 
+tk_error_code_t tk_mi355x_llm_model_fill_synthetic_f16(tk_mi355x_llm_model_t* m, uint64_t seed) {
+    if (!m) return TK_ERROR_INVALID_ARGUMENT;
+    if (!m->model.fill_synthetic(seed, true)) return fail(TK_ERROR_GPU_ROCM_ERROR, m->model.error);
+    return TK_SUCCESS;
+}
+
 tk_error_code_t tk_mi355x_llm_model_set_tensor(tk_mi355x_llm_model_t* m, int layer, int which, int type, const void* data, size_t nbytes) {
     if (!m || !data) return TK_ERROR_INVALID_ARGUMENT;
     if (!m->model.set_tensor(layer, which, type, data, nbytes)) return fail(TK_ERROR_INVALID_INPUT_TENSOR, m->model.error);
@@ -411,11 +417,13 @@ tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_m
     tk_error_code_t rc;
     if (parse_synthetic(path, &name, &seed)) {
         tk_mi355x_llm_hparams_t h{};
+        const bool f16 = name.size() > 4 && name.compare(name.size() - 4, 4, "-f16") == 0; /* the fp16 checkpoint recipe (BASELINE configs[4]) */
+        if (f16) name.resize(name.size() - 4);
         if (name == "mistral-7b") h = tk_mi355x_llm_hparams_t{32, 4096, 32, 8, 128, 14336, 32000, 1e-5f, 10000.0f, 0, 0, 0, 0, 1};
         else if (name == "tiny") h = tk_mi355x_llm_hparams_t{2, 256, 8, 2, 64, 512, 512, 1e-5f, 10000.0f, 0, 0, 0, 0, 1};
         else return fail(TK_ERROR_FILE_NOT_FOUND, "unknown synthetic model: " + name);
         rc = tk_mi355x_llm_model_create(&m, &h, device);
-        if (rc == TK_SUCCESS) rc = tk_mi355x_llm_model_fill_synthetic(m, seed);
+        if (rc == TK_SUCCESS) rc = f16 ? tk_mi355x_llm_model_fill_synthetic_f16(m, seed) : tk_mi355x_llm_model_fill_synthetic(m, seed);
         if (rc != TK_SUCCESS) { tk_mi355x_llm_model_destroy(&m); return rc; }
         m->path = path;
     } else {

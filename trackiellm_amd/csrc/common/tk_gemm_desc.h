@@ -21,6 +21,9 @@ struct TkGemm {
     /* optional second batch level: z = zo * batch_inner + zi ; offset = zo * s?2 + zi * s? (batch_inner == 0: single level) */
     int batch_inner;
     int64_t sA2, sB2, sC2, sR2;
+    /* B holds IEEE f16 values (2 bytes each, same [N][ldb] / [K][ldb] indexing in elements): each is widened to f32 exactly, the chain
+     * arithmetic is unchanged — f16 checkpoints (LLM fp16 weights) stream half the bytes */
+    int b_f16;
 };
 
 

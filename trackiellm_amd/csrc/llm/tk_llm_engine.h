@@ -53,7 +53,9 @@ public:
     ~TkLlmModel();
     /* returns false and sets `error` on failure */
     bool init(const TkLlmHParams& hp, int device);
-    bool fill_synthetic(uint64_t seed);
+    /* f16: the fp16 checkpoint recipe (every matrix and the embedding IEEE f16, norms f32) instead of Q4_K_M */
+    bool fill_synthetic(uint64_t seed, bool f16 = false);
+    bool has_f16 = false; /* some matrix is f16: sessions also keep f16-rounded f32 activations */
     /* `host_blocks` is the tensor in GGUF layout (F32 for norms) */
     bool set_tensor(int layer, int which, int type, const void* host_blocks, size_t nbytes);
     bool ready() const;
@@ -101,6 +103,7 @@ public:
 private:
     void enqueue_pass(int nrows, bool lm_head, bool fused_attn);
     void enqueue_range(int nrows, int l0, int l1, bool embed, bool fold_out, bool lm_head, bool fused_attn);
+    int enqueue_matmul(const TkDevTensor* const* t, int nseg, int K, int ks, int n_total, const TkActQ8& act, float* out, int nrows);
     uint16_t *kcache = nullptr, *vcache = nullptr;
     float *x = nullptr, *qbuf = nullptr, *partial = nullptr, *logits = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
     TkActQ8 act_d{}, act_qd{}, act_ff{};

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include "../common/tk_ggml_blocks.h"
+#include "../nn/tk_nn_kernels.h"
 
 #define HIPQ(expr)                                                                              \
     do {                                                                                        \
@@ -98,11 +99,19 @@ bool TkLlmModel::install(TkDevTensor* t, int type, int64_t rows, int64_t cols, c
         HIPQ(hipMemcpyAsync(t->data, dev_blocks, t->bytes, hipMemcpyDeviceToDevice, s));
         return true;
     }
-    if (type != TK_TYPE_Q4_K && type != TK_TYPE_Q6_K) { error = "unsupported tensor type (want F32, Q4_K or Q6_K)"; return false; }
+    if (type == TK_TYPE_F16) { /* fp16 checkpoints: rows stay row-major f16, the exact fp32 GEMM widens them on load (csrc/nn/tk_nn_kernels.hip) */
+        if (cols % 8) { error = "f16 matrices need a multiple of 8 columns"; return false; }
+        t->bytes = (size_t)rows * cols * 2;
+        HIPQ(hipMalloc((void**)&t->data, t->bytes));
+        HIPQ(hipMemcpyAsync(t->data, dev_blocks, t->bytes, hipMemcpyDeviceToDevice, s));
+        if (is_matrix) has_f16 = true;
+        return true;
+    }
+    if (type != TK_TYPE_Q4_K && type != TK_TYPE_Q6_K) { error = "unsupported tensor type (want F32, F16, Q4_K or Q6_K)"; return false; }
     t->bytes = (size_t)rows * cols / 256 * tk_type_block_bytes(type);
     HIPQ(hipMalloc((void**)&t->data, t->bytes));
     if (!is_matrix) { /* token_embd stays in GGUF layout: one row is gathered per token */
-        if (type != TK_TYPE_Q4_K) { error = "token_embd must be Q4_K"; return false; }
+        if (type != TK_TYPE_Q4_K) { error = "token_embd must be Q4_K or F16"; return false; }
         HIPQ(hipMemcpyAsync(t->data, dev_blocks, t->bytes, hipMemcpyDeviceToDevice, s));
         return true;
     }
@@ -128,15 +137,19 @@ bool TkLlmModel::set_tensor(int layer, int which, int type, const void* host_blo
     return ok;
 }
 
-bool TkLlmModel::fill_synthetic(uint64_t seed) {
+bool TkLlmModel::fill_synthetic(uint64_t seed, bool f16) {
     HIPQ(hipSetDevice(device));
+    auto type_of = [&](int l, int w) {
+        const int t = recipe_type(hp, l, w);
+        return (f16 && t != TK_TYPE_F32) ? (int)TK_TYPE_F16 : t; /* fp16 checkpoint: every matrix and the embedding f16, norms f32 */
+    };
     /* scratch big enough for the largest tensor in GGUF layout */
     size_t maxb = 0;
     for (int l = -1; l < hp.n_layer; ++l)
         for (int w = 0; w < (l < 0 ? 3 : (int)TK_L_COUNT); ++w) {
             int64_t r, c;
             shape(l, w, &r, &c);
-            int type = recipe_type(hp, l, w);
+            int type = type_of(l, w);
             size_t b = (size_t)r * c / tk_type_block_elems(type) * tk_type_block_bytes(type);
             maxb = b > maxb ? b : maxb;
         }
@@ -147,9 +160,10 @@ bool TkLlmModel::fill_synthetic(uint64_t seed) {
         for (int w = 0; w < (l < 0 ? 3 : (int)TK_L_COUNT) && ok; ++w) {
             int64_t r, c;
             shape(l, w, &r, &c);
-            int type = recipe_type(hp, l, w);
+            int type = type_of(l, w);
             uint64_t tid = l < 0 ? (uint64_t)w : (uint64_t)(16 + l * 16 + w);
             if (type == TK_TYPE_F32) tk_launch_synth_f32(seed, tid, r * c, (float*)tmp, nullptr);
+            else if (type == TK_TYPE_F16) tk_launch_synth_f16(seed, tid, r * c, 0.02f, (uint16_t*)tmp, nullptr);
             else tk_launch_synth_blocks(type, seed, tid, r * c / 256, 0.02f, tmp, nullptr);
             ok = install(slot(l, w), type, r, c, tmp, nullptr);
             if (ok && hipStreamSynchronize(nullptr) != hipSuccess) { error = "synthetic weight generation failed"; ok = false; }
@@ -160,16 +174,23 @@ bool TkLlmModel::fill_synthetic(uint64_t seed) {
 
 bool TkLlmModel::ready() const {
     if (!token_embd.data || !out_norm.data || !output.data) return false;
-    for (const auto& L : layers)
+    for (const auto& L : layers) {
         if (!L.attn_norm.data || !L.ffn_norm.data || !L.q.data || !L.k.data || !L.v.data || !L.o.data || !L.gate.data || !L.up.data || !L.down.data)
             return false;
+        /* the tensors of one fused launch (q|k|v, gate|up) are all k-quants or all f16 */
+        const bool f_qkv = L.q.type == TK_TYPE_F16, f_gu = L.gate.type == TK_TYPE_F16;
+        if ((L.k.type == TK_TYPE_F16) != f_qkv || (L.v.type == TK_TYPE_F16) != f_qkv || (L.up.type == TK_TYPE_F16) != f_gu) return false;
+    }
     return true;
 }
 
 /* ------------------------------------------------------------------ session ---------------- */
 
-static bool alloc_act(TkActQ8* a, int K, std::string& error) {
+static bool alloc_act(TkActQ8* a, int K, bool want_f16, std::string& error) {
     a->aq_ts = TK_AQ_BYTES(K); a->ad_ts = TK_AD_FLOATS(K); a->abs_ts = TK_ABS_BYTES(K);
+    a->af = nullptr; a->af_ld = K;
+    if (want_f16 && hipMalloc((void**)&a->af, (size_t)TK_MAX_ROWS * K * 4) != hipSuccess) { error = "out of device memory (f16 activation buffers)"; return false; }
+    if (a->af) (void)hipMemset(a->af, 0, (size_t)TK_MAX_ROWS * K * 4);
     if (hipMalloc((void**)&a->aq, TK_MAX_TILES * a->aq_ts) != hipSuccess || hipMalloc((void**)&a->ad, TK_MAX_TILES * a->ad_ts * 4) != hipSuccess ||
         hipMalloc((void**)&a->abs, TK_MAX_TILES * a->abs_ts) != hipSuccess || hipMalloc((void**)&a->abs16, TK_MAX_TILES * a->abs_ts * 2) != hipSuccess) {
         error = "out of device memory (activation buffers)";
@@ -186,6 +207,7 @@ static void free_act(TkActQ8* a) {
     if (a->ad) (void)hipFree(a->ad);
     if (a->abs) (void)hipFree(a->abs);
     if (a->abs16) (void)hipFree(a->abs16);
+    if (a->af) (void)hipFree(a->af);
     *a = TkActQ8{};
 }
 
@@ -216,7 +238,8 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     pmax = std::max(pmax, (size_t)h.ks_down * h.d_model);
     HIPQ(hipMalloc((void**)&partial, pmax * TK_MAX_ROWS * 4));
     HIPQ(hipMalloc((void**)&logits, (size_t)TK_MAX_ROWS * h.vocab * 4));
-    if (!alloc_act(&act_d, h.d_model, error) || !alloc_act(&act_qd, QD, error) || !alloc_act(&act_ff, h.d_ff, error)) return false;
+    if (!alloc_act(&act_d, h.d_model, m->has_f16, error) || !alloc_act(&act_qd, QD, m->has_f16, error) || !alloc_act(&act_ff, h.d_ff, m->has_f16, error)) return false;
+    if (m->has_f16 && !tk_nn_prepare_device()) { error = "LDS opt-in of the fp32 GEMM failed"; return false; }
     HIPQ(hipMalloc((void**)&d_seq, TK_MAX_ROWS * 4));
     HIPQ(hipMalloc((void**)&d_pos, TK_MAX_ROWS * 4));
     HIPQ(hipMalloc((void**)&d_tok, TK_MAX_ROWS * 4));
@@ -274,48 +297,63 @@ void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) { enqu
 /* layers [l0, l1) of one pass.  embed: the residual stream starts from the token embeddings (first pipeline stage), otherwise x
  * already holds it.  fold_out: finish the last layer's residual update so x is the complete stream (it leaves this GPU).
  * head: final norm + lm_head + arg max (last stage). */
+/* one matmul group of a pass: the K-quant tensors of a launch go to the W4A8 kernels (K-split partial slabs, canonical plan `ks`); an f16
+ * group goes, tensor by tensor, through the exact fp32 GEMM on the f16-rounded activations (one chain over K: a single slab).  Returns
+ * the number of partial slabs the consumers must add. */
+int TkLlmSession::enqueue_matmul(const TkDevTensor* const* t, int nseg, int K, int ks, int n_total, const TkActQ8& act, float* out, int nrows) {
+    hipStream_t s = stream;
+    if (t[0]->type == TK_TYPE_F16) {
+        int col = 0;
+        for (int i = 0; i < nseg; ++i) {
+            TkGemm g{};
+            g.A = act.af; g.B = (const float*)t[i]->data; g.C = out + col;
+            g.M = nrows; g.N = (int)t[i]->rows; g.K = K; g.lda = act.af_ld; g.ldb = K; g.ldc = n_total;
+            g.alpha = 1.0f; g.batch = 1; g.b_f16 = 1;
+            tk_launch_gemm(g, s);
+            col += (int)t[i]->rows;
+        }
+        return 1;
+    }
+    TkGemvArgs a{};
+    for (int i = 0; i < nseg; ++i) a.seg[i] = seg_of(*t[i]);
+    a.nseg = nseg; a.K = K; a.ks = ks; a.n_total = n_total; a.nrows = nrows;
+    set_act(a, act); a.out = out;
+    tk_launch_gemv(a, s);
+    return ks;
+}
+
 void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fold_out, bool lm_head, bool fused_attn) {
     const TkLlmHParams& h = model->hp;
     const int D = h.d_model, QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim, FF = h.d_ff;
     hipStream_t s = stream;
-    if (embed) tk_launch_embed(model->token_embd.data, D, d_tok, nrows, x, s);
+    if (embed) tk_launch_embed(model->token_embd.data, model->token_embd.type, D, d_tok, nrows, x, s);
+    int ks_res = 1; /* slabs of the pending residual update (the previous layer's down projection) */
     for (int l = l0; l < l1; ++l) {
         const TkLlmLayer& L = model->layers[l];
-        tk_launch_rmsnorm_q8(x, l == l0 ? nullptr : partial, h.ks_down, D, (const float*)L.attn_norm.data, h.rms_eps, D, nrows, act_d, s);
-        TkGemvArgs a{};
-        a.seg[0] = seg_of(L.q); a.seg[1] = seg_of(L.k); a.seg[2] = seg_of(L.v);
-        a.nseg = 3; a.K = D; a.ks = h.ks_qkv; a.n_total = QD + 2 * KVD; a.nrows = nrows;
-        set_act(a, act_d); a.out = partial;
-        tk_launch_gemv(a, s);
+        tk_launch_rmsnorm_q8(x, l == l0 ? nullptr : partial, ks_res, D, (const float*)L.attn_norm.data, h.rms_eps, D, nrows, act_d, s);
+        const TkDevTensor* qkv[3] = {&L.q, &L.k, &L.v};
+        const int ks_qkv = enqueue_matmul(qkv, 3, D, h.ks_qkv, QD + 2 * KVD, act_d, partial, nrows);
         if (!fused_attn)
-            tk_launch_qkv_rope_append(partial, h.ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
+            tk_launch_qkv_rope_append(partial, ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
                                       qbuf, kcache, vcache, l, max_seq, max_ctx, s);
-        tk_launch_attention(qbuf, partial, h.ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
+        tk_launch_attention(qbuf, partial, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
                             h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
-        TkGemvArgs o{};
-        o.seg[0] = seg_of(L.o); o.nseg = 1; o.K = QD; o.ks = h.ks_o; o.n_total = D; o.nrows = nrows;
-        set_act(o, act_qd); o.out = partial;
-        tk_launch_gemv(o, s);
-        tk_launch_rmsnorm_q8(x, partial, h.ks_o, D, (const float*)L.ffn_norm.data, h.rms_eps, D, nrows, act_d, s);
-        TkGemvArgs gu{};
-        gu.seg[0] = seg_of(L.gate); gu.seg[1] = seg_of(L.up); gu.nseg = 2; gu.K = D; gu.ks = h.ks_gateup; gu.n_total = 2 * FF; gu.nrows = nrows;
-        set_act(gu, act_d); gu.out = partial;
-        tk_launch_gemv(gu, s);
-        tk_launch_swiglu_q8(partial, h.ks_gateup, FF, nrows, act_ff, s);
-        TkGemvArgs dn{};
-        dn.seg[0] = seg_of(L.down); dn.nseg = 1; dn.K = FF; dn.ks = h.ks_down; dn.n_total = D; dn.nrows = nrows;
-        set_act(dn, act_ff); dn.out = partial;
-        tk_launch_gemv(dn, s);
+        const TkDevTensor* ot[1] = {&L.o};
+        const int ks_o = enqueue_matmul(ot, 1, QD, h.ks_o, D, act_qd, partial, nrows);
+        tk_launch_rmsnorm_q8(x, partial, ks_o, D, (const float*)L.ffn_norm.data, h.rms_eps, D, nrows, act_d, s);
+        const TkDevTensor* gu[2] = {&L.gate, &L.up};
+        const int ks_gu = enqueue_matmul(gu, 2, D, h.ks_gateup, 2 * FF, act_d, partial, nrows);
+        tk_launch_swiglu_q8(partial, ks_gu, FF, nrows, act_ff, s);
+        const TkDevTensor* dn[1] = {&L.down};
+        ks_res = enqueue_matmul(dn, 1, FF, h.ks_down, D, act_ff, partial, nrows);
     }
     if (!lm_head) { /* prompt rows whose logits nobody reads (K/V are already appended), or a pipeline stage that hands x on */
-        if (fold_out && l1 > l0) tk_launch_residual_fold(x, partial, h.ks_down, D, D, nrows, s);
+        if (fold_out && l1 > l0) tk_launch_residual_fold(x, partial, ks_res, D, D, nrows, s);
         return;
     }
-    tk_launch_rmsnorm_q8(x, l1 > l0 ? partial : nullptr, h.ks_down, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
-    TkGemvArgs lm{};
-    lm.seg[0] = seg_of(model->output); lm.nseg = 1; lm.K = D; lm.ks = 1; lm.n_total = h.vocab; lm.nrows = nrows;
-    set_act(lm, act_d); lm.out = logits;
-    tk_launch_gemv(lm, s);
+    tk_launch_rmsnorm_q8(x, l1 > l0 ? partial : nullptr, ks_res, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
+    const TkDevTensor* lm[1] = {&model->output};
+    (void)enqueue_matmul(lm, 1, D, 1, h.vocab, act_d, logits, nrows);
     tk_launch_argmax(logits, h.vocab, nrows, mask_on ? d_mask : nullptr, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
 }
 

@@ -39,6 +39,10 @@ struct TkActQ8 { /* quantised-activation buffers for one K */
     int8_t* abs; /* (l, h) images of the sub-block sums, 256 B per 256-block */
     uint16_t* abs16; /* (hh, ll) f16 images of the same sums, 512 B per 256-block: the batched kernel's one-MFMA min term */
     size_t aq_ts, ad_ts, abs_ts; /* M-tile strides */
+    /* f16-weight matrices (fp16 checkpoints) consume the activations as f32 values rounded through f16 — what a CPU engine's f16 matmul
+     * does to its f32 input — row-major [row][K]; null when the model has no such matrix */
+    float* af;
+    int af_ld;
 };
 
 /* weights */
@@ -47,7 +51,8 @@ void tk_launch_synth_f32(uint64_t seed, uint64_t tensor_id, int64_t n, float* ou
 void tk_launch_repack(int type, const void* blocks, int64_t rows, int64_t K, uint8_t* tiles, hipStream_t s);
 
 /* step kernels */
-void tk_launch_embed(const void* embd_q4k, int D, const int32_t* tok, int nrows, float* x, hipStream_t s);
+void tk_launch_embed(const void* embd, int type /* TK_TYPE_Q4_K or TK_TYPE_F16 */, int D, const int32_t* tok, int nrows, float* x, hipStream_t s);
+void tk_launch_synth_f16(uint64_t seed, uint64_t tensor_id, int64_t n, float scale, uint16_t* out, hipStream_t s);
 void tk_launch_rmsnorm_q8(float* x, const float* partial, int ks, int n_total_partial, const float* w, float eps, int D, int nrows,
                           TkActQ8 out, hipStream_t s);
 void tk_launch_residual_fold(float* x, const float* partial, int ks, int n_total, int D, int nrows, hipStream_t s);

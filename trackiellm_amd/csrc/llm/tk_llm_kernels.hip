@@ -49,6 +49,14 @@ __global__ void k_synth_f32(uint64_t seed, uint64_t tid, int64_t n, float* out) 
     if (i < n) out[i] = 1.0f + 0.1f * tk_synth_normal(seed, tid, (uint64_t)i);
 }
 
+__global__ void k_synth_f16(uint64_t seed, uint64_t tid, int64_t n, float scale, uint16_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = tk_f32_to_f16(scale * tk_synth_normal(seed, tid, (uint64_t)i));
+}
+void tk_launch_synth_f16(uint64_t seed, uint64_t tensor_id, int64_t n, float scale, uint16_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_synth_f16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, tensor_id, n, scale, out);
+}
+
 void tk_launch_synth_blocks(int type, uint64_t seed, uint64_t tensor_id, int64_t nblocks, float scale, void* out, hipStream_t s) {
     int64_t grid = (nblocks + 63) / 64;
     hipLaunchKernelGGL(k_synth_blocks, dim3((unsigned)grid), dim3(64), 0, s, type, seed, tensor_id, nblocks, scale, (uint8_t*)out);
@@ -131,16 +139,20 @@ void tk_launch_repack(int type, const void* blocks, int64_t rows, int64_t K, uin
 /* ------------------------------------------------------------------------------------------
  * token embedding: one Q4_K row (GGUF layout) de-quantised per row slot
  * ------------------------------------------------------------------------------------------ */
-__global__ void k_embed(const tk_block_q4_K* embd, int D, const int32_t* tok, float* x) {
+__global__ void k_embed(const void* embd, int type, int D, const int32_t* tok, float* x) {
     const int r = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
-    const tk_block_q4_K* row = embd + (int64_t)tok[r] * (D / 256);
-    x[(int64_t)r * D + i] = tk_q4k_dequant(row + i / 256, i % 256);
+    if (type == TK_TYPE_F16) {
+        x[(int64_t)r * D + i] = tk_f16_to_f32(((const uint16_t*)embd)[(int64_t)tok[r] * D + i]);
+    } else {
+        const tk_block_q4_K* row = (const tk_block_q4_K*)embd + (int64_t)tok[r] * (D / 256);
+        x[(int64_t)r * D + i] = tk_q4k_dequant(row + i / 256, i % 256);
+    }
 }
 
-void tk_launch_embed(const void* embd_q4k, int D, const int32_t* tok, int nrows, float* x, hipStream_t s) {
-    hipLaunchKernelGGL(k_embed, dim3((D + 255) / 256, nrows), dim3(256), 0, s, (const tk_block_q4_K*)embd_q4k, D, tok, x);
+void tk_launch_embed(const void* embd, int type, int D, const int32_t* tok, int nrows, float* x, hipStream_t s) {
+    hipLaunchKernelGGL(k_embed, dim3((D + 255) / 256, nrows), dim3(256), 0, s, embd, type, D, tok, x);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -165,6 +177,14 @@ __device__ __forceinline__ float block_sum256(float v, float* red /* >= 4 floats
  * (lane order == chunk order), so the block amax / sub-block sums come from shuffles.
  */
 __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot, TkActQ8 out) {
+    if (out.af) { /* the f16-weight matmuls' input: the same values, rounded through f16 (row = slot of the pass, 8 c .. 8 c + 7) */
+        float* dst = out.af + (size_t)slot * out.af_ld + 8 * c;
+        v4f lo, hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lo[i] = tk_f16_to_f32(tk_f32_to_f16(v[i])); hi[i] = tk_f16_to_f32(tk_f32_to_f16(v[4 + i])); }
+        *(v4f*)dst = lo;
+        *(v4f*)(dst + 4) = hi;
+    }
     float amax = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = tk_fmaxf(amax, tk_fabsf(v[i]));

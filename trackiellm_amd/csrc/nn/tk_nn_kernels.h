@@ -20,6 +20,9 @@
 #include "../common/tk_gemm_desc.h"
 
 void tk_launch_gemm(const TkGemm& g, hipStream_t s);
+/* opts the large-tile GEMM into its dynamic LDS on the calling thread's current device; idempotent, thread-safe.  tk_launch_gemm does
+ * it on first use; callers that capture launches into a hipGraph call it beforehand. */
+bool tk_nn_prepare_device();
 
 /* NHWC im2col: col[b*Ho*Wo + oy*Wo + ox][(ky*kw + kx)*C + c]; input row stride ldx floats per pixel */
 void tk_launch_im2col(const float* x, int B, int H, int W, int C, int ldx, int kh, int kw, int stride, int pad, float* col, hipStream_t s);

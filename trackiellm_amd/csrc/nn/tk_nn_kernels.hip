@@ -12,6 +12,21 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #define BK 32
 #define LDS_LD (BK + 1)
 
+/* B element i (in elements) of an f32 or f16 matrix; 4 consecutive elements as one 16- or 8-byte load */
+__device__ __forceinline__ float ldb1(const float* B, int f16, int64_t i) {
+    return f16 ? (float)((const _Float16*)B)[i] : B[i];
+}
+__device__ __forceinline__ void ldb4(const float* B, int f16, int64_t i, float* out) {
+    if (f16) {
+        const uint2 t = *(const uint2*)((const _Float16*)B + i);
+        const _Float16* h = (const _Float16*)&t;
+        out[0] = (float)h[0]; out[1] = (float)h[1]; out[2] = (float)h[2]; out[3] = (float)h[3];
+    } else {
+        const float4 t = *(const float4*)(B + i);
+        out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+    }
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case TK_ACT_SILU: return tk_siluf(v);
@@ -42,13 +57,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
         oA = (int64_t)blockIdx.z * g.sA; oB = (int64_t)blockIdx.z * g.sB; oC = (int64_t)blockIdx.z * g.sC; oR = (int64_t)blockIdx.z * g.sR;
     }
     const float* A = g.A + oA;
-    const float* B = g.B + oB;
+    const float* B = g.b_f16 ? (const float*)((const _Float16*)g.B + oB) : g.B + oB;
     float* C = g.C + oC;
     v16f acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
-    const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & 15) == 0;
+    const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & (g.b_f16 ? 7 : 15)) == 0;
     float ra[2][4], rb[2][4]; /* the next k slab on its way from global memory while the current one feeds the MFMAs */
 
     /* A: 64 rows x 32 k, thread -> (row = e / 8, 4 consecutive k) for e = tid, tid + 256; B likewise ([N][K]) or, for [K][N],
@@ -75,22 +90,22 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
                 const int row = e >> 3, kc = (e & 7) * 4;
                 const int n = n0 + row, k = k0 + kc;
                 if (n < g.N) {
-                    const float* p = B + (int64_t)n * g.ldb + k;
-                    if (b_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; rb[h][0] = t.x; rb[h][1] = t.y; rb[h][2] = t.z; rb[h][3] = t.w; }
+                    const int64_t p = (int64_t)n * g.ldb + k;
+                    if (b_vec && k + 3 < g.K) ldb4(B, g.b_f16, p, rb[h]);
                     else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[h][i] = p[i];
+                        for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[h][i] = ldb1(B, g.b_f16, p + i);
                     }
                 }
             } else {
                 const int kk = e >> 4, nc = (e & 15) * 4;
                 const int k = k0 + kk, n = n0 + nc;
                 if (k < g.K) {
-                    const float* p = B + (int64_t)k * g.ldb + n;
-                    if (b_vec && n + 3 < g.N) { const float4 t = *(const float4*)p; rb[h][0] = t.x; rb[h][1] = t.y; rb[h][2] = t.z; rb[h][3] = t.w; }
+                    const int64_t p = (int64_t)k * g.ldb + n;
+                    if (b_vec && n + 3 < g.N) ldb4(B, g.b_f16, p, rb[h]);
                     else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) if (n + i < g.N) rb[h][i] = p[i];
+                        for (int i = 0; i < 4; ++i) if (n + i < g.N) rb[h][i] = ldb1(B, g.b_f16, p + i);
                     }
                 }
             }
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
         oA = (int64_t)blockIdx.z * g.sA; oB = (int64_t)blockIdx.z * g.sB; oC = (int64_t)blockIdx.z * g.sC; oR = (int64_t)blockIdx.z * g.sR;
     }
     const float* A = g.A + oA;
-    const float* B = g.B + oB;
+    const float* B = g.b_f16 ? (const float*)((const _Float16*)g.B + oB) : g.B + oB;
     float* C = g.C + oC;
     v16f acc[2][2];
 #pragma unroll
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
-    const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & 15) == 0;
+    const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & (g.b_f16 ? 7 : 15)) == 0;
     float ra[4][4], rb[4][4]; /* register staging of the next slab: 4 float4 per thread per operand */
 
     auto gload = [&](int k0) {
@@ -200,22 +215,22 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
                 const int row = e >> 3, kc = (e & 7) * 4;
                 const int n = n0 + row, k = k0 + kc;
                 if (n < g.N) {
-                    const float* p = B + (int64_t)n * g.ldb + k;
-                    if (b_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; rb[h][0] = t.x; rb[h][1] = t.y; rb[h][2] = t.z; rb[h][3] = t.w; }
+                    const int64_t p = (int64_t)n * g.ldb + k;
+                    if (b_vec && k + 3 < g.K) ldb4(B, g.b_f16, p, rb[h]);
                     else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[h][i] = p[i];
+                        for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[h][i] = ldb1(B, g.b_f16, p + i);
                     }
                 }
             } else { /* B is [K][N]: 4 consecutive n of one k */
                 const int kk = e >> 5, nc = (e & 31) * 4;
                 const int k = k0 + kk, n = n0 + nc;
                 if (k < g.K) {
-                    const float* p = B + (int64_t)k * g.ldb + n;
-                    if (b_vec && n + 3 < g.N) { const float4 t = *(const float4*)p; rb[h][0] = t.x; rb[h][1] = t.y; rb[h][2] = t.z; rb[h][3] = t.w; }
+                    const int64_t p = (int64_t)k * g.ldb + n;
+                    if (b_vec && n + 3 < g.N) ldb4(B, g.b_f16, p, rb[h]);
                     else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) if (n + i < g.N) rb[h][i] = p[i];
+                        for (int i = 0; i < 4; ++i) if (n + i < g.N) rb[h][i] = ldb1(B, g.b_f16, p + i);
                     }
                 }
             }
@@ -285,21 +300,27 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
     }
 }
 
+/* > 64 KiB of dynamic LDS is an opt-in HIP keeps per (function, device): one flag per device, set once under a lock (several host
+ * threads drive the detector / ASR / VAD streams, possibly on different GPUs).  Callers that capture launches into a hipGraph (the LLM's
+ * f16-weight passes) call tk_nn_prepare_device() first so that no attribute is ever set inside a capture. */
+static std::atomic<bool> g_big_opted[64];
+static std::mutex g_big_mu;
+bool tk_nn_prepare_device() {
+    const size_t lds = (size_t)2 * (LBM + LBN) * LDS_LD * sizeof(float);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (g_big_opted[dev].load(std::memory_order_acquire)) return true;
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    if (hipFuncSetAttribute((const void*)k_gemm_f32_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    g_big_opted[dev].store(true, std::memory_order_release);
+    return true;
+}
+
 void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
     const int nz = g.batch > 0 ? g.batch : 1;
     if (g.M >= 256 && g.N >= 96) {
         const size_t lds = (size_t)2 * (LBM + LBN) * LDS_LD * sizeof(float);
-        /* > 64 KiB of dynamic LDS is an opt-in HIP keeps per (function, device): one flag per device, set once under a lock (several host
-         * threads drive the detector / ASR / VAD streams, possibly on different GPUs) */
-        static std::atomic<bool> opted[64];
-        static std::mutex opt_mu;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !opted[dev].load(std::memory_order_acquire)) {
-            std::lock_guard<std::mutex> lk(opt_mu);
-            if (hipFuncSetAttribute((const void*)k_gemm_f32_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-                opted[dev].store(true, std::memory_order_release);
-        }
+        (void)tk_nn_prepare_device();
         dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
         hipLaunchKernelGGL(k_gemm_f32_big, grid, dim3(256), lds, s, g);
         return;

@@ -114,9 +114,17 @@ class LlmPipeline:
             t = self.torch.from_numpy(ids.copy())
             self._isend(t.cuda() if self.cuda else t, 0)
 
-    def _recv_ids(self, n):
+    def _post_recv_ids(self, n):
+        """stage 0: post the receive of a group's sampled ids as soon as that group's pass has left this stage — a send that finds its
+        receive posted does not depend on the transport buffering it eagerly (any number of row groups may be in flight)"""
         t = self.torch.empty(n, dtype=self.torch.int32, device="cuda" if self.cuda else "cpu")
-        self.dist.recv(t, src=self.world - 1)
+        return (self.dist.irecv(t, src=self.world - 1), t)
+
+    def _wait_ids(self, posted):
+        work, t = posted
+        work.wait()
+        if self.cuda:
+            self.torch.cuda.current_stream().synchronize()
         return t.cpu().numpy()
 
     def generate(self, prompts, n_steps, rows_per_pass=128):
@@ -128,7 +136,7 @@ class LlmPipeline:
         base = np.cumsum([0] + [g.shape[0] for g in groups])
         out = [np.zeros((n_steps, g.shape[0]), np.int32) for g in groups]
         cur = [None] * len(groups)      # the ids a group feeds next (rank 0 and last rank)
-        owed = [False] * len(groups)    # rank 0: ids of this group are on their way from the last stage
+        owed = [None] * len(groups)     # rank 0: the posted receive of this group's ids, on their way from the last stage
         for gi, g in enumerate(groups):
             nseq, n_prompt = g.shape
             seq = np.repeat(np.arange(nseq, dtype=np.int32) + base[gi], n_prompt - 1)
@@ -142,13 +150,13 @@ class LlmPipeline:
                 if not self.first:
                     self._send_ids(ids)
             elif self.first:
-                owed[gi] = True
+                owed[gi] = self._post_recv_ids(nseq)
         for step in range(n_steps):
             for gi, g in enumerate(groups):
                 nseq, n_prompt = g.shape
-                if self.first and owed[gi]:
-                    cur[gi] = self._recv_ids(nseq)
-                    owed[gi] = False
+                if self.first and owed[gi] is not None:
+                    cur[gi] = self._wait_ids(owed[gi])
+                    owed[gi] = None
                 if cur[gi] is not None:
                     out[gi][step] = cur[gi]
                 if step + 1 == n_steps:
@@ -159,6 +167,6 @@ class LlmPipeline:
                     if not self.first:
                         self._send_ids(ids)
                 elif self.first:
-                    owed[gi] = True
+                    owed[gi] = self._post_recv_ids(nseq)
         self._drain()
         return out

@@ -46,8 +46,9 @@ class LlmModel:
         lib().tk_mi355x_llm_model_weight_bytes.restype = C.c_uint64
         return lib().tk_mi355x_llm_model_weight_bytes(self.h)
 
-    def fill_synthetic(self, seed):
-        check(lib().tk_mi355x_llm_model_fill_synthetic(self.h, C.c_uint64(seed)))
+    def fill_synthetic(self, seed, f16=False):
+        fn = lib().tk_mi355x_llm_model_fill_synthetic_f16 if f16 else lib().tk_mi355x_llm_model_fill_synthetic
+        check(fn(self.h, C.c_uint64(seed)))
         return self
 
     def set_tensor(self, layer, which, ttype, data):
