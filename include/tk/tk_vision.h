@@ -3,7 +3,8 @@
  *   tk_object_detector_*                         src/vision/tk_object_detector.h:42-57 (config), :66-71 (result), :99-166 (API)
  *   tk_preprocessor_resize_and_normalize_to_chw  src/vision/tk_image_preprocessor.h:49-56
  *   tk_classify_dominant_color / _door_state    src/vision/tk_attribute_classifier.h (per-box attributes, tk_vision_pipeline.c:462-485)
- *   tk_vision_pipeline_* / tk_vision_result_*    src/vision/tk_vision_pipeline.h:118-335, restricted to the object-detection analysis
+ *   tk_vision_pipeline_* / tk_vision_result_*    src/vision/tk_vision_pipeline.h:118-335: object detection, depth estimation and the
+ *                                                object / depth fusion (tk_depth.h); OCR, navigation cues and the scene graph are out of scope
  * model_path forms: an Ultralytics YOLOv8n .onnx, a TKYOLO1 weight container or "synthetic://yolov8n?seed=5&cls_bias=-4"
  * (the network topology is fixed: YOLOv8n, nc = class_count).
  * Results: score-descending, at most 500, class-aware NMS applied, bbox in ORIGINAL frame pixels.
@@ -58,8 +59,8 @@ TK_API TK_NODISCARD tk_error_code_t tk_preprocessor_resize_and_normalize_to_chw(
 TK_API TK_NODISCARD tk_error_code_t tk_classify_dominant_color(const tk_video_frame_t* frame, const tk_rect_t* bbox, char** out_color_name);
 TK_API TK_NODISCARD tk_error_code_t tk_classify_door_state(const tk_video_frame_t* frame, const tk_rect_t* bbox, char** out_state_name);
 
-/* ---- vision pipeline, object-detection analysis only (depth / OCR / fusion / navigation are out of scope: their flags are accepted
- * and never set in valid_analyses_mask) ---- */
+/* ---- vision pipeline: object detection, depth estimation, object / depth fusion (OCR / navigation cues / scene graph are out of scope:
+ * their flags are accepted and never set in valid_analyses_mask) ---- */
 typedef struct tk_vision_pipeline_s tk_vision_pipeline_t;
 typedef struct tk_vision_result_s tk_vision_result_t;
 typedef uint32_t tk_vision_analysis_flags_t;
@@ -77,7 +78,7 @@ typedef struct {
     tk_vision_backend_e backend;
     int gpu_device_id;
     tk_path_t* object_detection_model_path;
-    tk_path_t* depth_estimation_model_path; /* ignored */
+    tk_path_t* depth_estimation_model_path; /* NULL: no depth analysis; run at 256 x 256 as the reference does (tk_vision_pipeline.c:388-394) */
     tk_path_t* tesseract_data_path;         /* ignored */
     float object_confidence_threshold;
     uint32_t max_detected_objects;
@@ -95,7 +96,7 @@ typedef struct {
     const char* label;      /* owned by the object here (a copy): tk_vision_result_destroy frees it, as the reference's does */
     float confidence;
     tk_rect_t bbox;
-    float distance_meters;  /* 0: fusion is out of scope */
+    float distance_meters;  /* set by TK_VISION_ANALYZE_FUSION_DISTANCE (Kalman-smoothed); 0 when the box has no valid depth */
     float width_meters;
     float height_meters;
     bool is_partially_occluded;
@@ -111,7 +112,7 @@ struct tk_vision_result_s {
     tk_vision_object_t* objects;
     size_t text_block_count;
     tk_vision_text_block_t* text_blocks; /* always NULL */
-    tk_vision_depth_map_t* depth_map;    /* always NULL */
+    tk_vision_depth_map_t* depth_map;    /* TK_VISION_ANALYZE_DEPTH_ESTIMATION: metres, owned by the result */
     char* serialized_scene_graph;        /* always NULL */
 };
 TK_API TK_NODISCARD tk_error_code_t tk_vision_pipeline_create(tk_vision_pipeline_t** out_pipeline, const tk_vision_pipeline_config_t* config);

@@ -90,6 +90,10 @@ def attr_ints(name, vals):
     return _ld(1, name.encode()) + b"".join(_vi(8, v & 0xFFFFFFFFFFFFFFFF) for v in vals) + _vi(20, 7)
 
 
+def attr_float(name, v):
+    return _ld(1, name.encode()) + _varint((2 << 3) | 5) + struct.pack("<f", v) + _vi(20, 1)
+
+
 def attr_str(name, s):
     return _ld(1, name.encode()) + _ld(4, s.encode()) + _vi(20, 3)
 
@@ -171,3 +175,91 @@ def vad_model(W, window=480, hop=32, hidden=32, extra_op=None):
     inputs = [value_info("input", 1, [1, window]), value_info("sr", 7, []), value_info("h", 1, [1, 1, hidden]), value_info("c", 1, [1, 1, hidden])]
     outputs = [value_info("output", 1, [1, 1]), value_info("hn", 1, [1, 1, hidden]), value_info("cn", 1, [1, 1, hidden])]
     return model(nodes, inits, inputs, outputs)
+
+
+# ---- a depth network of the convolutional MiDaS class (EfficientNet-lite-like encoder, feature-fusion decoder), small enough for fixtures ----
+
+def depth_weights(seed):
+    rng = np.random.default_rng(seed)
+    def conv(m, c, k, gain=1.0):
+        return (rng.standard_normal((m, c, k, k)) * gain / np.sqrt(c * k * k)).astype(np.float32), (rng.standard_normal(m) * 0.1).astype(np.float32)
+    W = {}
+    for name, (m, c, k) in {"stem": (16, 3, 3), "dw1": (16, 1, 3), "pw1": (24, 16, 1), "down": (32, 56, 3), "dw2": (32, 1, 3), "pw2": (32, 32, 1),
+                            "red": (24, 32, 1), "lat": (24, 24, 1), "fuse": (16, 24, 3), "head1": (8, 16, 3), "head2": (1, 8, 1)}.items():
+        W[name + ".w"], W[name + ".b"] = conv(m, c, k, 1.6)
+    W["bn.scale"] = (1.0 + 0.2 * rng.standard_normal(16)).astype(np.float32)
+    W["bn.bias"] = (0.1 * rng.standard_normal(16)).astype(np.float32)
+    W["bn.mean"] = (0.2 * rng.standard_normal(16)).astype(np.float32)
+    W["bn.var"] = (0.5 + rng.random(16)).astype(np.float32)
+    W["head2.b"] = np.array([0.3], np.float32)
+    W["c0"] = np.array(0.0, np.float32)
+    W["c6"] = np.array(6.0, np.float32)
+    W["up_scales"] = np.array([1, 1, 2, 2], np.float32)
+    W["roi"] = np.zeros(0, np.float32)
+    return W
+
+
+def depth_spec():
+    """nodes of the network as dicts (the oracle and the torch fixture script evaluate this list; depth_model() writes it as ONNX)"""
+    def n(op, i, o, **attrs):
+        return {"op": op, "in": i, "out": [o], "attrs": attrs}
+    p1 = [1, 1, 1, 1]
+    return [
+        n("Conv", ["input", "stem.w", "stem.b"], "s0", strides=[2, 2], pads=p1),
+        n("BatchNormalization", ["s0", "bn.scale", "bn.bias", "bn.mean", "bn.var"], "s1", epsilon=1e-3),
+        n("Clip", ["s1", "c0", "c6"], "f2"),
+        n("Conv", ["f2", "dw1.w", "dw1.b"], "d1", pads=p1, group=16),
+        n("Clip", ["d1"], "d1c", min=0.0, max=6.0),
+        n("Conv", ["d1c", "pw1.w", "pw1.b"], "b1"),
+        n("MaxPool", ["f2"], "mp", kernel_shape=[3, 3], strides=[1, 1], pads=p1),
+        n("AveragePool", ["f2"], "ap", kernel_shape=[3, 3], strides=[1, 1], pads=p1, count_include_pad=0),
+        n("Concat", ["b1", "mp", "ap"], "cat", axis=1),
+        n("Conv", ["cat", "down.w", "down.b"], "f4p", strides=[2, 2], pads=p1),
+        n("Relu", ["f4p"], "f4"),
+        n("Conv", ["f4", "dw2.w", "dw2.b"], "d2", pads=p1, group=32),
+        n("LeakyRelu", ["d2"], "d2a", alpha=0.1),
+        n("Conv", ["d2a", "pw2.w", "pw2.b"], "p2"),
+        n("Add", ["p2", "f4"], "b2r"),
+        n("GlobalAveragePool", ["b2r"], "se"),
+        n("Sigmoid", ["se"], "seg"),
+        n("Mul", ["b2r", "seg"], "b2"),
+        n("Conv", ["b2", "red.w", "red.b"], "r4"),
+        n("Resize", ["r4", "roi", "up_scales"], "up1", mode="linear", coordinate_transformation_mode="align_corners"),
+        n("Conv", ["b1", "lat.w", "lat.b"], "l1"),
+        n("Add", ["up1", "l1"], "m2"),
+        n("Conv", ["m2", "fuse.w", "fuse.b"], "d2p", pads=p1),
+        n("Relu", ["d2p"], "dd2"),
+        n("Resize", ["dd2", "roi", "up_scales"], "up2", mode="linear", coordinate_transformation_mode="half_pixel"),
+        n("Pad", ["up2", "pad1"], "up2p", mode="constant"),
+        n("Conv", ["up2p", "head1.w", "head1.b"], "h1"),
+        n("Relu", ["h1"], "h1r"),
+        n("Conv", ["h1r", "head2.w", "head2.b"], "h2"),
+        n("Relu", ["h2"], "h2r"),
+        n("Squeeze", ["h2r"], "output", axes=[1]),
+    ]
+
+
+def depth_consts(W):
+    c = dict(W)
+    c["pad1"] = np.array([0, 0, 1, 1, 0, 0, 1, 1], np.int64)
+    return c
+
+
+def depth_model(W, height=-1, width=-1, extra_op=None):
+    nodes = []
+    for nd in depth_spec():
+        attrs = []
+        for k, v in nd["attrs"].items():
+            if isinstance(v, str):
+                attrs.append(attr_str(k, v))
+            elif isinstance(v, float):
+                attrs.append(attr_float(k, v))
+            elif isinstance(v, int):
+                attrs.append(attr_int(k, v))
+            else:
+                attrs.append(attr_ints(k, v))
+        nodes.append(node(nd["op"], nd["in"], nd["out"], attrs, name=nd["out"][0] + "_node"))
+    if extra_op:
+        nodes.append(node(extra_op, ["output"], ["unused"], name="extra"))
+    inits = [tensor(k, v) for k, v in W.items()] + [int_tensor("pad1", [0, 0, 1, 1, 0, 0, 1, 1])]
+    return model(nodes, inits, [value_info("input", 1, [1, 3, height, width])], [value_info("output", 1, [1, height, width])])

@@ -1,0 +1,137 @@
+"""GPU parity for the depth path: tk_depth_estimator_* and the pipeline's depth / fusion analyses against the
+oracle (oracle/depth_oracle.py + the pre-processing oracle) and the torch-made fixture."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+import depth_oracle as DO  # noqa: E402
+import onnx_util as OX  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "depth_net.npz")
+TOL = 2e-5  # relative to the tensor's largest magnitude: fp32 contractions in a different association (fma chain vs mul + add)
+
+
+@pytest.fixture(scope="module")
+def depth_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("depth")
+    W = OX.depth_weights(11)
+    paths = {}
+    for name, (h, w) in {"64": (64, 64), "any": (-1, -1)}.items():
+        p = d / f"depth_{name}.onnx"
+        p.write_bytes(OX.depth_model(W, h, w))
+        paths[name] = str(p)
+    q = d / "depth_erf.onnx"
+    q.write_bytes(OX.depth_model(W, 64, 64, extra_op="Erf"))
+    paths["erf"] = str(q)
+    return W, paths
+
+
+def test_network_matches_torch_fixture_and_oracle(gpu, depth_files):
+    W, paths = depth_files
+    g = np.load(GOLD)
+    est = gpu.DepthEstimator(paths["64"], 64, 64)
+    got = est.forward_raw(g["input"][0])
+    scale = float(np.abs(g["output"]).max())
+    assert np.abs(got - g["output"][0]).max() <= TOL * scale, "GPU graph vs torch"
+    want = DO.run_graph(OX.depth_spec(), OX.depth_consts(W), {"input": g["input"]})["output"][0]
+    assert np.abs(got - want).max() <= TOL * scale, "GPU graph vs numpy oracle"
+    # run to run: bit-identical (no atomics, fixed chains)
+    assert np.array_equal(got.view(np.uint32), est.forward_raw(g["input"][0]).view(np.uint32))
+    est.close()
+
+
+@pytest.mark.parametrize("shape,rgba", [((480, 640), False), ((100, 75), True)])
+def test_estimate_frame_to_metric_depth(gpu, depth_files, shape, rgba):
+    """frame -> resize / normalise (ImageNet mean / std) -> network -> inverse-depth to metres, a symbolic-shape model at 96 x 80"""
+    W, paths = depth_files
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, shape + ((4,) if rgba else (3,)), dtype=np.uint8)
+    est = gpu.DepthEstimator(paths["any"], 96, 80)
+    depth = est.estimate(frame, rgba=rgba)
+    assert depth.shape == (80, 96)
+    chw = O.preprocess(frame, 96, 80, bpp=4 if rgba else 3)
+    raw = DO.run_graph(OX.depth_spec(), OX.depth_consts(W), {"input": chw[None]})["output"][0]
+    got_raw = est.last_raw()
+    scale = float(np.abs(raw).max())
+    assert np.abs(got_raw - raw).max() <= TOL * scale
+    # the metric conversion itself is bit-exact given the raw map it was applied to
+    assert np.array_equal(depth.view(np.uint32), DO.to_metric(got_raw).view(np.uint32))
+    assert np.abs(depth - DO.to_metric(raw)).max() <= 9.9 * 4 * TOL * scale / float(raw.max() - raw.min())
+    assert depth.min() >= np.float32(0.1) - 1e-6 and depth.max() == np.float32(10.0)
+    est.close()
+
+
+def test_flat_raw_map_becomes_max_depth(gpu, depth_files, tmp_path):
+    """all-equal network output (head bias only, weights zero): every pixel 10 m (src/vision/tk_depth_midas.c:485-491)"""
+    W, _ = depth_files
+    Z = {k: (np.zeros_like(v) if k.endswith(".w") else v) for k, v in W.items()}
+    p = tmp_path / "flat.onnx"
+    p.write_bytes(OX.depth_model(Z, 64, 64))
+    est = gpu.DepthEstimator(str(p), 64, 64)
+    depth = est.estimate(np.random.default_rng(1).integers(0, 256, (64, 64, 3), dtype=np.uint8))
+    assert np.all(est.last_raw() == est.last_raw()[0, 0]) and np.all(depth == np.float32(10.0))
+    est.close()
+
+
+def test_create_error_paths(gpu, depth_files, tmp_path):
+    W, paths = depth_files
+    with pytest.raises(gpu.TkError) as e:
+        gpu.DepthEstimator(paths["erf"], 64, 64)
+    assert e.value.code == 4000 and "Erf" in str(e.value)            # unsupported op, named
+    with pytest.raises(gpu.TkError) as e:
+        gpu.DepthEstimator(paths["64"], 128, 128)                      # static model dims differ from the configuration
+    assert e.value.code == 4000
+    with pytest.raises(gpu.TkError):
+        gpu.DepthEstimator(str(tmp_path / "none.onnx"), 64, 64)
+    with pytest.raises(gpu.TkError) as e:
+        gpu.DepthEstimator(paths["64"], 0, 64)
+    assert e.value.code == 1001 or e.value.code == 1000 or e.value.code > 0
+    with pytest.raises(gpu.TkError) as e:
+        gpu.DepthEstimator(paths["64"], 64, 64, backend=0)             # CPU backend: refused, no fallback
+    assert "CPU" in str(e.value)
+
+
+def test_pipeline_depth_and_fusion(gpu, depth_files):
+    """tk_vision_pipeline_process_frame with the depth and fusion analyses: the map comes back at 256 x 256 (the reference's fixed size),
+    every detected object gets the distance / size the oracle's fusion computes from that map, smoothed over consecutive frames"""
+    W, paths = depth_files
+    pipe = gpu.VisionPipeline(depth_model=paths["any"], fx=420.0, fy=410.0, max_objects=12)
+    f = DO.Fusion()
+    rng = np.random.default_rng(9)
+    frame = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    flags = gpu.vision.ANALYZE_OBJECTS | gpu.vision.ANALYZE_DEPTH | gpu.vision.ANALYZE_FUSION
+    for it in range(3):
+        mask, objs, depth = pipe.process_full(frame, flags)
+        assert mask & gpu.vision.RESULT_OBJECTS and mask & gpu.vision.RESULT_DEPTH and mask & gpu.vision.RESULT_FUSION
+        assert depth is not None and depth.shape == (256, 256) and len(objs) > 0
+        chw = O.preprocess(frame, 256, 256)
+        raw = DO.run_graph(OX.depth_spec(), OX.depth_consts(W), {"input": chw[None]})["output"][0]
+        assert np.abs(depth - DO.to_metric(raw)).max() <= 2e-3
+        want = f.fuse([o["bbox"] for o in objs], [o["class_id"] for o in objs], depth, 640, 480, 420.0, 410.0)
+        n_valid = 0
+        for o, w in zip(objs, want):
+            if w is None:
+                assert o["distance"] == 0 and o["width_m"] == 0
+            else:
+                n_valid += 1
+                assert (o["distance"], o["width_m"], o["height_m"]) == (w[0], w[1], w[2])
+        assert n_valid > 0
+        frame = np.roll(frame, 3, axis=1)  # the scene moves a little: the same trackers keep matching
+    # depth alone: no fusion bit, objects absent
+    mask, objs, depth = pipe.process_full(frame, gpu.vision.ANALYZE_DEPTH)
+    assert mask == gpu.vision.RESULT_DEPTH and depth is not None and objs == []
+    # depth disabled at run time: the flag is ignored
+    pipe.update(0.5, 0.5, enable=True, enable_depth=False)
+    mask, objs, depth = pipe.process_full(frame, flags)
+    assert mask == gpu.vision.RESULT_OBJECTS and depth is None
+    pipe.close()
+    # a pipeline without a depth model keeps working as before
+    pipe = gpu.VisionPipeline()
+    mask, objs, depth = pipe.process_full(frame, flags)
+    assert mask == gpu.vision.RESULT_OBJECTS and depth is None
+    pipe.close()

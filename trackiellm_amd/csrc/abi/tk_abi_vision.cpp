@@ -15,6 +15,8 @@
 #include "../vision/tk_vision_engine.h"
 #include "tk/tk_mi355x_ext.h"
 #include "tk/tk_vision.h"
+#include "tk/tk_depth.h"
+#include "../vision/tk_fusion.h"
 
 struct tk_object_detector_s {
     TkYoloModel model;
@@ -271,9 +273,12 @@ static const char* const TK_COCO_LABELS[80] = {
 
 struct tk_vision_pipeline_s {
     tk_object_detector_t* detector = nullptr;
+    tk_depth_estimator_t* depth = nullptr;
+    TkFusion fusion; /* this pipeline's distance trackers (the reference keeps one process-wide set) */
     std::mutex mu;
-    bool detection_enabled = false;
+    bool detection_enabled = false, depth_enabled = false;
     uint32_t max_objects = 0;
+    float fx = 0.0f, fy = 0.0f;
 };
 
 tk_error_code_t tk_vision_pipeline_create(tk_vision_pipeline_t** out_pipeline, const tk_vision_pipeline_config_t* config) {
@@ -295,6 +300,20 @@ tk_error_code_t tk_vision_pipeline_create(tk_vision_pipeline_t** out_pipeline, c
     if (tk_object_detector_create(&p->detector, &dc) != TK_SUCCESS) p->detector = nullptr;
     p->detection_enabled = p->detector != nullptr;
     p->max_objects = config->max_detected_objects;
+    p->fx = config->focal_length_x;
+    p->fy = config->focal_length_y;
+    /* the depth estimator at the reference's fixed 256 x 256 (tk_vision_pipeline.c:388-401); a missing or unloadable model disables the
+     * analysis, it does not fail the pipeline */
+    if (config->depth_estimation_model_path && config->depth_estimation_model_path->path_str) {
+        tk_depth_estimator_config_t zc{};
+        zc.backend = config->backend;
+        zc.gpu_device_id = config->gpu_device_id;
+        zc.model_path = config->depth_estimation_model_path;
+        zc.input_width = 256;
+        zc.input_height = 256;
+        if (tk_depth_estimator_create(&p->depth, &zc) != TK_SUCCESS) p->depth = nullptr;
+    }
+    p->depth_enabled = p->depth != nullptr;
     *out_pipeline = p.release();
     return TK_SUCCESS;
 }
@@ -302,6 +321,7 @@ tk_error_code_t tk_vision_pipeline_create(tk_vision_pipeline_t** out_pipeline, c
 void tk_vision_pipeline_destroy(tk_vision_pipeline_t** pipeline) {
     if (!pipeline || !*pipeline) return;
     if ((*pipeline)->detector) tk_object_detector_destroy(&(*pipeline)->detector);
+    if ((*pipeline)->depth) tk_depth_estimator_destroy(&(*pipeline)->depth);
     delete *pipeline;
     *pipeline = nullptr;
 }
@@ -310,6 +330,7 @@ tk_error_code_t tk_vision_pipeline_update_config(tk_vision_pipeline_t* pipeline,
     if (!pipeline || !config) return TK_ERROR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(pipeline->mu);
     pipeline->detection_enabled = config->enable_object_detection;
+    pipeline->depth_enabled = config->enable_depth_estimation;
     if (pipeline->detector) tk_object_detector_update_thresholds(pipeline->detector, config->object_confidence_threshold, config->iou_threshold);
     return TK_SUCCESS;
 }
@@ -323,6 +344,7 @@ void tk_vision_result_destroy(tk_vision_result_t** result) {
         free(r->objects[i].attributes);
     }
     free(r->objects);
+    if (r->depth_map) tk_depth_estimator_free_map(&r->depth_map); /* tk_vision_pipeline.c:321-326 */
     free(r);
     *result = nullptr;
 }
@@ -335,10 +357,11 @@ tk_error_code_t tk_vision_pipeline_process_frame(tk_vision_pipeline_t* pipeline,
     tk_vision_result_t* result = (tk_vision_result_t*)calloc(1, sizeof(tk_vision_result_t));
     if (!result) return TK_ERROR_OUT_OF_MEMORY;
     result->source_frame_timestamp_ns = timestamp_ns;
-    bool enabled;
+    bool enabled, depth_enabled;
     {
         std::lock_guard<std::mutex> lk(pipeline->mu);
         enabled = pipeline->detection_enabled;
+        depth_enabled = pipeline->depth_enabled;
     }
     if (enabled && (analysis_flags & TK_VISION_ANALYZE_OBJECT_DETECTION) && pipeline->detector) {
         /* perform_object_detection (tk_vision_pipeline.c:435-494): detections -> objects, then the per-box attributes; a failure is
@@ -376,6 +399,37 @@ tk_error_code_t tk_vision_pipeline_process_frame(tk_vision_pipeline_t* pipeline,
             result->valid_analyses_mask |= TK_VISION_RESULT_OBJECT_DETECTION;
         }
         if (det) tk_object_detector_free_results(&det);
+    }
+    /* depth estimation (tk_vision_pipeline.c:200-209, perform_depth_estimation :496-507): the map is owned by the result */
+    if (depth_enabled && (analysis_flags & TK_VISION_ANALYZE_DEPTH_ESTIMATION) && pipeline->depth && video_frame->data) {
+        if (tk_depth_estimator_estimate(pipeline->depth, video_frame, &result->depth_map) == TK_SUCCESS) result->valid_analyses_mask |= TK_VISION_RESULT_DEPTH_ESTIMATION;
+    }
+    /* object / depth fusion (:250-256, fuse_object_depth :653-713): a distance and a metric size per object */
+    const bool can_fuse = (result->valid_analyses_mask & TK_VISION_RESULT_OBJECT_DETECTION) && (result->valid_analyses_mask & TK_VISION_RESULT_DEPTH_ESTIMATION);
+    if ((analysis_flags & TK_VISION_ANALYZE_FUSION_DISTANCE) && can_fuse) {
+        if (result->object_count > 0) {
+            std::vector<TkBox> boxes(result->object_count);
+            std::vector<uint32_t> cls(result->object_count);
+            for (size_t i = 0; i < result->object_count; ++i) {
+                const tk_rect_t& b = result->objects[i].bbox;
+                boxes[i] = {b.x, b.y, b.w, b.h};
+                cls[i] = result->objects[i].class_id;
+            }
+            std::vector<TkFused> fused;
+            {
+                std::lock_guard<std::mutex> lk(pipeline->mu);
+                pipeline->fusion.fuse(boxes.data(), cls.data(), boxes.size(), result->depth_map->data, result->depth_map->width, result->depth_map->height,
+                                      video_frame->width, video_frame->height, pipeline->fx, pipeline->fy, &fused);
+            }
+            for (size_t i = 0; i < result->object_count; ++i) {
+                if (!fused[i].valid) continue; /* no valid depth under the box: the fields stay 0 */
+                result->objects[i].distance_meters = fused[i].distance_m;
+                result->objects[i].width_meters = fused[i].width_m;
+                result->objects[i].height_meters = fused[i].height_m;
+                result->objects[i].is_partially_occluded = false;
+            }
+        }
+        result->valid_analyses_mask |= TK_VISION_RESULT_FUSION_DISTANCE;
     }
     *out_result = result;
     return TK_SUCCESS;

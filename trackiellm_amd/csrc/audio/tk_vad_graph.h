@@ -4,7 +4,8 @@
  *
  * The reference creates an ORT session on silero_vad.onnx and runs it once per 30 ms window (src/sensors/tk_vad_silero.c:110-190 create,
  * :193-280 run_vad_inference: one float input [1, window], the first output's first element is the speech probability).  Here the graph
- * description comes from csrc/nn/tk_onnx_graph (wire-format reader) and every node becomes one small HIP kernel on the VAD stream:
+ * description comes from csrc/nn/tk_onnx_graph (wire-format reader) and every node becomes one small HIP kernel on the VAD stream
+ * (csrc/nn/tk_onnx_exec, the executor shared with the depth network); the ops a VAD graph of this class uses:
  *   Conv (1-D, group 1), Relu, Sigmoid, Tanh, Sqrt, Abs, Neg, Exp, Log, Add, Sub, Mul, Div, Pow (numpy broadcasting), Slice, Concat, Pad
  *   (constant / reflect), Transpose, ReduceMean, LSTM (forward, one direction), and the layout-only ops Unsqueeze, Squeeze, Reshape, Flatten,
  *   Identity, Cast(float), Constant.
@@ -24,7 +25,7 @@
 #include <string>
 #include <vector>
 
-#include "../nn/tk_onnx_graph.h"
+#include "../nn/tk_onnx_exec.h"
 
 class TkVadGraph {
 public:
@@ -37,28 +38,16 @@ public:
     bool infer(const float* windows_host, int n, float* prob_host);
     bool reset();
     bool stateful() const { return !states_.empty(); }
-    int node_count() const { return (int)g_.nodes.size(); }
+    int node_count() const { return (int)exec_.graph().nodes.size(); }
 
 private:
-    struct Val {
-        float* d = nullptr;            /* device data (float tensors) */
-        std::vector<int64_t> shape;
-        std::vector<int64_t> ints;     /* host data (int tensors: shapes, axes, slice bounds) */
-        bool is_int = false;
-        int64_t count() const { int64_t n = 1; for (int64_t s : shape) n *= s; return n; }
-    };
     struct State { std::string in, out; float* buf = nullptr; std::vector<int64_t> shape; };
     bool run_window(const float* x_dev, float* prob_dev);
-    bool exec(const TkOnnxNode& nd, std::map<std::string, Val>& v);
-    float* alloc(int64_t n);
-    TkOnnxGraph g_;
+    TkOnnxExec exec_; /* the node-by-node executor (csrc/nn/tk_onnx_exec.h) */
     int device_ = 0, window_ = 480, sample_rate_ = 16000;
     hipStream_t stream_ = nullptr;
-    std::map<std::string, Val> consts_;  /* initialisers + Constant nodes, resident */
     std::vector<State> states_;
     std::string audio_in_, sr_in_, prob_out_;
-    float* arena_ = nullptr;
-    size_t arena_cap_ = 0, arena_used_ = 0;
     float *x_dev_ = nullptr, *p_dev_ = nullptr;
     int xcap_ = 0;
 };

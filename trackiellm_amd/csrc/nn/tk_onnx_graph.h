@@ -8,8 +8,8 @@
  *   TensorProto.dims = 1, .data_type = 2 (1 FLOAT, 6 INT32, 7 INT64, 10 FLOAT16), .float_data = 4, .int32_data = 5, .int64_data = 7,
  *               .name = 8, .raw_data = 9
  *   ValueInfoProto.name = 1, .type = 2 -> TypeProto.tensor_type = 1 -> {elem_type = 1, shape = 2 -> dim = 1 -> {dim_value = 1, dim_param = 2}}
- * The reference hands silero_vad.onnx to ONNX Runtime (src/sensors/tk_vad_silero.c:110-280); csrc/audio/tk_vad_graph runs such a graph on
- * the GPU from this description.  Host-only code, tested without a GPU.
+ * The reference hands silero_vad.onnx (src/sensors/tk_vad_silero.c:110-280) and the MiDaS depth model (src/vision/tk_depth_midas.c:231-283)
+ * to ONNX Runtime; csrc/nn/tk_onnx_exec runs such graphs on the GPU from this description.  Host-only code, tested without a GPU.
  */
 #ifndef TK_ONNX_GRAPH_H
 #define TK_ONNX_GRAPH_H
@@ -43,6 +43,9 @@ struct TkOnnxNode {
     std::vector<std::string> in, out;
     std::map<std::string, TkOnnxAttr> attr;
     int64_t ai(const char* k, int64_t dflt) const { auto it = attr.find(k); return it == attr.end() ? dflt : it->second.i; }
+    float af(const char* k, float dflt) const { auto it = attr.find(k); return it == attr.end() ? dflt : it->second.f; }
+    bool has(const char* k) const { return attr.find(k) != attr.end(); }
+    const std::vector<float>* afloats(const char* k) const { auto it = attr.find(k); return it == attr.end() ? nullptr : &it->second.floats; }
     const std::vector<int64_t>* aints(const char* k) const { auto it = attr.find(k); return it == attr.end() ? nullptr : &it->second.ints; }
     std::string as(const char* k, const char* dflt) const { auto it = attr.find(k); return it == attr.end() ? std::string(dflt) : it->second.s; }
 };

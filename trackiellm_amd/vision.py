@@ -164,21 +164,51 @@ class VisionResult(C.Structure):
                 ("serialized_scene_graph", C.c_char_p)]
 
 
-class VisionPipeline:
-    """tk_vision_pipeline_* (object-detection analysis)"""
+class DepthMap(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("data", C.POINTER(C.c_float))]
 
-    def __init__(self, model="synthetic://yolov8n?seed=5&cls_bias=-0.45", conf=0.5, max_objects=0, device=0, backend=3):
+
+ANALYZE_OBJECTS, ANALYZE_DEPTH, ANALYZE_FUSION = 1, 2, 8
+RESULT_OBJECTS, RESULT_DEPTH, RESULT_FUSION = 1, 2, 8
+
+
+class VisionPipeline:
+    """tk_vision_pipeline_* (object detection, depth estimation, object / depth fusion)"""
+
+    def __init__(self, model="synthetic://yolov8n?seed=5&cls_bias=-0.45", conf=0.5, max_objects=0, device=0, backend=3, depth_model=None, fx=500.0,
+                 fy=500.0):
         lib().tk_path_create.restype = C.POINTER(_Path)
         p = lib().tk_path_create(model.encode())
-        cfg = _PipelineConfig(backend, device, p, None, None, conf, max_objects, 500.0, 500.0)
+        pd = lib().tk_path_create(depth_model.encode()) if depth_model else None
+        cfg = _PipelineConfig(backend, device, p, pd, None, conf, max_objects, fx, fy)
         self.h = C.c_void_p()
         try:
             check(lib().tk_vision_pipeline_create(C.byref(self.h), C.byref(cfg)))
         finally:
             lib().tk_path_destroy(C.byref(p))
+            if pd:
+                lib().tk_path_destroy(C.byref(pd))
 
-    def update(self, conf, iou, enable=True):
-        rc = _RuntimeConfig(conf, iou, enable, False)
+    def process_full(self, arr, flags, timestamp_ns=0):
+        """-> (mask, objects as dicts with the fused fields, depth map [H][W] float32 or None)"""
+        f, keep = make_frame(arr)
+        res = C.POINTER(VisionResult)()
+        check(lib().tk_vision_pipeline_process_frame(self.h, C.byref(f), flags, None, C.c_uint64(timestamp_ns), C.byref(res)))
+        r = res.contents
+        objs = [{"class_id": r.objects[i].class_id, "label": r.objects[i].label, "confidence": r.objects[i].confidence,
+                 "bbox": (r.objects[i].bbox.x, r.objects[i].bbox.y, r.objects[i].bbox.w, r.objects[i].bbox.h),
+                 "distance": np.float32(r.objects[i].distance_meters), "width_m": np.float32(r.objects[i].width_meters),
+                 "height_m": np.float32(r.objects[i].height_meters)} for i in range(r.object_count)]
+        depth = None
+        if r.depth_map:
+            dm = C.cast(r.depth_map, C.POINTER(DepthMap)).contents
+            depth = np.ctypeslib.as_array(dm.data, shape=(dm.height, dm.width)).copy()
+        mask = r.valid_analyses_mask
+        lib().tk_vision_result_destroy(C.byref(res))
+        return mask, objs, depth
+
+    def update(self, conf, iou, enable=True, enable_depth=True):
+        rc = _RuntimeConfig(conf, iou, enable, enable_depth)
         check(lib().tk_vision_pipeline_update_config(self.h, C.byref(rc)))
 
     def process(self, arr, flags=1, timestamp_ns=0):
@@ -197,3 +227,104 @@ class VisionPipeline:
         if self.h:
             lib().tk_vision_pipeline_destroy(C.byref(self.h))
             self.h = C.c_void_p()
+
+
+# ---- depth estimation + fusion: tk_depth_estimator_* / tk_vision_rust_fuse_data (include/tk/tk_depth.h) ----
+
+class _DepthConfig(C.Structure):
+    _fields_ = [("backend", C.c_int), ("gpu_device_id", C.c_int), ("model_path", C.POINTER(_Path)), ("input_width", C.c_uint32), ("input_height", C.c_uint32)]
+
+
+class EnrichedObject(C.Structure):
+    _fields_ = [("class_id", C.c_uint32), ("confidence", C.c_float), ("bbox", Rect), ("distance_meters", C.c_float), ("width_meters", C.c_float),
+                ("height_meters", C.c_float), ("is_partially_occluded", C.c_bool)]
+
+
+class _FusedResult(C.Structure):
+    _fields_ = [("objects", C.POINTER(EnrichedObject)), ("count", C.c_size_t)]
+
+
+class DepthEstimator:
+    def __init__(self, model, width=256, height=256, device=0, backend=3):
+        lib().tk_path_create.restype = C.POINTER(_Path)
+        p = lib().tk_path_create(model.encode())
+        cfg = _DepthConfig(backend, device, p, width, height)
+        self.h = C.c_void_p()
+        self.width, self.height = width, height
+        try:
+            check(lib().tk_depth_estimator_create(C.byref(self.h), C.byref(cfg)))
+        finally:
+            lib().tk_path_destroy(C.byref(p))
+
+    def estimate(self, arr, stride=None, rgba=False, width=None):
+        f, keep = make_frame(arr, stride, rgba, width)
+        m = C.POINTER(DepthMap)()
+        check(lib().tk_depth_estimator_estimate(self.h, C.byref(f), C.byref(m)))
+        out = np.ctypeslib.as_array(m.contents.data, shape=(m.contents.height, m.contents.width)).copy()
+        lib().tk_depth_estimator_free_map(C.byref(m))
+        return out
+
+    def forward_raw(self, chw):
+        chw = np.ascontiguousarray(chw, np.float32)
+        out = np.empty((self.height, self.width), np.float32)
+        check(lib().tk_mi355x_depth_forward_raw(self.h, chw.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)))
+        return out
+
+    def last_raw(self):
+        out = np.empty((self.height, self.width), np.float32)
+        check(lib().tk_mi355x_depth_last_raw(self.h, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().tk_depth_estimator_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def depth_onnx_probe(path):
+    n = C.c_int32(0)
+    check(lib().tk_mi355x_depth_onnx_probe(path.encode(), C.byref(n)))
+    return n.value
+
+
+def _depth_map(depth):
+    depth = np.ascontiguousarray(depth, np.float32)
+    return DepthMap(depth.shape[1], depth.shape[0], depth.ctypes.data_as(C.POINTER(C.c_float))), depth
+
+
+def fuse_data(boxes, classes, depth, frame_w, frame_h, fx, fy):
+    """tk_vision_rust_fuse_data: boxes [(x, y, w, h)], classes [int] -> [(class_id, confidence, bbox, distance, width_m, height_m)] for the
+    detections that have valid depth, in detection order (process-wide trackers)"""
+    n = len(boxes)
+    dets = (DetectionResult * max(n, 1))()
+    for i, b in enumerate(boxes):
+        dets[i] = DetectionResult(int(classes[i]), None, 0.9, Rect(*[int(t) for t in b]))
+    dm, keep = _depth_map(depth)
+    lib().tk_vision_rust_fuse_data.restype = C.POINTER(_FusedResult)
+    r = lib().tk_vision_rust_fuse_data(dets, C.c_size_t(n), C.byref(dm), C.c_uint32(frame_w), C.c_uint32(frame_h), C.c_float(fx), C.c_float(fy))
+    if not r:
+        return None
+    out = [(r.contents.objects[i].class_id, r.contents.objects[i].confidence,
+            (r.contents.objects[i].bbox.x, r.contents.objects[i].bbox.y, r.contents.objects[i].bbox.w, r.contents.objects[i].bbox.h),
+            np.float32(r.contents.objects[i].distance_meters), np.float32(r.contents.objects[i].width_meters), np.float32(r.contents.objects[i].height_meters))
+           for i in range(r.contents.count)]
+    lib().tk_vision_rust_free_fused_result.argtypes = [C.POINTER(_FusedResult)]
+    lib().tk_vision_rust_free_fused_result(r)
+    return out
+
+
+def fusion_reset():
+    lib().tk_mi355x_fusion_reset()
+
+
+def fusion_raw_distance(box, depth, frame_w, frame_h):
+    dm, keep = _depth_map(depth)
+    lib().tk_mi355x_fusion_raw_distance.restype = C.c_float
+    r = Rect(*[int(t) for t in box])
+    return np.float32(lib().tk_mi355x_fusion_raw_distance(C.byref(r), C.byref(dm), C.c_uint32(frame_w), C.c_uint32(frame_h)))
