@@ -35,7 +35,7 @@ typedef enum {
 typedef struct {
     const char* llm_model;
     const char* object_detection_model;
-    const char* depth_estimation_model; /* ignored */
+    const char* depth_estimation_model; /* NULL / "": no depth analysis; an ONNX file of the convolutional MiDaS class (tk_depth.h) */
     const char* asr_model;
     const char* tts_model_dir;          /* ignored */
     const char* vad_model;

@@ -124,3 +124,27 @@ def test_cortex_cycle_like_reference_test(gpu):
     assert s.responses_parsed == 0 and s.actions_parsed == 0   # a random-weight model does not speak the decision engine's JSON
     assert gpu.lib().tk_cortex_inject_video_frame(cx.h, None) == 1001
     cx.close()
+
+
+def test_cortex_with_depth_model_reports_distances(gpu, tmp_path):
+    """tk_cortex_config_t.model_paths.depth_estimation_model set: the cortex's vision pipeline runs the ENVIRONMENT_AWARENESS preset
+    (tk_cortex_main.c:1188) and the fused distances reach the prompt instead of 0.0 m"""
+    import re
+
+    import onnx_util as OX
+    p = tmp_path / "depth.onnx"
+    p.write_bytes(OX.depth_model(OX.depth_weights(11)))
+    cx = gpu.Cortex(llm="synthetic://tiny?seed=4", detector="synthetic://yolov8n?seed=5&cls_bias=-0.45", depth=str(p))
+    cx.set_max_tokens(4)
+    cx.start()
+    frame = np.random.default_rng(4).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    assert cx.inject_frame(frame) == 0
+    deadline = time.time() + 60
+    while time.time() < deadline and cx.stats().llm_responses < 1:
+        time.sleep(0.05)
+    cx.stop()
+    assert cx.stats().frames_with_objects == 1 and cx.stats().llm_responses >= 1
+    pr = cx.last_prompt().decode("utf-8", "replace")
+    dist = [float(m) for m in re.findall(r"\((\d+\.\d)m, ", pr)]
+    assert dist and any(0.1 <= d <= 10.0 for d in dist), pr[:400]
+    cx.close()

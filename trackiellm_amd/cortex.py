@@ -32,12 +32,12 @@ class CortexStats(C.Structure):
 
 
 class Cortex:
-    def __init__(self, llm=None, detector=None, asr=None, vad=None, device=0):
+    def __init__(self, llm=None, detector=None, asr=None, vad=None, device=0, depth=None):
         self.states = []
         self._scb = _STATE_CB(lambda s, u: self.states.append(s))
         self._tcb = _TTS_CB(lambda a, n, sr, u: None)
         enc = lambda s: s.encode() if s else None
-        cfg = _CortexConfig(_ModelPaths(enc(llm), enc(detector), None, enc(asr), None, enc(vad), None), device, 10.0, b"en", None)
+        cfg = _CortexConfig(_ModelPaths(enc(llm), enc(detector), enc(depth), enc(asr), None, enc(vad), None), device, 10.0, b"en", None)
         self.h = C.c_void_p()
         check(lib().tk_cortex_create(C.byref(self.h), C.byref(cfg), _Callbacks(self._scb, self._tcb)))
         self._thread = None

@@ -31,13 +31,6 @@
 #define TK_CORTEX_VIDEO_RING 4
 #define TK_CORTEX_PROMPT_QUEUE 8 /* prompts waiting for the response thread; the oldest scene prompt is dropped when full */
 
-static const char* kCoco[80] = {"person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light", "fire hydrant",
-    "stop sign", "parking meter", "bench", "bird", "cat", "dog", "horse", "sheep", "cow", "elephant", "bear", "zebra", "giraffe", "backpack", "umbrella",
-    "handbag", "tie", "suitcase", "frisbee", "skis", "snowboard", "sports ball", "kite", "baseball bat", "baseball glove", "skateboard", "surfboard",
-    "tennis racket", "bottle", "wine glass", "cup", "fork", "knife", "spoon", "bowl", "banana", "apple", "sandwich", "orange", "broccoli", "carrot",
-    "hot dog", "pizza", "donut", "cake", "chair", "couch", "potted plant", "bed", "dining table", "toilet", "tv", "laptop", "mouse", "remote", "keyboard",
-    "cell phone", "microwave", "oven", "toaster", "sink", "refrigerator", "book", "clock", "vase", "scissors", "teddy bear", "hair drier", "toothbrush"};
-
 struct CortexEvent {
     enum { VIDEO, SPEECH } kind;
     int slot = 0;            /* video ring slot */
@@ -54,7 +47,7 @@ struct tk_cortex_s {
     std::deque<CortexEvent> queue;
     struct Frame { tk_video_frame_t f; std::vector<uint8_t> data; } ring[TK_CORTEX_VIDEO_RING];
     int ring_next = 0;
-    tk_object_detector_t* det = nullptr;
+    tk_vision_pipeline_t* vis = nullptr; /* detection + depth + fusion, as the reference's cortex owns a vision pipeline (tk_cortex_main.c:773-790) */
     tk_asr_whisper_context_t* asr = nullptr;
     tk_vad_silero_context_t* vad = nullptr;
     tk_model_loader_t* loader = nullptr;
@@ -162,12 +155,20 @@ tk_error_code_t tk_cortex_create(tk_cortex_t** out_cortex, const tk_cortex_confi
     auto fail = [&](tk_error_code_t e) { tk_cortex_t* raw = c.release(); tk_cortex_destroy(&raw); return e; };
 
     if ((rc = mkpath(config->model_paths.object_detection_model, "synthetic://yolov8n?seed=5&cls_bias=-0.45", &p)) != TK_SUCCESS) return fail(rc);
-    tk_object_detector_config_t dc{};
-    dc.backend = TK_VISION_BACKEND_ROCM; dc.gpu_device_id = dev; dc.model_path = p; dc.input_width = 640; dc.input_height = 640;
-    dc.class_labels = kCoco; dc.class_count = 80; dc.confidence_threshold = 0.5f; dc.iou_threshold = 0.5f; /* tk_cortex_main.c:780, tk_vision_pipeline.c:377 */
-    rc = tk_object_detector_create(&c->det, &dc);
-    tk_path_destroy(&p);
-    if (rc != TK_SUCCESS) return fail(rc);
+    {
+        /* tk_cortex_main.c:774-782: confidence 0.5, at most 20 objects, focal lengths left at zero; the depth model is optional here (the
+         * reference's pipeline also only warns when it cannot load it, tk_vision_pipeline.c:395-401) */
+        tk_path_t* pd = nullptr;
+        if (config->model_paths.depth_estimation_model && config->model_paths.depth_estimation_model[0] &&
+            (rc = tk_path_create_from_string(&pd, config->model_paths.depth_estimation_model)) != TK_SUCCESS) { tk_path_destroy(&p); return fail(rc); }
+        tk_vision_pipeline_config_t vc{};
+        vc.backend = TK_VISION_BACKEND_ROCM; vc.gpu_device_id = dev; vc.object_detection_model_path = p; vc.depth_estimation_model_path = pd;
+        vc.object_confidence_threshold = 0.5f; vc.max_detected_objects = 20;
+        rc = tk_vision_pipeline_create(&c->vis, &vc);
+        tk_path_destroy(&p);
+        if (pd) tk_path_destroy(&pd);
+        if (rc != TK_SUCCESS) return fail(rc);
+    }
 
     if ((rc = mkpath(config->model_paths.asr_model, "synthetic://whisper-tiny.en?seed=6", &p)) != TK_SUCCESS) return fail(rc);
     tk_asr_whisper_config_t ac{};
@@ -217,7 +218,7 @@ void tk_cortex_destroy(tk_cortex_t** cortex) {
     if (c->runner) tk_llm_runner_destroy(&c->runner);
     if (c->reasoner) tk_contextual_reasoner_destroy(&c->reasoner);
     if (c->loader) { if (c->llm_model) (void)tk_model_loader_unload_model(c->loader, &c->llm_model); tk_model_loader_destroy(&c->loader); }
-    if (c->det) tk_object_detector_destroy(&c->det);
+    if (c->vis) tk_vision_pipeline_destroy(&c->vis);
     if (c->asr) tk_asr_whisper_destroy(&c->asr);
     if (c->vad) tk_vad_silero_destroy(&c->vad);
     delete c;
@@ -245,20 +246,15 @@ tk_error_code_t tk_cortex_run(tk_cortex_t* c) {
                 data = c->ring[ev.slot].data;
             }
             f.data = data.data();
-            tk_detection_result_t* res = nullptr;
-            size_t n = 0;
-            if (tk_object_detector_detect(c->det, &f, &res, &n) != TK_SUCCESS) continue;
-            /* detections -> the reasoner's environmental snapshot (cortex_process_vision_input, tk_cortex_main.c:1198-1222) */
-            const size_t shown = n < 20 ? n : 20; /* max_detected_objects 20: tk_cortex_main.c:781 */
-            std::vector<tk_vision_object_t> objs(shown);
-            for (size_t i = 0; i < shown; ++i) {
-                objs[i] = tk_vision_object_t{};
-                objs[i].class_id = res[i].class_id; objs[i].label = res[i].label; objs[i].confidence = res[i].confidence; objs[i].bbox = res[i].bbox;
-            }
-            tk_vision_result_t vr{};
-            vr.valid_analyses_mask = TK_VISION_RESULT_OBJECT_DETECTION; vr.object_count = shown; vr.objects = objs.data();
-            (void)tk_contextual_reasoner_update_vision_context(c->reasoner, &vr);
-            tk_object_detector_free_results(&res);
+            /* cortex_process_vision_input (tk_cortex_main.c:1186-1222): the ENVIRONMENT_AWARENESS preset through the vision pipeline, the
+             * result (objects with attributes and, when a depth model is configured, fused distances) into the reasoner's snapshot */
+            tk_vision_result_t* vr = nullptr;
+            const tk_vision_analysis_flags_t flags = TK_VISION_ANALYZE_OBJECT_DETECTION | TK_VISION_ANALYZE_DEPTH_ESTIMATION |
+                                                     TK_VISION_ANALYZE_FUSION_DISTANCE | TK_VISION_ANALYZE_NAVIGATION_CUES;
+            if (tk_vision_pipeline_process_frame(c->vis, &f, flags, nullptr, 0, &vr) != TK_SUCCESS || !vr) continue;
+            const size_t n = vr->object_count;
+            (void)tk_contextual_reasoner_update_vision_context(c->reasoner, vr);
+            tk_vision_result_destroy(&vr);
             {
                 std::lock_guard<std::mutex> lk(c->stat_mu);
                 c->stats.frames_processed++;
