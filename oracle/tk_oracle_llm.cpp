@@ -361,31 +361,36 @@ static void gemv_f32(const orc_tensor& t, const float* h, float* y) {
 }
 
 /* f16 weight matrix (fp16 checkpoints): the activation row is rounded through f16 — what a CPU engine's f16 matmul does to its f32 input
- * (ggml converts src1 to f16, then dots in f32) — and each output is ONE fp32 fma chain over k ascending (no K-split: a single slab) */
-static void gemv_f16(const orc_tensor& t, const float* h, float* y) {
-    const int K = (int)t.cols;
+ * (ggml converts src1 to f16, then dots in f32).  K-split like the quantised path: per slab ONE fp32 fma chain over k ascending from zero,
+ * the slabs added in ascending order */
+static void gemv_f16(const orc_tensor& t, int ks, const float* h, float* y) {
+    const int K = (int)t.cols, Kr = K / ks;
     std::vector<float> a(K);
     for (int i = 0; i < K; ++i) a[i] = tk_f16_to_f32(tk_f32_to_f16(h[i]));
     const uint16_t* w = (const uint16_t*)t.data.data();
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < t.rows; ++r) {
-        float acc = 0.0f;
-        for (int i = 0; i < K; ++i) acc = tk_fmaf(a[i], tk_f16_to_f32(w[r * K + i]), acc);
-        y[r] = acc;
+        float total = 0.0f;
+        for (int s = 0; s < ks; ++s) {
+            float acc = 0.0f;
+            for (int i = s * Kr; i < (s + 1) * Kr; ++i) acc = tk_fmaf(a[i], tk_f16_to_f32(w[r * K + i]), acc);
+            total = s == 0 ? acc : total + acc;
+        }
+        y[r] = total;
     }
 }
 
 /* a matmul on an already quantised row (q / d / bs) or, for f16 tensors, on the f32 row itself */
 static void mat(const orc_tensor& t, int ks, const float* h, const int8_t* q, const float* d, const int32_t* bs, float* y) {
     if (g_fp32_activations) { gemv_f32(t, h, y); return; }
-    if (t.type == TK_TYPE_F16) { gemv_f16(t, h, y); return; }
+    if (t.type == TK_TYPE_F16) { gemv_f16(t, ks, h, y); return; }
     orc_gemv_q8(t.type, t.data.data(), t.rows, (int)t.cols, ks, q, d, bs, y);
 }
 
 static void matvec(const orc_tensor& t, int ks, const float* h, float* y, std::vector<int8_t>& q, std::vector<float>& d,
                    std::vector<int32_t>& bs) {
     if (g_fp32_activations) { gemv_f32(t, h, y); return; }
-    if (t.type == TK_TYPE_F16) { gemv_f16(t, h, y); return; }
+    if (t.type == TK_TYPE_F16) { gemv_f16(t, ks, h, y); return; }
     int K = (int)t.cols;
     q.resize(K); d.resize(K / 256); bs.resize(K / 32);
     orc_q8k_quantize(h, K, q.data(), d.data(), bs.data());

@@ -99,12 +99,17 @@ bool TkLlmModel::install(TkDevTensor* t, int type, int64_t rows, int64_t cols, c
         HIPQ(hipMemcpyAsync(t->data, dev_blocks, t->bytes, hipMemcpyDeviceToDevice, s));
         return true;
     }
-    if (type == TK_TYPE_F16) { /* fp16 checkpoints: rows stay row-major f16, the exact fp32 GEMM widens them on load (csrc/nn/tk_nn_kernels.hip) */
-        if (cols % 8) { error = "f16 matrices need a multiple of 8 columns"; return false; }
+    if (type == TK_TYPE_F16) { /* fp16 checkpoints: matrices become fp32-MFMA operand tiles (TkF16Args::tiles), the embedding stays row-major */
+        if (cols % 32 || (is_matrix && rows % 16)) { error = "f16 matrices need rows % 16 == 0 and columns % 32 == 0"; return false; }
         t->bytes = (size_t)rows * cols * 2;
         HIPQ(hipMalloc((void**)&t->data, t->bytes));
-        HIPQ(hipMemcpyAsync(t->data, dev_blocks, t->bytes, hipMemcpyDeviceToDevice, s));
-        if (is_matrix) has_f16 = true;
+        if (is_matrix) {
+            tk_launch_repack(type, dev_blocks, rows, cols, t->data, s);
+            HIPQ(hipGetLastError());
+            has_f16 = true;
+        } else {
+            HIPQ(hipMemcpyAsync(t->data, dev_blocks, t->bytes, hipMemcpyDeviceToDevice, s));
+        }
         return true;
     }
     if (type != TK_TYPE_Q4_K && type != TK_TYPE_Q6_K) { error = "unsupported tensor type (want F32, F16, Q4_K or Q6_K)"; return false; }
@@ -188,7 +193,7 @@ bool TkLlmModel::ready() const {
 
 static bool alloc_act(TkActQ8* a, int K, bool want_f16, std::string& error) {
     a->aq_ts = TK_AQ_BYTES(K); a->ad_ts = TK_AD_FLOATS(K); a->abs_ts = TK_ABS_BYTES(K);
-    a->af = nullptr; a->af_ld = K;
+    a->af = nullptr; a->af_ts = (size_t)K * TK_ROW_SLOTS;
     if (want_f16 && hipMalloc((void**)&a->af, (size_t)TK_MAX_ROWS * K * 4) != hipSuccess) { error = "out of device memory (f16 activation buffers)"; return false; }
     if (a->af) (void)hipMemset(a->af, 0, (size_t)TK_MAX_ROWS * K * 4);
     if (hipMalloc((void**)&a->aq, TK_MAX_TILES * a->aq_ts) != hipSuccess || hipMalloc((void**)&a->ad, TK_MAX_TILES * a->ad_ts * 4) != hipSuccess ||
@@ -239,7 +244,6 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     HIPQ(hipMalloc((void**)&partial, pmax * TK_MAX_ROWS * 4));
     HIPQ(hipMalloc((void**)&logits, (size_t)TK_MAX_ROWS * h.vocab * 4));
     if (!alloc_act(&act_d, h.d_model, m->has_f16, error) || !alloc_act(&act_qd, QD, m->has_f16, error) || !alloc_act(&act_ff, h.d_ff, m->has_f16, error)) return false;
-    if (m->has_f16 && !tk_nn_prepare_device()) { error = "LDS opt-in of the fp32 GEMM failed"; return false; }
     HIPQ(hipMalloc((void**)&d_seq, TK_MAX_ROWS * 4));
     HIPQ(hipMalloc((void**)&d_pos, TK_MAX_ROWS * 4));
     HIPQ(hipMalloc((void**)&d_tok, TK_MAX_ROWS * 4));
@@ -303,16 +307,12 @@ void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) { enqu
 int TkLlmSession::enqueue_matmul(const TkDevTensor* const* t, int nseg, int K, int ks, int n_total, const TkActQ8& act, float* out, int nrows) {
     hipStream_t s = stream;
     if (t[0]->type == TK_TYPE_F16) {
-        int col = 0;
-        for (int i = 0; i < nseg; ++i) {
-            TkGemm g{};
-            g.A = act.af; g.B = (const float*)t[i]->data; g.C = out + col;
-            g.M = nrows; g.N = (int)t[i]->rows; g.K = K; g.lda = act.af_ld; g.ldb = K; g.ldc = n_total;
-            g.alpha = 1.0f; g.batch = 1; g.b_f16 = 1;
-            tk_launch_gemm(g, s);
-            col += (int)t[i]->rows;
-        }
-        return 1;
+        TkF16Args f{};
+        for (int i = 0; i < nseg; ++i) { f.tiles[i] = t[i]->data; f.row_tiles[i] = (int)(t[i]->rows / TK_TILE_ROWS); }
+        f.nseg = nseg; f.K = K; f.ks = ks; f.n_total = n_total; f.nrows = nrows;
+        f.a_img = act.af; f.a_ts = act.af_ts; f.out = out;
+        tk_launch_gemm_f16w(f, s);
+        return ks;
     }
     TkGemvArgs a{};
     for (int i = 0; i < nseg; ++i) a.seg[i] = seg_of(*t[i]);
