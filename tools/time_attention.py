@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Isolated k_attention timing over (rows per pass, cached positions) — developer tool, needs an MI355X.  TK_MI355X_LIB selects a variant build."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import trackiellm_amd as tk  # noqa: E402
+
+hp = tk.MISTRAL_7B()
+hp.n_layer = 2
+model = tk.LlmModel(hp).fill_synthetic(4)
+sess = tk.LlmSession(model, 256, 520)
+out = []
+for rows, ctx in [(256, 64), (256, 128), (256, 192), (256, 500), (16, 128), (16, 500), (1, 128)]:
+    ms, kvb = sess.time_attention(rows, ctx, 64)
+    out.append(f"{rows}x{ctx}: {1000 * ms:.1f} us ({kvb / ms / 1e6:.0f} GB/s)")
+print(os.environ.get("TK_MI355X_LIB", "default").split("/")[-1], " | ".join(out), flush=True)

@@ -1259,7 +1259,10 @@ void tk_launch_qkv_rope_append(const float* partial, int ks, int n_total, int n_
 #define TK_ATT_MAX_GRP 4
 #define TK_ATT_TSPLIT 4 /* canonical: 4 interleaved partial sums over positions (t mod 4), added in order */
 #define TK_ATT_CHUNK 64 /* positions per ring slot */
-#define TK_ATT_SLOTS 2  /* ring slots: the next chunk lands while the current one is used.  Measured on MI355X (256 rows x 128 cached
+#ifndef TK_ATT_SLOTS
+#define TK_ATT_SLOTS 2
+#endif
+/* TK_ATT_SLOTS 2: ring slots: the next chunk lands while the current one is used.  Measured on MI355X (256 rows x 128 cached
                          * positions, profiles/r02_attention_variants.txt): 2 x 64 rows 53.5 us, 8 x 32 rows 86 us — a workgroup's life is a
                          * chain of short dependent phases, so what pays is workgroups per CU (LDS footprint), not bytes in flight per workgroup */
 
@@ -1315,10 +1318,12 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     float* qs = (float*)(att_lds + TK_ATT_SLOTS * slot_bytes); /* [GQ][head_dim] */
     float* sc = qs + W;                                   /* [GQ][max_ctx] */
     float* red = sc + (size_t)GQ * max_ctx;               /* [4 waves][GQ] */
-    float* part = red + 4 * TK_ATT_MAX_GRP;               /* [TSPLIT][W] partial outputs */
+    uint16_t* own = (uint16_t*)(red + 4 * TK_ATT_MAX_GRP); /* [2][head_dim]: this row's own K and V (FUSED) */
+    /* the epilogue's arrays live in the ring, which is idle once the last V chunk is consumed (a barrier separates the two uses): 10 KiB
+     * less LDS per workgroup = four workgroups per CU instead of three at the bench's context length */
+    float* part = (float*)ring;                           /* [TSPLIT][W] partial outputs */
     float* lpart = part + TK_ATT_TSPLIT * W;              /* [TSPLIT][GQ] partial denominators */
     float* obuf = lpart + TK_ATT_TSPLIT * TK_ATT_MAX_GRP; /* [W] */
-    uint16_t* own = (uint16_t*)(obuf + W);                /* [2][head_dim]: this row's own K and V (FUSED) */
     const int64_t run0 = (((int64_t)layer * max_seq + sq) * n_kv_head + kvh) * (int64_t)max_ctx * head_dim;
     const uint16_t* krun = kcache + run0;
     const uint16_t* vrun = vcache + run0;
@@ -1471,6 +1476,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
             }
         }
     }
+    __syncthreads(); /* every wave is done with the ring: it now holds the epilogue's arrays */
 #pragma unroll
     for (int h = 0; h < GQ; ++h) {
 #pragma unroll
@@ -1501,8 +1507,9 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
 
 size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx) {
     const size_t W = (size_t)gq * head_dim;
-    return (size_t)TK_ATT_SLOTS * TK_ATT_CHUNK * head_dim * 2 +
-           (W + (size_t)gq * max_ctx + 4 * TK_ATT_MAX_GRP + (size_t)TK_ATT_TSPLIT * W + TK_ATT_TSPLIT * TK_ATT_MAX_GRP + W) * sizeof(float) + (size_t)2 * head_dim * 2;
+    const size_t ring = (size_t)TK_ATT_SLOTS * TK_ATT_CHUNK * head_dim * 2;
+    const size_t epilogue = ((size_t)TK_ATT_TSPLIT * W + TK_ATT_TSPLIT * TK_ATT_MAX_GRP + W) * sizeof(float); /* aliases the ring */
+    return (ring > epilogue ? ring : epilogue) + (W + (size_t)gq * max_ctx + 4 * TK_ATT_MAX_GRP) * sizeof(float) + (size_t)2 * head_dim * 2;
 }
 
 void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_total, const float* rope_cos, const float* rope_sin,
