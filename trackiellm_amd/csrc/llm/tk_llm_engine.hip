@@ -223,7 +223,7 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     if (!m || !m->ready()) { error = "model has missing tensors"; return false; }
     if (mseq <= 0 || mctx <= 0) { error = "max_seq and max_ctx must be positive"; return false; }
     const TkLlmHParams& h = m->hp;
-    if (tk_attention_lds_bytes(h.n_head / h.n_kv_head, h.head_dim, mctx) > 160 * 1024) {
+    if (tk_attention_lds_bytes(h.n_head / h.n_kv_head, h.head_dim, mctx, 64) > 160 * 1024) {
         error = "max_ctx too large: the attention kernel keeps one score row per query head of a KV group in LDS (about 9000 positions for 4 x 128)";
         return false;
     }

@@ -1258,7 +1258,6 @@ void tk_launch_qkv_rope_append(const float* partial, int ks, int n_total, int n_
  * ------------------------------------------------------------------------------------------ */
 #define TK_ATT_MAX_GRP 4
 #define TK_ATT_TSPLIT 4 /* canonical: 4 interleaved partial sums over positions (t mod 4), added in order */
-#define TK_ATT_CHUNK 64 /* positions per ring slot */
 #ifndef TK_ATT_SLOTS
 #define TK_ATT_SLOTS 2
 #endif
@@ -1281,8 +1280,8 @@ __device__ __forceinline__ float sum_partials_wide(const float* partial, int ks,
 /* stage rows [row0, row0 + 32) of one (sequence, kv head) cache run into an LDS slot; rows past `last_row` are clamped (their
  * content is never used).  swz: XOR-swizzle the 16-byte pieces of a row by the row number (K); plain copy otherwise (V).
  * Every wave issues exactly chunk_bytes / 4096 one-KiB pieces: the counted waits rely on it. */
-__device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int last_row, int rb /* row bytes */, uint8_t* slot, bool swz, int wave, int lane) {
-    const int pieces = TK_ATT_CHUNK * rb / 1024, ppr = rb / 16; /* 1 KiB pieces per chunk; 16-byte pieces per row */
+__device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int last_row, int rb /* row bytes */, uint8_t* slot, bool swz, int wave, int lane, int chunk) {
+    const int pieces = chunk * rb / 1024, ppr = rb / 16; /* 1 KiB pieces per chunk; 16-byte pieces per row */
     for (int pc = wave; pc < pieces; pc += 4) {
         const int idx = pc * 64 + lane;           /* 16-byte piece index inside the chunk */
         const int r = idx / ppr, cs = idx % ppr;  /* row inside the chunk, piece slot inside the row */
@@ -1295,7 +1294,7 @@ __device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int las
     }
 }
 
-template <int GQ, bool FUSED, int HD /* head_dim when it is 64 or 128 (loops unroll, LDS reads batch), 0 = any */>
+template <int GQ, bool FUSED, int HD /* head_dim when it is 64 or 128 (loops unroll, LDS reads batch), 0 = any */, int CH /* positions per ring slot */>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbuf, const float* __restrict__ partial, int ks, int n_total,
                                                     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                                     uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache, const int32_t* __restrict__ seq,
@@ -1312,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     const int W = GQ * head_dim;               /* outputs of this WG */
     const int rb = head_dim * 2;               /* bytes of one cache row */
     const int half = head_dim / 2, QD = n_head * head_dim, KVD = n_kv_head * head_dim;
-    const int slot_bytes = TK_ATT_CHUNK * rb;
+    const int slot_bytes = CH * rb;
     /* LDS: the ring (K chunks, then V chunks: one stream), then the float arrays */
     uint8_t* ring = att_lds;
     float* qs = (float*)(att_lds + TK_ATT_SLOTS * slot_bytes); /* [GQ][head_dim] */
@@ -1327,7 +1326,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     const int64_t run0 = (((int64_t)layer * max_seq + sq) * n_kv_head + kvh) * (int64_t)max_ctx * head_dim;
     const uint16_t* krun = kcache + run0;
     const uint16_t* vrun = vcache + run0;
-    const int nchunk = (T + TK_ATT_CHUNK - 1) / TK_ATT_CHUNK;
+    const int nchunk = (T + CH - 1) / CH;
     const int total = 2 * nchunk;              /* the stream: K chunks 0 .. nchunk - 1, then V chunks 0 .. nchunk - 1 */
     const int last_row = max_ctx - 1;
     const int ppw = slot_bytes / 4096;         /* DMA pieces per wave and chunk */
@@ -1335,7 +1334,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     auto issue = [&](int j) { /* chunk j of the stream into slot j % SLOTS; always issued (a chunk with nothing cached yet re-reads clamped rows) */
         const bool is_k = j < nchunk;
         const int c = is_k ? j : j - nchunk;
-        att_stage(is_k ? krun : vrun, c * TK_ATT_CHUNK, last_row, rb, ring + (j % TK_ATT_SLOTS) * slot_bytes, is_k, wave, lane);
+        att_stage(is_k ? krun : vrun, c * CH, last_row, rb, ring + (j % TK_ATT_SLOTS) * slot_bytes, is_k, wave, lane, CH);
     };
     /* before touching chunk j: all but the chunks issued after it have landed; everybody is done with chunk j - 1, whose slot takes
      * chunk j + SLOTS - 1 */
@@ -1383,12 +1382,12 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
         acquire(c); /* the first barrier also publishes qs and own */
         uint8_t* slot = ring + (c % TK_ATT_SLOTS) * slot_bytes;
         if (FUSED && c == nchunk - 1) { /* the row's own key (position p, always in the last chunk) comes from LDS, swizzled like the rest */
-            const int rr = p - c * TK_ATT_CHUNK;
+            const int rr = p - c * CH;
             if (t < ppr) *(uint4*)(slot + rr * rb + ((t ^ (rr & (ppr - 1))) * 16)) = *(const uint4*)((const uint8_t*)own + t * 16);
             __syncthreads();
         }
-        for (int idx = t; idx < GQ * TK_ATT_CHUNK; idx += 256) {
-            const int h = idx / TK_ATT_CHUNK, rr = idx % TK_ATT_CHUNK, tt = c * TK_ATT_CHUNK + rr;
+        for (int idx = t; idx < GQ * CH; idx += 256) {
+            const int h = idx / CH, rr = idx % CH, tt = c * CH + rr;
             if (tt < T) {
                 const uint8_t* kr = slot + rr * rb;
                 const float* qh = qs + h * head_dim;
@@ -1418,8 +1417,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     /* row maximum per head: thread idx = h * CHUNK + rr served head h in every chunk (GQ * CHUNK <= 256 threads: one idx per thread) */
     {
         float m = mx;
-        for (int s = TK_ATT_CHUNK / 2; s >= 1; s >>= 1) m = tk_fmaxf(m, wave_xor_f(m, s)); /* over the CHUNK lanes of one head */
-        if ((lane & (TK_ATT_CHUNK - 1)) == 0 && t < GQ * TK_ATT_CHUNK) red[t / TK_ATT_CHUNK] = m;
+        for (int s = CH / 2; s >= 1; s >>= 1) m = tk_fmaxf(m, wave_xor_f(m, s)); /* over the CHUNK lanes of one head */
+        if ((lane & (CH - 1)) == 0 && t < GQ * CH) red[t / CH] = m;
     }
     __syncthreads(); /* every score is written */
     for (int h = 0; h < GQ; ++h) {
@@ -1434,11 +1433,11 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
         acquire(nchunk + c); /* the first barrier also publishes the probabilities */
         uint8_t* slot = ring + ((nchunk + c) % TK_ATT_SLOTS) * slot_bytes;
         if (FUSED && c == nchunk - 1) {
-            const int rr = p - c * TK_ATT_CHUNK;
+            const int rr = p - c * CH;
             if (t < ppr) *(uint4*)(slot + rr * rb + t * 16) = *(const uint4*)((const uint8_t*)(own + head_dim) + t * 16);
             __syncthreads();
         }
-        const int t_end = T - c * TK_ATT_CHUNK < TK_ATT_CHUNK ? T - c * TK_ATT_CHUNK : TK_ATT_CHUNK;
+        const int t_end = T - c * CH < CH ? T - c * CH : CH;
         /* positions in batches of PB: every LDS read of a batch is issued before its first fma (out-of-range slots of the last batch
          * read a clamped row and enter with probability 0: fma(0, v, acc) == acc and l + 0 == l exactly, the canonical order is untouched) */
         constexpr int PB = 4;
@@ -1451,7 +1450,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
                 const bool live = rr < t_end;
                 const int rc = live ? rr : t_end - 1;
 #pragma unroll
-                for (int h = 0; h < GQ; ++h) pr[u][h] = live ? sc[(size_t)h * max_ctx + c * TK_ATT_CHUNK + rc] : 0.0f;
+                for (int h = 0; h < GQ; ++h) pr[u][h] = live ? sc[(size_t)h * max_ctx + c * CH + rc] : 0.0f;
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const int d0 = 2 * lane + 128 * db;
@@ -1505,9 +1504,9 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     }
 }
 
-size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx) {
+size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk) {
     const size_t W = (size_t)gq * head_dim;
-    const size_t ring = (size_t)TK_ATT_SLOTS * TK_ATT_CHUNK * head_dim * 2;
+    const size_t ring = (size_t)TK_ATT_SLOTS * chunk * head_dim * 2;
     const size_t epilogue = ((size_t)TK_ATT_TSPLIT * W + TK_ATT_TSPLIT * TK_ATT_MAX_GRP + W) * sizeof(float); /* aliases the ring */
     return (ring > epilogue ? ring : epilogue) + (W + (size_t)gq * max_ctx + 4 * TK_ATT_MAX_GRP) * sizeof(float) + (size_t)2 * head_dim * 2;
 }
@@ -1519,16 +1518,22 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
     /* few rows: two workgroups per KV head (two query heads each) — twice the workgroups, half the dependent work in each; K / V are then
      * read twice, which costs nothing while the launch is latency-bound (16 rows: 15.9 -> see profiles/r02_attention_variants.txt) */
     if (gq == 4 && (2 * head_dim) % 256 == 0 && nrows * n_kv_head < 2 * TK_NUM_CU) gq = 2;
-    const size_t lds = tk_attention_lds_bytes(gq, head_dim, max_ctx);
-#define TK_ATT_LAUNCH_HD(G, F, H)                                                                                                             \
-    hipLaunchKernelGGL((k_attention<G, F, H>), dim3(n_head / gq, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin, kcache, \
+    /* positions per ring slot: 64 while the launch is a latency chain of few workgroups (fewer, longer phases), 32 once several
+     * workgroups per CU are resident (16 KiB less LDS each: more of them fit; 256 rows: 47.9 -> 43.3 us, 16 rows would lose 24 %;
+     * profiles/r02_attention_variants.txt) */
+    const int chunk = (n_head / gq) * nrows > 4 * TK_NUM_CU ? 32 : 64;
+    const size_t lds = tk_attention_lds_bytes(gq, head_dim, max_ctx, chunk);
+#define TK_ATT_LAUNCH_CH(G, F, H, C)                                                                                                          \
+    hipLaunchKernelGGL((k_attention<G, F, H, C>), dim3(n_head / gq, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin, kcache, \
                        vcache, seq, pos, n_head, n_kv_head, head_dim, layer, max_seq, max_ctx, out)
+#define TK_ATT_LAUNCH_HD(G, F, H) do { if (chunk == 32) TK_ATT_LAUNCH_CH(G, F, H, 32); else TK_ATT_LAUNCH_CH(G, F, H, 64); } while (0)
 #define TK_ATT_LAUNCH(G, F) do { if (head_dim == 128) TK_ATT_LAUNCH_HD(G, F, 128); else if (head_dim == 64) TK_ATT_LAUNCH_HD(G, F, 64); else TK_ATT_LAUNCH_HD(G, F, 0); } while (0)
     if (fused) {
         if (gq == 4) TK_ATT_LAUNCH(4, true); else if (gq == 2) TK_ATT_LAUNCH(2, true); else TK_ATT_LAUNCH(1, true);
     } else {
         if (gq == 4) TK_ATT_LAUNCH(4, false); else if (gq == 2) TK_ATT_LAUNCH(2, false); else TK_ATT_LAUNCH(1, false);
     }
+#undef TK_ATT_LAUNCH_CH
 #undef TK_ATT_LAUNCH_HD
 #undef TK_ATT_LAUNCH
 }
@@ -1626,8 +1631,9 @@ const char* tk_llm_prepare_device(int device) {
     TK_OPT((k_gemm_f16w<1>)); TK_OPT((k_gemm_f16w<2>)); TK_OPT((k_gemm_f16w<4>)); TK_OPT((k_gemm_f16w<8>)); TK_OPT((k_gemm_f16w<16>));
 #define TK_OPT_GEMV(PFV, MTV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3>)); } while (0)
     TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
-#define TK_OPT_ATT(H) do { TK_OPT((k_attention<1, true, H>)); TK_OPT((k_attention<2, true, H>)); TK_OPT((k_attention<4, true, H>)); \
-                         TK_OPT((k_attention<1, false, H>)); TK_OPT((k_attention<2, false, H>)); TK_OPT((k_attention<4, false, H>)); } while (0)
+#define TK_OPT_ATT_C(H, C) do { TK_OPT((k_attention<1, true, H, C>)); TK_OPT((k_attention<2, true, H, C>)); TK_OPT((k_attention<4, true, H, C>)); \
+                              TK_OPT((k_attention<1, false, H, C>)); TK_OPT((k_attention<2, false, H, C>)); TK_OPT((k_attention<4, false, H, C>)); } while (0)
+#define TK_OPT_ATT(H) do { TK_OPT_ATT_C(H, 32); TK_OPT_ATT_C(H, 64); } while (0)
     TK_OPT_ATT(0); TK_OPT_ATT(64); TK_OPT_ATT(128);
 #undef TK_OPT_ATT
 #undef TK_OPT_GEMV
