@@ -69,6 +69,7 @@ struct CpuAudioOps {
             for (int i = 0; i < D; ++i) y[(int64_t)r * D + i] = ((xr[i] - mean) * rstd) * w[i] + b[i];
         }
     }
+    bool attend1(const float*, const float*, const float*, float*, int, int, int64_t, int64_t, int, int) { return false; }
     void softmax_rows(float* x, int rows, int cols, int ld) {
         for (int r = 0; r < rows; ++r) {
             float* xr = x + (int64_t)r * ld;

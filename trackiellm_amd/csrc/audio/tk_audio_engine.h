@@ -20,6 +20,11 @@ public:
     TkWhManifest man;
     int device = 0;
     std::vector<float*> w; /* device tensors in manifest order */
+    /* the linear layers' weights once more as the tiled GEMM's f32 weight tiles (csrc/nn/tk_gemm_tiled.h), null where a tensor is not a
+     * linear weight or its K is not a multiple of 128; built by prepare_tiles(), refreshed by set_tensor() */
+    std::vector<uint8_t*> wt;
+    bool prepare_tiles();
+    int tensor_of(const float* dev_ptr) const; /* manifest index of a device tensor, -1 when it is none */
     std::string error;
     ~TkWhisperModel();
     bool init(const TkWhisperHP& hp, int device);

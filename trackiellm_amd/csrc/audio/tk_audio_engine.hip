@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "../nn/tk_gemm_tiled.h"
 #include "../nn/tk_nn_kernels.h"
 
 /* Perception streams run at the highest stream priority: their kernels are small and many, and behind the LLM's large GEMM
@@ -69,7 +70,80 @@ __global__ __launch_bounds__(1024) void k_logmel_finish(float* mel, int per_b) {
     for (int i = threadIdx.x; i < per_b; i += 1024) m[i] = (tk_fmaxf(m[i], floor_v) + 4.0f) * 0.25f;
 }
 
+
+/* ---------------------------------------------------------------- decoder-step attention, fused
+
+ * One query row per (sequence, head): scores, softmax and the value contraction in one workgroup, with exactly the arithmetic of the
+ * three-launch form it replaces (tk_whisper_graph.h: attention()): score = (fp32 fma chain over the head dimension, ascending) * scale
+ * + 0.0f (the GEMM epilogue's bias slot); softmax as k_softmax_rows evaluates it (256 strided partial maxima / sums, shuffle tree,
+ * ((w0 + w1) + w2) + w3); output = one fp32 fma chain over the keys in ascending order, + 0.0f.  The decoder steps of 32 utterances were
+ * sixteen 64x64-tile GEMM launches of one live row each per step; this is eight short launches. */
+__global__ __launch_bounds__(256) void k_attend1(const float* q, const float* k, const float* v, float* out, int Tk, int64_t q_bstride, int64_t kv_bstride, int d,
+                                                 int hd, float scale) {
+    extern __shared__ float att1_lds[];
+    __shared__ float red[4];
+    float* sc = att1_lds;      /* [Tk] */
+    float* qs = att1_lds + Tk; /* [hd] */
+    const int h = blockIdx.x, b = blockIdx.y, t0 = threadIdx.x;
+    const float* qp = q + (int64_t)b * q_bstride + (int64_t)h * hd;
+    const float* kp = k + (int64_t)b * kv_bstride + (int64_t)h * hd;
+    const float* vp = v + (int64_t)b * kv_bstride + (int64_t)h * hd;
+    for (int i = t0; i < hd; i += 256) qs[i] = qp[i];
+    __syncthreads();
+    float m = -INFINITY;
+    for (int t = t0; t < Tk; t += 256) {
+        const float* kr = kp + (int64_t)t * d;
+        float a = 0.0f;
+        for (int i = 0; i < hd; i += 4) {
+            const float4 kk = *(const float4*)(kr + i);
+            a = tk_fmaf(qs[i], kk.x, a); a = tk_fmaf(qs[i + 1], kk.y, a); a = tk_fmaf(qs[i + 2], kk.z, a); a = tk_fmaf(qs[i + 3], kk.w, a);
+        }
+        a = a * scale;
+        a = a + 0.0f;
+        sc[t] = a;
+        m = tk_fmaxf(m, a);
+    }
+    for (int s = 32; s >= 1; s >>= 1) m = tk_fmaxf(m, __shfl_xor(m, s, 64));
+    if ((t0 & 63) == 0) red[t0 >> 6] = m;
+    __syncthreads();
+    m = tk_fmaxf(tk_fmaxf(red[0], red[1]), tk_fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.0f;
+    for (int t = t0; t < Tk; t += 256) { const float e = tk_expf(sc[t] - m); sc[t] = e; s = s + e; }
+    for (int w = 32; w >= 1; w >>= 1) s = s + __shfl_xor(s, w, 64);
+    if ((t0 & 63) == 0) red[t0 >> 6] = s;
+    __syncthreads();
+    const float tot = ((red[0] + red[1]) + red[2]) + red[3];
+    for (int t = t0; t < Tk; t += 256) sc[t] = tk_divf(sc[t], tot);
+    __syncthreads();
+    if (t0 < hd) {
+        float a = 0.0f;
+        int t = 0;
+        for (; t + 8 <= Tk; t += 8) { /* eight value loads in flight, the chain itself stays sequential */
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = vp[(int64_t)(t + u) * d + t0];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = tk_fmaf(sc[t + u], vv[u], a);
+        }
+        for (; t < Tk; ++t) a = tk_fmaf(sc[t], vp[(int64_t)t * d + t0], a);
+        out[(int64_t)b * q_bstride + (int64_t)h * hd + t0] = a + 0.0f;
+    }
+}
+
 /* ---------------------------------------------------------------- GPU ops for the shared graph */
+
+/* shapes the tiled GEMM takes: a plain linear layer C = act(A W^T + b) + R with K a multiple of 128 */
+static inline bool tk_tiled_gemm_applies(const TkGemm& g) {
+    return g.b_kn == 0 && g.batch <= 1 && g.batch_inner == 0 && g.alpha == 1.0f && !g.b_f16 && g.ldb == g.K && g.K % 128 == 0 && g.M > 0;
+}
+/* floats of the activation image: whole row blocks (16 M-tiles, or the M-tile count of a short pass) */
+static inline size_t tk_tiled_gemm_scratch(const TkGemm& g) {
+    const int rows_blk = g.M < TK_TW_MAX_BLOCK_ROWS ? g.M : TK_TW_MAX_BLOCK_ROWS;
+    const int mt = rows_blk > 128 ? 16 : rows_blk > 64 ? 8 : rows_blk > 32 ? 4 : rows_blk > 16 ? 2 : 1;
+    const int64_t blk = (int64_t)mt * 16, padded = ((int64_t)g.M + blk - 1) / blk * blk;
+    return (size_t)padded * (size_t)g.K;
+}
 
 struct TkAudioGpuOps {
     TkAsr* a;
@@ -81,10 +155,33 @@ struct TkAudioGpuOps {
         return p;
     }
     int32_t* alloc_i32(size_t n) { return (int32_t*)alloc(n); }
-    void gemm(const TkGemm& g) { tk_launch_gemm(g, s); }
+    /* a linear layer whose weights have tiles runs on the tiled GEMM (same k-ascending fp32 chain, bit-identical, ~3x the rate of the
+     * LDS-staged kernel on these shapes and one short launch instead of a latency chain for the decoder's few rows); its activation
+     * image is scratch taken from the arena and handed back at once (reuse is stream-ordered) */
+    void gemm(const TkGemm& g) {
+        const int idx = tk_tiled_gemm_applies(g) ? a->model->tensor_of(g.B) : -1;
+        if (idx < 0 || !a->model->wt[(size_t)idx]) { tk_launch_gemm(g, s); return; }
+        const size_t mark = a->arena_used;
+        float* img = alloc(tk_tiled_gemm_scratch(g));
+        tk_launch_pack_a(g.A, g.M, g.K, g.lda, 0, img, s);
+        TkTiledGemm t{};
+        t.tiles[0] = a->model->wt[(size_t)idx]; t.row_tiles[0] = (g.N + 15) / 16; t.nseg = 1; t.wbytes = 4;
+        t.K = g.K; t.ks = 1; t.ldc = g.ldc; t.n_valid = g.N; t.nrows = g.M; t.slab_rows = 0;
+        t.a_img = img; t.a_ts = (size_t)g.K * 16; t.out = g.C;
+        t.bias = g.bias; t.residual = g.residual; t.ldr = g.ldr; t.act = g.act; t.add_zero_bias = 1;
+        tk_launch_gemm_tiled(t, s);
+        a->arena_used = mark;
+    }
     void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) { tk_launch_im2col1d(x, B, T, C, ldx, kw, stride, pad, col, s); }
     void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) { tk_launch_layernorm(x, rows, D, w, b, TK_WH_LN_EPS, y, s); }
     void softmax_rows(float* x, int rows, int cols, int ld) { tk_launch_softmax_rows(x, rows, cols, ld, s); }
+    bool attend1(const float* q, const float* k, const float* v, float* out, int B, int Tk, int64_t q_bstride, int64_t kv_bstride, int d, int nh) {
+        const int hd = d / nh;
+        if (hd > 256 || (hd & 3) || (size_t)Tk * 4 + (size_t)hd * 4 > 60 * 1024) return false;
+        hipLaunchKernelGGL(k_attend1, dim3(nh, B), dim3(256), (size_t)Tk * 4 + (size_t)hd * 4, s, q, k, v, out, Tk, q_bstride, kv_bstride, d, hd,
+                           tk_divf(1.0f, tk_sqrtf((float)hd)));
+        return true;
+    }
     void add_rows(float* x, const float* add, int rows, int D, int add_rows) { tk_launch_add_rows(x, add, rows, D, add_rows, s); }
     void embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out) {
         tk_launch_embed_rows(table, pos, idx, pos_idx, rows, D, out, s);
@@ -103,13 +200,18 @@ struct TkAudioGpuOps {
 
 /* sizing twin of the ops (counts arena floats for a given batch) */
 struct TkAudioSizeOps {
-    size_t used = 0;
-    float* alloc(size_t n) { used += (n + 63) & ~(size_t)63; return nullptr; }
+    size_t used = 0, peak = 0;
+    float* alloc(size_t n) { used += (n + 63) & ~(size_t)63; if (used > peak) peak = used; return nullptr; }
     int32_t* alloc_i32(size_t n) { return (int32_t*)alloc(n); }
-    void gemm(const TkGemm&) {}
+    void gemm(const TkGemm& g) { /* the tiled path's activation image is scratch on top of the live allocations */
+        if (!tk_tiled_gemm_applies(g)) return;
+        const size_t top = used + ((tk_tiled_gemm_scratch(g) + 63) & ~(size_t)63);
+        if (top > peak) peak = top;
+    }
     void im2col1d(const float*, int, int, int, int, int, int, int, float*) {}
     void layernorm(const float*, int, int, const float*, const float*, float*) {}
     void softmax_rows(float*, int, int, int) {}
+    bool attend1(const float*, const float*, const float*, float*, int, int, int64_t, int64_t, int, int) { return true; } /* needs no scratch */
     void add_rows(float*, const float*, int, int, int) {}
     void embed_rows(const float*, const float*, const int32_t*, const int32_t*, int, int, float*) {}
     void argmax_rows(const float*, int, int, int, int32_t*) {}
@@ -123,6 +225,25 @@ struct TkAudioSizeOps {
 TkWhisperModel::~TkWhisperModel() {
     (void)hipSetDevice(device);
     for (auto p : w) if (p) (void)hipFree(p);
+    for (auto p : wt) if (p) (void)hipFree(p);
+}
+
+int TkWhisperModel::tensor_of(const float* dev_ptr) const {
+    for (size_t i = 0; i < w.size(); ++i) if (w[i] == dev_ptr) return (int)i;
+    return -1;
+}
+
+bool TkWhisperModel::prepare_tiles() {
+    HIPQ(hipSetDevice(device));
+    if (wt.size() != man.t.size()) wt.assign(man.t.size(), nullptr);
+    for (size_t i = 0; i < man.t.size(); ++i) {
+        const bool linear = man.t[i].kind == TK_WK_LINEAR_W || (int)i == man.tok_emb; /* the token embedding is also the logits matrix */
+        if (!linear || man.t[i].cols % 128 || man.t[i].rows < 16 || wt[i]) continue;
+        HIPQ(hipMalloc((void**)&wt[i], tk_tiled_weight_bytes(man.t[i].rows, man.t[i].cols, 4)));
+        tk_launch_tile_weights(w[i], 4, man.t[i].rows, man.t[i].cols, wt[i], nullptr);
+    }
+    HIPQ(hipDeviceSynchronize());
+    return true;
 }
 
 bool TkWhisperModel::init(const TkWhisperHP& h, int dev) {
@@ -141,6 +262,10 @@ bool TkWhisperModel::set_tensor(int idx, const float* host, size_t n) {
     if (idx < 0 || idx >= (int)man.t.size() || n != (size_t)man.t[idx].rows * man.t[idx].cols) { error = "tensor index / size mismatch"; return false; }
     HIPQ(hipSetDevice(device));
     HIPQ(hipMemcpy(w[idx], host, n * 4, hipMemcpyHostToDevice));
+    if ((size_t)idx < wt.size() && wt[(size_t)idx]) { /* keep the tiled twin current */
+        tk_launch_tile_weights(w[idx], 4, man.t[idx].rows, man.t[idx].cols, wt[(size_t)idx], nullptr);
+        HIPQ(hipDeviceSynchronize());
+    }
     return true;
 }
 
@@ -218,7 +343,9 @@ bool TkAsr::init(TkWhisperModel* m, int mb) {
     float* ml = g.mel(so, nullptr, mb, 0, 0);
     float* enc = g.encode(so, ml, mb);
     (void)g.begin_decode(so, enc, mb);
-    arena_floats = so.used + 4096;
+    arena_floats = so.peak + 4096;
+    if (!m->prepare_tiles()) { error = m->error; return false; }
+    if (!tk_gemm_tiled_prepare_device()) { error = "LDS opt-in of the tiled GEMM failed"; return false; }
     HIPQ(hipMalloc((void**)&arena, arena_floats * 4));
     return true;
 }

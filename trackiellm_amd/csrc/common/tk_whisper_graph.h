@@ -13,6 +13,7 @@
  *   void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col);
  *   void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y);
  *   void softmax_rows(float* x, int rows, int cols, int ld);
+ *   bool attend1(...): optional fused form of attention() for one query row per sequence (same arithmetic); false = not provided
  *   void add_rows(float* x, const float* add, int rows, int D, int add_rows);
  *   void embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out);
  *   void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out);
@@ -202,6 +203,7 @@ struct TkWhisperGraph {
     void attention(Ops& o, const float* q, const float* k, const float* v, float* out, int B, int Tq, int Tk, int64_t q_bstride, int64_t kv_bstride,
                    int d, int nh, float* scores) const {
         const int hd = d / nh;
+        if (Tq == 1 && o.attend1(q, k, v, out, B, Tk, q_bstride, kv_bstride, d, nh)) return; /* decoder steps: one kernel, same arithmetic */
         TkGemm s{};
         s.A = q; s.B = k; s.C = scores; s.M = Tq; s.N = Tk; s.K = hd; s.lda = d; s.ldb = d; s.ldc = Tk; s.b_kn = 0; s.act = 0;
         s.alpha = tk_divf(1.0f, tk_sqrtf((float)hd));

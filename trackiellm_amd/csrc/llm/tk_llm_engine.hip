@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include "../common/tk_ggml_blocks.h"
+#include "../nn/tk_gemm_tiled.h"
 #include "../nn/tk_nn_kernels.h"
 
 #define HIPQ(expr)                                                                              \
@@ -99,12 +100,12 @@ bool TkLlmModel::install(TkDevTensor* t, int type, int64_t rows, int64_t cols, c
         HIPQ(hipMemcpyAsync(t->data, dev_blocks, t->bytes, hipMemcpyDeviceToDevice, s));
         return true;
     }
-    if (type == TK_TYPE_F16) { /* fp16 checkpoints: matrices become fp32-MFMA operand tiles (TkF16Args::tiles), the embedding stays row-major */
+    if (type == TK_TYPE_F16) { /* fp16 checkpoints: matrices become the tiled GEMM's weight tiles (csrc/nn/tk_gemm_tiled.h), the embedding stays row-major */
         if (cols % 32 || (is_matrix && rows % 16)) { error = "f16 matrices need rows % 16 == 0 and columns % 32 == 0"; return false; }
         t->bytes = (size_t)rows * cols * 2;
         HIPQ(hipMalloc((void**)&t->data, t->bytes));
         if (is_matrix) {
-            tk_launch_repack(type, dev_blocks, rows, cols, t->data, s);
+            tk_launch_tile_weights(dev_blocks, 2, rows, cols, t->data, s);
             HIPQ(hipGetLastError());
             has_f16 = true;
         } else {
@@ -267,6 +268,7 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     HIPQ(hipMemcpy(rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
     /* kernels that want more than the default 64 KiB of dynamic LDS: a per-device opt-in */
     if (const char* e = tk_llm_prepare_device(m->device)) { error = std::string("LDS opt-in failed: ") + e; return false; }
+    if (m->has_f16 && !tk_gemm_tiled_prepare_device()) { error = "LDS opt-in of the tiled GEMM failed"; return false; }
     HIPQ(hipDeviceSynchronize());
     return true;
 }
@@ -307,11 +309,11 @@ void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) { enqu
 int TkLlmSession::enqueue_matmul(const TkDevTensor* const* t, int nseg, int K, int ks, int n_total, const TkActQ8& act, float* out, int nrows) {
     hipStream_t s = stream;
     if (t[0]->type == TK_TYPE_F16) {
-        TkF16Args f{};
+        TkTiledGemm f{};
         for (int i = 0; i < nseg; ++i) { f.tiles[i] = t[i]->data; f.row_tiles[i] = (int)(t[i]->rows / TK_TILE_ROWS); }
-        f.nseg = nseg; f.K = K; f.ks = ks; f.n_total = n_total; f.nrows = nrows;
+        f.nseg = nseg; f.wbytes = 2; f.K = K; f.ks = ks; f.ldc = n_total; f.n_valid = n_total; f.nrows = nrows; f.slab_rows = TK_MAX_ROWS;
         f.a_img = act.af; f.a_ts = act.af_ts; f.out = out;
-        tk_launch_gemm_f16w(f, s);
+        tk_launch_gemm_tiled(f, s);
         return ks;
     }
     TkGemvArgs a{};

@@ -41,21 +41,10 @@ struct TkActQ8 { /* quantised-activation buffers for one K */
     size_t aq_ts, ad_ts, abs_ts; /* M-tile strides */
     /* f16-weight matrices (fp16 checkpoints) consume the activations as f32 values rounded through f16 — what a CPU engine's f16 matmul
      * does to its f32 input; null when the model has no such matrix */
-    float* af;    /* MFMA operand image: [M-tile][K / 16][4 g][16 rows][4 t] floats, element (row, k) with k = 16 j + 4 t + g */
+    float* af;    /* the tiled GEMM's operand image (csrc/nn/tk_gemm_tiled.h): [M-tile][K / 16][4 g][16 rows][4 t] floats, k = 16 j + 4 t + g */
     size_t af_ts; /* floats between M-tiles = 16 K */
 };
 
-/* one matmul on f16 weight tiles (fp16 checkpoints), any row count up to TK_MAX_ROWS: out[ks][row][n_total] partial sums like the W4A8 path */
-struct TkF16Args {
-    const uint8_t* tiles[3]; /* per segment: [row tile][K / 32][64 lanes][8 halves]; lane (n = l % 16, g = l / 16) holds k = 32 c + 4 t + g, t = 0 .. 7 */
-    int row_tiles[3];
-    int nseg;
-    int K, ks, n_total, nrows;
-    const float* a_img;
-    size_t a_ts;
-    float* out;
-};
-void tk_launch_gemm_f16w(const TkF16Args& a, hipStream_t s);
 
 /* weights */
 void tk_launch_synth_blocks(int type, uint64_t seed, uint64_t tensor_id, int64_t nblocks, float scale, void* out, hipStream_t s);

@@ -130,24 +130,7 @@ __global__ void k_repack_q6k(const tk_block_q6_K* src, int64_t nblk, uint8_t* ti
     }
 }
 
-/* f16 rows [N][K] -> MFMA B-operand tiles (TkF16Args::tiles): one workgroup per (32-k chunk, row tile) */
-__global__ void k_repack_f16(const uint16_t* src, int64_t K, uint8_t* tiles) {
-    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
-    const int64_t chunk = blockIdx.x, rt = blockIdx.y;
-    const uint16_t* row = src + (rt * 16 + n) * K + chunk * 32;
-    uint16_t h[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) h[t] = row[4 * t + g];
-    uint4 o;
-    o.x = h[0] | ((uint32_t)h[1] << 16); o.y = h[2] | ((uint32_t)h[3] << 16); o.z = h[4] | ((uint32_t)h[5] << 16); o.w = h[6] | ((uint32_t)h[7] << 16);
-    *(uint4*)(tiles + ((rt * (K / 32) + chunk) * 64 + lane) * 16) = o;
-}
-
 void tk_launch_repack(int type, const void* blocks, int64_t rows, int64_t K, uint8_t* tiles, hipStream_t s) {
-    if (type == TK_TYPE_F16) {
-        hipLaunchKernelGGL(k_repack_f16, dim3((unsigned)(K / 32), (unsigned)(rows / 16)), dim3(64), 0, s, (const uint16_t*)blocks, K, tiles);
-        return;
-    }
     dim3 grid((unsigned)(K / 256), (unsigned)(rows / 16));
     if (type == TK_TYPE_Q4_K) hipLaunchKernelGGL(k_repack_q4k, grid, dim3(64), 0, s, (const tk_block_q4_K*)blocks, K / 256, tiles);
     else hipLaunchKernelGGL(k_repack_q6k, grid, dim3(64), 0, s, (const tk_block_q6_K*)blocks, K / 256, tiles);
@@ -194,7 +177,7 @@ __device__ __forceinline__ float block_sum256(float v, float* red /* >= 4 floats
  * (lane order == chunk order), so the block amax / sub-block sums come from shuffles.
  */
 __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot, TkActQ8 out) {
-    if (out.af) { /* the f16-weight matmuls' input: the same values rounded through f16, in the fp32 MFMA's operand order (TkActQ8::af) */
+    if (out.af) { /* the f16-weight matmuls' input: the same values rounded through f16, in the tiled GEMM's operand-image order (csrc/nn/tk_gemm_tiled.h) */
         float* dst = out.af + (size_t)(slot >> 4) * out.af_ts + (size_t)(c >> 1) * 256 + (size_t)(slot & 15) * 4;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -993,115 +976,6 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #undef TK_VMW
 }
 
-/* ------------------------------------------------------------------------------------------
- * f16 weight matrices (fp16 checkpoints) x f16-rounded fp32 activations on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32: an fma chain over
- * its four k, bitwise), for every pass width.  Contract = the oracle's gemv_f16: per K-split slab one fp32 chain over k ascending from
- * zero; the slabs are summed in ascending order by the consumer kernels, exactly like the W4A8 partial sums.
- *
- * A wave owns one weight row tile (16 outputs) of one K range and streams it as 1 KiB pieces, one per 32 k, PF pieces in flight in
- * registers; a piece feeds 8 MFMAs per M-tile.  The activations' operand image (TkActQ8::af) is staged through an LDS ring by LDS-DMA,
- * 1 KiB per (16 k, M-tile), shared by the workgroup's waves; a lane's operand of four consecutive MFMAs is one ds_read_b128.
- * At 16 rows the path is HBM-bound (2 bytes per weight: 14.2 GB per decode step of Mistral-7B) with the fp32 MFMA pipe at ~60 % of
- * it; from 32 rows up it is bound by the fp32 MFMA rate (157 TFLOP/s), 1/16 of the int8 rate the W4A8 path has.
- * ------------------------------------------------------------------------------------------ */
-#define TK_F16W_SLOT_BYTES 65536
-
-template <int MT>
-__global__ __launch_bounds__(512) void k_gemm_f16w(TkF16Args a, int groups, int total_row_tiles, int rk /* k per ring slot */) {
-    /* weight pieces in flight per wave; a ring slot holds a multiple of PF chunks (the launcher's rk), so piece c sits in register c % PF */
-    constexpr int TK_F16W_PF = MT == 16 ? 2 : 4;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = blockDim.x >> 6;
-    const int Kr = a.K / a.ks;               /* k of this workgroup's range */
-    const int ksi = blockIdx.x % a.ks;
-    const int k0 = ksi * Kr;
-    const int nslots = Kr / rk, cps = rk / 32; /* ring slots of the range, 32-k chunks per slot */
-    const int gps = rk / 16;                  /* 16-k groups per slot */
-
-    int rt = blockIdx.x / a.ks + wave * groups;
-    const bool active = rt < total_row_tiles;
-    if (!active) rt = 0;
-    int seg = 0, row_base = 0;
-    while (seg < a.nseg - 1 && rt >= a.row_tiles[seg]) { rt -= a.row_tiles[seg]; row_base += a.row_tiles[seg] * TK_TILE_ROWS; ++seg; }
-    const int nchunk_total = a.K / 32, nchunk = Kr / 32;
-    const uint8_t* wbase = a.tiles[seg] + ((size_t)rt * nchunk_total + k0 / 32) * 1024 + lane * 16;
-
-    /* ring staging: slot s holds [group j][M-tile m] pieces of 1 KiB; piece p = j * MT + m goes to wave p % nw */
-    const int ppslot = gps * MT;
-    const uint32_t voff = lane * 16;
-    auto stage = [&](int s, int slot) {
-        for (int p = wave; p < ppslot; p += nw) {
-            const int j = p / MT, m = p % MT;
-            const uint8_t* src = (const uint8_t*)(a.a_img + (size_t)m * a.a_ts + ((size_t)(k0 + s * rk) / 16 + j) * 256);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + voff),
-                                             (__attribute__((address_space(3))) void*)(lds + (size_t)slot * TK_F16W_SLOT_BYTES + (size_t)p * 1024), 16, 0, 0);
-        }
-    };
-
-    float acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[m][r] = 0.0f;
-
-    /* weight pieces in flight; a request past the range re-reads the last piece (no branch around a load, static wait counts) */
-    uint4 wq[TK_F16W_PF];
-    auto wload = [&](int c) { return ldg_nt(wbase + (size_t)(c < nchunk ? c : nchunk - 1) * 1024); };
-    stage(0, 0);
-#pragma unroll
-    for (int i = 0; i < TK_F16W_PF; ++i) wq[i] = wload(i);
-
-#pragma unroll 1
-    for (int s = 0; s < nslots; ++s) {
-        /* slot s has landed once all but the PF youngest requests are done: those are weight pieces requested after its DMA */
-        wait_vmcnt(TK_F16W_PF); /* cps >= PF weight requests follow every slot's DMA (PF initial ones the first) */
-        __syncthreads();
-        if (s + 1 < nslots) stage(s + 1, (s + 1) & 1);
-        const uint8_t* slot = lds + (size_t)(s & 1) * TK_F16W_SLOT_BYTES + lane * 16;
-#pragma unroll 1
-        for (int cc = 0; cc < cps; cc += TK_F16W_PF) {
-#pragma unroll
-            for (int u = 0; u < TK_F16W_PF; ++u) {
-                {
-                    const int c = s * cps + cc + u;
-                    const uint4 w = wq[u];
-                    wq[u] = wload(c + TK_F16W_PF);
-                    float wf[8];
-                    wf[0] = f16bits_to_f32(w.x & 0xffffu); wf[1] = f16bits_to_f32(w.x >> 16);
-                    wf[2] = f16bits_to_f32(w.y & 0xffffu); wf[3] = f16bits_to_f32(w.y >> 16);
-                    wf[4] = f16bits_to_f32(w.z & 0xffffu); wf[5] = f16bits_to_f32(w.z >> 16);
-                    wf[6] = f16bits_to_f32(w.w & 0xffffu); wf[7] = f16bits_to_f32(w.w >> 16);
-                    const uint8_t* ap = slot + (size_t)(2 * (cc + u)) * MT * 1024;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const v4f a0 = *(const v4f*)(ap + m * 1024), a1 = *(const v4f*)(ap + (MT + m) * 1024);
-                        if (active) {
-                            v4f d = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]};
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], wf[t], d, 0, 0, 0);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], wf[4 + t], d, 0, 0, 0);
-                            acc[m][0] = d[0]; acc[m][1] = d[1]; acc[m][2] = d[2]; acc[m][3] = d[3];
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (!active) return;
-    const int g = lane >> 4;
-    const int n = row_base + rt * TK_TILE_ROWS + (lane & 15);
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m * TK_ROW_SLOTS + 4 * g + r;
-            if (row < a.nrows) __builtin_nontemporal_store(acc[m][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
-        }
-}
-
 #define TK_NUM_CU 256
 
 /* Dynamic LDS above 64 KiB is an opt-in that HIP keeps per (function, DEVICE): a process that drives several GPUs (the ABI takes a
@@ -1166,30 +1040,6 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     else { if (pf == 2) TK_GEMV_TY(2, 2); else TK_GEMV_TY(1, 2); }
 #undef TK_GEMV_TY
 #undef TK_GEMV_LAUNCH
-}
-
-void tk_launch_gemm_f16w(const TkF16Args& a, hipStream_t s) {
-    int row_tiles = 0;
-    for (int i = 0; i < a.nseg; ++i) row_tiles += a.row_tiles[i];
-    int groups = TK_NUM_CU / a.ks;
-    if (groups < 1) groups = 1;
-    if (groups > row_tiles) groups = row_tiles;
-    int waves = (row_tiles + groups - 1) / groups;
-    while (waves > 8) { groups *= 2; waves = (row_tiles + groups - 1) / groups; }
-    const int mt = a.nrows > 8 * TK_ROW_SLOTS ? 16 : a.nrows > 4 * TK_ROW_SLOTS ? 8 : a.nrows > 2 * TK_ROW_SLOTS ? 4 : a.nrows > TK_ROW_SLOTS ? 2 : 1;
-    const int Kr = a.K / a.ks;
-    int rk = 1024 / mt; /* 64 KiB per ring slot; Kr is a multiple of 256, so the halving ends at 256 or above for <= 4 M-tiles */
-    while (rk > 64 && Kr % rk) rk >>= 1;
-    const size_t ldsb = (size_t)2 * TK_F16W_SLOT_BYTES;
-#define TK_F16W_LAUNCH(MTV) hipLaunchKernelGGL((k_gemm_f16w<MTV>), dim3(groups * a.ks), dim3(64 * waves), ldsb, s, a, groups, row_tiles, rk)
-    switch (mt) {
-        case 1: TK_F16W_LAUNCH(1); break;
-        case 2: TK_F16W_LAUNCH(2); break;
-        case 4: TK_F16W_LAUNCH(4); break;
-        case 8: TK_F16W_LAUNCH(8); break;
-        default: TK_F16W_LAUNCH(16); break;
-    }
-#undef TK_F16W_LAUNCH
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1628,7 +1478,6 @@ const char* tk_llm_prepare_device(int device) {
 #define TK_OPT(fn) do { if (e == hipSuccess) e = opt_in_lds(fn); } while (0)
 #define TK_OPT_GEMM(MTV) do { TK_OPT((k_gemm_w4a8<MTV, 1, 1>)); TK_OPT((k_gemm_w4a8<MTV, 2, 1>)); TK_OPT((k_gemm_w4a8<MTV, 3, 1>)); } while (0)
     TK_OPT_GEMM(4); TK_OPT_GEMM(8); TK_OPT_GEMM(16);
-    TK_OPT((k_gemm_f16w<1>)); TK_OPT((k_gemm_f16w<2>)); TK_OPT((k_gemm_f16w<4>)); TK_OPT((k_gemm_f16w<8>)); TK_OPT((k_gemm_f16w<16>));
 #define TK_OPT_GEMV(PFV, MTV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3>)); } while (0)
     TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
 #define TK_OPT_ATT_C(H, C) do { TK_OPT((k_attention<1, true, H, C>)); TK_OPT((k_attention<2, true, H, C>)); TK_OPT((k_attention<4, true, H, C>)); \
