@@ -179,18 +179,28 @@ def vad_model(W, window=480, hop=32, hidden=32, extra_op=None):
 
 # ---- a depth network of the convolutional MiDaS class (EfficientNet-lite-like encoder, feature-fusion decoder), small enough for fixtures ----
 
-def depth_weights(seed):
+def _depth_dims(width):
+    """channel counts of the depth graph; width = 1 is the test fixture's size, width = 4 is close to MiDaS v2.1 small in work per pixel"""
+    w = width
+    return {"stem": 16 * w, "b1": 24 * w, "f4": 32 * w, "dec": 24 * w, "d2": 16 * w, "h1": 8 * w}
+
+
+def depth_weights(seed, width=1):
     rng = np.random.default_rng(seed)
+    D = _depth_dims(width)
     def conv(m, c, k, gain=1.0):
         return (rng.standard_normal((m, c, k, k)) * gain / np.sqrt(c * k * k)).astype(np.float32), (rng.standard_normal(m) * 0.1).astype(np.float32)
     W = {}
-    for name, (m, c, k) in {"stem": (16, 3, 3), "dw1": (16, 1, 3), "pw1": (24, 16, 1), "down": (32, 56, 3), "dw2": (32, 1, 3), "pw2": (32, 32, 1),
-                            "red": (24, 32, 1), "lat": (24, 24, 1), "fuse": (16, 24, 3), "head1": (8, 16, 3), "head2": (1, 8, 1)}.items():
+    shapes = {"stem": (D["stem"], 3, 3), "dw1": (D["stem"], 1, 3), "pw1": (D["b1"], D["stem"], 1), "down": (D["f4"], D["b1"] + 2 * D["stem"], 3),
+              "dw2": (D["f4"], 1, 3), "pw2": (D["f4"], D["f4"], 1), "red": (D["dec"], D["f4"], 1), "lat": (D["dec"], D["b1"], 1),
+              "fuse": (D["d2"], D["dec"], 3), "head1": (D["h1"], D["d2"], 3), "head2": (1, D["h1"], 1)}
+    for name, (m, c, k) in shapes.items():
         W[name + ".w"], W[name + ".b"] = conv(m, c, k, 1.6)
-    W["bn.scale"] = (1.0 + 0.2 * rng.standard_normal(16)).astype(np.float32)
-    W["bn.bias"] = (0.1 * rng.standard_normal(16)).astype(np.float32)
-    W["bn.mean"] = (0.2 * rng.standard_normal(16)).astype(np.float32)
-    W["bn.var"] = (0.5 + rng.random(16)).astype(np.float32)
+    n = D["stem"]
+    W["bn.scale"] = (1.0 + 0.2 * rng.standard_normal(n)).astype(np.float32)
+    W["bn.bias"] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    W["bn.mean"] = (0.2 * rng.standard_normal(n)).astype(np.float32)
+    W["bn.var"] = (0.5 + rng.random(n)).astype(np.float32)
     W["head2.b"] = np.array([0.3], np.float32)
     W["c0"] = np.array(0.0, np.float32)
     W["c6"] = np.array(6.0, np.float32)
@@ -199,8 +209,9 @@ def depth_weights(seed):
     return W
 
 
-def depth_spec():
+def depth_spec(width=1):
     """nodes of the network as dicts (the oracle and the torch fixture script evaluate this list; depth_model() writes it as ONNX)"""
+    D = _depth_dims(width)
     def n(op, i, o, **attrs):
         return {"op": op, "in": i, "out": [o], "attrs": attrs}
     p1 = [1, 1, 1, 1]
@@ -208,7 +219,7 @@ def depth_spec():
         n("Conv", ["input", "stem.w", "stem.b"], "s0", strides=[2, 2], pads=p1),
         n("BatchNormalization", ["s0", "bn.scale", "bn.bias", "bn.mean", "bn.var"], "s1", epsilon=1e-3),
         n("Clip", ["s1", "c0", "c6"], "f2"),
-        n("Conv", ["f2", "dw1.w", "dw1.b"], "d1", pads=p1, group=16),
+        n("Conv", ["f2", "dw1.w", "dw1.b"], "d1", pads=p1, group=D["stem"]),
         n("Clip", ["d1"], "d1c", min=0.0, max=6.0),
         n("Conv", ["d1c", "pw1.w", "pw1.b"], "b1"),
         n("MaxPool", ["f2"], "mp", kernel_shape=[3, 3], strides=[1, 1], pads=p1),
@@ -216,7 +227,7 @@ def depth_spec():
         n("Concat", ["b1", "mp", "ap"], "cat", axis=1),
         n("Conv", ["cat", "down.w", "down.b"], "f4p", strides=[2, 2], pads=p1),
         n("Relu", ["f4p"], "f4"),
-        n("Conv", ["f4", "dw2.w", "dw2.b"], "d2", pads=p1, group=32),
+        n("Conv", ["f4", "dw2.w", "dw2.b"], "d2", pads=p1, group=D["f4"]),
         n("LeakyRelu", ["d2"], "d2a", alpha=0.1),
         n("Conv", ["d2a", "pw2.w", "pw2.b"], "p2"),
         n("Add", ["p2", "f4"], "b2r"),
@@ -245,9 +256,9 @@ def depth_consts(W):
     return c
 
 
-def depth_model(W, height=-1, width=-1, extra_op=None):
+def depth_model(W, height=-1, width=-1, extra_op=None, channels=1):
     nodes = []
-    for nd in depth_spec():
+    for nd in depth_spec(channels):
         attrs = []
         for k, v in nd["attrs"].items():
             if isinstance(v, str):

@@ -36,3 +36,21 @@ timed("detector (32 frames)", lambda: det.detect_batch(frames))
 timed("vad (32 x 1 s)", vad_pass)
 timed("asr 16 steps (32 x 1 s)", lambda: asr.transcribe_tokens(pcm, 16, want_aux=False))
 timed("asr 1 step (32 x 1 s)", lambda: asr.transcribe_tokens(pcm, 1, want_aux=False))
+
+# depth: a graph of the convolutional MiDaS class (tests/onnx_util.depth_spec at 4x the fixture's channel counts), one 640x480 frame -> 256x256 map
+import tempfile  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import onnx_util as OX  # noqa: E402
+
+with tempfile.TemporaryDirectory() as td:
+    path = os.path.join(td, "depth_w4.onnx")
+    open(path, "wb").write(OX.depth_model(OX.depth_weights(11, 4), channels=4))
+    est = tk.DepthEstimator(path, 256, 256)
+    frame = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    est.estimate(frame)
+    t = time.time()
+    for _ in range(10):
+        est.estimate(frame)
+    print(f"{'depth (1 frame, 256x256)':28s} {1000 * (time.time() - t) / 10:9.2f} ms per frame ({est_nodes if (est_nodes := len(OX.depth_spec(4))) else 0} graph nodes)", flush=True)
+    est.close()

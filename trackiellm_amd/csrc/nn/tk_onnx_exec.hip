@@ -281,6 +281,18 @@ __global__ void k_oe_pool(const float* x, float* y, int64_t NC, int H, int W, in
     y[i] = is_max ? acc : tk_divf(acc, (float)(cnt > 0 ? cnt : 1));
 }
 
+/* GlobalAveragePool: one workgroup per (n, c) plane; 256 strided partial sums, wave butterflies, ((w0 + w1) + w2) + w3 */
+__global__ __launch_bounds__(256) void k_oe_gap(const float* x, float* y, int64_t HW) {
+    __shared__ float red[4];
+    const float* xp = x + (int64_t)blockIdx.x * HW;
+    float s = 0.0f;
+    for (int64_t i = threadIdx.x; i < HW; i += 256) s = s + xp[i];
+    for (int w = 32; w >= 1; w >>= 1) s = s + __shfl_xor(s, w, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) y[blockIdx.x] = tk_divf(((red[0] + red[1]) + red[2]) + red[3], (float)HW);
+}
+
 __global__ void k_oe_batchnorm(const float* x, float* y, const float* scale, const float* bias, const float* mean, const float* var, float eps, int C,
                                int64_t HW, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -935,6 +947,10 @@ bool TkOnnxExec::exec_image_op(const TkOnnxNode& nd, std::map<std::string, Val>&
         if (kh < 1 || kw < 1 || sh < 1 || sw < 1 || Ho < 1 || Wo < 1) { error = "empty output"; return false; }
         Val* y = out_f(0, {xc.shape[0], xc.shape[1], Ho, Wo});
         if (!y) return false;
+        if (op == "GlobalAveragePool") {
+            hipLaunchKernelGGL(k_oe_gap, dim3((unsigned)(xc.shape[0] * xc.shape[1])), dim3(256), 0, stream_, xc.d, y->d, (int64_t)H * W);
+            return true;
+        }
         hipLaunchKernelGGL(k_oe_pool, grid_for(y->count()), dim3(128), 0, stream_, xc.d, y->d, xc.shape[0] * xc.shape[1], H, W, kh, kw, sh, sw, pt, pl, Ho, Wo,
                            op == "MaxPool" ? 1 : 0, (int)nd.ai("count_include_pad", 0));
         return true;
