@@ -343,7 +343,7 @@ bool TkAsr::init(TkWhisperModel* m, int mb) {
     float* ml = g.mel(so, nullptr, mb, 0, 0);
     float* enc = g.encode(so, ml, mb);
     (void)g.begin_decode(so, enc, mb);
-    arena_floats = so.peak + 4096;
+    arena_floats = so.peak + 4096 + (size_t)3 * m->hp.n_text_ctx * mb + 64; /* + the decode loop's token / position / arg-max tables */
     if (!m->prepare_tiles()) { error = m->error; return false; }
     if (!tk_gemm_tiled_prepare_device()) { error = "LDS opt-in of the tiled GEMM failed"; return false; }
     HIPQ(hipMalloc((void**)&arena, arena_floats * 4));
@@ -374,31 +374,39 @@ bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* 
     HIPQ(hipGetLastError());
     if (mel_out) { mel_out->resize((size_t)B * h.n_frames() * h.n_mels); HIPQ(hipMemcpyAsync(mel_out->data(), ml, mel_out->size() * 4, hipMemcpyDeviceToHost, stream)); }
     if (enc_out) { enc_out->resize((size_t)B * h.n_audio_ctx * h.n_audio_state); HIPQ(hipMemcpyAsync(enc_out->data(), enc, enc_out->size() * 4, hipMemcpyDeviceToHost, stream)); }
-    std::vector<int32_t> tok(B), pos(B);
+    /* The whole greedy loop is enqueued without touching the host: prompt tokens and positions sit in device tables uploaded once, step p
+     * reads its token from the prompt table or from the previous step's arg-max slot and writes its own arg-max into slot p of an output
+     * table; one copy and one synchronisation at the end.  (A synchronisation and three small copies per step made the 16 steps of 32
+     * utterances 1.2 ms each on a 0.3 ms GPU workload.) */
     const int total = n_prompt + n_steps - 1; /* the last generated token is not fed back */
+    int32_t* tab = (int32_t*)(arena + arena_used); /* [n_prompt][B] prompt tokens, [total][B] positions, [total][B] arg-max slots */
+    const size_t tab_ints = ((size_t)n_prompt + 2 * (size_t)total) * B;
+    if (arena_used + tab_ints + 64 > arena_floats) { error = "ASR arena too small for the decode tables"; return false; }
+    arena_used += (tab_ints + 63) & ~(size_t)63;
+    int32_t* tok_tab = tab;
+    int32_t* pos_tab = tab + (size_t)n_prompt * B;
+    int32_t* out_tab = pos_tab + (size_t)total * B;
+    std::vector<int32_t> host_tab(((size_t)n_prompt + total) * B);
+    for (int p = 0; p < n_prompt; ++p)
+        for (int b = 0; b < B; ++b) host_tab[(size_t)p * B + b] = prompt[p];
+    for (int p = 0; p < total; ++p)
+        for (int b = 0; b < B; ++b) host_tab[((size_t)n_prompt + p) * B + b] = p;
+    HIPQ(hipMemcpyAsync(tok_tab, host_tab.data(), host_tab.size() * 4, hipMemcpyHostToDevice, stream));
     for (int p = 0; p < total; ++p) {
-        if (p < n_prompt) {
-            for (int b = 0; b < B; ++b) tok[b] = prompt[p];
-            HIPQ(hipMemcpyAsync(st.tok, tok.data(), B * 4, hipMemcpyHostToDevice, stream));
-        } else {
-            HIPQ(hipMemcpyAsync(st.tok, st.next, B * 4, hipMemcpyDeviceToDevice, stream));
-        }
-        for (int b = 0; b < B; ++b) pos[b] = p;
-        HIPQ(hipMemcpyAsync(st.pos, pos.data(), B * 4, hipMemcpyHostToDevice, stream));
+        st.tok = p < n_prompt ? tok_tab + (size_t)p * B : out_tab + (size_t)(p - 1) * B;
+        st.pos = pos_tab + (size_t)p * B;
+        st.next = out_tab + (size_t)p * B;
         g.decode_step(ops, st, p);
-        if (p >= n_prompt - 1) {
-            const int step = p - (n_prompt - 1);
-            if (step == 0 && first_logits) {
-                first_logits->resize((size_t)B * h.n_vocab);
-                HIPQ(hipMemcpyAsync(first_logits->data(), st.logits, first_logits->size() * 4, hipMemcpyDeviceToHost, stream));
-            }
-            HIPQ(hipMemcpyAsync(tok.data(), st.next, B * 4, hipMemcpyDeviceToHost, stream));
-            HIPQ(hipStreamSynchronize(stream)); /* tok/pos staging buffers are reused next iteration */
-            for (int b = 0; b < B; ++b) tokens_out[(size_t)b * n_steps + step] = tok[b];
-        } else {
-            HIPQ(hipStreamSynchronize(stream));
+        if (p == n_prompt - 1 && first_logits) {
+            first_logits->resize((size_t)B * h.n_vocab);
+            HIPQ(hipMemcpyAsync(first_logits->data(), st.logits, first_logits->size() * 4, hipMemcpyDeviceToHost, stream));
         }
     }
+    std::vector<int32_t> outs((size_t)n_steps * B);
+    HIPQ(hipMemcpyAsync(outs.data(), out_tab + (size_t)(n_prompt - 1) * B, outs.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIPQ(hipStreamSynchronize(stream)); /* host_tab and outs live until here */
+    for (int step = 0; step < n_steps; ++step)
+        for (int b = 0; b < B; ++b) tokens_out[(size_t)b * n_steps + step] = outs[(size_t)step * B + b];
     HIPQ(hipGetLastError());
     return true;
 }
