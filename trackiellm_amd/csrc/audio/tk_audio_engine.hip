@@ -117,16 +117,29 @@ __global__ __launch_bounds__(256) void k_attend1(const float* q, const float* k,
     for (int t = t0; t < Tk; t += 256) sc[t] = tk_divf(sc[t], tot);
     __syncthreads();
     if (t0 < hd) {
+        /* the chain over the keys is sequential; what can overlap is the value loads: four groups of eight rows stay in flight */
+        constexpr int PD = 4;
+        float vb[PD][8];
+        const int ngrp = Tk / 8;
+        auto vload = [&](int grp, float* dst) {
+            const int gg = grp < ngrp ? grp : (ngrp > 0 ? ngrp - 1 : 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = ngrp > 0 ? vp[(int64_t)(8 * gg + u) * d + t0] : 0.0f;
+        };
+#pragma unroll
+        for (int p = 0; p < PD; ++p) vload(p, vb[p]);
         float a = 0.0f;
-        int t = 0;
-        for (; t + 8 <= Tk; t += 8) { /* eight value loads in flight, the chain itself stays sequential */
-            float vv[8];
+        for (int gb = 0; gb < ngrp; gb += PD) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = vp[(int64_t)(t + u) * d + t0];
+            for (int p = 0; p < PD; ++p) {
+                if (gb + p < ngrp) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a = tk_fmaf(sc[t + u], vv[u], a);
+                    for (int u = 0; u < 8; ++u) a = tk_fmaf(sc[8 * (gb + p) + u], vb[p][u], a);
+                    vload(gb + p + PD, vb[p]);
+                }
+            }
         }
-        for (; t < Tk; ++t) a = tk_fmaf(sc[t], vp[(int64_t)t * d + t0], a);
+        for (int t = 8 * ngrp; t < Tk; ++t) a = tk_fmaf(sc[t], vp[(int64_t)t * d + t0], a);
         out[(int64_t)b * q_bstride + (int64_t)h * hd + t0] = a + 0.0f;
     }
 }
