@@ -554,7 +554,7 @@ def main():
         roof1 = gemv_roofline(s1, hp, 1, model.weight_bytes)
         s1.close()
         out["reference_abi_b1"] = reference_abi_b1(tk, hp, N, roof1)
-        out["reference_abi_batched"] = [reference_abi_runners(tk, K, N) for K in (16, 64)]
+        out["reference_abi_batched"] = [reference_abi_runners(tk, K, N) for K in (16, 64, 256)]
     if extras and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(tk, model, hp, P, N, args.asr_steps)
     print(json.dumps(out))

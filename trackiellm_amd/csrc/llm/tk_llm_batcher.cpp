@@ -1,5 +1,6 @@
 #include "tk_llm_batcher.h"
 
+#include <algorithm>
 #include <chrono>
 
 TkLlmBatcher::~TkLlmBatcher() {
@@ -72,8 +73,12 @@ void TkLlmBatcher::loop() {
             }
             /* the owners of the requests the last pass finished are about to ask for their next token: give them a moment so that K
              * runners decoding in lock step share every pass (a late one simply rides the next pass) */
-            if (queue_.size() < expect_)
-                cv_.wait_for(lk, std::chrono::microseconds(200), [&] { return stop_ || queue_.size() >= expect_; });
+            if (queue_.size() < expect_) {
+                /* the window grows with the number of owners expected back (waking K host threads takes time) and stays well under the cost
+                 * of the pass it fills: 200 us + 8 us per expected request, at most 2.5 ms (a 256-row pass is ~8 ms, a 16-row pass ~2.3 ms) */
+                const int64_t us = std::min<int64_t>(2500, 200 + 8 * (int64_t)expect_);
+                cv_.wait_for(lk, std::chrono::microseconds(us), [&] { return stop_ || queue_.size() >= expect_; });
+            }
             /* FIFO; a request contributes as many of its remaining rows as the pass still holds.  A grammar-masked request samples
              * under its own token mask, which the arg max kernel takes per pass: it rides alone. */
             for (Request* r : queue_) {
