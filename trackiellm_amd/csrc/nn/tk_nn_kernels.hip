@@ -344,9 +344,31 @@ __global__ void k_im2col(const float* x, int B, int H, int W, int C, int ldx, in
     }
 }
 
+/* the same matrix, four channels per thread as one 16-byte load and store, 32-bit index arithmetic (the element-wise kernel above spends
+ * ~250 instructions per element on 64-bit divisions: 0.4 TB/s; this one streams).  Needs C % 4 == 0, ldx % 4 == 0 and < 2^31 vectors. */
+__global__ void k_im2col_v4(const float* x, int H, int W, int C4, int ldx, int kh, int kw, int stride, int pad, int Ho, int Wo, uint32_t total4, float* col) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total4) return;
+    const uint32_t taps = (uint32_t)(kh * kw);
+    const uint32_t c4 = t % (uint32_t)C4, q = t / (uint32_t)C4;
+    const uint32_t tap = q % taps, pix = q / taps;
+    const uint32_t kx = tap % (uint32_t)kw, ky = tap / (uint32_t)kw;
+    const uint32_t ox = pix % (uint32_t)Wo, r = pix / (uint32_t)Wo;
+    const uint32_t oy = r % (uint32_t)Ho, b = r / (uint32_t)Ho;
+    const int iy = (int)(oy * stride + ky) - pad, ix = (int)(ox * stride + kx) - pad;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const float4*)(x + (((int64_t)b * H + iy) * W + ix) * ldx + 4 * c4);
+    *(float4*)(col + (int64_t)t * 4) = v;
+}
+
 void tk_launch_im2col(const float* x, int B, int H, int W, int C, int ldx, int kh, int kw, int stride, int pad, float* col, hipStream_t s) {
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     const int64_t total = (int64_t)B * Ho * Wo * kh * kw * C;
+    if ((C & 3) == 0 && (ldx & 3) == 0 && total / 4 < ((int64_t)1 << 31) && (((uintptr_t)x | (uintptr_t)col) & 15) == 0) {
+        const uint32_t total4 = (uint32_t)(total / 4);
+        hipLaunchKernelGGL(k_im2col_v4, dim3((total4 + 255u) / 256u), dim3(256), 0, s, x, H, W, C / 4, ldx, kh, kw, stride, pad, Ho, Wo, total4, col);
+        return;
+    }
     int64_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_im2col, dim3((unsigned)blocks), dim3(256), 0, s, x, B, H, W, C, ldx, kh, kw, stride, pad, Ho, Wo, col);
