@@ -103,6 +103,13 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_grammar_next_bytes(const char* gbn
 struct tk_llm_runner_s;
 TK_API const char* tk_mi355x_llm_runner_tool_call_text(struct tk_llm_runner_s* runner);
 
+/* test hook for the two exact fp32 GEMMs: C[M][N] = act(A[M][K] W[N][K]^T + bias) + residual on host buffers, once through the LDS-staged
+ * kernel (k_gemm_f32 / k_gemm_f32_big) into c_staged and once through the tiled kernel (csrc/nn/tk_gemm_tiled.h: weights as f32 tiles, or
+ * as f16 tiles with f16-rounded activations when f16 != 0) into c_tiled.  K must be a multiple of 128.  bias / residual may be NULL;
+ * act: 0 none, 1 SiLU, 2 GELU, 3 sigmoid. */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_gemm_pair(int device, int M, int N, int K, const float* a, const float* w, const float* bias,
+                                                        const float* residual, int act, int f16, float* c_staged, float* c_tiled);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,8 +5,14 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <vector>
+
+#include "../common/tk_exact_math.h"
+#include "tk/tk_mi355x_ext.h"
+
 #include "../vision/tk_vision_engine.h"
 #include "tk/tk_rocm_hal.h"
+#include "../nn/tk_gemm_tiled.h"
 #include "../nn/tk_nn_kernels.h"
 
 struct tk_gpu_buffer_s {
@@ -108,6 +114,63 @@ tk_error_code_t tk_kernels_softmax(const tk_softmax_params_t* p, tk_hip_stream_t
         return TK_ERROR_GPU_ROCM_ERROR;
     tk_launch_softmax_rows((float*)p->d_output_tensor, (int)p->num_rows, (int)p->num_cols, (int)p->num_cols, (hipStream_t)stream);
     return launch_status();
+}
+
+tk_error_code_t tk_mi355x_gemm_pair(int device, int M, int N, int K, const float* a, const float* w, const float* bias, const float* residual, int act,
+                                    int f16, float* c_staged, float* c_tiled) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 128 || !a || !w || !c_staged || !c_tiled || act < 0 || act > 3) return TK_ERROR_INVALID_ARGUMENT;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TK_ERROR_GPU_DEVICE_NOT_FOUND;
+    if (device < 0 || device >= n || hipSetDevice(device) != hipSuccess) return TK_ERROR_INVALID_ARGUMENT;
+    if (!tk_nn_prepare_device() || !tk_gemm_tiled_prepare_device()) return TK_ERROR_GPU_ROCM_ERROR;
+    const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
+    const int64_t blk = M >= 256 ? 256 : (M > 128 ? 256 : M > 64 ? 128 : M > 32 ? 64 : M > 16 ? 32 : 16);
+    const size_t nimg = (size_t)(((int64_t)M + blk - 1) / blk * blk) * K;
+    float *da = nullptr, *dw = nullptr, *db = nullptr, *dr = nullptr, *dc = nullptr, *dimg = nullptr;
+    uint16_t* dwh = nullptr;
+    uint8_t* dt = nullptr;
+    bool ok = hipMalloc((void**)&da, na * 4) == hipSuccess && hipMalloc((void**)&dw, nw * 4) == hipSuccess && hipMalloc((void**)&dc, nc * 4) == hipSuccess &&
+              hipMalloc((void**)&dimg, nimg * 4) == hipSuccess && hipMalloc((void**)&dt, tk_tiled_weight_bytes(N, K, f16 ? 2 : 4)) == hipSuccess &&
+              (!bias || hipMalloc((void**)&db, (size_t)N * 4) == hipSuccess) && (!residual || hipMalloc((void**)&dr, nc * 4) == hipSuccess) &&
+              (!f16 || hipMalloc((void**)&dwh, nw * 2) == hipSuccess);
+    ok = ok && hipMemcpy(da, a, na * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, w, nw * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         (!bias || hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+         (!residual || hipMemcpy(dr, residual, nc * 4, hipMemcpyHostToDevice) == hipSuccess) && hipMemset(dimg, 0, nimg * 4) == hipSuccess;
+    if (ok) {
+        std::vector<uint16_t> wh;
+        if (f16) { /* the f16 checkpoint's weights; the staged kernel reads the same values through its f16 B operand */
+            wh.resize(nw);
+            for (size_t i = 0; i < nw; ++i) wh[i] = tk_f32_to_f16(w[i]);
+            ok = hipMemcpy(dwh, wh.data(), nw * 2, hipMemcpyHostToDevice) == hipSuccess;
+        }
+        /* staged kernel: with f16 the activations must already be f16-rounded values, as the LLM's producers write them */
+        std::vector<float> ar;
+        if (ok && f16) {
+            ar.resize(na);
+            for (size_t i = 0; i < na; ++i) ar[i] = tk_f16_to_f32(tk_f32_to_f16(a[i]));
+            ok = hipMemcpy(da, ar.data(), na * 4, hipMemcpyHostToDevice) == hipSuccess;
+        }
+        if (ok) {
+            TkGemm g{};
+            g.A = da; g.B = f16 ? (const float*)dwh : dw; g.C = dc; g.bias = db; g.residual = dr;
+            g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N; g.act = act; g.alpha = 1.0f; g.batch = 1; g.b_f16 = f16 ? 1 : 0;
+            tk_launch_gemm(g, nullptr);
+            ok = hipMemcpy(c_staged, dc, nc * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemset(dc, 0, nc * 4) == hipSuccess;
+        }
+        if (ok) {
+            tk_launch_tile_weights(f16 ? (const void*)dwh : (const void*)dw, f16 ? 2 : 4, N, K, dt, nullptr);
+            tk_launch_pack_a(da, M, K, K, 0, dimg, nullptr); /* da already holds the f16-rounded values in the f16 case */
+            TkTiledGemm t{};
+            t.tiles[0] = dt; t.row_tiles[0] = (N + 15) / 16; t.nseg = 1; t.wbytes = f16 ? 2 : 4;
+            t.K = K; t.ks = 1; t.ldc = N; t.n_valid = N; t.nrows = M; t.a_img = dimg; t.a_ts = (size_t)K * 16; t.out = dc;
+            t.bias = db; t.residual = dr; t.ldr = N; t.act = act; t.add_zero_bias = 1;
+            tk_launch_gemm_tiled(t, nullptr);
+            ok = hipGetLastError() == hipSuccess && hipMemcpy(c_tiled, dc, nc * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+    }
+    void* ptrs[] = {da, dw, db, dr, dc, dimg, dwh, dt};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    return ok ? TK_SUCCESS : TK_ERROR_GPU_ROCM_ERROR;
 }
 
 tk_error_code_t tk_kernels_depth_to_point_cloud(const tk_depth_to_points_params_t* p, tk_hip_stream_t stream) {
