@@ -164,8 +164,7 @@ tk_error_code_t tk_mi355x_gemm_pair(int device, int M, int N, int K, const float
             t.tiles[0] = dt; t.row_tiles[0] = (N + 15) / 16; t.nseg = 1; t.wbytes = f16 ? 2 : 4;
             t.K = K; t.ks = 1; t.ldc = N; t.n_valid = N; t.nrows = M; t.a_img = dimg; t.a_ts = (size_t)K * 16; t.out = dc;
             t.bias = db; t.residual = dr; t.ldr = N; t.act = act; t.add_zero_bias = 1;
-            tk_launch_gemm_tiled(t, nullptr);
-            ok = hipGetLastError() == hipSuccess && hipMemcpy(c_tiled, dc, nc * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            ok = tk_launch_gemm_tiled(t, nullptr) && hipGetLastError() == hipSuccess && hipMemcpy(c_tiled, dc, nc * 4, hipMemcpyDeviceToHost) == hipSuccess;
         }
     }
     void* ptrs[] = {da, dw, db, dr, dc, dimg, dwh, dt};

@@ -47,7 +47,8 @@ struct TkTiledGemm {
     int add_zero_bias;       /* k_gemm_f32 adds 0.0f when there is no bias (-0 + 0 = +0): reproduce it where results must match that kernel */
 };
 
-void tk_launch_gemm_tiled(const TkTiledGemm& g, hipStream_t s);
+/* false (nothing launched): K / ks is not a multiple of the ring granularity (128 k; 64 k from 129 rows per block on) or a field is inconsistent */
+bool tk_launch_gemm_tiled(const TkTiledGemm& g, hipStream_t s);
 /* row-major f16 / f32 [N][K] (device) -> tiles; N is padded up to a multiple of 16 with zero rows, K must be a multiple of 32 */
 size_t tk_tiled_weight_bytes(int64_t N, int64_t K, int wbytes);
 void tk_launch_tile_weights(const void* src, int wbytes, int64_t N, int64_t K, uint8_t* tiles, hipStream_t s);

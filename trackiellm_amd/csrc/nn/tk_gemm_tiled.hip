@@ -118,16 +118,44 @@ __global__ __launch_bounds__(512) void k_gemm_tiled(TkTiledGemm a, int groups, i
                 }
                 wload(c + PF, wq[u]);
                 const uint8_t* ap = slot + (size_t)(2 * (cc + u)) * MT * 1024;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const v4f a0 = *(const v4f*)(ap + m * 1024), a1 = *(const v4f*)(ap + (MT + m) * 1024);
+                if (MT == 1) {
+                    const v4f a0 = *(const v4f*)ap, a1 = *(const v4f*)(ap + 1024);
                     if (active) {
-                        v4f d = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]};
+                        v4f d = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
 #pragma unroll
                         for (int t = 0; t < 4; ++t) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], wf[t], d, 0, 0, 0);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], wf[4 + t], d, 0, 0, 0);
-                        acc[m][0] = d[0]; acc[m][1] = d[1]; acc[m][2] = d[2]; acc[m][3] = d[3];
+                        acc[0][0] = d[0]; acc[0][1] = d[1]; acc[0][2] = d[2]; acc[0][3] = d[3];
+                    }
+                } else {
+                    /* M-tiles in pairs: the two accumulators' chains alternate (a chain step's 40-cycle dependent latency hides behind the
+                     * other chain's MFMA) and the next pair's operand reads are issued before this pair's MFMAs */
+                    v4f A0[2][2], A1[2][2]; /* [buffer][tile of the pair] */
+                    A0[0][0] = *(const v4f*)(ap); A1[0][0] = *(const v4f*)(ap + MT * 1024);
+                    A0[0][1] = *(const v4f*)(ap + 1024); A1[0][1] = *(const v4f*)(ap + (MT + 1) * 1024);
+#pragma unroll
+                    for (int m = 0; m < MT; m += 2) {
+                        const int cur = (m >> 1) & 1, nxt = cur ^ 1;
+                        if (m + 2 < MT) {
+                            A0[nxt][0] = *(const v4f*)(ap + (m + 2) * 1024); A1[nxt][0] = *(const v4f*)(ap + (MT + m + 2) * 1024);
+                            A0[nxt][1] = *(const v4f*)(ap + (m + 3) * 1024); A1[nxt][1] = *(const v4f*)(ap + (MT + m + 3) * 1024);
+                        }
+                        if (active) {
+                            v4f d0 = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]}, d1 = {acc[m + 1][0], acc[m + 1][1], acc[m + 1][2], acc[m + 1][3]};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][0][t], wf[t], d0, 0, 0, 0);
+                                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][1][t], wf[t], d1, 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][0][t], wf[4 + t], d0, 0, 0, 0);
+                                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][1][t], wf[4 + t], d1, 0, 0, 0);
+                            }
+                            acc[m][0] = d0[0]; acc[m][1] = d0[1]; acc[m][2] = d0[2]; acc[m][3] = d0[3];
+                            acc[m + 1][0] = d1[0]; acc[m + 1][1] = d1[1]; acc[m + 1][2] = d1[2]; acc[m + 1][3] = d1[3];
+                        }
                     }
                 }
             }
@@ -231,7 +259,8 @@ bool tk_gemm_tiled_prepare_device() {
     return true;
 }
 
-void tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
+bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
+    if (a.nseg < 1 || a.nseg > 3 || a.ks < 1 || a.K <= 0 || a.K % (32 * a.ks) || a.nrows <= 0 || (a.wbytes != 2 && a.wbytes != 4) || (a.ks > 1 && a.nrows > TK_TW_MAX_BLOCK_ROWS)) return false;
     int row_tiles = 0;
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.row_tiles[i];
     const int rows_blk = a.nrows < TK_TW_MAX_BLOCK_ROWS ? a.nrows : TK_TW_MAX_BLOCK_ROWS;
@@ -254,6 +283,7 @@ void tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
     int rk = 1024 / mt; /* 64 KiB per ring slot; halved until it divides the K range (a multiple of 32 PF) */
     const int pf = mt == 16 ? 2 : 4;
     while (rk > 32 * pf && Kr % rk) rk >>= 1;
+    if (Kr % rk) return false;
     const size_t ldsb = (size_t)2 * TK_TW_SLOT_BYTES;
 #define TK_TW_LAUNCH(MTV, WBV) hipLaunchKernelGGL((k_gemm_tiled<MTV, WBV>), dim3(groups * a.ks, ny), dim3(64 * waves), ldsb, s, a, groups, row_tiles, rk)
 #define TK_TW_WB(MTV) do { if (a.wbytes == 2) TK_TW_LAUNCH(MTV, 2); else TK_TW_LAUNCH(MTV, 4); } while (0)
@@ -266,4 +296,5 @@ void tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
     }
 #undef TK_TW_WB
 #undef TK_TW_LAUNCH
+    return true;
 }
