@@ -161,7 +161,18 @@ static inline size_t tk_tiled_gemm_scratch(const TkGemm& g) {
 struct TkAudioGpuOps {
     TkAsr* a;
     hipStream_t s;
+    /* the operand image of the last packed activation matrix: consecutive linear layers on the same input (q / k / v, cross k / v) pack it
+     * once.  It sits on top of the arena and is dropped — its space handed back — by every other op, by any allocation of the graph and
+     * by a GEMM that writes into the matrix it was made from. */
+    struct { const float* A = nullptr; int M = 0, K = 0, lda = 0; float* img = nullptr; size_t mark = 0; bool live = false; } pk;
+    void drop_image() {
+        if (pk.live) { a->arena_used = pk.mark; pk.live = false; }
+    }
     float* alloc(size_t n) {
+        drop_image();
+        return raw_alloc(n);
+    }
+    float* raw_alloc(size_t n) {
         n = (n + 63) & ~(size_t)63;
         float* p = a->arena + a->arena_used;
         a->arena_used += n;
@@ -169,46 +180,58 @@ struct TkAudioGpuOps {
     }
     int32_t* alloc_i32(size_t n) { return (int32_t*)alloc(n); }
     /* a linear layer whose weights have tiles runs on the tiled GEMM (same k-ascending fp32 chain, bit-identical, ~3x the rate of the
-     * LDS-staged kernel on these shapes and one short launch instead of a latency chain for the decoder's few rows); its activation
-     * image is scratch taken from the arena and handed back at once (reuse is stream-ordered) */
+     * LDS-staged kernel on these shapes and one short launch instead of a latency chain for the decoder's few rows) */
     void gemm(const TkGemm& g) {
         const int idx = tk_tiled_gemm_applies(g) ? a->model->tensor_of(g.B) : -1;
-        if (idx < 0 || !a->model->wt[(size_t)idx]) { tk_launch_gemm(g, s); return; }
-        const size_t mark = a->arena_used;
-        float* img = alloc(tk_tiled_gemm_scratch(g));
-        tk_launch_pack_a(g.A, g.M, g.K, g.lda, 0, img, s);
+        if (idx < 0 || !a->model->wt[(size_t)idx]) { drop_image(); tk_launch_gemm(g, s); return; }
+        if (!(pk.live && pk.A == g.A && pk.M == g.M && pk.K == g.K && pk.lda == g.lda)) {
+            drop_image();
+            pk.mark = a->arena_used;
+            pk.img = raw_alloc(tk_tiled_gemm_scratch(g));
+            tk_launch_pack_a(g.A, g.M, g.K, g.lda, 0, pk.img, s);
+            pk.A = g.A; pk.M = g.M; pk.K = g.K; pk.lda = g.lda; pk.live = true;
+        }
         TkTiledGemm t{};
         t.tiles[0] = a->model->wt[(size_t)idx]; t.row_tiles[0] = (g.N + 15) / 16; t.nseg = 1; t.wbytes = 4;
         t.K = g.K; t.ks = 1; t.ldc = g.ldc; t.n_valid = g.N; t.nrows = g.M; t.slab_rows = 0;
-        t.a_img = img; t.a_ts = (size_t)g.K * 16; t.out = g.C;
+        t.a_img = pk.img; t.a_ts = (size_t)g.K * 16; t.out = g.C;
         t.bias = g.bias; t.residual = g.residual; t.ldr = g.ldr; t.act = g.act; t.add_zero_bias = 1;
         if (!tk_launch_gemm_tiled(t, s)) tk_launch_gemm(g, s); /* not reached: tk_tiled_gemm_applies() admits only shapes the launcher takes */
-        a->arena_used = mark;
+        /* the output may overwrite the packed matrix (an in-place layer): the image is then stale */
+        const float* c0 = g.C;
+        const float* c1 = g.C + (size_t)(g.M - 1) * g.ldc + g.N;
+        const float* a0 = g.A;
+        const float* a1 = g.A + (size_t)(g.M - 1) * g.lda + g.K;
+        if (c0 < a1 && a0 < c1) drop_image();
     }
-    void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) { tk_launch_im2col1d(x, B, T, C, ldx, kw, stride, pad, col, s); }
-    void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) { tk_launch_layernorm(x, rows, D, w, b, TK_WH_LN_EPS, y, s); }
-    void softmax_rows(float* x, int rows, int cols, int ld) { tk_launch_softmax_rows(x, rows, cols, ld, s); }
+    void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) { drop_image(); tk_launch_im2col1d(x, B, T, C, ldx, kw, stride, pad, col, s); }
+    void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) { drop_image(); tk_launch_layernorm(x, rows, D, w, b, TK_WH_LN_EPS, y, s); }
+    void softmax_rows(float* x, int rows, int cols, int ld) { drop_image(); tk_launch_softmax_rows(x, rows, cols, ld, s); }
     bool attend1(const float* q, const float* k, const float* v, float* out, int B, int Tk, int64_t q_bstride, int64_t kv_bstride, int d, int nh) {
+        drop_image();
         const int hd = d / nh;
         if (hd > 256 || (hd & 3) || (size_t)Tk * 4 + (size_t)hd * 4 > 60 * 1024) return false;
         hipLaunchKernelGGL(k_attend1, dim3(nh, B), dim3(256), (size_t)Tk * 4 + (size_t)hd * 4, s, q, k, v, out, Tk, q_bstride, kv_bstride, d, hd,
                            tk_divf(1.0f, tk_sqrtf((float)hd)));
         return true;
     }
-    void add_rows(float* x, const float* add, int rows, int D, int add_rows) { tk_launch_add_rows(x, add, rows, D, add_rows, s); }
+    void add_rows(float* x, const float* add, int rows, int D, int add_rows) { drop_image(); tk_launch_add_rows(x, add, rows, D, add_rows, s); }
     void embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out) {
+        drop_image();
         tk_launch_embed_rows(table, pos, idx, pos_idx, rows, D, out, s);
     }
-    void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out) { tk_launch_argmax_rows(x, rows, cols, ld, out, s); }
+    void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out) { drop_image(); tk_launch_argmax_rows(x, rows, cols, ld, out, s); }
     void frames(const int16_t* pcm, int B, int n_samples, int pcm_stride, int n_total, int T, const float* window, float* out) {
+        drop_image();
         const int64_t per = (int64_t)T * TK_WH_NFFT;
         hipLaunchKernelGGL(k_frames, dim3((unsigned)((per + 255) / 256), 1, B), dim3(256), 0, s, pcm, n_samples, pcm_stride, n_total, T, window, out);
     }
     void power(const float* ri, int rows, int nb, float* out) {
+        drop_image();
         const int64_t n = (int64_t)rows * nb;
         hipLaunchKernelGGL(k_power, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ri, (int64_t)rows, nb, out);
     }
-    void logmel_finish(float* mel, int B, int per_b) { hipLaunchKernelGGL(k_logmel_finish, dim3(B), dim3(1024), 0, s, mel, per_b); }
+    void logmel_finish(float* mel, int B, int per_b) { drop_image(); hipLaunchKernelGGL(k_logmel_finish, dim3(B), dim3(1024), 0, s, mel, per_b); }
 };
 
 /* sizing twin of the ops (counts arena floats for a given batch) */
@@ -392,10 +415,10 @@ bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* 
      * table; one copy and one synchronisation at the end.  (A synchronisation and three small copies per step made the 16 steps of 32
      * utterances 1.2 ms each on a 0.3 ms GPU workload.) */
     const int total = n_prompt + n_steps - 1; /* the last generated token is not fed back */
-    int32_t* tab = (int32_t*)(arena + arena_used); /* [n_prompt][B] prompt tokens, [total][B] positions, [total][B] arg-max slots */
     const size_t tab_ints = ((size_t)n_prompt + 2 * (size_t)total) * B;
+    ops.drop_image();
     if (arena_used + tab_ints + 64 > arena_floats) { error = "ASR arena too small for the decode tables"; return false; }
-    arena_used += (tab_ints + 63) & ~(size_t)63;
+    int32_t* tab = ops.alloc_i32(tab_ints); /* [n_prompt][B] prompt tokens, [total][B] positions, [total][B] arg-max slots */
     int32_t* tok_tab = tab;
     int32_t* pos_tab = tab + (size_t)n_prompt * B;
     int32_t* out_tab = pos_tab + (size_t)total * B;
