@@ -603,3 +603,27 @@ def test_f16_weights_bit_exact_and_pipeline_split(gpu):
     assert np.array_equal(am, wam)
     for s in (sess, se2, a, b):
         s.close()
+
+
+@pytest.mark.parametrize("nseq,npos", [(5, 14), (8, 25)])  # 70 rows (8 M-tiles) and 200 rows (16 M-tiles)
+def test_f16_weights_wide_passes_bit_exact(gpu, nseq, npos):
+    """fp16 checkpoint, prefill-shaped passes of 70 / 200 rows: the tiled GEMM's 8- and 16-M-tile variants against the oracle, bit for bit,
+    and the rows of a wide pass equal the same rows fed through narrow passes (the K-split plan does not depend on the pass width)"""
+    model = gpu.LlmModel(gpu.TINY()).fill_synthetic(13, f16=True)
+    hp = model.hparams
+    sess = gpu.LlmSession(model, nseq, 32)
+    orc = O.OracleLlm(oracle_cfg_from(hp, 32, nseq), seed=13, f16=True)
+    rng = np.random.default_rng(nseq)
+    seq = np.repeat(np.arange(nseq, dtype=np.int32), npos)
+    pos = np.tile(np.arange(npos, dtype=np.int32), nseq)
+    tok = rng.integers(3, hp.vocab, nseq * npos).astype(np.int32)
+    want, wam = orc.forward(seq, pos, tok)
+    got, gam = sess.forward(seq, pos, tok)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.array_equal(gam, wam)
+    narrow = gpu.LlmSession(model, nseq, 32)
+    for s in range(nseq):  # one sequence per pass: 14 / 25 rows
+        sel = seq == s
+        g1, _ = narrow.forward(seq[sel], pos[sel], tok[sel])
+        assert np.array_equal(g1.view(np.uint32), got[sel].view(np.uint32))
+    sess.close(); narrow.close(); model.close()
