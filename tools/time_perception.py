@@ -52,5 +52,5 @@ with tempfile.TemporaryDirectory() as td:
     t = time.time()
     for _ in range(10):
         est.estimate(frame)
-    print(f"{'depth (1 frame, 256x256)':28s} {1000 * (time.time() - t) / 10:9.2f} ms per frame ({est_nodes if (est_nodes := len(OX.depth_spec(4))) else 0} graph nodes)", flush=True)
+    print(f"{'depth (1 frame, 256x256)':28s} {1000 * (time.time() - t) / 10:9.2f} ms per frame ({len(OX.depth_spec(4))} graph nodes)", flush=True)
     est.close()
