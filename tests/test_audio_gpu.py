@@ -49,6 +49,26 @@ def test_whisper_tiny_en_full_size_encoder(gpu):
     assert np.array_equal(toks, wt) and np.array_equal(lg, wlg)
 
 
+def test_asr_batch_composition_invariance_full_size(gpu):
+    """size-independent property at the BASELINE geometry: an utterance's mel, encoder states, logits and tokens do not depend on which
+    other utterances share its batch (5 utterances: 7500 encoder rows, 30 row blocks of the tiled GEMM; alone: 6 row blocks; the decoder
+    runs 1 M-tile instead of 1 — and at 20 utterances 2), for different utterance lengths in one batch"""
+    rng = np.random.default_rng(8)
+    pcm = np.clip(rng.normal(0, 3000, (5, 16000)), -32768, 32767).astype(np.int16)
+    pcm[3, 9000:] = 0                                   # a shorter utterance among full ones
+    batch = gpu.Asr(hp=gpu.WHISPER_TINY_EN(), seed=6, max_batch=20)
+    toks, mel, enc, lg = batch.transcribe_tokens(pcm, 4)
+    for b in (0, 3):
+        t1, m1, e1, l1 = batch.transcribe_tokens(pcm[b:b + 1], 4)
+        assert np.array_equal(m1[0], mel[b]) and np.array_equal(e1[0].view(np.uint32), enc[b].view(np.uint32))
+        assert np.array_equal(l1[0].view(np.uint32), lg[b].view(np.uint32)) and np.array_equal(t1[0], toks[b])
+    wide = np.concatenate([pcm] * 4)                    # 20 utterances: the decoder's linears run two M-tiles
+    t20, _, _, l20 = batch.transcribe_tokens(wide, 4)
+    for r in range(4):
+        assert np.array_equal(t20[5 * r:5 * r + 5], toks) and np.array_equal(l20[5 * r:5 * r + 5].view(np.uint32), lg.view(np.uint32))
+    batch.close()
+
+
 def test_whisper_ggml_checkpoint_end_to_end(gpu, tmp_path):
     """a whisper.cpp ggml .bin (f16 weights) goes in through tk_asr_whisper_create's model_path; geometry, filter bank and vocabulary
     come from the file; mel / encoder / logits / forced ids equal the oracle run on the same (f16-rounded) weights"""
