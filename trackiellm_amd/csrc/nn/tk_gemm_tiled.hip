@@ -264,7 +264,16 @@ bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
     int row_tiles = 0;
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.row_tiles[i];
     const int rows_blk = a.nrows < TK_TW_MAX_BLOCK_ROWS ? a.nrows : TK_TW_MAX_BLOCK_ROWS;
-    const int mt = rows_blk > 128 ? 16 : rows_blk > 64 ? 8 : rows_blk > 32 ? 4 : rows_blk > 16 ? 2 : 1;
+    int mt = rows_blk > 128 ? 16 : rows_blk > 64 ? 8 : rows_blk > 32 ? 4 : rows_blk > 16 ? 2 : 1;
+    if (mt == 16 && a.nrows > TK_TW_MAX_BLOCK_ROWS) {
+        /* many row blocks: one workgroup per CU at a time (128 KiB of ring), so the launch takes ceil(workgroups / 256) rounds of ~mt
+         * units each; 128-row blocks win when they waste less of the last round (N = 384: 564 workgroups = 3 rounds of 16 against
+         * 1125 = 5 rounds of 8; measured -2 % on the Whisper encoder) */
+        const int wg_per_blk = (row_tiles + 7) / 8;
+        const long r16 = ((long)((a.nrows + 255) / 256) * wg_per_blk + 255) / 256 * 16;
+        const long r8 = ((long)((a.nrows + 127) / 128) * wg_per_blk + 255) / 256 * 8;
+        if (r8 < r16) mt = 8;
+    }
     const int ny = (a.nrows + mt * TK_TW_ROWS_PER_TILE - 1) / (mt * TK_TW_ROWS_PER_TILE);
     /* one pass of <= 256 rows (the LLM): spread the row tiles over the CUs, K-split ranges side by side; many row blocks: eight tiles
      * per workgroup share one activation ring */
