@@ -289,9 +289,13 @@ bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
         groups = (row_tiles + waves - 1) / waves;
     }
     const int Kr = a.K / a.ks;
-    int rk = 1024 / mt; /* 64 KiB per ring slot; halved until it divides the K range (a multiple of 32 PF) */
+    /* k per ring slot: the largest multiple of 32 PF that divides the K range and fits a 64 KiB slot (rk / 16 * mt KiB) — a whole short
+     * range in one slot spares a small launch its ring hand-overs (Whisper decoder: K = 384 at two M-tiles is one 48 KiB slot) */
     const int pf = mt == 16 ? 2 : 4;
-    while (rk > 32 * pf && Kr % rk) rk >>= 1;
+    int rk = 0;
+    for (int c = (1024 / mt) / (32 * pf) * (32 * pf); c >= 32 * pf; c -= 32 * pf)
+        if (Kr % c == 0) { rk = c; break; }
+    if (rk == 0) return false;
     if (Kr % rk) return false;
     const size_t ldsb = (size_t)2 * TK_TW_SLOT_BYTES;
 #define TK_TW_LAUNCH(MTV, WBV) hipLaunchKernelGGL((k_gemm_tiled<MTV, WBV>), dim3(groups * a.ks, ny), dim3(64 * waves), ldsb, s, a, groups, row_tiles, rk)
