@@ -107,3 +107,41 @@ def test_tts_priority_queue_and_interruption(stub_lib):
     gate.set()
     assert ap.drain() == 0 and spoken[:2] == [b"urgent", b"fire"] and len(spoken) == 16
     ap.close()
+
+
+def test_reference_listening_timeout_replay(stub_lib):
+    """tests/tk_audio_pipeline_full_test.c:127-170 (test_listening_timeout): a wake-word pipeline fed 60 chunks of 1600 zero samples (6 s of
+    silence) stays in AWAITING_WAKE_WORD; nothing is reported."""
+    ap = make(stub_lib, wake_word="porcupine.pv")
+    assert ap.state() == 1                                      # TK_PIPELINE_STATE_AWAITING_WAKE_WORD
+    silence = np.zeros(1600, np.int16)
+    for _ in range(60):
+        assert ap.feed(silence) == 0
+        time.sleep(0.002)                                       # the reference sleeps 100 ms per chunk; the state machine has no clock to wait for here
+    assert ap.drain() == 0 and ap.state() == 1
+    assert ap.vad_events == [] and ap.transcriptions == []
+    ap.close()
+
+
+def test_reference_tts_interruption_replay(stub_lib):
+    """tests/tk_audio_pipeline_full_test.c:172-214 (test_tts_interruption): a LOW request in progress, a CRITICAL one 50 ms later ->
+    on_tts_interrupt fires; the interrupted request's remaining audio is dropped and the critical text is spoken next."""
+    ap = make(stub_lib)
+    spoken = []
+
+    def synth(text, emit):                                      # stands in for Piper: a long message takes a while, in chunks
+        spoken.append(text)
+        for _ in range(40 if len(text) > 20 else 1):
+            emit(np.full(160, 3, np.int16))
+            time.sleep(0.01)
+        return 0
+
+    ap.set_synthesizer(synth)
+    assert ap.say("This is a long, low-priority message that should be interrupted.", LOW) == 0
+    time.sleep(0.05)
+    assert ap.say("Alert!", CRITICAL) == 0
+    assert ap.drain() == 0
+    assert ap.interrupts >= 1
+    assert spoken == [b"This is a long, low-priority message that should be interrupted.", b"Alert!"]
+    assert len(ap.tts_audio) < 41                               # the long message did not get all of its 40 chunks out
+    ap.close()
