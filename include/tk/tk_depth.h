@@ -1,8 +1,8 @@
 /*
  * tk_depth.h — monocular depth estimation and object / depth fusion of the vision stream.
- *   tk_depth_estimator_*            src/vision/tk_depth_midas.h:51-60 (config), :84-131 (API); implementation src/vision/tk_depth_midas.c
+ *   tk_depth_estimator_*            src/vision/tk_depth_midas.h:42-50 (config), :75-131 (API); implementation src/vision/tk_depth_midas.c
  *   tk_vision_rust_fuse_data / _free_fused_result
- *                                   src/vision/src/lib.rs:163-231 (C-ABI exported by the reference's Rust crate, called from
+ *                                   src/vision/src/lib.rs:173-253 (C-ABI exported by the reference's Rust crate, called from
  *                                   fuse_object_depth, src/vision/tk_vision_pipeline.c:653-713); logic src/vision/src/object_analysis.rs
  * model_path: an ONNX file of the convolutional MiDaS class (MiDaS v2.1 small / large: Conv with groups, Relu / Clip, Add, Concat,
  * Resize, pooling, BatchNormalization — the op list of csrc/nn/tk_onnx_exec.h), input "[1, 3, input_height, input_width]" float,
@@ -39,12 +39,12 @@ TK_API void tk_depth_estimator_free_map(tk_vision_depth_map_t** depth_map);
 /* ---- fusion: the C-ABI the reference's Rust crate exports (EnrichedObject / CFusedResult are #[repr(C)] there) ---- */
 typedef struct {
     uint32_t class_id;
-    float confidence;      /* 1.0: the reference reports the tracker, not the detection (object_analysis.rs:176) */
+    float confidence;      /* 1.0: the reference reports the tracker, not the detection (object_analysis.rs:201) */
     tk_rect_t bbox;
     float distance_meters;
     float width_meters;
     float height_meters;
-    bool is_partially_occluded; /* always false (object_analysis.rs:181) */
+    bool is_partially_occluded; /* always false (object_analysis.rs:206) */
 } tk_enriched_object_t;
 typedef struct {
     const tk_enriched_object_t* objects;
@@ -64,7 +64,7 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_depth_onnx_probe(const char* path,
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_depth_forward_raw(tk_depth_estimator_t* estimator, const float* chw, float* raw_out, size_t raw_floats);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_depth_last_raw(tk_depth_estimator_t* estimator, float* raw_out, size_t raw_floats);
 TK_API void tk_mi355x_fusion_reset(void);
-/* raw (unsmoothed) distance under one box: calculate_raw_distance, object_analysis.rs:196-247; -1 when fewer than 10 valid depths */
+/* raw (unsmoothed) distance under one box: calculate_raw_distance, object_analysis.rs:227-279; -1 when fewer than 10 valid depths */
 TK_API float tk_mi355x_fusion_raw_distance(const tk_rect_t* bbox, const tk_vision_depth_map_t* depth_map, uint32_t frame_width, uint32_t frame_height);
 
 #ifdef __cplusplus

@@ -7,9 +7,9 @@ What it restates
     half_pixel, pytorch_half_pixel, align_corners and asymmetric coordinate modes), Squeeze.  A graph is a list of node dicts
     {"op", "in", "out", "attrs"} (tests/onnx_util.depth_spec builds one and writes the same list as an ONNX file).
   * convert_inverse_depth_to_metric (src/vision/tk_depth_midas.c:471-499), bit for bit in float32.
-  * calculate_raw_distance and fuse_object_and_depth_data (src/vision/src/object_analysis.rs:104-247), with trackers in creation order.
+  * calculate_raw_distance and fuse_object_and_depth_data (src/vision/src/object_analysis.rs:134-279), with trackers in creation order.
 Pinning: the network semantics against torch on a seeded graph (tests/golden/depth_net.npz, made by tests/golden/make_depth_golden.py);
-the fusion against the reference's own unit test vector (object_analysis.rs:257-311: 10 m, then 12 m -> between 10 and 12).
+the fusion against the reference's own unit test vector (object_analysis.rs:286-347: 10 m, then 12 m -> between 10 and 12).
 Convolutions accumulate in float32 in (input channel, kernel row, kernel column) order with separate multiply and add, the GPU uses one
 fma chain in the same order: agreement is to rounding (tests allow 2e-5 relative to the tensor's scale), not bit-exact.
 """
@@ -164,7 +164,7 @@ def _round_half_away(v):
 
 
 def raw_distance(box, depth, frame_w, frame_h):
-    """calculate_raw_distance, object_analysis.rs:196-247.  box = (x, y, w, h) ints; depth [dh][dw] float32"""
+    """calculate_raw_distance, object_analysis.rs:227-279.  box = (x, y, w, h) ints; depth [dh][dw] float32"""
     dh, dw = depth.shape
     x, y, w, h = box
     n = [F(F(x) / F(frame_w)), F(F(y) / F(frame_h)), F(F(x + w) / F(frame_w)), F(F(y + h) / F(frame_h))]
@@ -202,7 +202,7 @@ def iou(a, b):
 
 
 class Fusion:
-    """fuse_object_and_depth_data, object_analysis.rs:104-194; one result per detection (None: no valid depth under the box)"""
+    """fuse_object_and_depth_data, object_analysis.rs:134-223; one result per detection (None: no valid depth under the box)"""
 
     def __init__(self):
         self.trackers = []  # dicts: cls, box, x, p, unseen

@@ -48,7 +48,7 @@ def test_oracle_metric_conversion_known_answers():
 
 
 def test_oracle_fusion_replays_reference_unit_test():
-    """src/vision/src/object_analysis.rs:257-311 (test_kalman_filter_smoothes_distance): a 20x20 box over depth 10, then the box moved by one
+    """src/vision/src/object_analysis.rs:286-347 (test_kalman_filter_smoothes_distance): a 20x20 box over depth 10, then the box moved by one
     pixel over depth 12: first distance within 0.1 of 10, second strictly between 10 and 12 (one Kalman step: K = 1.1 / 1.6)"""
     f = DO.Fusion()
     d1 = np.zeros((100, 100), np.float32)

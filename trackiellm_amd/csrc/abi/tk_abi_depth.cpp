@@ -1,6 +1,6 @@
 /*
- * tk_abi_depth.cpp — tk_depth_estimator_* (src/vision/tk_depth_midas.h:84-131) on the HIP depth engine, and the fusion C-ABI of the
- * reference's Rust vision crate (src/vision/src/lib.rs:163-231).
+ * tk_abi_depth.cpp — tk_depth_estimator_* (src/vision/tk_depth_midas.h:75-131) on the HIP depth engine, and the fusion C-ABI of the
+ * reference's Rust vision crate (src/vision/src/lib.rs:173-253).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -112,7 +112,7 @@ tk_error_code_t tk_mi355x_depth_last_raw(tk_depth_estimator_t* estimator, float*
 
 tk_fused_result_t* tk_vision_rust_fuse_data(const tk_detection_result_t* detections, size_t detection_count, const tk_vision_depth_map_t* depth_map,
                                             uint32_t frame_width, uint32_t frame_height, float focal_length_x, float focal_length_y) {
-    if (!detections || !depth_map) return nullptr; /* lib.rs:176-178 */
+    if (!detections || !depth_map) return nullptr; /* lib.rs:203-205 */
     std::vector<TkBox> boxes(detection_count);
     std::vector<uint32_t> cls(detection_count);
     for (size_t i = 0; i < detection_count; ++i) { boxes[i] = {detections[i].bbox.x, detections[i].bbox.y, detections[i].bbox.w, detections[i].bbox.h}; cls[i] = detections[i].class_id; }
@@ -134,7 +134,7 @@ tk_fused_result_t* tk_vision_rust_fuse_data(const tk_detection_result_t* detecti
         if (!fused[i].valid) continue;
         tk_enriched_object_t& o = objs[k++];
         o.class_id = cls[i];
-        for (const auto& t : after) if (t.id == fused[i].tracker_id) o.class_id = t.class_id; /* the tracker's class (object_analysis.rs:174) */
+        for (const auto& t : after) if (t.id == fused[i].tracker_id) o.class_id = t.class_id; /* the tracker's class (object_analysis.rs:200) */
         o.confidence = 1.0f;
         o.bbox = detections[i].bbox;
         o.distance_meters = fused[i].distance_m;

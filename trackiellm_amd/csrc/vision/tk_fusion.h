@@ -2,10 +2,10 @@
  * tk_fusion.h — object / depth fusion: a distance, a metric width and height for every detected box (host code, a few boxes per frame).
  *
  * Restates src/vision/src/object_analysis.rs (the Rust half of fuse_object_depth, src/vision/tk_vision_pipeline.c:653-713):
- *   calculate_raw_distance (:196-247): the box is scaled into the depth map (normalised corners * (dim - 1), rounded), depths in
+ *   calculate_raw_distance (:227-279): the box is scaled into the depth map (normalised corners * (dim - 1), rounded), depths in
  *   (0.1, 100) are collected row by row; with >= 10 of them the inter-quartile filter [q1 - 1.5 iqr, q3 + 1.5 iqr] is applied
  *   (q1 = sorted[len / 4], q3 = sorted[len * 3 / 4]) and the mean of the survivors is the raw distance; otherwise -1.
- *   fuse_object_and_depth_data (:104-194): a detection matches the tracker with the highest IoU > 0.4 (integer boxes); a matched tracker
+ *   fuse_object_and_depth_data (:134-223): a detection matches the tracker with the highest IoU > 0.4 (integer boxes); a matched tracker
  *   runs one scalar Kalman step (F = H = 1, Q = 0.1, R = 0.5, P0 = 1; predict, then update with the raw distance), an unmatched
  *   detection starts a tracker at its raw distance; trackers unseen for more than 5 frames are dropped; width = w * distance / fx,
  *   height = h * distance / fy.
