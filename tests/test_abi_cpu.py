@@ -3,6 +3,7 @@ import ctypes
 import glob
 import os
 import re
+import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -59,3 +60,33 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"liboracle|oracle_lib|/oracle/|orc_[a-z]+\(", s):
                     bad.append(os.path.join(root, f))
     assert not bad, bad
+
+
+def test_headers_are_plain_c_and_a_c_host_links(tmp_path):
+    """the drop-in boundary is a C ABI: every public header compiles as C11 (no C++-isms, self-contained), and a C translation unit that
+    references one entry point per header links against the library and runs without a GPU (it only asks for the version / device count and
+    exercises an argument check)"""
+    inc = os.path.join(ROOT, "include")
+    headers = sorted(h for h in os.listdir(os.path.join(inc, "tk")) if h.endswith(".h"))
+    src = tmp_path / "host.c"
+    src.write_text("".join('#include "tk/%s"\n' % h for h in headers) + '''
+#include <stdio.h>
+int main(void) {
+    /* one symbol per header, referenced so that the link must resolve it */
+    typedef void (*fn_t)(void);
+    fn_t refs[] = {(fn_t)tk_object_detector_create, (fn_t)tk_asr_whisper_create, (fn_t)tk_audio_pipeline_create, (fn_t)tk_cortex_create,
+                   (fn_t)tk_depth_estimator_create, (fn_t)tk_llm_runner_create, (fn_t)tk_contextual_reasoner_create,
+                   (fn_t)tk_kernels_softmax, (fn_t)tk_path_create_from_string, (fn_t)tk_mi355x_version};
+    if (sizeof refs / sizeof refs[0] != 10 || !refs[0]) return 2;
+    if (tk_depth_estimator_create(NULL, NULL) != TK_ERROR_INVALID_ARGUMENT) return 3;
+    printf("%s %d\\n", tk_mi355x_version(), tk_mi355x_device_count());
+    return 0;
+}
+''')
+    exe = tmp_path / "host"
+    libdir = os.path.join(ROOT, "trackiellm_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-I" + inc, str(src), "-o", str(exe), "-L" + libdir, "-ltrackie_mi355x",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0]
