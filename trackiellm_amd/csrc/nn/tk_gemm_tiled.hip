@@ -284,6 +284,10 @@ bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
         if (groups > row_tiles) groups = row_tiles;
         waves = (row_tiles + groups - 1) / groups;
         while (waves > 8) { groups *= 2; waves = (row_tiles + groups - 1) / groups; }
+        if (waves == 1 && row_tiles >= 4) { /* fewer tiles than CUs: four one-tile waves (one per SIMD) share a workgroup's ring staging */
+            waves = 4;
+            groups = (row_tiles + 3) / 4;
+        }
     } else {
         waves = row_tiles < 8 ? row_tiles : 8;
         groups = (row_tiles + waves - 1) / waves;
