@@ -209,6 +209,33 @@ def test_full_7b_pass_width_invariance(gpu):
     assert np.isfinite(outs[0]).all() and len(np.unique(outs[0].argmax(-1))) > 8
 
 
+def test_full_7b_f16_pass_width_invariance(gpu):
+    """the same property for BASELINE configs[4]'s weights (full 32-layer Mistral-7B as an fp16 checkpoint, 14.2 GB, synthetic): 64 rows in one
+    pass (4 M-tiles of the tiled GEMM), as 2 x 32 (2 M-tiles) and as 4 x 16 (1 M-tile) give bit-identical logits over two positions"""
+    model = gpu.LlmModel(gpu.MISTRAL_7B()).fill_synthetic(4, f16=True)
+    hp = model.hparams
+    rng = np.random.default_rng(9)
+    n = 64
+    seq = np.arange(n, dtype=np.int32)
+    pos = np.zeros(n, np.int32)
+    tok = rng.integers(3, hp.vocab, n).astype(np.int32)
+    tok2 = rng.integers(3, hp.vocab, n).astype(np.int32)
+    outs = []
+    for width in (64, 32, 16):
+        sess = gpu.LlmSession(model, n, 4)
+        lg = np.empty((2, n, hp.vocab), np.float32)
+        for i in range(0, n, width):
+            lg[0, i:i + width], _ = sess.forward(seq[i:i + width], pos[i:i + width], tok[i:i + width])
+        for i in range(0, n, width):
+            lg[1, i:i + width], _ = sess.forward(seq[i:i + width], pos[i:i + width] + 1, tok2[i:i + width])
+        outs.append(lg)
+        sess.close()
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
+    assert np.isfinite(outs[0]).all() and len(np.unique(outs[0].argmax(-1))) > 4
+    model.close()
+
+
 def test_reference_runner_surface(gpu):
     """tk_model_loader_* + tk_llm_runner_* as the reference's Rust GgufRunner drives them"""
     loader = gpu.ModelLoader()
