@@ -564,7 +564,8 @@ def main():
 
 def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N):
     # one model, layers split over the ranks; every rank builds the same weights and walks the same pass order
-    model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4)
+    f16 = args.weights == "f16"  # BASELINE configs[4]: the fp16 checkpoint layer-sharded over the node
+    model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4, f16=f16)
     hp = model.hparams
     if dist is None:
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
@@ -586,9 +587,10 @@ def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N):
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": round(G * B * args.steps / elapsed, 3), "unit": "cycles/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 2),
-                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-                          "config": {"workload": "configs[1] LLM stream only, layer-sharded: Mistral-7B Q4_K_M, 64-token prefill + 128-token greedy decode "
-                                                 "per cycle, host-driven passes (no hipGraph), %d row groups of %d" % (G, B),
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": "f16 weights x f16-rounded f32 activations, fp32 MFMA chain" if f16 else DTYPE, "data": "synthetic",
+                          "config": {"workload": ("configs[4] LLM stream, layer-sharded: Mistral-7B fp16" if f16 else "configs[1] LLM stream only, layer-sharded: Mistral-7B Q4_K_M") +
+                                                 ", 64-token prefill + 128-token greedy decode per cycle, host-driven passes (no hipGraph), %d row groups of %d" % (G, B),
                                      "concurrent_cycles": G * B, "layers_per_rank": [pipe.bounds[r + 1] - pipe.bounds[r] for r in range(world)],
                                      "parallelism": "pipeline x%d (RCCL send/recv of [rows, 4096] fp32 between consecutive stages)" % world},
                           "llm_tok_per_s": round(G * B * N * args.steps / elapsed, 1)}))
