@@ -21,7 +21,13 @@ tk_error_code_t tk_vad_silero_process_audio_with_events(tk_vad_silero_context_t*
 tk_error_code_t tk_vad_silero_get_state(tk_vad_silero_context_t* c, tk_vad_silero_state_t* s) { memset(s, 0, sizeof *s); s->is_speech_active = c->active; return TK_SUCCESS; }
 tk_error_code_t tk_asr_whisper_create(tk_asr_whisper_context_t** o, const tk_asr_whisper_config_t*) { *o = new tk_asr_whisper_context_s{0}; return TK_SUCCESS; }
 void tk_asr_whisper_destroy(tk_asr_whisper_context_t** c) { delete *c; *c = nullptr; }
+static int g_asr_fail = 0, g_asr_calls = 0, g_asr_resets = 0; static size_t g_asr_max_n = 0;
+__attribute__((visibility("default"))) void stub_asr_set_fail(int on) { g_asr_fail = on; }
+__attribute__((visibility("default"))) void stub_asr_stats(int* calls, int* resets, size_t* max_n) { *calls = g_asr_calls; *resets = g_asr_resets; *max_n = g_asr_max_n; }
+tk_error_code_t tk_asr_whisper_reset(tk_asr_whisper_context_t*) { ++g_asr_resets; return TK_SUCCESS; }
 tk_error_code_t tk_asr_whisper_process_audio(tk_asr_whisper_context_t*, const int16_t*, size_t n, bool fin, tk_asr_whisper_result_t** out) {
+    ++g_asr_calls; if (n > g_asr_max_n) g_asr_max_n = n;
+    if (g_asr_fail) { *out = nullptr; return TK_ERROR_BUFFER_TOO_SMALL; }
     tk_asr_whisper_result_t* r = (tk_asr_whisper_result_t*)calloc(1, sizeof *r); char b[64]; snprintf(b, 64, "seg%zu", n); r->text = strdup(b); r->text_length = strlen(b); r->confidence = 0.9f; r->is_partial = !fin; *out = r; return TK_SUCCESS; }
 void tk_asr_whisper_free_result(tk_asr_whisper_result_t** r) { free((*r)->text); free(*r); *r = nullptr; }
 }

@@ -145,3 +145,28 @@ def test_reference_tts_interruption_replay(stub_lib):
     assert spoken == [b"This is a long, low-priority message that should be interrupted.", b"Alert!"]
     assert len(ap.tts_audio) < 41                               # the long message did not get all of its 40 chunks out
     ap.close()
+
+
+def test_failed_asr_pass_drops_the_segment_instead_of_overrunning(stub_lib):
+    """when the ASR engine fails at the 30 s limit (GPU error, or a segment longer than the engine's buffer at sample rates
+    above 16 kHz) the segment must be dropped — the next chunk is copied to the START of the buffer, never past its end — and the
+    engine is reset.  40 s of speech with every ASR call failing: no call ever sees more than the 30 s buffer; then the engine
+    recovers and the next segment is transcribed from its own start."""
+    ap = make(stub_lib)
+    calls, resets, max_n = C.c_int(), C.c_int(), C.c_size_t()
+    stub_lib.stub_asr_stats(C.byref(calls), C.byref(resets), C.byref(max_n))
+    calls0, resets0 = calls.value, resets.value
+    stub_lib.stub_asr_set_fail(1)
+    loud = np.full(8000, 5000, np.int16)
+    try:
+        for _ in range(80):                                   # 40 s > the 30 s segment buffer
+            assert ap.feed(loud) == 0 and ap.drain(5000) == 0
+        stub_lib.stub_asr_stats(C.byref(calls), C.byref(resets), C.byref(max_n))
+        assert calls.value - calls0 >= 1 and resets.value - resets0 == calls.value - calls0
+        assert max_n.value <= 30 * 16000
+        assert ap.force_end() != 0                            # the pending (failing) final pass reports the engine's error ...
+        assert ap.force_end() == 0                            # ... and consumed the segment: nothing left to fail on
+    finally:
+        stub_lib.stub_asr_set_fail(0)
+    assert ap.transcriptions == []
+    ap.close()

@@ -11,7 +11,7 @@ O=gpurun_out
 export TK_MI355X_NO_GRAPH=1
 for B in 256 16; do
   for C in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pmc_$B_$C
+    rm -rf "/tmp/pmc_${B}_${C}"
     timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_${B}_$C -o p -- python3 bench.py --llm-only --no-extras --batch $B --sessions 1 --steps 1 --warmup 0 --prompt 4 --decode 8 > $O/${R}_pmc_${B}_$C.log 2>&1 || { echo "pmc $B $C failed"; tail -5 $O/${R}_pmc_${B}_$C.log; exit 1; }
     echo "pmc $B $C done"
   done

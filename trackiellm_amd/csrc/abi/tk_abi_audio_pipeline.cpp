@@ -32,7 +32,9 @@ struct tk_audio_pipeline_s {
     tk_vad_silero_context_t* vad = nullptr;
     tk_asr_whisper_context_t* asr = nullptr;
     std::atomic<int> state{TK_PIPELINE_STATE_IDLE};
-    std::mutex mu; /* the reference's worker_mutex: ring, ASR buffer, TTS queue */
+    std::mutex mu; /* the reference's worker_mutex: ring, TTS queue */
+    std::mutex asr_mu; /* the ASR segment buffer, the transcription text and the VAD / ASR contexts: the worker holds it across process_vad (mu is
+                        * released there), tk_audio_pipeline_force_transcription_end takes it too.  Lock order: mu, then asr_mu. */
     std::condition_variable cv, idle_cv;
     std::vector<int16_t> ring;
     size_t head = 0, tail = 0;
@@ -73,12 +75,20 @@ static size_t ring_fill(const tk_audio_pipeline_s* p) { return (p->head + TK_AP_
 
 static void reset_asr_state(tk_audio_pipeline_s* p) { p->transcription.clear(); }
 
-/* process_asr (:660-740): final = the accumulated segment; the transcription replaces (final) or extends (partial) the current text */
+/* process_asr (:660-740): final = the accumulated segment; the transcription replaces (final) or extends (partial) the current text.
+ * Caller holds asr_mu.  The segment is consumed on EVERY exit — also when the engine fails (a GPU error, a segment longer than the
+ * engine's buffer at sample rates above 16 kHz): a failed segment is dropped, never kept to be overrun by the next chunk. */
 static tk_error_code_t process_asr(tk_audio_pipeline_s* p, bool is_final) {
     if (p->asr_size == 0) return TK_SUCCESS;
     tk_asr_whisper_result_t* r = nullptr;
-    tk_error_code_t rc = tk_asr_whisper_process_audio(p->asr, p->asr_buf.data(), p->asr_size, is_final, &r);
-    if (rc != TK_SUCCESS) return rc;
+    const size_t n = p->asr_size;
+    p->asr_size = 0;
+    tk_error_code_t rc = tk_asr_whisper_process_audio(p->asr, p->asr_buf.data(), n, is_final, &r);
+    if (rc != TK_SUCCESS) {
+        if (r) tk_asr_whisper_free_result(&r);
+        (void)tk_asr_whisper_reset(p->asr); /* whatever part of the segment the engine buffered goes with it */
+        return rc;
+    }
     if (r && r->text && r->text[0]) {
         if (is_final) p->transcription.assign(r->text, strnlen(r->text, TK_AP_MAX_TRANSCRIPTION - 1));
         else p->transcription.append(r->text, strnlen(r->text, TK_AP_MAX_TRANSCRIPTION - 1 - p->transcription.size()));
@@ -90,8 +100,7 @@ static tk_error_code_t process_asr(tk_audio_pipeline_s* p, bool is_final) {
     }
     if (r) tk_asr_whisper_free_result(&r);
     /* the reference clears the ASR buffer only after a final pass (:735-737): a partial pass at the 30 s limit would leave it full and the
-     * following memcpy would overrun; the partial pass consumes the buffer here */
-    p->asr_size = 0;
+     * following memcpy would overrun; every pass consumes the buffer here (asr_size = 0 above) */
     return TK_SUCCESS;
 }
 
@@ -110,12 +119,14 @@ static void vad_event(tk_vad_silero_event_e e, void* u) { /* vad_event_callback 
 
 /* process_vad (:611-658): events first, then the chunk joins the segment while speech is active */
 static void process_vad(tk_audio_pipeline_s* p, const int16_t* chunk, size_t n) {
+    std::lock_guard<std::mutex> alk(p->asr_mu); /* the VAD callback (vad_event -> process_asr) runs inside this call, on this thread */
     if (tk_vad_silero_process_audio_with_events(p->vad, chunk, n, vad_event, p) != TK_SUCCESS) return;
     tk_vad_silero_state_t st;
     if (tk_vad_silero_get_state(p->vad, &st) != TK_SUCCESS) return;
     p->is_speech_active = st.is_speech_active;
     if (p->is_speech_active) {
-        if (p->asr_size + n > p->asr_buf.size()) (void)process_asr(p, false);
+        if (p->asr_size + n > p->asr_buf.size()) (void)process_asr(p, false); /* empties the buffer whether or not the engine succeeded */
+        if (p->asr_size + n > p->asr_buf.size()) return;                       /* a chunk longer than the whole 30 s buffer: dropped */
         memcpy(p->asr_buf.data() + p->asr_size, chunk, n * sizeof(int16_t));
         p->asr_size += n;
     }
@@ -283,6 +294,7 @@ tk_error_code_t tk_audio_pipeline_synthesize_text(tk_audio_pipeline_t* p, const 
 tk_error_code_t tk_audio_pipeline_force_transcription_end(tk_audio_pipeline_t* p) {
     if (!p) return TK_ERROR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(p->mu);
+    std::lock_guard<std::mutex> alk(p->asr_mu); /* waits for a process_vad in flight on the worker: one user of the segment and of the ASR context at a time */
     if (!p->is_speech_active) return TK_SUCCESS;
     tk_error_code_t rc = process_asr(p, true);
     p->is_speech_active = false;

@@ -132,9 +132,27 @@ uint64_t tk_mi355x_llm_model_weight_bytes(const tk_mi355x_llm_model_t* m) {
     return b;
 }
 
+/* Weights are immutable and 4.3 GB: a model file resident on a device is shared by every loader of the process (the reference caches
+ * per loader, src/ai_models/tk_model_loader.c:918-1083; K cortex handles — each with its own loader, tk_cortex_main.c:779-925 — would
+ * otherwise hold K copies and could not share decode passes).  force_reload loads a private copy.
+ * Lifetime: refcount = the creator / the loaders that hold the handle + every live tk_llm_runner_t created on it (a runner keeps raw
+ * pointers into the model's shared decode sessions, so the model must outlive it whatever order the host destroys things in). */
+static std::mutex g_models_mu;
+static std::vector<tk_mi355x_llm_model_t*> g_models;
+
+static void release_model(tk_mi355x_llm_model_t* m) { /* g_models_mu held */
+    if (--m->refcount > 0) return;
+    for (size_t i = 0; i < g_models.size(); ++i)
+        if (g_models[i] == m) { g_models.erase(g_models.begin() + i); break; }
+    delete m;
+}
+
 void tk_mi355x_llm_model_destroy(tk_mi355x_llm_model_t** m) {
     if (!m || !*m) return;
-    delete *m;
+    {
+        std::lock_guard<std::mutex> gl(g_models_mu);
+        release_model(*m); /* freed once the last runner created on it is gone too */
+    }
     *m = nullptr;
 }
 
@@ -336,19 +354,6 @@ struct tk_model_loader_s {
     uint32_t max_models = 4;
 };
 
-/* Weights are immutable and 4.3 GB: a model file resident on a device is shared by every loader of the process (the reference caches
- * per loader, src/ai_models/tk_model_loader.c:918-1083; K cortex handles — each with its own loader, tk_cortex_main.c:779-925 — would
- * otherwise hold K copies and could not share decode passes).  force_reload loads a private copy. */
-static std::mutex g_models_mu;
-static std::vector<tk_mi355x_llm_model_t*> g_models;
-
-static void release_model(tk_mi355x_llm_model_t* m) { /* g_models_mu held */
-    if (--m->refcount > 0) return;
-    for (size_t i = 0; i < g_models.size(); ++i)
-        if (g_models[i] == m) { g_models.erase(g_models.begin() + i); break; }
-    tk_mi355x_llm_model_destroy(&m);
-}
-
 static size_t distinct_held(const tk_model_loader_s* l) {
     size_t n = 0;
     for (size_t i = 0; i < l->held.size(); ++i) {
@@ -424,7 +429,7 @@ tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_m
         else return fail(TK_ERROR_FILE_NOT_FOUND, "unknown synthetic model: " + name);
         rc = tk_mi355x_llm_model_create(&m, &h, device);
         if (rc == TK_SUCCESS) rc = f16 ? tk_mi355x_llm_model_fill_synthetic_f16(m, seed) : tk_mi355x_llm_model_fill_synthetic(m, seed);
-        if (rc != TK_SUCCESS) { tk_mi355x_llm_model_destroy(&m); return rc; }
+        if (rc != TK_SUCCESS) { if (m) release_model(m); return rc; } /* g_models_mu is held here */
         m->path = path;
     } else {
         rc = tk_mi355x_llm_model_load_gguf(&m, path.c_str(), device);
@@ -528,6 +533,10 @@ tk_error_code_t tk_llm_runner_create(tk_llm_runner_t** out_runner, void* model_h
     std::string gerr;
     r->has_grammar = r->grammar.parse(load_tool_grammar_text(), &gerr);
     if (!r->has_grammar) tk_error_set_detail("tool-call grammar rejected (%s): tool grammar disabled", gerr.c_str()); /* the reference logs and goes on */
+    {
+        std::lock_guard<std::mutex> gl(g_models_mu);
+        r->model->refcount++; /* released in tk_llm_runner_destroy: unloading the model under a live runner cannot free its sessions */
+    }
     *out_runner = r.release();
     return TK_SUCCESS;
 }
@@ -535,6 +544,10 @@ tk_error_code_t tk_llm_runner_create(tk_llm_runner_t** out_runner, void* model_h
 void tk_llm_runner_destroy(tk_llm_runner_t** runner) {
     if (!runner || !*runner) return;
     if ((*runner)->batcher) (*runner)->batcher->release_slot((*runner)->slot); /* the shared session lives as long as the model */
+    {
+        std::lock_guard<std::mutex> gl(g_models_mu);
+        release_model((*runner)->model);
+    }
     delete *runner;
     *runner = nullptr;
 }

@@ -46,6 +46,7 @@ bool TkVadGraph::load(const char* path, int device, int window, int sample_rate)
         extra.push_back(&vi);
     }
     if (audio_in_.empty()) { error = "the graph has no float input for the audio window"; return false; }
+    if (g.outputs.empty()) { error = "the graph declares no outputs"; return false; }
     prob_out_ = g.outputs[0].name;
     for (size_t i = 0; i < extra.size(); ++i) {
         State st;

@@ -58,11 +58,12 @@ bool TkLlmBatcher::submit(int slot, int pos0, const int32_t* toks, int n, const 
 
 void TkLlmBatcher::loop() {
     std::vector<int32_t> sq, ps, tk, am;
+    std::vector<const uint32_t*> masks;
     std::vector<Request*> in_pass, completing;
     for (;;) {
         in_pass.clear(); completing.clear();
-        sq.clear(); ps.clear(); tk.clear();
-        const uint32_t* mask = nullptr;
+        sq.clear(); ps.clear(); tk.clear(); masks.clear();
+        bool any_mask = false;
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
@@ -80,30 +81,28 @@ void TkLlmBatcher::loop() {
                 cv_.wait_for(lk, std::chrono::microseconds(us), [&] { return stop_ || queue_.size() >= expect_; });
             }
             /* FIFO; a request contributes as many of its remaining rows as the pass still holds.  A grammar-masked request samples
-             * under its own token mask, which the arg max kernel takes per pass: it rides alone. */
+             * under its own token mask, which the arg max kernel takes per ROW: masked and unmasked requests share passes. */
             for (Request* r : queue_) {
                 if ((int)sq.size() >= TK_MAX_ROWS) break;
-                if (r->mask) {
-                    if (!in_pass.empty()) continue;
-                    mask = r->mask;
-                } else if (mask) {
-                    break;
-                }
                 const int take = std::min(r->n - r->done_rows, TK_MAX_ROWS - (int)sq.size());
                 for (int i = 0; i < take; ++i) {
                     sq.push_back(r->slot);
                     ps.push_back(r->pos0 + r->done_rows + i);
                     tk.push_back(r->toks[r->done_rows + i]);
+                    masks.push_back(nullptr);
                 }
                 in_pass.push_back(r);
-                if (r->done_rows + take == r->n) completing.push_back(r);
-                if (mask) break;
+                if (r->done_rows + take == r->n) {
+                    completing.push_back(r);
+                    masks.back() = r->mask; /* the row that is sampled */
+                    any_mask = any_mask || r->mask != nullptr;
+                }
             }
         }
         const int nrows = (int)sq.size();
         am.assign((size_t)nrows, -1);
         const bool head = !completing.empty();
-        const bool ok = session_.forward(nrows, sq.data(), ps.data(), tk.data(), nullptr, head ? am.data() : nullptr, head, head ? mask : nullptr);
+        const bool ok = session_.forward(nrows, sq.data(), ps.data(), tk.data(), nullptr, head ? am.data() : nullptr, head, head && any_mask ? masks.data() : nullptr);
         {
             std::lock_guard<std::mutex> lk(mu_);
             passes_++;

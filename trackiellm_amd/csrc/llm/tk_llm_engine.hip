@@ -252,7 +252,10 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     HIPQ(hipMemset(d_nsteps, 0, TK_MAX_ROWS * 4));
     hist_cap = mctx;
     HIPQ(hipMalloc((void**)&d_hist, (size_t)hist_cap * TK_MAX_ROWS * 4));
-    HIPQ(hipMalloc((void**)&d_mask, ((size_t)h.vocab + 31) / 32 * 4));
+    HIPQ(hipMalloc((void**)&d_mask, (size_t)TK_MAX_ROWS * (((size_t)h.vocab + 31) / 32) * 4));
+    HIPQ(hipMalloc((void**)&d_mask_row, TK_MAX_ROWS * 4));
+    HIPQ(hipMemset(d_mask_row, 0xFF, TK_MAX_ROWS * 4));
+    mask_rows_dirty = false;
     /* RoPE table, double precision on the host (same formula as the oracle) */
     std::vector<float> cs((size_t)mctx * half), sn((size_t)mctx * half);
     for (int p = 0; p < mctx; ++p)
@@ -279,7 +282,7 @@ TkLlmSession::~TkLlmSession() {
     for (auto& g : graph_exec) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : graph_prefill) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : graph_head_nf) if (g) (void)hipGraphExecDestroy(g);
-    void* ptrs[] = {kcache, vcache, x, qbuf, partial, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_tab};
+    void* ptrs[] = {kcache, vcache, x, qbuf, partial, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_mask_row, d_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     free_act(&act_d); free_act(&act_qd); free_act(&act_ff);
     if (stream) (void)hipStreamDestroy(stream);
@@ -313,7 +316,9 @@ int TkLlmSession::enqueue_matmul(const TkDevTensor* const* t, int nseg, int K, i
         for (int i = 0; i < nseg; ++i) { f.tiles[i] = t[i]->data; f.row_tiles[i] = (int)(t[i]->rows / TK_TILE_ROWS); }
         f.nseg = nseg; f.wbytes = 2; f.K = K; f.ks = ks; f.ldc = n_total; f.n_valid = n_total; f.nrows = nrows; f.slab_rows = TK_MAX_ROWS;
         f.a_img = act.af; f.a_ts = act.af_ts; f.out = out;
-        (void)tk_launch_gemm_tiled(f, s); /* shapes were validated when the model was installed (K a multiple of 256 ks) */
+        /* shapes were validated when the model was installed (K a multiple of 256 ks); a refusal here would leave the slab unwritten, so it is
+         * recorded and fails the pass (forward / decode / capture_pass check launch_error) instead of producing garbage silently */
+        if (!tk_launch_gemm_tiled(f, s) && launch_error.empty()) launch_error = "tiled GEMM launch refused (shape outside what the f16 path supports)";
         return ks;
     }
     TkGemvArgs a{};
@@ -356,7 +361,7 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
     tk_launch_rmsnorm_q8(x, l1 > l0 ? partial : nullptr, ks_res, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
     const TkDevTensor* lm[1] = {&model->output};
     (void)enqueue_matmul(lm, 1, D, 1, h.vocab, act_d, logits, nrows);
-    tk_launch_argmax(logits, h.vocab, nrows, mask_on ? d_mask : nullptr, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
+    tk_launch_argmax(logits, h.vocab, nrows, d_mask, d_mask_row, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
 }
 
 static bool graphs_enabled() {
@@ -374,15 +379,26 @@ bool TkLlmSession::capture_pass(hipGraphExec_t* slot, int nrows, bool lm_head, b
     std::lock_guard<std::mutex> lk(g_capture_mu);
     hipGraph_t g = nullptr;
     HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+    launch_error.clear();
     enqueue_pass(nrows, lm_head, fused_attn);
-    HIPQ(hipStreamEndCapture(stream, &g));
-    HIPQ(hipGraphInstantiate(slot, g, nullptr, nullptr, 0));
-    HIPQ(hipGraphDestroy(g));
+    /* from here on the stream must leave capture mode and the graph must be freed whatever fails */
+    const hipError_t e_end = hipStreamEndCapture(stream, &g);
+    hipError_t e_inst = hipSuccess;
+    if (e_end == hipSuccess && launch_error.empty()) e_inst = hipGraphInstantiate(slot, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (e_end != hipSuccess || e_inst != hipSuccess || !launch_error.empty()) {
+        if (*slot && e_inst != hipSuccess) { (void)hipGraphExecDestroy(*slot); }
+        *slot = nullptr;
+        (void)hipGetLastError();
+        error = !launch_error.empty() ? launch_error
+                : std::string("graph capture of a pass failed: ") + hipGetErrorString(e_end != hipSuccess ? e_end : e_inst);
+        return false;
+    }
     return true;
 }
 
 bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
-                           bool lm_head, const uint32_t* allow_mask) {
+                           bool lm_head, const uint32_t* const* row_masks) {
     if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,256]"; return false; }
     for (int r = 0; r < nrows; ++r) {
         if (seq[r] < 0 || seq[r] >= max_seq || pos[r] < 0 || pos[r] >= max_ctx || tok[r] < 0 || tok[r] >= model->hp.vocab) {
@@ -399,19 +415,34 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
     for (int a = 0; a < nrows && distinct; ++a)
         for (int b = a + 1; b < nrows; ++b)
             if (seq[a] == seq[b]) { distinct = false; break; }
-    if (allow_mask && lm_head) HIPQ(hipMemcpyAsync(d_mask, allow_mask, ((size_t)model->hp.vocab + 31) / 32 * 4, hipMemcpyHostToDevice, stream));
-    mask_on = allow_mask != nullptr && lm_head;
-    /* unmasked passes replay a captured pass (one graph per (row count, form)): a host that asks for one token at a time — the
-     * reference's runner API — pays one graph launch, not ~260 kernel launches, per token */
-    hipGraphExec_t* slot = mask_on || !graphs_enabled() ? nullptr
+    if (lm_head) { /* per-row sampling masks: the masks of the constrained rows, compacted, + the row -> mask table the arg max kernel reads */
+        int32_t rowtab[TK_MAX_ROWS];
+        int nmask = 0;
+        const size_t words = ((size_t)model->hp.vocab + 31) / 32;
+        for (int r = 0; r < TK_MAX_ROWS; ++r) rowtab[r] = -1;
+        for (int r = 0; r < nrows; ++r) {
+            if (row_masks && row_masks[r]) {
+                HIPQ(hipMemcpyAsync(d_mask + (size_t)nmask * words, row_masks[r], words * 4, hipMemcpyHostToDevice, stream));
+                rowtab[r] = nmask++;
+            }
+        }
+        if (nmask > 0 || mask_rows_dirty) {
+            HIPQ(hipMemcpyAsync(d_mask_row, rowtab, TK_MAX_ROWS * 4, hipMemcpyHostToDevice, stream)); /* whole table (a wider pass may have left entries); pageable source: staged before the call returns */
+            mask_rows_dirty = nmask > 0;
+        }
+    }
+    /* a pass replays a captured graph (one per (row count, form)): a host that asks for one token at a time — the reference's runner
+     * API — pays one graph launch, not ~260 kernel launches, per token; masked rows ride the same graphs (the table above is data) */
+    hipGraphExec_t* slot = !graphs_enabled() ? nullptr
                            : !lm_head ? &graph_prefill[nrows] : distinct ? &graph_exec[nrows] : &graph_head_nf[nrows];
     if (slot) {
-        if (!capture_pass(slot, nrows, lm_head, lm_head && distinct)) { mask_on = false; return false; }
+        if (!capture_pass(slot, nrows, lm_head, lm_head && distinct)) return false;
         HIPQ(hipGraphLaunch(*slot, stream));
     } else {
+        launch_error.clear();
         enqueue_pass(nrows, lm_head, distinct);
     }
-    mask_on = false;
+    if (!launch_error.empty()) { error = launch_error; (void)hipStreamSynchronize(stream); return false; }
     HIPQ(hipGetLastError());
     if (!lm_head) { HIPQ(hipStreamSynchronize(stream)); return true; }
     if (logits_host) HIPQ(hipMemcpyAsync(logits_host, logits, (size_t)nrows * model->hp.vocab * 4, hipMemcpyDeviceToHost, stream));
@@ -438,13 +469,16 @@ bool TkLlmSession::forward_stage(int nrows, const int32_t* seq, const int32_t* p
     HIPQ(hipMemcpyAsync(d_pos, pos, nrows * 4, hipMemcpyHostToDevice, stream));
     if (tok) HIPQ(hipMemcpyAsync(d_tok, tok, nrows * 4, hipMemcpyHostToDevice, stream));
     HIPQ(hipMemsetAsync(d_nsteps, 0, TK_MAX_ROWS * 4, stream));
+    if (mask_rows_dirty) { HIPQ(hipMemsetAsync(d_mask_row, 0xFF, TK_MAX_ROWS * 4, stream)); mask_rows_dirty = false; }
     const size_t xb = (size_t)nrows * h.d_model * 4;
     if (x_in) HIPQ(hipMemcpyAsync(x, x_in, xb, x_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream));
     bool distinct = true;
     for (int a = 0; a < nrows && distinct; ++a)
         for (int b = a + 1; b < nrows; ++b)
             if (seq[a] == seq[b]) { distinct = false; break; }
+    launch_error.clear();
     enqueue_range(nrows, l0, l1, tok != nullptr, !head, head, distinct);
+    if (!launch_error.empty()) { error = launch_error; (void)hipStreamSynchronize(stream); return false; }
     HIPQ(hipGetLastError());
     if (!head) HIPQ(hipMemcpyAsync(x_out, x, xb, x_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, stream));
     else if (argmax_host) HIPQ(hipMemcpyAsync(argmax_host, d_tok, nrows * 4, hipMemcpyDeviceToHost, stream));
@@ -490,7 +524,7 @@ bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_
             if (use_graph && !capture_pass(&graph_prefill[n], n, false, false)) return false;
             hipLaunchKernelGGL(k_stage_rows, dim3((n + 255) / 256), dim3(256), 0, stream, d_tab + off, n, (int)total, d_seq, d_pos, d_tok);
             if (use_graph) HIPQ(hipGraphLaunch(graph_prefill[n], stream));
-            else enqueue_pass(n, false, false);
+            else { launch_error.clear(); enqueue_pass(n, false, false); if (!launch_error.empty()) { error = launch_error; return false; } }
         }
         HIPQ(hipGetLastError());
     }
@@ -513,14 +547,16 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     const bool use_graph = graphs_enabled();
     if (use_graph && !capture_pass(&graph_exec[nrows], nrows, true, true)) return false;
     HIPQ(hipMemsetAsync(d_nsteps, 0, TK_MAX_ROWS * 4, stream));
+    if (mask_rows_dirty) { HIPQ(hipMemsetAsync(d_mask_row, 0xFF, TK_MAX_ROWS * 4, stream)); mask_rows_dirty = false; } /* the loop samples unconstrained */
     hipEvent_t e0, e1;
     HIPQ(hipEventCreate(&e0));
     HIPQ(hipEventCreate(&e1));
     HIPQ(hipEventRecord(e0, stream));
     for (int i = 0; i < n_steps; ++i) {
         if (use_graph) HIPQ(hipGraphLaunch(graph_exec[nrows], stream));
-        else enqueue_pass(nrows, true, true);
+        else { launch_error.clear(); enqueue_pass(nrows, true, true); if (!launch_error.empty()) { error = launch_error; break; } }
     }
+    if (!launch_error.empty()) { (void)hipStreamSynchronize(stream); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); launch_error.clear(); return false; }
     HIPQ(hipGetLastError());
     HIPQ(hipEventRecord(e1, stream));
     if (out_tokens_host) HIPQ(hipMemcpyAsync(out_tokens_host, d_hist, (size_t)n_steps * TK_MAX_ROWS * 4, hipMemcpyDeviceToHost, stream));

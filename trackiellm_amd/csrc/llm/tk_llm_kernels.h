@@ -65,7 +65,8 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
                          uint16_t* kcache, uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows, int n_head, int n_kv_head,
                          int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, bool fused, hipStream_t s);
 void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ8 out, hipStream_t s);
-void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow /* optional allowed-token bits */, int32_t* tok, int32_t* pos,
+/* allow_base / allow_row (both optional): per-row allowed-token bit masks, allow_row[r] = mask index or -1 */
+void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow_base, const int32_t* allow_row, int32_t* tok, int32_t* pos,
                       int32_t* nsteps, int32_t* hist, int hist_stride, hipStream_t s);
 
 size_t tk_gemv_lds_bytes(int K, int ks, int mtiles);

@@ -1425,12 +1425,16 @@ void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ
  * greedy sampling: first index of the maximum; feeds the next step entirely on-device
  * (tok <- argmax, pos <- pos + 1, history append) so a decode loop is a pure graph replay.
  * ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab, const uint32_t* allow, int32_t* tok, int32_t* pos, int32_t* nsteps,
-                                                  int32_t* hist, int hist_stride) {
+__global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab, const uint32_t* allow_base, const int32_t* allow_row, int32_t* tok,
+                                                  int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     const int r = blockIdx.x, t = threadIdx.x;
     const float* lg = logits + (int64_t)r * vocab;
+    /* per-row token masks: allow_row[r] = index of this row's mask ((vocab + 31) / 32 words each) or -1 = unconstrained, so rows sampling
+     * under different grammars — and rows under none — share one pass */
+    const int mi = allow_row ? allow_row[r] : -1;
+    const uint32_t* allow = mi >= 0 ? allow_base + (size_t)mi * ((vocab + 31) / 32) : nullptr;
     float best = -INFINITY;
     int idx = 0x7fffffff;
     for (int i = t; i < vocab; i += 1024) {
@@ -1458,9 +1462,9 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab,
     }
 }
 
-void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow, int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist,
-                      int hist_stride, hipStream_t s) {
-    hipLaunchKernelGGL(k_argmax, dim3(nrows), dim3(1024), 0, s, logits, vocab, allow, tok, pos, nsteps, hist, hist_stride);
+void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow_base, const int32_t* allow_row, int32_t* tok, int32_t* pos,
+                      int32_t* nsteps, int32_t* hist, int hist_stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_argmax, dim3(nrows), dim3(1024), 0, s, logits, vocab, allow_base, allow_row, tok, pos, nsteps, hist, hist_stride);
 }
 
 /* ------------------------------------------------------------------------------------------

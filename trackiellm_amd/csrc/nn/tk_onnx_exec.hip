@@ -539,6 +539,7 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         } else if (op == "Flatten") {
             int64_t ax = nd.ai("axis", 1);
             if (ax < 0) ax += (int64_t)y.shape.size();
+            if (ax < 0 || ax > (int64_t)y.shape.size()) { error = "Flatten axis outside the rank of its input"; return false; }
             int64_t a = 1, b = 1;
             for (size_t i = 0; i < y.shape.size(); ++i) ((int64_t)i < ax ? a : b) *= y.shape[i];
             y.shape = {a, b};
@@ -608,6 +609,7 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         if (r > 4) { error = "rank > 4"; return false; }
         int64_t ax = nd.ai("axis", 0);
         if (ax < 0) ax += (int64_t)r;
+        if (ax < 0 || ax >= (int64_t)r) { error = "Concat axis outside the rank of its inputs"; return false; }
         std::vector<int64_t> os = parts[0].shape;
         os[(size_t)ax] = 0;
         for (const Val& p : parts) {
@@ -636,6 +638,7 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         std::vector<int64_t> pads;
         if (!ints_arg("pads", 1, &pads)) { error = "pads are missing"; return false; }
         const size_t r = xc.shape.size();
+        if (r == 0) { error = "Pad of a rank-0 tensor"; return false; }
         if (pads.size() != 2 * r) { error = "pads have the wrong length"; return false; }
         const std::string mode = nd.as("mode", "constant");
         if (mode != "constant" && mode != "reflect") { error = "pad mode '" + mode + "' is not supported"; return false; }

@@ -71,6 +71,7 @@ bool TkDepthEngine::load(const char* onnx_path, int device, uint32_t in_w, uint3
             break;
         }
     if (in_name_.empty()) { error = "the model has no float input"; return false; }
+    if (g.outputs.empty()) { error = "the graph declares no outputs"; return false; }
     out_name_ = g.outputs[0].name;
     const size_t px = (size_t)in_w_ * in_h_;
     DQ(hipMalloc((void**)&chw_dev_, 3 * px * 4));
