@@ -465,6 +465,9 @@ def main():
         args.llm_only, args.steps, args.warmup = True, 0, 0
     fused = not args.llm_only
     cb = CycleBench(tk, model, G, B, P, N, fused, rank, local_rank, args.perception_batch, args.asr_steps)
+    if os.environ.get("TK_BENCH_DUMP_MAPS"):  # the load map of THIS process, for symbolising a profiler abort against it (tools/symbolise_crash.py)
+        with open("/proc/self/maps") as f, open(os.environ["TK_BENCH_DUMP_MAPS"], "w") as g:
+            g.write(f.read())
     r = cb.run(args.steps, args.warmup, barrier) if args.steps > 0 else None
     elapsed = r["elapsed"] if r else 0.0
     if dist is not None and r:

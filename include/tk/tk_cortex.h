@@ -5,9 +5,13 @@
  * Scope: a minimal cortex that wires the three GPU streams and reports state changes —
  *   frame  -> tk_object_detector_detect -> (>= 1 object) -> context string -> LLM      (tk_cortex_main.c:1149-1237, 1323-1379)
  *   PCM    -> VAD (events) -> accumulate -> speech end -> ASR final -> LLM              (tk_cortex_main.c:660-666, 1662-1684)
- * Decision engine, contextual reasoner, navigation, sensor fusion and TTS stay outside (§8 "out of scope");
- * on_tts_audio_ready is therefore never invoked and tk_cortex_inject_sensor_event accepts and drops the event.
- * model paths accept the synthetic:// forms of the per-stream headers; NULL picks the synthetic default.
+ * The contextual reasoner (tk_reasoner.h) assembles the prompt and the decision engine's parser reads the response; navigation, sensor
+ * fusion and TTS synthesis stay outside (§8 "out of scope"): on_tts_audio_ready is never invoked and tk_cortex_inject_sensor_event
+ * accepts and drops the event.
+ * model paths accept the synthetic:// forms of the per-stream headers; a NULL path picks that stream's synthetic default — unless ALL of
+ * llm / object_detection / depth / asr / vad are NULL: that cortex has no engines, only its contextual reasoner (what the reference's
+ * tests/tk_cortex_full_test.c:20-34 creates: "All paths are NULL", gpu_device_id -1); it runs without a GPU and refuses injected
+ * frames / audio with TK_ERROR_INVALID_STATE.
  * Unlike the reference (which stores the caller's frame pointer, tk_cortex_main.c:682), injected frames are copied.
  */
 #ifndef TK_MI355X_CORTEX_H
@@ -68,6 +72,9 @@ TK_API TK_NODISCARD tk_error_code_t tk_cortex_inject_audio_frame(tk_cortex_t* co
 TK_API TK_NODISCARD tk_error_code_t tk_cortex_inject_video_frame(tk_cortex_t* cortex, const tk_video_frame_t* frame);
 TK_API TK_NODISCARD tk_error_code_t tk_cortex_inject_sensor_event(tk_cortex_t* cortex, const tk_sensor_event_t* event);
 TK_API TK_NODISCARD tk_error_code_t tk_cortex_get_state(const tk_cortex_t* cortex, tk_system_state_e* out_state);
+/* src/cortex/tk_cortex_main.h:321-331 ("for testing purposes only"): the cortex's contextual reasoner, or NULL */
+struct tk_contextual_reasoner_s;
+TK_API struct tk_contextual_reasoner_s* tk_cortex_get_contextual_reasoner(tk_cortex_t* cortex);
 
 /* ---- extensions ---- */
 typedef struct {

@@ -76,6 +76,14 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_forward(tk_mi355x_llm_session_
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_forward_stage(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos,
                                                                 const int32_t* tok, const float* x_in, float* x_out, int x_on_host, int layer0,
                                                                 int layer1, int head, int32_t* argmax);
+/* KV cache import / export: positions [pos0, pos0 + n_pos) of one (layer, sequence) as IEEE f16 bits, host arrays laid out
+ * [position][kv head][head_dim] (what llama.cpp's llama_state_seq_* moves for one sequence; the reference clears the cache per prompt,
+ * src/ai_models/tk_runner_streaming.c:31, so it has no counterpart there).  Restores a saved prompt prefix; the parity tests use it to put
+ * the attention launch at any context length in one decode step.  Synchronous. */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_session_kv_write(tk_mi355x_llm_session_t* s, int layer, int seq, int pos0, int n_pos,
+                                                                   const uint16_t* k, const uint16_t* v);
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_session_kv_read(tk_mi355x_llm_session_t* s, int layer, int seq, int pos0, int n_pos,
+                                                                  uint16_t* k, uint16_t* v);
 /* equal-length prompts for sequences 0..nseq-1; first_tokens[nseq] optional */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_prefill(tk_mi355x_llm_session_t* s, int nseq, int n_prompt, const int32_t* tokens,
                                                           int32_t* first_tokens);

@@ -9,8 +9,14 @@
  * Same names, argument meaning and error codes as the reference.  Both reference TUs are unbuildable here (undeclared
  * tk_critical_event_cb_t / TK_ERROR_SYSTEM_ERROR, cJSON absent): the formats are restated from the sources cited above and
  * pinned by hand-derived strings in tests/test_reasoner_cpu.py — "parity unpinned" against a compiled reference.
- * Out of scope (navigation / sensor fusion): _update_navigation_context and _update_motion_context take types of those
- * subsystems; the navigation sentence of the context string is driven through tk_mi355x_reasoner_set_navigation instead.
+ * The rest of the reasoner's public surface (src/cortex/tk_contextual_reasoner.h:198-389) is here too: ambient sound / navigation cue /
+ * navigation / motion updates (.c:243-352, 443-519, 1121-1160), relevance decay + pruning (_process_context .c:604-622, 965-1012), the
+ * structured summary (_get_context_summary .c:626-677) and _get_motion_state (.c:226-239).  The navigation and sensor-fusion ENGINES that
+ * produce their inputs stay out of scope: only the plain structs those entry points read are declared below, field for
+ * field (src/navigation/tk_path_planner.h:71-85, tk_free_space_detector.h:50-68, tk_obstacle_avoider.h:46-77, src/sensors/tk_sensors_fusion.h:65-93).
+ * The prompt generator the reference keeps on its Rust side — tk_cortex_rust_init_reasoner / tk_cortex_generate_prompt / tk_cortex_rust_set_fact
+ * (src/cortex/src/ffi.rs:262,370,427; body src/cortex/src/reasoning.rs:436-480) — is restated in C++ (csrc/cortex/tk_prompt.cpp) and pinned by
+ * the reference's own enabled test, tests/tk_cortex_full_test.c:36-70, replayed in tests/test_reasoner_cpu.py and as a C host.
  * Pure host code: no GPU is involved.
  */
 #ifndef TK_MI355X_REASONER_H
@@ -40,7 +46,62 @@ typedef enum {
     TK_CONTEXT_TYPE_SYSTEM_STATE
 } tk_context_type_e;
 
+/* src/cortex/tk_contextual_reasoner.h:88-112 */
+typedef enum { TK_AMBIENT_SOUND_NONE, TK_AMBIENT_SOUND_FIRE_ALARM, TK_AMBIENT_SOUND_CAR_HORN, TK_AMBIENT_SOUND_SIREN, TK_AMBIENT_SOUND_BABY_CRYING, TK_AMBIENT_SOUND_DOORBELL } tk_ambient_sound_type_e;
+typedef enum { TK_NAVIGATION_CUE_NONE, TK_NAVIGATION_CUE_STEP_UP, TK_NAVIGATION_CUE_STEP_DOWN, TK_NAVIGATION_CUE_DOORWAY, TK_NAVIGATION_CUE_STAIRS_UP, TK_NAVIGATION_CUE_STAIRS_DOWN } tk_navigation_cue_type_e;
+
+/* inputs of the navigation / motion updates: plain structs of the (out of scope) engines that fill them */
+typedef enum { TK_TRAVERSABILITY_UNKNOWN, TK_TRAVERSABILITY_TRAVERSABLE, TK_TRAVERSABILITY_OBSTACLE, TK_TRAVERSABILITY_HAZARD_STEP_UP, TK_TRAVERSABILITY_HAZARD_STEP_DOWN, TK_TRAVERSABILITY_HAZARD_HOLE } tk_traversability_type_e;
+typedef struct { uint32_t width; uint32_t height; float resolution_m_per_cell; tk_traversability_type_e* grid; } tk_traversability_map_t;   /* tk_path_planner.h:71-75 */
+typedef struct { tk_traversability_type_e type; float distance_m; float direction_deg; } tk_navigation_hazard_t;                          /* tk_path_planner.h:81-85 */
+typedef struct { float center_angle_deg; float max_clear_distance_m; bool is_clear; } tk_space_sector_t;                                  /* tk_free_space_detector.h:50-54 */
+typedef struct { const tk_space_sector_t* sectors; size_t sector_count; bool is_any_path_clear; float clearest_path_angle_deg; float clearest_path_distance_m; } tk_free_space_analysis_t; /* :60-68 */
+typedef enum { TK_OBSTACLE_STATUS_NEW, TK_OBSTACLE_STATUS_TRACKED, TK_OBSTACLE_STATUS_COASTED } tk_obstacle_status_e;
+typedef struct { float x; float y; } tk_vector2d_t;
+typedef struct { uint32_t id; tk_obstacle_status_e status; tk_vector2d_t position_m; tk_vector2d_t velocity_mps; tk_vector2d_t dimensions_m; uint32_t age_frames; uint32_t unseen_frames; } tk_obstacle_t; /* tk_obstacle_avoider.h:69-77 */
+typedef enum { TK_MOTION_STATE_UNKNOWN, TK_MOTION_STATE_STATIONARY, TK_MOTION_STATE_WALKING, TK_MOTION_STATE_RUNNING, TK_MOTION_STATE_FALLING } tk_motion_state_e; /* tk_sensors_fusion.h:65-71 */
+typedef struct { float w, x, y, z; } tk_quaternion_t;
+typedef struct { uint64_t last_update_timestamp_ns; tk_quaternion_t orientation; tk_motion_state_e motion_state; bool is_speech_detected; } tk_world_state_t; /* tk_sensors_fusion.h:88-93 */
+
+/* src/cortex/tk_contextual_reasoner.h:132-176 */
+typedef struct { uint64_t timestamp_ns; bool is_user_input; char* content; float confidence; } tk_conversation_turn_t;
+typedef struct {
+    size_t visible_object_count;
+    const tk_vision_object_t* visible_objects;
+    bool has_clear_path;
+    float clear_path_direction_deg;
+    float clear_path_distance_m;
+    size_t hazard_count;
+    const tk_navigation_hazard_t* hazards;
+    size_t conversation_turn_count;
+    const tk_conversation_turn_t* recent_conversation; /* the circular buffer itself, max_conversation_history_turns entries (read-only) */
+    char* recent_events_summary;                       /* always NULL ("left for future use", .c:667) */
+    bool is_navigation_active;
+    bool is_listening_for_commands;
+    float system_confidence;
+    tk_motion_state_e user_motion_state;
+    tk_ambient_sound_type_e detected_sound_type;
+    tk_navigation_cue_type_e detected_navigation_cue;
+} tk_context_summary_t;
+
 TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_create(tk_contextual_reasoner_t** out_reasoner, const tk_context_config_t* config);
+/* remembers the sound and files "<Sound> detected (confidence: <c>%)" as an ENVIRONMENTAL item (fire alarm CRITICAL, siren / horn HIGH, baby
+ * MEDIUM, doorbell LOW); NONE only clears the remembered sound (.c:243-297) */
+TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_update_ambient_sound(tk_contextual_reasoner_t* reasoner, tk_ambient_sound_type_e sound_type, float confidence);
+/* remembers the cue and files "<Cue> detected at <d>m" as a NAVIGATIONAL item (HIGH; doorway MEDIUM) (.c:301-350) */
+TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_update_navigation_cues(tk_contextual_reasoner_t* reasoner, tk_navigation_cue_type_e cue_type, float distance_m);
+/* clear-path snapshot from the free-space analysis (the hazard list is reset and, as in the reference, never refilled), one item for the
+ * path and one per obstacle for the first five (HIGH below 1.5 m) (.c:443-519) */
+TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_update_navigation_context(tk_contextual_reasoner_t* reasoner, const tk_traversability_map_t* traversability_map,
+                                                                                     const tk_free_space_analysis_t* free_space_analysis, const tk_obstacle_t* obstacles,
+                                                                                     size_t obstacle_count);
+/* motion state from sensor fusion; a change files a USER_STATE item ("User started walking", "Fall detected!", ...) (.c:1121-1160) */
+TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_update_motion_context(tk_contextual_reasoner_t* reasoner, const tk_world_state_t* world_state);
+/* relevance *= exp(-memory_decay_rate * age_s) for every item, then items below context_relevance_threshold are dropped (.c:604-622, 965-1012) */
+TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_process_context(tk_contextual_reasoner_t* reasoner, uint64_t current_time_ns);
+/* pointers stay owned by the reasoner, valid until the next update (.c:626-677) */
+TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_get_context_summary(tk_contextual_reasoner_t* reasoner, tk_context_summary_t* out_summary);
+TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_get_motion_state(tk_contextual_reasoner_t* reasoner, tk_motion_state_e* out_state);
 TK_API void tk_contextual_reasoner_destroy(tk_contextual_reasoner_t** reasoner);
 /* copies up to 64 objects (labels are copied too: the result may be destroyed afterwards) and files one context item
  * "Detected <label> at <d>m (confidence <c>%)" per object with confidence >= 0.7 */
@@ -58,9 +119,17 @@ TK_API tk_error_code_t tk_contextual_reasoner_free_context_string(char* ptr);
 TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_clear_context(tk_contextual_reasoner_t* reasoner);
 TK_API TK_NODISCARD tk_error_code_t tk_contextual_reasoner_get_memory_stats(tk_contextual_reasoner_t* reasoner, size_t* out_total_items,
                                                                             size_t* out_total_memory_bytes, size_t* out_conversation_turns);
-/* extension: the navigation state the reference fills from its path planner (out of scope) */
-TK_API TK_NODISCARD tk_error_code_t tk_mi355x_reasoner_set_navigation(tk_contextual_reasoner_t* reasoner, bool has_clear_path, float direction_deg,
-                                                                      float distance_m, size_t hazard_count);
+
+/* ---- prompt generator (the reference's Rust side: src/cortex/src/ffi.rs:262,370,427; src/cortex/src/reasoning.rs:436-480) ----
+ * One process-wide generator bound to a reasoner, as the reference's `static REASONER`.  tk_cortex_generate_prompt reads the reasoner's
+ * summary and writes, in this order: "URGENTE: ALARME DE INCÊNDIO DETECTADO. " (fire alarm) / "URGENTE: QUEDA DO USUÁRIO DETECTADA. "
+ * (falling), the navigation cue sentence ("Há um degrau para baixo à frente. " ...), the motion sentence ("O usuário está andando. " /
+ * "... correndo. " / "... parado. "), "O nome do usuário é <name>. " when the fact user_name is set, "O usuário perguntou: '<query>'. " and
+ * "Com base em tudo isso, qual a ação mais segura e útil?"; copied with strncpy semantics into prompt_buffer (always NUL terminated).
+ * Returns false for a NULL / empty buffer; an unbound generator writes the reference's fallback prompt and returns true. */
+TK_API void tk_cortex_rust_init_reasoner(tk_contextual_reasoner_t* reasoner_ptr);
+TK_API bool tk_cortex_generate_prompt(char* prompt_buffer, size_t buffer_size, const char* user_query);
+TK_API void tk_cortex_rust_set_fact(const char* key, const char* value);
 
 /* ---- LLM response parsing: src/cortex/tk_decision_engine.h:61-190 ---- */
 typedef enum {

@@ -15,6 +15,14 @@
  *   - llama.cpp's CPU numerics structure for k-quants: activations are quantised per
  *     256-block to int8 (Q8_K: d = amax/127, bsums) and the dot product is integer inside
  *     a block, float across blocks (ggml_vec_dot_q4_K_q8_K / q6_K_q8_K as published).
+ *     Q8_K scale convention, stated because it differs from the published quantize_row_q8_K
+ *     by one rounding: here id = 127 / amax (one division), q = rint(x * id), d = amax / 127
+ *     (a second, independent division).  Published ggml picks the signed extreme `max`,
+ *     iscale = -127 / max (older revisions -128 / max), q = nearest_int(iscale * x) clamped to
+ *     127, d = 1 / iscale: the same integers up to the sign convention of the extreme element
+ *     and a d that is the reciprocal of the rounded iscale instead of amax / 127 — a relative
+ *     difference of at most one ulp in d (<= 6e-8), far inside the 1e-3 logit tolerance north_star
+ *     names; the HIP path and this oracle share THIS convention and agree bit for bit.
  * It is pinned by (i) an independent fp32 torch implementation on de-quantised weights
  * (tests/golden/make_llm_golden.py -> tests/golden/llm_tiny.npz) and (ii) the codec
  * round-trip fixtures.
@@ -493,6 +501,24 @@ void orc_llm_forward(orc_llm* m, int n_rows, const int32_t* seq, const int32_t* 
             argmax[r] = best;
         }
     }
+}
+
+/* test hooks: write / read cache rows [pos0, pos0 + n_pos) of one (layer, sequence) as f16 bits in [position][kv head][dim] order, so a
+ * long-context attention case needs one decode step instead of a whole prefill (the product's twin: tk_mi355x_llm_session_kv_write) */
+void orc_llm_kv_write(orc_llm* m, int layer, int seq, int pos0, int n_pos, const uint16_t* k, const uint16_t* v) {
+    const orc_llm_config_t& c = m->cfg;
+    const size_t row = (size_t)c.n_kv_head * c.head_dim;
+    const size_t base = (((size_t)layer * c.max_seq + seq) * c.max_ctx + pos0) * row;
+    memcpy(&m->kcache[base], k, (size_t)n_pos * row * 2);
+    memcpy(&m->vcache[base], v, (size_t)n_pos * row * 2);
+}
+
+void orc_llm_kv_read(orc_llm* m, int layer, int seq, int pos0, int n_pos, uint16_t* k, uint16_t* v) {
+    const orc_llm_config_t& c = m->cfg;
+    const size_t row = (size_t)c.n_kv_head * c.head_dim;
+    const size_t base = (((size_t)layer * c.max_seq + seq) * c.max_ctx + pos0) * row;
+    memcpy(k, &m->kcache[base], (size_t)n_pos * row * 2);
+    memcpy(v, &m->vcache[base], (size_t)n_pos * row * 2);
 }
 
 void orc_llm_reset(orc_llm* m) {

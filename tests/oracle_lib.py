@@ -55,6 +55,8 @@ def lib():
         L.orc_llm_get_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int64]
         L.orc_llm_tensor_type.argtypes = [C.POINTER(LlmConfig), C.c_int, C.c_int]
         L.orc_llm_forward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.orc_llm_kv_write.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 2
+        L.orc_llm_kv_read.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 2
         L.orc_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         L.orc_q8k_quantize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_gemv_q8.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 4
@@ -113,6 +115,19 @@ class OracleLlm:
             lib().orc_dequant_row(t, ptr(buf), cols, r, ptr(row))
             out[r] = row
         return out
+
+    def kv_write(self, layer, seq, pos0, k, v):
+        """k, v: uint16 (f16 bits) [n_pos][n_kv_head][head_dim]"""
+        k = np.ascontiguousarray(k, dtype=np.uint16)
+        v = np.ascontiguousarray(v, dtype=np.uint16)
+        assert k.shape == v.shape and k.shape[1:] == (self.cfg.n_kv_head, self.cfg.head_dim) and pos0 + k.shape[0] <= self.cfg.max_ctx
+        lib().orc_llm_kv_write(self.h, layer, seq, pos0, k.shape[0], ptr(k), ptr(v))
+
+    def kv_read(self, layer, seq, pos0, n_pos):
+        k = np.empty((n_pos, self.cfg.n_kv_head, self.cfg.head_dim), np.uint16)
+        v = np.empty_like(k)
+        lib().orc_llm_kv_read(self.h, layer, seq, pos0, n_pos, ptr(k), ptr(v))
+        return k, v
 
     def forward(self, seq, pos, tok, want_logits=True):
         seq = np.ascontiguousarray(seq, dtype=np.int32)

@@ -153,6 +153,16 @@ tk_error_code_t tk_cortex_create(tk_cortex_t** out_cortex, const tk_cortex_confi
     tk_error_code_t rc;
     tk_path_t* p = nullptr;
     auto fail = [&](tk_error_code_t e) { tk_cortex_t* raw = c.release(); tk_cortex_destroy(&raw); return e; };
+    const tk_model_paths_t& mp = config->model_paths;
+    if (!mp.llm_model && !mp.object_detection_model && !mp.depth_estimation_model && !mp.asr_model && !mp.vad_model) {
+        /* no model at all (tests/tk_cortex_full_test.c:20-34: "All paths are NULL", device -1): a cortex whose only subsystem is the contextual
+         * reasoner.  No GPU is touched; injected frames / audio are refused (TK_ERROR_INVALID_STATE). */
+        tk_context_config_t cc{100, 20, 0.3f, 0.95f, 100}; /* tk_cortex_main.c:835-841 */
+        if ((rc = tk_contextual_reasoner_create(&c->reasoner, &cc)) != TK_SUCCESS) return fail(rc);
+        set_state(c.get(), TK_STATE_IDLE);
+        *out_cortex = c.release();
+        return TK_SUCCESS;
+    }
 
     if ((rc = mkpath(config->model_paths.object_detection_model, "synthetic://yolov8n?seed=5&cls_bias=-0.45", &p)) != TK_SUCCESS) return fail(rc);
     {
@@ -288,8 +298,11 @@ static bool enqueue(tk_cortex_s* c, CortexEvent&& ev) {
     return true;
 }
 
+tk_contextual_reasoner_t* tk_cortex_get_contextual_reasoner(tk_cortex_t* cortex) { return cortex ? cortex->reasoner : NULL; } /* tk_cortex_main.c:743-748 */
+
 tk_error_code_t tk_cortex_inject_video_frame(tk_cortex_t* c, const tk_video_frame_t* frame) {
     if (!c || !frame || !frame->data || frame->width == 0 || frame->height == 0) return TK_ERROR_INVALID_ARGUMENT;
+    if (!c->vis) return TK_ERROR_INVALID_STATE; /* a cortex created without models */
     const uint32_t bpp = frame->format == TK_PIXEL_FORMAT_RGBA8 ? 4 : 3;
     const uint32_t stride = frame->stride ? frame->stride : frame->width * bpp;
     int slot;
@@ -316,6 +329,7 @@ static void on_vad(tk_vad_silero_event_e e, void* u) {
 
 tk_error_code_t tk_cortex_inject_audio_frame(tk_cortex_t* c, const int16_t* audio_data, size_t frame_count) {
     if (!c || !audio_data) return TK_ERROR_INVALID_ARGUMENT;
+    if (!c->vad || !c->asr) return TK_ERROR_INVALID_STATE; /* a cortex created without models */
     std::lock_guard<std::mutex> lk(c->audio_mu);
     VadCtx v{c, false, false};
     tk_error_code_t rc = tk_vad_silero_process_audio_with_events(c->vad, audio_data, frame_count, on_vad, &v);

@@ -252,6 +252,18 @@ tk_error_code_t tk_mi355x_llm_forward(tk_mi355x_llm_session_t* s, int nrows, con
     return TK_SUCCESS;
 }
 
+tk_error_code_t tk_mi355x_llm_session_kv_write(tk_mi355x_llm_session_t* s, int layer, int seq, int pos0, int n_pos, const uint16_t* k, const uint16_t* v) {
+    if (!s || !k || !v) return TK_ERROR_INVALID_ARGUMENT;
+    if (!s->session.kv_write(layer, seq, pos0, n_pos, k, v)) return fail(TK_ERROR_INVALID_ARGUMENT, s->session.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_session_kv_read(tk_mi355x_llm_session_t* s, int layer, int seq, int pos0, int n_pos, uint16_t* k, uint16_t* v) {
+    if (!s || !k || !v) return TK_ERROR_INVALID_ARGUMENT;
+    if (!s->session.kv_read(layer, seq, pos0, n_pos, k, v)) return fail(TK_ERROR_INVALID_ARGUMENT, s->session.error);
+    return TK_SUCCESS;
+}
+
 tk_error_code_t tk_mi355x_llm_prefill(tk_mi355x_llm_session_t* s, int nseq, int n_prompt, const int32_t* tokens, int32_t* first_tokens) {
     if (!s || !tokens) return TK_ERROR_INVALID_ARGUMENT;
     if (!s->session.prefill(nseq, n_prompt, tokens, first_tokens)) return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);

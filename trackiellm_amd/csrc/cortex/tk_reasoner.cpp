@@ -20,7 +20,7 @@
 namespace {
 struct ContextItem { uint64_t ts; tk_context_type_e type; tk_context_priority_e prio; float relevance; std::string text; size_t data_size; };
 struct Turn { uint64_t ts; bool user; std::string content; float confidence; bool used = false; };
-struct VisibleObject { std::string label; float distance_m, confidence; };
+struct VisibleObject { std::string label, attributes; tk_vision_object_t c; };
 
 uint64_t now_ns() {
     struct timespec ts;
@@ -37,9 +37,22 @@ struct tk_contextual_reasoner_s {
     std::vector<Turn> turns;                 /* circular buffer of max_conversation_history_turns */
     size_t turn_next = 0, turn_count = 0;
     std::vector<VisibleObject> visible;      /* capacity 64 (tk_contextual_reasoner.c:181) */
+    /* navigation_state (.c:87-97) */
     bool has_clear_path = false;
     float path_dir = 0.0f, path_dist = 0.0f;
-    size_t hazards = 0;
+    size_t hazards = 0;                      /* reset by every navigation update and never refilled (.c:463, nothing writes the list) */
+    tk_motion_state_e motion = TK_MOTION_STATE_UNKNOWN;
+    tk_navigation_cue_type_e last_cue = TK_NAVIGATION_CUE_NONE;
+    /* audio_state (.c:79-82) */
+    tk_ambient_sound_type_e last_sound = TK_AMBIENT_SOUND_NONE;
+    uint64_t last_sound_ns = 0;
+    /* system_state (.c:102-107): defaults of _create (.c:209-211) */
+    uint64_t last_process_ns = 0;
+    bool listening = false;
+    float system_confidence = 0.8f;
+    /* C views handed out by get_context_summary: rebuilt there, owned here, valid until the next update */
+    std::vector<tk_vision_object_t> visible_c;
+    std::vector<tk_conversation_turn_t> turns_c;
 };
 
 static void add_item(tk_contextual_reasoner_s* r, tk_context_type_e type, tk_context_priority_e prio, float relevance, const char* text, size_t data_size) {
@@ -49,6 +62,14 @@ static void add_item(tk_contextual_reasoner_s* r, tk_context_type_e type, tk_con
     else { r->items[r->item_next % cap] = std::move(it); }
     r->item_next = (r->item_next + 1) % cap;
 }
+
+/* tk_contextual_reasoner_add_context_item (.c:561-600): relevance starts at 1 */
+static void add_item_locked(tk_contextual_reasoner_s* r, tk_context_type_e type, tk_context_priority_e prio, const char* text) {
+    std::lock_guard<std::mutex> lk(r->mu);
+    add_item(r, type, prio, 1.0f, text, 0);
+}
+
+void tk_prompt_forget_reasoner(tk_contextual_reasoner_t* r); /* tk_prompt.cpp */
 
 extern "C" {
 
@@ -65,8 +86,65 @@ tk_error_code_t tk_contextual_reasoner_create(tk_contextual_reasoner_t** out, co
 
 void tk_contextual_reasoner_destroy(tk_contextual_reasoner_t** reasoner) {
     if (!reasoner || !*reasoner) return;
+    tk_prompt_forget_reasoner(*reasoner);
     delete *reasoner;
     *reasoner = nullptr;
+}
+
+tk_error_code_t tk_contextual_reasoner_get_motion_state(tk_contextual_reasoner_t* r, tk_motion_state_e* out_state) { /* .c:226-239 */
+    if (!r || !out_state) return TK_ERROR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(r->mu);
+    *out_state = r->motion;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_contextual_reasoner_update_ambient_sound(tk_contextual_reasoner_t* r, tk_ambient_sound_type_e sound_type, float confidence) { /* .c:243-297 */
+    if (!r) return TK_ERROR_INVALID_ARGUMENT;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->last_sound = sound_type;
+        r->last_sound_ns = now_ns();
+    }
+    if (sound_type != TK_AMBIENT_SOUND_NONE) {
+        const char* what = "Unknown sound";
+        tk_context_priority_e prio = TK_CONTEXT_PRIORITY_MEDIUM;
+        switch (sound_type) {
+            case TK_AMBIENT_SOUND_FIRE_ALARM: what = "Fire alarm detected"; prio = TK_CONTEXT_PRIORITY_CRITICAL; break;
+            case TK_AMBIENT_SOUND_SIREN: what = "Siren detected"; prio = TK_CONTEXT_PRIORITY_HIGH; break;
+            case TK_AMBIENT_SOUND_CAR_HORN: what = "Car horn detected"; prio = TK_CONTEXT_PRIORITY_HIGH; break;
+            case TK_AMBIENT_SOUND_BABY_CRYING: what = "Baby crying detected"; prio = TK_CONTEXT_PRIORITY_MEDIUM; break;
+            case TK_AMBIENT_SOUND_DOORBELL: what = "Doorbell detected"; prio = TK_CONTEXT_PRIORITY_LOW; break;
+            default: break;
+        }
+        char desc[128];
+        snprintf(desc, sizeof desc, "%s (confidence: %.0f%%)", what, confidence * 100.0f);
+        add_item_locked(r, TK_CONTEXT_TYPE_ENVIRONMENTAL, prio, desc);
+    }
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_contextual_reasoner_update_navigation_cues(tk_contextual_reasoner_t* r, tk_navigation_cue_type_e cue_type, float distance_m) { /* .c:301-350 */
+    if (!r) return TK_ERROR_INVALID_ARGUMENT;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->last_cue = cue_type;
+    }
+    if (cue_type != TK_NAVIGATION_CUE_NONE) {
+        const char* what = "Unknown navigation cue";
+        tk_context_priority_e prio = TK_CONTEXT_PRIORITY_HIGH;
+        switch (cue_type) {
+            case TK_NAVIGATION_CUE_STEP_UP: what = "Step up detected"; break;
+            case TK_NAVIGATION_CUE_STEP_DOWN: what = "Step down detected"; break;
+            case TK_NAVIGATION_CUE_DOORWAY: what = "Doorway detected"; prio = TK_CONTEXT_PRIORITY_MEDIUM; break;
+            case TK_NAVIGATION_CUE_STAIRS_UP: what = "Stairs up detected"; break;
+            case TK_NAVIGATION_CUE_STAIRS_DOWN: what = "Stairs down detected"; break;
+            default: break;
+        }
+        char desc[128];
+        snprintf(desc, sizeof desc, "%s at %.1fm", what, distance_m);
+        add_item_locked(r, TK_CONTEXT_TYPE_NAVIGATIONAL, prio, desc);
+    }
+    return TK_SUCCESS;
 }
 
 tk_error_code_t tk_contextual_reasoner_update_vision_context(tk_contextual_reasoner_t* r, const tk_vision_result_t* vr) {
@@ -75,9 +153,14 @@ tk_error_code_t tk_contextual_reasoner_update_vision_context(tk_contextual_reaso
     size_t n = vr->object_count;
     if (n > 64) n = 64;
     r->visible.clear();
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t i = 0; i < n; ++i) { /* the reference memcpy's the structs, label pointers included (.c:394-397); here the strings are copied so the result may be destroyed */
         const tk_vision_object_t& o = vr->objects[i];
-        r->visible.push_back(VisibleObject{o.label ? o.label : "object", o.distance_meters, o.confidence});
+        VisibleObject v;
+        v.label = o.label ? o.label : "object";
+        v.attributes = o.attributes ? o.attributes : "";
+        v.c = o;
+        v.c.recognized_text = nullptr;
+        r->visible.push_back(std::move(v));
     }
     for (size_t i = 0; i < n; ++i) {
         const tk_vision_object_t& o = vr->objects[i];
@@ -85,6 +168,56 @@ tk_error_code_t tk_contextual_reasoner_update_vision_context(tk_contextual_reaso
         char desc[256];
         snprintf(desc, sizeof desc, "Detected %s at %.1fm (confidence %.0f%%)", o.label ? o.label : "object", o.distance_meters, o.confidence * 100.0f);
         add_item(r, TK_CONTEXT_TYPE_ENVIRONMENTAL, o.distance_meters < 2.0f ? TK_CONTEXT_PRIORITY_HIGH : TK_CONTEXT_PRIORITY_MEDIUM, o.confidence, desc, 0);
+    }
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_contextual_reasoner_update_navigation_context(tk_contextual_reasoner_t* r, const tk_traversability_map_t* map, const tk_free_space_analysis_t* fs,
+                                                                 const tk_obstacle_t* obstacles, size_t obstacle_count) { /* .c:443-519 */
+    if (!r || !map || !fs) return TK_ERROR_INVALID_ARGUMENT;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->has_clear_path = fs->is_any_path_clear;
+        r->path_dir = fs->clearest_path_angle_deg;
+        r->path_dist = fs->clearest_path_distance_m;
+        r->hazards = 0; /* "will be filled later if needed" — nothing does */
+    }
+    if (fs->is_any_path_clear) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "Clear path at %.0f\xC2\xB0, distance %.1fm", fs->clearest_path_angle_deg, fs->clearest_path_distance_m);
+        add_item_locked(r, TK_CONTEXT_TYPE_NAVIGATIONAL, TK_CONTEXT_PRIORITY_HIGH, buf);
+    } else {
+        add_item_locked(r, TK_CONTEXT_TYPE_NAVIGATIONAL, TK_CONTEXT_PRIORITY_CRITICAL, "No clear navigation path detected");
+    }
+    const size_t n = obstacles ? (obstacle_count < 5 ? obstacle_count : 5) : 0; /* the reference dereferences `obstacles` unchecked; a NULL list is read as empty here */
+    for (size_t i = 0; i < n; ++i) {
+        const tk_obstacle_t& o = obstacles[i];
+        char buf[256];
+        snprintf(buf, sizeof buf, "Obstacle at (%.1f, %.1f)m size %.1fx%.1fm", o.position_m.x, o.position_m.y, o.dimensions_m.x, o.dimensions_m.y);
+        const float dist = sqrtf(o.position_m.x * o.position_m.x + o.position_m.y * o.position_m.y);
+        add_item_locked(r, TK_CONTEXT_TYPE_NAVIGATIONAL, dist < 1.5f ? TK_CONTEXT_PRIORITY_HIGH : TK_CONTEXT_PRIORITY_MEDIUM, buf);
+    }
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_contextual_reasoner_update_motion_context(tk_contextual_reasoner_t* r, const tk_world_state_t* ws) { /* .c:1121-1160 */
+    if (!r || !ws) return TK_ERROR_INVALID_ARGUMENT;
+    tk_motion_state_e old;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        old = r->motion;
+        r->motion = ws->motion_state;
+    }
+    if (old != ws->motion_state) {
+        const char* what = "UNKNOWN";
+        switch (ws->motion_state) {
+            case TK_MOTION_STATE_STATIONARY: what = "User is now stationary"; break;
+            case TK_MOTION_STATE_WALKING: what = "User started walking"; break;
+            case TK_MOTION_STATE_RUNNING: what = "User started running"; break;
+            case TK_MOTION_STATE_FALLING: what = "Fall detected!"; break;
+            default: break;
+        }
+        add_item_locked(r, TK_CONTEXT_TYPE_USER_STATE, TK_CONTEXT_PRIORITY_MEDIUM, what);
     }
     return TK_SUCCESS;
 }
@@ -108,10 +241,55 @@ tk_error_code_t tk_contextual_reasoner_add_context_item(tk_contextual_reasoner_t
     return TK_SUCCESS;
 }
 
-tk_error_code_t tk_mi355x_reasoner_set_navigation(tk_contextual_reasoner_t* r, bool has_clear_path, float direction_deg, float distance_m, size_t hazard_count) {
+/* .c:604-622: decay every item's relevance by exp(-rate * age) (.c:980-989; applied to the CURRENT score, so repeated calls compound, as in
+ * the reference), drop what falls below the threshold keeping the order (.c:991-1012) */
+tk_error_code_t tk_contextual_reasoner_process_context(tk_contextual_reasoner_t* r, uint64_t current_time_ns) {
     if (!r) return TK_ERROR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(r->mu);
-    r->has_clear_path = has_clear_path; r->path_dir = direction_deg; r->path_dist = distance_m; r->hazards = hazard_count;
+    for (ContextItem& it : r->items) {
+        const double age_s = (double)(current_time_ns - it.ts) / 1e9; /* unsigned difference, as the reference computes it */
+        it.relevance = it.relevance * expf(-r->config.memory_decay_rate * (float)age_s);
+    }
+    size_t w = 0;
+    for (size_t i = 0; i < r->items.size(); ++i)
+        if (r->items[i].relevance >= r->config.context_relevance_threshold) { if (w != i) r->items[w] = std::move(r->items[i]); ++w; }
+    r->items.resize(w);
+    const size_t cap = r->config.max_context_history_items ? r->config.max_context_history_items : 1;
+    r->item_next = w % cap;
+    r->last_process_ns = current_time_ns;
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_contextual_reasoner_get_context_summary(tk_contextual_reasoner_t* r, tk_context_summary_t* out) { /* .c:626-677 */
+    if (!r || !out) return TK_ERROR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof *out);
+    std::lock_guard<std::mutex> lk(r->mu);
+    r->visible_c.clear();
+    for (VisibleObject& v : r->visible) {
+        tk_vision_object_t o = v.c;
+        o.label = v.label.c_str();
+        o.attributes = v.attributes.empty() ? nullptr : &v.attributes[0];
+        r->visible_c.push_back(o);
+    }
+    out->visible_object_count = r->visible_c.size();
+    out->visible_objects = r->visible_c.empty() ? nullptr : r->visible_c.data();
+    out->has_clear_path = r->has_clear_path;
+    out->clear_path_direction_deg = r->path_dir;
+    out->clear_path_distance_m = r->path_dist;
+    out->hazard_count = r->hazards;
+    out->hazards = nullptr;
+    r->turns_c.assign(r->turns.size(), tk_conversation_turn_t{0, false, nullptr, 0.0f});
+    for (size_t i = 0; i < r->turns.size(); ++i)
+        if (r->turns[i].used) r->turns_c[i] = tk_conversation_turn_t{r->turns[i].ts, r->turns[i].user, &r->turns[i].content[0], r->turns[i].confidence};
+    out->conversation_turn_count = r->turn_count;
+    out->recent_conversation = r->turns_c.data();
+    out->recent_events_summary = nullptr;
+    out->is_navigation_active = r->has_clear_path;
+    out->is_listening_for_commands = r->listening;
+    out->system_confidence = r->system_confidence;
+    out->user_motion_state = r->motion;
+    out->detected_sound_type = r->last_sound;
+    out->detected_navigation_cue = r->last_cue;
     return TK_SUCCESS;
 }
 
@@ -124,7 +302,7 @@ static std::string environment(const tk_contextual_reasoner_s* r) {
     size_t pos = 0;
     for (size_t i = 0; i < limit; ++i) {
         const VisibleObject& o = r->visible[i];
-        int n = snprintf(buf + pos, sizeof buf - pos, "%s (%.1fm, %.0f%% confidence); ", o.label.c_str(), o.distance_m, o.confidence * 100.0f);
+        int n = snprintf(buf + pos, sizeof buf - pos, "%s (%.1fm, %.0f%% confidence); ", o.label.c_str(), o.c.distance_meters, o.c.confidence * 100.0f);
         if (n < 0 || (size_t)n >= sizeof buf - pos) { buf[pos] = 0; break; }
         pos += (size_t)n;
     }
@@ -190,14 +368,15 @@ tk_error_code_t tk_contextual_reasoner_free_context_string(char* ptr) {
     return TK_SUCCESS;
 }
 
+/* .c:756-793: the generic items, the conversation and the bookkeeping go; the environment / navigation / audio SNAPSHOTS stay (the
+ * reference does not touch them either: the next frame or update replaces them) */
 tk_error_code_t tk_contextual_reasoner_clear_context(tk_contextual_reasoner_t* r) {
     if (!r) return TK_ERROR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> lk(r->mu);
     r->items.clear(); r->item_next = 0;
     for (Turn& t : r->turns) t = Turn{};
     r->turn_next = r->turn_count = 0;
-    r->visible.clear();
-    r->has_clear_path = false; r->path_dir = r->path_dist = 0.0f; r->hazards = 0;
+    r->last_process_ns = 0;
     return TK_SUCCESS;
 }
 

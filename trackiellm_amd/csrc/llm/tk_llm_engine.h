@@ -94,6 +94,11 @@ public:
      * (tok, pos) state left by the previous forward()/decode(); out_tokens[n_steps][nrows]. */
     bool decode(int nrows, int n_steps, int32_t* out_tokens_host);
     bool reset();
+    /* KV cache import / export: rows [pos0, pos0 + n_pos) of one (layer, sequence) as f16 bits, host arrays in [position][kv head][dim]
+     * order (the cache itself is [layer][sequence][kv head][position][dim]).  Restores a saved prompt prefix without re-running it; the
+     * parity tests use it to put an attention launch at any context length in one decode step. */
+    bool kv_write(int layer, int seq, int pos0, int n_pos, const uint16_t* k, const uint16_t* v);
+    bool kv_read(int layer, int seq, int pos0, int n_pos, uint16_t* k, uint16_t* v);
     /* per-launch timing of the last decode(): average ms of one step measured with HIP events */
     float last_step_ms = 0.0f;
     /* stand-alone timing of the dominant GEMV (gate/up of layer 0) for bench.py's roofline leg */

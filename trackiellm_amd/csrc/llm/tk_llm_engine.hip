@@ -295,6 +295,34 @@ bool TkLlmSession::reset() {
     return true;
 }
 
+bool TkLlmSession::kv_write(int layer, int seq, int pos0, int n_pos, const uint16_t* k, const uint16_t* v) {
+    const TkLlmHParams& h = model->hp;
+    if (layer < 0 || layer >= h.n_layer || seq < 0 || seq >= max_seq || pos0 < 0 || n_pos <= 0 || pos0 + n_pos > max_ctx || !k || !v) { error = "kv_write: (layer, sequence, positions) outside the cache"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    const size_t hd = (size_t)h.head_dim * 2; /* bytes of one cache row */
+    for (int kvh = 0; kvh < h.n_kv_head; ++kvh) { /* host pitch = one position of all heads; device run of one head = consecutive positions */
+        const size_t dst = ((((size_t)layer * max_seq + seq) * h.n_kv_head + kvh) * max_ctx + pos0) * h.head_dim;
+        HIPQ(hipMemcpy2DAsync(kcache + dst, hd, k + (size_t)kvh * h.head_dim, hd * h.n_kv_head, hd, (size_t)n_pos, hipMemcpyHostToDevice, stream));
+        HIPQ(hipMemcpy2DAsync(vcache + dst, hd, v + (size_t)kvh * h.head_dim, hd * h.n_kv_head, hd, (size_t)n_pos, hipMemcpyHostToDevice, stream));
+    }
+    HIPQ(hipStreamSynchronize(stream));
+    return true;
+}
+
+bool TkLlmSession::kv_read(int layer, int seq, int pos0, int n_pos, uint16_t* k, uint16_t* v) {
+    const TkLlmHParams& h = model->hp;
+    if (layer < 0 || layer >= h.n_layer || seq < 0 || seq >= max_seq || pos0 < 0 || n_pos <= 0 || pos0 + n_pos > max_ctx || !k || !v) { error = "kv_read: (layer, sequence, positions) outside the cache"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    const size_t hd = (size_t)h.head_dim * 2;
+    for (int kvh = 0; kvh < h.n_kv_head; ++kvh) {
+        const size_t src = ((((size_t)layer * max_seq + seq) * h.n_kv_head + kvh) * max_ctx + pos0) * h.head_dim;
+        HIPQ(hipMemcpy2DAsync(k + (size_t)kvh * h.head_dim, hd * h.n_kv_head, kcache + src, hd, hd, (size_t)n_pos, hipMemcpyDeviceToHost, stream));
+        HIPQ(hipMemcpy2DAsync(v + (size_t)kvh * h.head_dim, hd * h.n_kv_head, vcache + src, hd, hd, (size_t)n_pos, hipMemcpyDeviceToHost, stream));
+    }
+    HIPQ(hipStreamSynchronize(stream));
+    return true;
+}
+
 static void set_act(TkGemvArgs& a, const TkActQ8& q) {
     a.aq = q.aq; a.ad = q.ad; a.abs = q.abs; a.abs16 = q.abs16; a.aq_ts = q.aq_ts; a.ad_ts = q.ad_ts; a.abs_ts = q.abs_ts;
 }

@@ -98,6 +98,20 @@ class LlmSession:
                                                 layer0, layer1, 1 if head else 0, _p(am)))
         return am
 
+    def kv_write(self, layer, seq, pos0, k, v):
+        """k, v: uint16 (f16 bits) [n_pos][n_kv_head][head_dim]"""
+        k = np.ascontiguousarray(k, dtype=np.uint16)
+        v = np.ascontiguousarray(v, dtype=np.uint16)
+        assert k.shape == v.shape and k.ndim == 3
+        check(lib().tk_mi355x_llm_session_kv_write(self.h, layer, seq, pos0, k.shape[0], _p(k), _p(v)))
+
+    def kv_read(self, layer, seq, pos0, n_pos):
+        hp = self.model.hparams
+        k = np.empty((n_pos, hp.n_kv_head, hp.head_dim), np.uint16)
+        v = np.empty_like(k)
+        check(lib().tk_mi355x_llm_session_kv_read(self.h, layer, seq, pos0, n_pos, _p(k), _p(v)))
+        return k, v
+
     def prefill(self, tokens):
         tokens = np.ascontiguousarray(tokens, dtype=np.int32)
         nseq, n_prompt = tokens.shape
