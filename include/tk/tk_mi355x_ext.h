@@ -90,6 +90,32 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_prefill(tk_mi355x_llm_session_
 /* greedy decode of n_steps tokens for rows 0..nrows-1, hipGraph replay; out_tokens[n_steps][tk_mi355x_llm_max_rows()] */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t* s, int nrows, int n_steps, int32_t* out_tokens,
                                                          float* ms_per_step);
+/* ---- the LLM layer-sharded over GPUs, stage hand-off inside the library (BASELINE configs[4]; what is sharded is the reference's
+ * llama_decode call, src/ai_models/tk_runner_streaming.c:34,77).  Stage `stage` of `n_stages` runs layers [layer0, layer1) of every pass on its
+ * session's GPU; the [rows, d_model] residual stream is stored by the producer's last kernel straight into the consumer's device mailbox (mapped
+ * with hipIpc across processes — one process per GPU — or by pointer inside one process: peer memory over xGMI), the last stage samples and
+ * returns the ids to stage 0 the same way.  No host synchronisation, host copy or collective per pass; a stage's decode step is one captured
+ * hipGraph.  payload_f16 = 0: the stream crosses as exact fp32 (tokens and logits bit-identical to one GPU); 1: IEEE f16, half the bytes, the
+ * stream rounded once per boundary.  Every device-side wait is bounded (20 s): tk_mi355x_pipe_sync then returns TK_ERROR_TIMEOUT.
+ * All stages must enqueue the same passes in the same order.  csrc/llm/tk_llm_pipe.h has the protocol. ---- */
+typedef struct tk_mi355x_pipe_s tk_mi355x_pipe_t;
+typedef struct { uint8_t ipc[64]; uint64_t bytes; int32_t device; int32_t pid; } tk_mi355x_pipe_handle_t; /* plain bytes: move them between processes any way */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_create(tk_mi355x_pipe_t** out, tk_mi355x_llm_session_t* s, int stage, int n_stages, int layer0, int layer1,
+                                                          int payload_f16, tk_mi355x_pipe_handle_t* my_handle);
+TK_API void tk_mi355x_pipe_destroy(tk_mi355x_pipe_t** p);
+/* the mailboxes of stage (stage + 1) % n and (stage - 1 + n) % n, from the processes that own them */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_connect(tk_mi355x_pipe_t* p, const tk_mi355x_pipe_handle_t* next, const tk_mi355x_pipe_handle_t* prev);
+/* the same for stages created in this process (several GPUs driven by one process, or the tests' two stages on one GPU) */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_connect_local(tk_mi355x_pipe_t* p, tk_mi355x_pipe_t* next, tk_mi355x_pipe_t* prev);
+/* enqueue one pass (returns at once).  tok: stage 0 only; NULL = feed the ids the last stage sampled for these rows.  head != 0: the last stage
+ * samples and returns the ids to stage 0; every stage's device-side positions then stand one past the rows' (a decode loop may follow). */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_pass(tk_mi355x_pipe_t* p, int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, int head);
+/* enqueue n_steps greedy decode steps for the rows of the last sampling pass: n_steps replays of this stage's captured pass */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_decode(tk_mi355x_pipe_t* p, int nrows, int n_steps);
+/* wait for everything enqueued.  out_tokens [n_steps][tk_mi355x_llm_max_rows()] (optional): on the last stage the ids sampled at each decode step,
+ * on stage 0 the ids fed at each step (the first one = the token the prompt's sampling pass produced) */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_sync(tk_mi355x_pipe_t* p, int32_t* out_tokens, int n_steps);
+
 /* HIP-event timing of one GEMV launch on the session stream: which = 0 gate+up, 1 down, 2 qkv, 3 lm_head, 4 o */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int layer, int which, int nrows, int iters, float* avg_ms,
                                                             double* algorithmic_bytes);

@@ -4,7 +4,9 @@ What it restates
   * the ONNX node semantics the depth network needs (the reference hands the file to ONNX Runtime, src/vision/tk_depth_midas.c:397-440;
     ONNX operator specification, opset 11-17): Conv (groups, strides, pads, dilations), BatchNormalization, Clip, Relu, LeakyRelu, Sigmoid,
     Add / Mul with broadcasting, Concat, MaxPool, AveragePool, GlobalAveragePool, Pad (constant), Resize (linear / nearest with the
-    half_pixel, pytorch_half_pixel, align_corners and asymmetric coordinate modes), Squeeze.  A graph is a list of node dicts
+    half_pixel, pytorch_half_pixel, align_corners and asymmetric coordinate modes), Squeeze; and the token-sequence ops of the DPT / Swin class
+    (the model the reference names, tk_depth_midas.c:8): LayerNormalization, Erf, Gelu, MatMul, Softmax, Transpose, Reshape, Gather, strided
+    Slice, ReduceL2 / ReduceSum / ReduceMax / ReduceMin, Max / Min / Where, Expand, Shape, ConvTranspose (_seq_op).  A graph is a list of node dicts
     {"op", "in", "out", "attrs"} (tests/onnx_util.depth_spec builds one and writes the same list as an ONNX file).
   * convert_inverse_depth_to_metric (src/vision/tk_depth_midas.c:471-499), bit for bit in float32.
   * calculate_raw_distance and fuse_object_and_depth_data (src/vision/src/object_analysis.rs:134-279), with trackers in creation order.
@@ -128,7 +130,7 @@ def run_graph(spec, consts, feeds):
         elif op == "Mul":
             y = (x * v[i[1]]).astype(F)
         elif op == "Concat":
-            y = np.concatenate([v[k] for k in i], axis=a.get("axis", 1))
+            y = np.concatenate([np.atleast_1d(v[k]) for k in i], axis=a.get("axis", 1))
         elif op == "MaxPool" or op == "AveragePool":
             y = pool(x, a["kernel_shape"], a.get("strides", [1, 1]), a.get("pads", [0, 0, 0, 0]), op == "MaxPool", a.get("count_include_pad", 0))
         elif op == "GlobalAveragePool":
@@ -144,9 +146,88 @@ def run_graph(spec, consts, feeds):
         elif op == "Squeeze":
             y = np.squeeze(x, axis=tuple(a["axes"]))
         else:
-            raise NotImplementedError(op)
-        v[o[0]] = np.ascontiguousarray(y, F)
+            y = _seq_op(op, i, a, v)
+        v[o[0]] = np.ascontiguousarray(y, np.int64 if y.dtype.kind in "iub" else F)
     return v
+
+
+def conv_transpose2d(x, w, b, strides, pads, output_padding):
+    """ONNX ConvTranspose, group 1: y[n, co, iy * sh - pt + ky, ix * sw - pl + kx] += x[n, ci, iy, ix] * w[ci, co, ky, kx]"""
+    n, ci, h, wd = x.shape
+    _, co, kh, kw = w.shape
+    sh, sw = strides
+    pt, pl, pb, pr = pads
+    ho = (h - 1) * sh + kh - pt - pb + output_padding[0]
+    wo = (wd - 1) * sw + kw - pl - pr + output_padding[1]
+    full = np.zeros((n, co, (h - 1) * sh + kh + output_padding[0], (wd - 1) * sw + kw + output_padding[1]), F)
+    for c in range(ci):
+        for ky in range(kh):
+            for kx in range(kw):
+                full[:, :, ky:ky + (h - 1) * sh + 1:sh, kx:kx + (wd - 1) * sw + 1:sw] += (x[:, c, None, :, :] * w[c, :, ky, kx][None, :, None, None]).astype(F)
+    y = full[:, :, pt:pt + ho, pl:pl + wo]
+    return (y + b.reshape(1, -1, 1, 1)).astype(F) if b is not None else y.astype(F)
+
+
+def _seq_op(op, i, a, v):
+    """the token-sequence ops of the DPT / Swin graph class (ONNX operator specification, opsets 13-20)"""
+    from scipy.special import erf
+    x = v[i[0]] if i and i[0] else None
+    if op == "LayerNormalization":
+        mu = x.mean(axis=-1, keepdims=True, dtype=F)
+        d = (x - mu).astype(F)
+        var = (d * d).mean(axis=-1, keepdims=True, dtype=F)
+        y = (d / np.sqrt((var + F(a.get("epsilon", 1e-5))).astype(F))).astype(F) * v[i[1]]
+        return (y + v[i[2]]).astype(F) if len(i) > 2 and i[2] else y.astype(F)
+    if op == "Erf":
+        return erf(x.astype(np.float64)).astype(F)
+    if op == "Gelu":
+        x64 = x.astype(np.float64)
+        if a.get("approximate", "none") == "tanh":
+            return (0.5 * x64 * (1 + np.tanh(math.sqrt(2 / math.pi) * (x64 + 0.044715 * x64 ** 3)))).astype(F)
+        return (0.5 * x64 * (1 + erf(x64 / math.sqrt(2.0)))).astype(F)
+    if op == "MatMul":
+        return np.matmul(x, v[i[1]]).astype(F)
+    if op == "Softmax":
+        e = np.exp((x - x.max(axis=a.get("axis", -1), keepdims=True)).astype(np.float64))
+        return (e / e.sum(axis=a.get("axis", -1), keepdims=True)).astype(F)
+    if op == "Transpose":
+        return np.transpose(x, a["perm"])
+    if op == "Reshape":
+        return x.reshape([int(t) for t in v[i[1]]])
+    if op == "Unsqueeze":
+        return np.expand_dims(x, tuple(int(t) for t in np.asarray(v[i[1]]).reshape(-1)))
+    if op == "Shape":
+        return np.array(x.shape, np.int64)
+    if op == "Gather":
+        return np.take(x, np.asarray(v[i[1]], np.int64), axis=a.get("axis", 0))
+    if op == "Slice":
+        st, en = np.asarray(v[i[1]]).reshape(-1), np.asarray(v[i[2]]).reshape(-1)
+        ax = np.asarray(v[i[3]]).reshape(-1) if len(i) > 3 and i[3] else np.arange(len(st))
+        sp = np.asarray(v[i[4]]).reshape(-1) if len(i) > 4 and i[4] else np.ones(len(st), np.int64)
+        sl = [slice(None)] * x.ndim
+        for s_, e_, a_, p_ in zip(st, en, ax, sp):
+            sl[int(a_)] = slice(int(s_), int(e_), int(p_))
+        return x[tuple(sl)]
+    if op == "Div":
+        return (x / v[i[1]]).astype(F)
+    if op == "Max":
+        return np.maximum(x, v[i[1]]).astype(F)
+    if op == "Min":
+        return np.minimum(x, v[i[1]]).astype(F)
+    if op == "Where":
+        return np.where(np.asarray(v[i[0]]) != 0, v[i[1]], v[i[2]]).astype(F)
+    if op == "Expand":
+        return np.broadcast_to(x, np.broadcast_shapes(x.shape, tuple(int(t) for t in v[i[1]]))).astype(F)
+    if op in ("ReduceL2", "ReduceSum", "ReduceMax", "ReduceMin"):
+        axes = a["axes"] if "axes" in a else [int(t) for t in np.asarray(v[i[1]]).reshape(-1)]
+        keep = bool(a.get("keepdims", 1))
+        if op == "ReduceL2":
+            return np.sqrt((x.astype(np.float64) ** 2).sum(axis=tuple(axes), keepdims=keep)).astype(F)
+        fn = {"ReduceSum": np.sum, "ReduceMax": np.max, "ReduceMin": np.min}[op]
+        return fn(x.astype(np.float64), axis=tuple(axes), keepdims=keep).astype(F)
+    if op == "ConvTranspose":
+        return conv_transpose2d(x, v[i[1]], v[i[2]] if len(i) > 2 and i[2] else None, a.get("strides", [1, 1]), a.get("pads", [0, 0, 0, 0]), a.get("output_padding", [0, 0]))
+    raise NotImplementedError(op)
 
 
 def to_metric(raw, min_depth=0.1, max_depth=10.0):

@@ -82,6 +82,12 @@ def int_tensor(name, values, dims=None):
     return t + _ld(8, name.encode())
 
 
+def bool_tensor(name, values, dims=None):
+    values = np.asarray(values).reshape(-1).astype(np.uint8)
+    dims = [len(values)] if dims is None else dims
+    return b"".join(_vi(1, int(d)) for d in dims) + _vi(2, 9) + _ld(9, values.tobytes()) + _ld(8, name.encode())
+
+
 def attr_int(name, v):
     return _ld(1, name.encode()) + _vi(3, v & 0xFFFFFFFFFFFFFFFF) + _vi(20, 2)
 
@@ -274,3 +280,234 @@ def depth_model(W, height=-1, width=-1, extra_op=None, channels=1):
         nodes.append(node(extra_op, ["output"], ["unused"], name="extra"))
     inits = [tensor(k, v) for k, v in W.items()] + [int_tensor("pad1", [0, 0, 1, 1, 0, 0, 1, 1])]
     return model(nodes, inits, [value_info("input", 1, [1, 3, height, width])], [value_info("output", 1, [1, height, width])])
+
+
+# ---- a depth network of the DPT / Swin-transformer class (the model the reference names: DPT-SwinV2-Tiny-256, src/vision/tk_depth_midas.c:8,
+# tests/tk_cortex_test.cpp:42), small enough for fixtures.  Structure after the published SwinV2 + DPT definitions as an ONNX export spells
+# them: patch embedding (strided Conv -> tokens -> LayerNormalization), window attention with cosine similarity (ReduceL2 / Clip / Max, Div),
+# a learned logit scale, a relative-position bias gathered from a table (Gather -> Reshape -> Transpose -> Sigmoid * 16), shifted windows
+# (roll as Slice + Concat, the mask through Where), post-norm residuals, an MLP with GELU spelled with Erf (and once as the Gelu op), patch
+# merging (four strided Slices -> Concat -> MatMul -> LayerNormalization), a squeeze gate (ReduceSum), and a DPT-style head: tokens back to
+# feature maps (Transpose + Reshape, one of them with a Shape-driven dynamic target), 1x1 / 3x3 Conv, Resize (align_corners), ConvTranspose
+# (overlapping k3 s2 and non-overlapping k2 s2), Relu.  Not a real checkpoint's graph: there is none offline. ----
+
+SWIN = dict(H=64, patch=4, C=16, heads=2, ws=4, shift=2, eps=1e-5)
+
+
+def _rel_index(ws):
+    """relative position index of a ws x ws window, as Swin computes it: [N, N] entries in [0, (2 ws - 1)^2)"""
+    coords = np.stack(np.meshgrid(np.arange(ws), np.arange(ws), indexing="ij")).reshape(2, -1)
+    rel = coords[:, :, None] - coords[:, None, :] + (ws - 1)
+    return (rel[0] * (2 * ws - 1) + rel[1]).astype(np.int64)
+
+
+def _shift_mask(hw, ws, shift):
+    """Swin's attention mask of a shifted-window block: [nW, N, N], 1 where two tokens of a window come from different image regions"""
+    img = np.zeros((hw, hw), np.int64)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[hs, wsl] = cnt
+            cnt += 1
+    win = img.reshape(hw // ws, ws, hw // ws, ws).transpose(0, 2, 1, 3).reshape(-1, ws * ws)
+    return (win[:, :, None] != win[:, None, :]).astype(np.int64)
+
+
+def swin_weights(seed):
+    rng = np.random.default_rng(seed)
+    S = SWIN
+    C, heads, ws = S["C"], S["heads"], S["ws"]
+    W = {}
+
+    def lin(name, k, n, gain=1.0):
+        W[name + ".w"] = (rng.standard_normal((k, n)) * gain / np.sqrt(k)).astype(np.float32)
+        W[name + ".b"] = (rng.standard_normal(n) * 0.1).astype(np.float32)
+
+    def ln(name, n):
+        W[name + ".g"] = (1.0 + 0.2 * rng.standard_normal(n)).astype(np.float32)
+        W[name + ".b"] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+
+    def conv(name, m, c, k, gain=1.4):
+        W[name + ".w"] = (rng.standard_normal((m, c, k, k)) * gain / np.sqrt(c * k * k)).astype(np.float32)
+        W[name + ".b"] = (rng.standard_normal(m) * 0.1).astype(np.float32)
+
+    conv("pe", C, 3, S["patch"])
+    ln("ln0", C)
+    for blk, c in (("b1", C), ("b2", C), ("b3", 2 * C)):
+        lin(blk + ".qkv", c, 3 * c, 1.5)
+        lin(blk + ".proj", c, c)
+        ln(blk + ".ln1", c)
+        lin(blk + ".fc1", c, 4 * c, 1.3)
+        lin(blk + ".fc2", 4 * c, c)
+        ln(blk + ".ln2", c)
+        W[blk + ".logit_scale"] = (4.0 + rng.random((heads, 1, 1)) * 4.0).astype(np.float32)
+        W[blk + ".rpb"] = rng.standard_normal(((2 * ws - 1) ** 2, heads)).astype(np.float32)
+    W["red.w"] = (rng.standard_normal((4 * C, 2 * C)) / np.sqrt(4 * C)).astype(np.float32)
+    ln("lnm", 2 * C)
+    conv("r1", 8, C, 1)
+    conv("r2", 8, 2 * C, 1)
+    conv("fu", 8, 8, 3)
+    W["up1.w"] = (rng.standard_normal((8, 8, 3, 3)) / np.sqrt(8 * 9 / 4)).astype(np.float32)   # ConvTranspose: [Cin][Cout][kh][kw]
+    W["up1.b"] = (rng.standard_normal(8) * 0.1).astype(np.float32)
+    W["up2.w"] = (rng.standard_normal((8, 8, 2, 2)) / np.sqrt(8)).astype(np.float32)
+    conv("h1", 4, 8, 3)
+    conv("h2", 1, 4, 1)
+    W["h2.b"] = np.array([0.4], np.float32)
+    W["sqrt2"] = np.array(np.sqrt(2.0), np.float32)
+    W["one"] = np.array(1.0, np.float32)
+    W["half"] = np.array(0.5, np.float32)
+    W["sixteen"] = np.array(16.0, np.float32)
+    W["eps12"] = np.array(1e-12, np.float32)
+    W["neg100"] = np.array(-100.0, np.float32)
+    W["inv_tokens"] = np.array(1.0 / 64.0, np.float32)
+    W["up_scales"] = np.array([1, 1, 2, 2], np.float32)
+    W["roi"] = np.zeros(0, np.float32)
+    return W
+
+
+def swin_ints():
+    """the integer initialisers of the graph: Reshape targets, Slice bounds, Gather indices, the shifted-window mask"""
+    S = SWIN
+    C, heads, ws, shift = S["C"], S["heads"], S["ws"], S["shift"]
+    hw = S["H"] // S["patch"]
+    I = {"i0": (np.array(0), []), "i1": (np.array(1), []), "i2": (np.array(2), []), "ax0": ([0], None), "ax1": ([1], None), "ax2": ([2], None),
+         "rel_index": (_rel_index(ws).reshape(-1), None), "mask": (_shift_mask(hw, ws, shift).reshape(-1), [1, (hw // ws) ** 2, 1, ws * ws, ws * ws]),
+         "s_shift": ([shift], None), "s_zero": ([0], None), "s_end": ([1 << 30], None), "s_back": ([-shift], None),
+         "pm_ax": ([1, 2], None), "pm_end": ([1 << 30, 1 << 30], None), "pm_step": ([2, 2], None),
+         "pm00": ([0, 0], None), "pm10": ([1, 0], None), "pm01": ([0, 1], None), "pm11": ([1, 1], None), "tail_hw_c": ([hw, hw, C], None)}
+    for tag, h, c in (("1", hw, C), ("2", hw // 2, 2 * C)):
+        nw, n, hd = (h // ws) ** 2, ws * ws, c // heads
+        I.update({"sh_img" + tag: ([1, h, h, c], None), "sh_part" + tag: ([1, h // ws, ws, h // ws, ws, c], None), "sh_win" + tag: ([nw, n, c], None),
+                  "sh_qkv" + tag: ([nw, n, 3, heads, hd], None), "sh_rpb": ([n, n, heads], None), "sh_att5_" + tag: ([1, nw, heads, n, n], None),
+                  "sh_att4_" + tag: ([nw, heads, n, n], None), "sh_merge" + tag: ([1, h // ws, h // ws, ws, ws, c], None), "sh_tok" + tag: ([1, h * h, c], None),
+                  "sh_map" + tag: ([1, c, h, h], None)})
+    I["sh_pm"] = ([1, (hw // 2) ** 2, 4 * C], None)
+    I["sh_pe"] = ([1, C, hw * hw], None)
+    return I
+
+
+def swin_spec():
+    """nodes as dicts (the numpy oracle and the torch fixture script evaluate this list; swin_model() writes it as ONNX)"""
+    S = SWIN
+    hw = S["H"] // S["patch"]
+    out = []
+
+    def n(op, i, o, **attrs):
+        out.append({"op": op, "in": i, "out": [o], "attrs": attrs})
+        return o
+
+    def layer_norm(x, name, o):
+        return n("LayerNormalization", [x, name + ".g", name + ".b"], o, axis=-1, epsilon=S["eps"])
+
+    def roll(x, p, first, second, axis_name, axis):
+        """torch.roll along one axis as an export spells it: two Slices and a Concat"""
+        a = n("Slice", [x, first, "s_end", axis_name], p + "_a")
+        b = n("Slice", [x, "s_zero", first, axis_name], p + "_b")
+        return n("Concat", [a, b], p + "_r", axis=axis)
+
+    def block(x, p, tag, shifted, gelu_op):
+        xs = n("Reshape", [x, "sh_img" + tag], p + "_img")
+        if shifted:  # roll by -shift on both image axes
+            xs = roll(roll(xs, p + "_rh", "s_shift", None, "ax1", 1), p + "_rw", "s_shift", None, "ax2", 2)
+        t = n("Reshape", [xs, "sh_part" + tag], p + "_part")
+        t = n("Transpose", [t], p + "_partt", perm=[0, 1, 3, 2, 4, 5])
+        win = n("Reshape", [t, "sh_win" + tag], p + "_win")
+        qkv = n("Add", [n("MatMul", [win, p + ".qkv.w"], p + "_qkvm"), p + ".qkv.b"], p + "_qkv")
+        t = n("Transpose", [n("Reshape", [qkv, "sh_qkv" + tag], p + "_qkvr")], p + "_qkvt", perm=[2, 0, 3, 1, 4])
+        q, k, v = (n("Gather", [t, ix], p + "_" + nm, axis=0) for nm, ix in (("q", "i0"), ("k", "i1"), ("v", "i2")))
+        qn = n("Div", [q, n("Clip", [n("ReduceL2", [q], p + "_qn2", axes=[-1], keepdims=1), "eps12"], p + "_qnc")], p + "_qn")
+        kn = n("Div", [k, n("Max", [n("ReduceL2", [k], p + "_kn2", axes=[-1], keepdims=1), "eps12"], p + "_knc")], p + "_kn")
+        att = n("MatMul", [qn, n("Transpose", [kn], p + "_kt", perm=[0, 1, 3, 2])], p + "_qk")
+        att = n("Mul", [att, p + ".logit_scale"], p + "_qks")
+        bias = n("Gather", [p + ".rpb", "rel_index"], p + "_rpbg", axis=0)
+        bias = n("Transpose", [n("Reshape", [bias, "sh_rpb"], p + "_rpbr")], p + "_rpbt", perm=[2, 0, 1])
+        bias = n("Unsqueeze", [n("Mul", [n("Sigmoid", [bias], p + "_rpbs"), "sixteen"], p + "_rpb16"), "ax0"], p + "_bias")
+        att = n("Add", [att, bias], p + "_qkb")
+        if shifted:  # masked_fill(mask, -100) through Where, on the [1, nW, heads, N, N] view
+            a5 = n("Reshape", [att, "sh_att5_" + tag], p + "_a5")
+            a5 = n("Where", ["mask", n("Add", [a5, "neg100"], p + "_a5m"), a5], p + "_a5w")
+            att = n("Reshape", [a5, "sh_att4_" + tag], p + "_a4")
+        pr = n("Softmax", [att], p + "_p", axis=-1)
+        o = n("Transpose", [n("MatMul", [pr, v], p + "_pv")], p + "_pvt", perm=[0, 2, 1, 3])
+        o = n("Reshape", [o, "sh_win" + tag], p + "_o")
+        o = n("Add", [n("MatMul", [o, p + ".proj.w"], p + "_pm"), p + ".proj.b"], p + "_proj")
+        t = n("Transpose", [n("Reshape", [o, "sh_merge" + tag], p + "_mg")], p + "_mgt", perm=[0, 1, 3, 2, 4, 5])
+        xs = n("Reshape", [t, "sh_img" + tag], p + "_back")
+        if shifted:  # roll by +shift
+            xs = roll(roll(xs, p + "_uh", "s_back", None, "ax1", 1), p + "_uw", "s_back", None, "ax2", 2)
+        o = n("Reshape", [xs, "sh_tok" + tag], p + "_tok")
+        x = n("Add", [x, layer_norm(o, p + ".ln1", p + "_n1")], p + "_x1")
+        h = n("Add", [n("MatMul", [x, p + ".fc1.w"], p + "_f1m"), p + ".fc1.b"], p + "_f1")
+        if gelu_op:
+            g = n("Gelu", [h], p + "_g")
+        else:  # 0.5 * h * (1 + erf(h / sqrt(2)))
+            e = n("Add", [n("Erf", [n("Div", [h, "sqrt2"], p + "_hd")], p + "_he"), "one"], p + "_he1")
+            g = n("Mul", [n("Mul", [h, e], p + "_hm"), "half"], p + "_g")
+        m = n("Add", [n("MatMul", [g, p + ".fc2.w"], p + "_f2m"), p + ".fc2.b"], p + "_f2")
+        return n("Add", [x, layer_norm(m, p + ".ln2", p + "_n2")], p + "_x2")
+
+    t = n("Conv", ["input", "pe.w", "pe.b"], "pe", strides=[S["patch"], S["patch"]])
+    t = n("Transpose", [n("Reshape", [t, "sh_pe"], "pe_r")], "pe_t", perm=[0, 2, 1])
+    x = layer_norm(t, "ln0", "x0")
+    x = block(x, "b1", "1", False, False)
+    x1 = block(x, "b2", "1", True, False)
+    # patch merging: x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :] -> concat -> reduction -> norm
+    # (the image view's target comes from a Shape sub-graph, as exports with a dynamic batch axis spell it)
+    dyn = n("Concat", [n("Gather", [n("Shape", [x1], "x1_shape"), "ax0"], "x1_b", axis=0), "tail_hw_c"], "x1_imgshape", axis=0)
+    img = n("Reshape", [x1, dyn], "pm_img")
+    parts = [n("Slice", [img, st, "pm_end", "pm_ax", "pm_step"], "pm_" + st) for st in ("pm00", "pm10", "pm01", "pm11")]
+    t = n("Reshape", [n("Concat", parts, "pm_cat", axis=-1), "sh_pm"], "pm_tok")
+    x = layer_norm(n("MatMul", [t, "red.w"], "pm_red"), "lnm", "xm")
+    x2 = block(x, "b3", "2", False, True)
+    # a squeeze gate over the tokens of the deep stage
+    gate = n("Sigmoid", [n("Mul", [n("ReduceSum", [x2, "ax1"], "x2_sum", keepdims=1), "inv_tokens"], "x2_mean")], "x2_gate")
+    x2 = n("Mul", [x2, gate], "x2g")
+    # DPT head
+    f1 = n("Conv", [n("Reshape", [n("Transpose", [x1], "x1_t", perm=[0, 2, 1]), "sh_map1"], "x1_map"), "r1.w", "r1.b"], "f1")
+    f2 = n("Conv", [n("Reshape", [n("Transpose", [x2], "x2_t", perm=[0, 2, 1]), "sh_map2"], "x2_map"), "r2.w", "r2.b"], "f2")
+    up = n("Resize", [f2, "roi", "up_scales"], "f2_up", mode="linear", coordinate_transformation_mode="align_corners")
+    m = n("Relu", [n("Conv", [n("Add", [f1, up], "fsum"), "fu.w", "fu.b"], "fuc", pads=[1, 1, 1, 1])], "fur")
+    m = n("ConvTranspose", [m, "up1.w", "up1.b"], "u1", kernel_shape=[3, 3], strides=[2, 2], pads=[1, 1, 1, 1], output_padding=[1, 1])
+    m = n("ConvTranspose", [m, "up2.w"], "u2", kernel_shape=[2, 2], strides=[2, 2])
+    m = n("Relu", [n("Conv", [m, "h1.w", "h1.b"], "h1c", pads=[1, 1, 1, 1])], "h1r")
+    m = n("Relu", [n("Conv", [m, "h2.w", "h2.b"], "h2c")], "h2r")
+    n("Squeeze", [m], "output", axes=[1])
+    for nd in out:  # roll() passed None placeholders for unused slots: none may survive
+        assert all(i is not None for i in nd["in"]), nd
+    return out
+
+
+def spec_model(spec, floats, ints, in_dims, out_dims, extra_op=None):
+    """any node-dict list as an ONNX file: float initialisers `floats`, int64 initialisers `ints` (name -> (values, dims or None))"""
+    nodes = []
+    for nd in spec:
+        attrs = []
+        for k, v in nd["attrs"].items():
+            if isinstance(v, str):
+                attrs.append(attr_str(k, v))
+            elif isinstance(v, float):
+                attrs.append(attr_float(k, v))
+            elif isinstance(v, int):
+                attrs.append(attr_int(k, v))
+            else:
+                attrs.append(attr_ints(k, v))
+        nodes.append(node(nd["op"], nd["in"], nd["out"], attrs, name=nd["out"][0] + "_node"))
+    if extra_op:
+        nodes.append(node(extra_op, ["output"], ["unused"], name="extra"))
+    # the Where mask goes out as ONNX bool (what masked_fill exports), everything else as int64
+    inits = [tensor(k, v) for k, v in floats.items()] + [(bool_tensor if k == "mask" else int_tensor)(k, np.asarray(v[0]).reshape(-1), v[1]) for k, v in ints.items()]
+    return model(nodes, inits, [value_info("input", 1, in_dims)], [value_info("output", 1, out_dims)])
+
+
+def swin_model(W, extra_op=None):
+    H = SWIN["H"]
+    return spec_model(swin_spec(), W, swin_ints(), [1, 3, H, H], [1, H, H], extra_op)
+
+
+def swin_consts(W):
+    """every constant by name as ndarrays, for the numpy oracle and the torch script"""
+    c = dict(W)
+    for k, (vals, dims) in swin_ints().items():
+        a = np.asarray(vals, np.int64)
+        c[k] = a.reshape(dims) if dims is not None else a
+    return c

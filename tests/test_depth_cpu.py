@@ -116,10 +116,41 @@ def test_depth_onnx_probe(tk, tmp_path):
     p = tmp_path / "depth.onnx"
     p.write_bytes(OX.depth_model(W, 64, 64))
     assert tk.depth_onnx_probe(str(p)) == len(OX.depth_spec())
-    q = tmp_path / "depth_erf.onnx"
-    q.write_bytes(OX.depth_model(W, 64, 64, extra_op="Erf"))  # an op of the DPT / Swin exports: refused with its name
+    q = tmp_path / "depth_einsum.onnx"
+    q.write_bytes(OX.depth_model(W, 64, 64, extra_op="Einsum"))  # an op of the DPT / Swin exports: refused with its name
     with pytest.raises(tk.TkError) as e:
         tk.depth_onnx_probe(str(q))
-    assert e.value.code == 4001 and "Erf" in str(e.value)
+    assert e.value.code == 4001 and "Einsum" in str(e.value)
     with pytest.raises(tk.TkError):
         tk.depth_onnx_probe(str(tmp_path / "missing.onnx"))
+
+
+def test_swin_class_graph_oracle_matches_torch_fixture_and_is_accepted(tk, tmp_path):
+    """the DPT / Swin-transformer graph class (the depth model the reference names: src/vision/tk_depth_midas.c:8, tests/tk_cortex_test.cpp:42):
+    the numpy restatement of its ops agrees with the torch-made fixture (tests/golden/depth_swin.npz), and the op check of the GPU executor
+    accepts the file (26 distinct ops, among them LayerNormalization, Erf, Gelu, Gather, ReduceL2, Where on a bool mask, ConvTranspose,
+    strided Slice, Shape-driven Reshape, rank-6 Transpose)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "depth_swin.npz"))
+    W = OX.swin_weights(int(g["seed"]))
+    v = DO.run_graph(OX.swin_spec(), OX.swin_consts(W), {"input": g["input"]})
+    scale = float(np.abs(g["output"]).max())
+    assert np.abs(v["output"] - g["output"]).max() <= 2e-5 * scale
+    for k in ("b2_x2", "x2g", "u1"):
+        assert np.abs(v[k] - g["tap_" + k]).max() <= 2e-5 * float(np.abs(g["tap_" + k]).max()), k
+    ops = {n["op"] for n in OX.swin_spec()}
+    assert {"LayerNormalization", "Erf", "Gelu", "Gather", "ReduceL2", "ReduceSum", "Where", "ConvTranspose", "Shape", "Softmax", "MatMul"} <= ops
+    p = tmp_path / "swin.onnx"
+    p.write_bytes(OX.swin_model(W))
+    assert tk.depth_onnx_probe(str(p)) == len(OX.swin_spec())
+    q = tmp_path / "swin_bad.onnx"
+    q.write_bytes(OX.swin_model(W, extra_op="NonMaxSuppression"))
+    with pytest.raises(tk.TkError) as e:
+        tk.depth_onnx_probe(str(q))
+    assert "NonMaxSuppression" in str(e.value)
+    # a graph that declares no outputs is refused at load (ADVICE r02)
+    r = tmp_path / "noout.onnx"
+    r.write_bytes(OX.model([OX.node("Relu", ["input"], ["y"])], [], [OX.value_info("input", 1, [1, 3, 8, 8])], []))
+    with pytest.raises(tk.TkError) as e:
+        tk.depth_onnx_probe(str(r))
+    assert "no outputs" in str(e.value)

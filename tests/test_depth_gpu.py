@@ -25,9 +25,9 @@ def depth_files(tmp_path_factory):
         p = d / f"depth_{name}.onnx"
         p.write_bytes(OX.depth_model(W, h, w))
         paths[name] = str(p)
-    q = d / "depth_erf.onnx"
-    q.write_bytes(OX.depth_model(W, 64, 64, extra_op="Erf"))
-    paths["erf"] = str(q)
+    q = d / "depth_einsum.onnx"
+    q.write_bytes(OX.depth_model(W, 64, 64, extra_op="Einsum"))
+    paths["einsum"] = str(q)
     return W, paths
 
 
@@ -81,8 +81,8 @@ def test_flat_raw_map_becomes_max_depth(gpu, depth_files, tmp_path):
 def test_create_error_paths(gpu, depth_files, tmp_path):
     W, paths = depth_files
     with pytest.raises(gpu.TkError) as e:
-        gpu.DepthEstimator(paths["erf"], 64, 64)
-    assert e.value.code == 4000 and "Erf" in str(e.value)            # unsupported op, named
+        gpu.DepthEstimator(paths["einsum"], 64, 64)
+    assert e.value.code == 4000 and "Einsum" in str(e.value)            # unsupported op, named
     with pytest.raises(gpu.TkError) as e:
         gpu.DepthEstimator(paths["64"], 128, 128)                      # static model dims differ from the configuration
     assert e.value.code == 4000
@@ -135,3 +135,53 @@ def test_pipeline_depth_and_fusion(gpu, depth_files):
     mask, objs, depth = pipe.process_full(frame, flags)
     assert mask == gpu.vision.RESULT_OBJECTS and depth is None
     pipe.close()
+
+
+def test_swin_class_depth_model_matches_torch_fixture_and_oracle(gpu, tmp_path):
+    """f3 for the model class the reference names (DPT-SwinV2-Tiny, src/vision/tk_depth_midas.c:8,471-499; tests/tk_cortex_test.cpp:42): a seeded
+    graph of that class — window attention with cosine similarity, relative-position bias, shifted windows (roll + Where mask), post-norm
+    residuals, Erf / Gelu MLPs, patch merging, a DPT-style head with ConvTranspose — through tk_depth_estimator_* against the torch fixture
+    and the numpy oracle at 2e-5 of the map's scale, then frame -> metres through the estimator's full path."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "depth_swin.npz"))
+    W = OX.swin_weights(int(g["seed"]))
+    H = OX.SWIN["H"]
+    p = tmp_path / "dpt_swin.onnx"
+    p.write_bytes(OX.swin_model(W))
+    est = gpu.DepthEstimator(str(p), H, H)
+    got = est.forward_raw(g["input"][0])
+    scale = float(np.abs(g["output"]).max())
+    assert got.shape == (H, H)
+    assert np.abs(got - g["output"][0]).max() <= TOL * scale, ("GPU graph vs torch", np.abs(got - g["output"][0]).max() / scale)
+    want = DO.run_graph(OX.swin_spec(), OX.swin_consts(W), {"input": g["input"]})["output"][0]
+    assert np.abs(got - want).max() <= TOL * scale, "GPU graph vs numpy oracle"
+    assert np.array_equal(got.view(np.uint32), est.forward_raw(g["input"][0]).view(np.uint32))   # run to run bit-identical
+    # frame -> metric depth (resize / normalise, network, inverse depth to metres)
+    frame = np.random.default_rng(12).integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    depth = est.estimate(frame)
+    chw = O.preprocess(frame, H, H)
+    raw = DO.run_graph(OX.swin_spec(), OX.swin_consts(W), {"input": chw[None]})["output"][0]
+    assert np.array_equal(depth.view(np.uint32), DO.to_metric(est.last_raw()).view(np.uint32))
+    assert np.abs(est.last_raw() - raw).max() <= TOL * float(np.abs(raw).max())
+    est.close()
+
+
+def test_graph_executor_rejects_bad_attributes_at_load(gpu, tmp_path):
+    """model-file data that would index past a shape is an error message from tk_depth_estimator_create, not a crash:
+    Concat / Gather / reduction axes outside the rank, a Gather index outside the table, Pad of a rank-0 tensor"""
+    def build(nodes, ints=None, floats=None):
+        inits = [OX.tensor(k, v) for k, v in (floats or {}).items()] + [OX.int_tensor(k, v[0], v[1]) for k, v in (ints or {}).items()]
+        return OX.model(nodes, inits, [OX.value_info("input", 1, [1, 3, 16, 16])], [OX.value_info("output", 1, [1, 16, 16])])
+    tail = [OX.node("ReduceMean", ["y"], ["output"], [OX.attr_ints("axes", [1]), OX.attr_int("keepdims", 0)])]
+    cases = {
+        "concat_axis": build([OX.node("Concat", ["input", "input"], ["y"], [OX.attr_int("axis", 7)])] + tail),
+        "gather_axis": build([OX.node("Gather", ["input", "ix"], ["y"], [OX.attr_int("axis", 5)])] + tail, ints={"ix": ([0], None)}),
+        "gather_index": build([OX.node("Gather", ["input", "ix"], ["y"], [OX.attr_int("axis", 1)])] + tail, ints={"ix": ([0, 1, 9], None)}),
+        "reduce_axis": build([OX.node("ReduceSum", ["input", "ax"], ["y"])] + tail, ints={"ax": ([6], None)}),
+        "pad_scalar": build([OX.node("Pad", ["c", "pads"], ["z"]), OX.node("Add", ["input", "z"], ["y"])] + tail, ints={"pads": ([], [0])},
+                            floats={"c": np.array(1.0, np.float32)}),
+    }
+    for name, data in cases.items():
+        p = tmp_path / (name + ".onnx")
+        p.write_bytes(data)
+        with pytest.raises(gpu.TkError):
+            gpu.DepthEstimator(str(p), 16, 16)

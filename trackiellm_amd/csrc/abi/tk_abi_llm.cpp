@@ -26,6 +26,7 @@
 #include "../llm/tk_grammar.h"
 #include "../llm/tk_llm_batcher.h"
 #include "../llm/tk_llm_engine.h"
+#include "../llm/tk_llm_pipe.h"
 #include "../llm/tk_tokenizer.h"
 #include "../common/tk_ggml_blocks.h"
 #include "tk/tk_mi355x_ext.h"
@@ -277,6 +278,55 @@ tk_error_code_t tk_mi355x_llm_forward_stage(tk_mi355x_llm_session_t* s, int nrow
     if (!s || !seq || !pos) return TK_ERROR_INVALID_ARGUMENT;
     if (!s->session.forward_stage(nrows, seq, pos, tok, x_in, x_out, x_on_host != 0, layer0, layer1, head != 0, argmax))
         return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);
+    return TK_SUCCESS;
+}
+
+/* ---- layer-sharded pipeline with the hand-off inside the library (csrc/llm/tk_llm_pipe.h) ---- */
+struct tk_mi355x_pipe_s { TkLlmPipe pipe; };
+static_assert(sizeof(tk_mi355x_pipe_handle_t) == sizeof(TkPipeHandle), "public and internal pipe handles must have one layout");
+
+tk_error_code_t tk_mi355x_pipe_create(tk_mi355x_pipe_t** out, tk_mi355x_llm_session_t* s, int stage, int n_stages, int layer0, int layer1, int payload_f16,
+                                      tk_mi355x_pipe_handle_t* my_handle) {
+    if (!out || !s) return TK_ERROR_INVALID_ARGUMENT;
+    std::unique_ptr<tk_mi355x_pipe_s> p(new tk_mi355x_pipe_s());
+    if (!p->pipe.init(&s->session, stage, n_stages, layer0, layer1, payload_f16 != 0, (TkPipeHandle*)my_handle)) return fail(TK_ERROR_INVALID_ARGUMENT, p->pipe.error);
+    *out = p.release();
+    return TK_SUCCESS;
+}
+
+void tk_mi355x_pipe_destroy(tk_mi355x_pipe_t** p) {
+    if (!p || !*p) return;
+    delete *p;
+    *p = nullptr;
+}
+
+tk_error_code_t tk_mi355x_pipe_connect(tk_mi355x_pipe_t* p, const tk_mi355x_pipe_handle_t* next, const tk_mi355x_pipe_handle_t* prev) {
+    if (!p) return TK_ERROR_INVALID_ARGUMENT;
+    if (!p->pipe.connect((const TkPipeHandle*)next, (const TkPipeHandle*)prev)) return fail(TK_ERROR_GPU_ROCM_ERROR, p->pipe.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_pipe_connect_local(tk_mi355x_pipe_t* p, tk_mi355x_pipe_t* next, tk_mi355x_pipe_t* prev) {
+    if (!p) return TK_ERROR_INVALID_ARGUMENT;
+    if (!p->pipe.connect_local(next ? &next->pipe : nullptr, prev ? &prev->pipe : nullptr)) return fail(TK_ERROR_GPU_ROCM_ERROR, p->pipe.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_pipe_pass(tk_mi355x_pipe_t* p, int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, int head) {
+    if (!p || !seq || !pos) return TK_ERROR_INVALID_ARGUMENT;
+    if (!p->pipe.pass(nrows, seq, pos, tok, head != 0)) return fail(TK_ERROR_INFERENCE_FAILED, p->pipe.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_pipe_decode(tk_mi355x_pipe_t* p, int nrows, int n_steps) {
+    if (!p) return TK_ERROR_INVALID_ARGUMENT;
+    if (!p->pipe.decode(nrows, n_steps)) return fail(TK_ERROR_INFERENCE_FAILED, p->pipe.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_pipe_sync(tk_mi355x_pipe_t* p, int32_t* out_tokens, int n_steps) {
+    if (!p) return TK_ERROR_INVALID_ARGUMENT;
+    if (!p->pipe.sync(out_tokens, n_steps)) return fail(TK_ERROR_TIMEOUT, p->pipe.error);
     return TK_SUCCESS;
 }
 

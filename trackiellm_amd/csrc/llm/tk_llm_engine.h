@@ -67,6 +67,8 @@ private:
     bool install(TkDevTensor* t, int type, int64_t rows, int64_t cols, const void* dev_blocks, hipStream_t s);
 };
 
+class TkLlmPipe;
+
 class TkLlmSession {
 public:
     TkLlmModel* model = nullptr;
@@ -107,6 +109,8 @@ public:
     bool time_attention(int nrows, int ctx, int iters, float* avg_ms, double* kv_bytes);
 
 private:
+    friend class TkLlmPipe; /* tk_llm_pipe.h: a pipeline stage enqueues layer ranges of this session between its hand-off kernels */
+    int last_ks_res = 1;    /* slabs of the residual update the last enqueue_range left pending in `partial` */
     void enqueue_pass(int nrows, bool lm_head, bool fused_attn);
     void enqueue_range(int nrows, int l0, int l1, bool embed, bool fold_out, bool lm_head, bool fused_attn);
     int enqueue_matmul(const TkDevTensor* const* t, int nseg, int K, int ks, int n_total, const TkActQ8& act, float* out, int nrows);

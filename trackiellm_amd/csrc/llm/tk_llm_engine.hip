@@ -382,6 +382,7 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         const TkDevTensor* dn[1] = {&L.down};
         ks_res = enqueue_matmul(dn, 1, FF, h.ks_down, D, act_ff, partial, nrows);
     }
+    last_ks_res = ks_res;
     if (!lm_head) { /* prompt rows whose logits nobody reads (K/V are already appended), or a pipeline stage that hands x on */
         if (fold_out && l1 > l0) tk_launch_residual_fold(x, partial, ks_res, D, D, nrows, s);
         return;

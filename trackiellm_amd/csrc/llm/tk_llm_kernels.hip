@@ -963,6 +963,307 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
 }
 
 
+/* ------------------------------------------------------------------------------------------
+ * Wide passes (129..256 rows): the same arithmetic on v_mfma_i32_32x32x32_i8.
+ *
+ * Why: per (16 rows x 16 weight rows x 256 k) the 16x16x64 formulation above issues 8 int8 MFMAs + 1 f16 MFMA (9 x 8 issue cycles) and four
+ * ds_read_b128; the 32x32x32 form does the same multiply-adds with HALF the MFMA issue slots and HALF the LDS operand bytes per MAC (one
+ * 16-byte A read feeds 32 weight rows instead of 16), which is what the 16x16 kernel is bound by (profiles/r02_gemm_sq_counters.txt:
+ * issue port 67 %, matrix pipe 43 %).  Matrix-pipe cycles per MAC are unchanged (the Q4_K scale digit split still doubles them).
+ *
+ * Mapping: a wave owns TWO adjacent 16-row weight tiles (32 weight rows = the N of the MFMA) and four 32-row M-tiles (128 rows); the
+ * workgroup's waves w and w + 4 — SIMD partners — own the same weight rows and the two row halves, so while one finishes a tile on the
+ * VALU (two fp32 FMAs per output and block, the oracle's) the other runs its MFMAs.  Both read the SAME HBM layouts as the kernels above:
+ *  - weight tiles: lane (n, g) of a 16-row tile holds the k-slice g of every sub-block; the B operand of the 32x32x32 MFMA wants lane
+ *    (n32, h) to hold 16 k of weight row n32.  One v_permlane16_swap_b32 per dword pair (tile 0's dword, tile 1's dword) moves the odd
+ *    16-lane rows of tile 0 against the even rows of tile 1: afterwards register 0 holds k-slice 2h and register 1 k-slice 2h + 1 of
+ *    weight row n32 in lane (n32, h) — for rows 0..15 from tile 0, rows 16..31 from tile 1.  No second copy of the weights in HBM.
+ *  - activation image [K/64][4 g][16 slots][2 sub-blocks][8]: lane (m32, h) reads the 16 bytes of (g = 2h + gp, slot m32 % 16) of M-tile
+ *    m32 / 16 — the same (sub-block pair, k-slice) its B operand register gp carries; the k order inside an MFMA is free as long as A
+ *    and B agree.  One base VGPR, immediate offsets for all 64 reads of a block.
+ *  - the Q4_K min term: one v_mfma_f32_32x32x16_f16 per M-tile on the (hh, ll) f16 sums, as above.
+ * Integer-exact: P and M are the oracle's integers; the float epilogue per block is unchanged.
+ * ------------------------------------------------------------------------------------------ */
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+
+struct Ops32 { v4i bl[8], bh[8]; v8h bm16; float dw, dmin; };
+
+/* (a: this lane's dword of tile 0, b: of tile 1) -> (k-slice 2h, k-slice 2h + 1) of weight row n32 = lane & 31, h = lane >> 5 */
+__device__ __forceinline__ void pair_swap(uint32_t a, uint32_t b, uint32_t* s0, uint32_t* s1) {
+    const v2u32 r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    *s0 = r.x;
+    *s1 = r.y;
+}
+
+__device__ __forceinline__ void unpack_q4_x32(const FragQ4& f0, const FragQ4& f1, int lane, Ops32& o) {
+    const bool up = (lane & 16) != 0; /* weight rows 16..31 of the pair: tile 1's header */
+    const uint4 hdr = up ? f1.h : f0.h;
+    const uint32_t q0[8] = {f0.q0.x, f0.q0.y, f0.q0.z, f0.q0.w, f0.q1.x, f0.q1.y, f0.q1.z, f0.q1.w};
+    const uint32_t q1[8] = {f1.q0.x, f1.q0.y, f1.q0.z, f1.q0.w, f1.q1.x, f1.q1.y, f1.q1.z, f1.q1.w};
+    uint32_t sc_lo, sc_hi, mn_lo, mn_hi;
+    q4k_scales(hdr, &sc_lo, &sc_hi, &mn_lo, &mn_hi);
+    const uint32_t dl_lo = sc_lo & 0x07070707u, dl_hi = sc_hi & 0x07070707u;
+    const uint32_t dh_lo = (sc_lo >> 3) & 0x07070707u, dh_hi = (sc_hi >> 3) & 0x07070707u;
+    const uint32_t DL[4] = {dl_lo & 0x00FF00FFu, (dl_lo >> 8) & 0x00FF00FFu, dl_hi & 0x00FF00FFu, (dl_hi >> 8) & 0x00FF00FFu};
+    const uint32_t DH[4] = {dh_lo & 0x00FF00FFu, (dh_lo >> 8) & 0x00FF00FFu, dh_hi & 0x00FF00FFu, (dh_hi >> 8) & 0x00FF00FFu};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint32_t s[2];
+        pair_swap(q0[j], q1[j], &s[0], &s[1]);
+        const int di = 2 * (j >> 2) + (j & 1), sh = 16 * ((j >> 1) & 1), e = j & 1;
+        const unsigned short sl = (unsigned short)(DL[di] >> sh), shh = (unsigned short)(DH[di] >> sh);
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) { /* MFMA u = 2 (j / 2) + gp contracts k-slices 2h + gp of sub-blocks 2 (j / 2) and 2 (j / 2) + 1 */
+            const uint32_t lo = s[gp] & 0x0F0F0F0Fu, hi = (s[gp] >> 4) & 0x0F0F0F0Fu;
+            const int u = 2 * (j >> 1) + gp;
+            o.bl[u][2 * e] = (int)pk_scale(lo, sl);
+            o.bl[u][2 * e + 1] = (int)pk_scale(hi, sl);
+            o.bh[u][2 * e] = (int)pk_scale(lo, shh);
+            o.bh[u][2 * e + 1] = (int)pk_scale(hi, shh);
+        }
+    }
+    /* min term: k-slots 0..7 (lane half 0) pair 2 m_j with hh_j, k-slots 8..15 (half 1) pair m_j with ll_j */
+    const float wsc = (lane >> 5) == 0 ? 2.0f : 1.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.bm16[e] = (_Float16)((float)(((e < 4 ? mn_lo : mn_hi) >> (8 * (e & 3))) & 0xFFu) * wsc);
+    o.dw = f16bits_to_f32(hdr.x & 0xffffu);
+    o.dmin = f16bits_to_f32(hdr.x >> 16);
+}
+
+__device__ __forceinline__ void unpack_q6_x32(const FragQ6& f0, const FragQ6& f1, int lane, Ops32& o) {
+    const bool up = (lane & 16) != 0;
+    const uint32_t x0[8] = {f0.q0.x, f0.q0.y, f0.q0.z, f0.q0.w, f0.q1.x, f0.q1.y, f0.q1.z, f0.q1.w};
+    const uint32_t x1[8] = {f1.q0.x, f1.q0.y, f1.q0.z, f1.q0.w, f1.q1.x, f1.q1.y, f1.q1.z, f1.q1.w};
+    const uint32_t h0[4] = {f0.qh.x, f0.qh.y, f0.qh.z, f0.qh.w}, h1[4] = {f1.qh.x, f1.qh.y, f1.qh.z, f1.qh.w};
+    const uint32_t scw[4] = {up ? f1.sc.x : f0.sc.x, up ? f1.sc.y : f0.sc.y, up ? f1.sc.z : f0.sc.z, up ? f1.sc.w : f0.sc.w};
+    const int upper = lane >> 5; /* lane half h holds k 16 h .. 16 h + 15 of every sub-block: group scale 2 j + h */
+    uint32_t H[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pair_swap(h0[u], h1[u], &H[u][0], &H[u][1]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uint32_t s[2];
+        pair_swap(x0[j], x1[j], &s[0], &s[1]);
+        const int e = j & 1;
+        const short sc = (short)(int8_t)(scw[j >> 1] >> (16 * e + 8 * upper));
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            const uint32_t x = s[gp], Hh = H[j >> 1][gp];
+            const uint32_t lo = ((x << 2) & 0x3C3C3C3Cu) | ((Hh << (6 - 4 * e)) & 0xC0C0C0C0u);
+            const uint32_t hi = ((x >> 2) & 0x3C3C3C3Cu) | ((Hh << (4 - 4 * e)) & 0xC0C0C0C0u);
+            int l0, hh0, l1, hh1;
+            q6_digits(lo, sc, &l0, &hh0);
+            q6_digits(hi, sc, &l1, &hh1);
+            const int u = 2 * (j >> 1) + gp;
+            o.bl[u][2 * e] = l0; o.bl[u][2 * e + 1] = l1;
+            o.bh[u][2 * e] = hh0; o.bh[u][2 * e + 1] = hh1;
+        }
+    }
+    o.dw = f16bits_to_f32(up ? f1.d : f0.d);
+    o.dmin = 0.0f;
+}
+
+#define TK_MFMA32 __builtin_amdgcn_mfma_i32_32x32x32_i8
+#define TK_G32_MTW 4 /* 32-row M-tiles per wave */
+#ifndef TK_G32_STAGGER
+#define TK_G32_STAGGER 0 /* s_sleep units (64 clocks each) waves 4..7 wait after every block barrier: their VALU phases then face their SIMD partner's MFMA phases */
+#endif
+#ifdef TK_G32_STAMPS /* diagnostic build: s_memtime stamps of workgroup 0's waves 0 and 4 (tools/build_variant.sh stamps -DTK_G32_STAMPS), read back by tk_mi355x_debug_stamps */
+__device__ unsigned long long g_tk_stamps[2][16][16];
+#define TK_STAMP(slot) do { if (stamp_on && b < 16) g_tk_stamps[half][b][slot] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int tk_mi355x_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tk_stamps), sizeof(g_tk_stamps)); }
+#else
+#define TK_STAMP(slot) do { } while (0)
+#endif
+#ifndef TK_G32_STAGE_UPPER
+#define TK_G32_STAGE_UPPER 0 /* 1: waves 4..7 issue the whole ring staging (a stagger made of useful work) */
+#endif
+
+/* one 256-k block: this wave's 32 weight rows x its four 32-row M-tiles (row half `half` of the ring block `blk`) */
+template <bool Q4>
+__device__ __forceinline__ void gemm_block32(const Ops32& o, const uint8_t* blk, int half, int lane, float (&acc)[TK_G32_MTW][16], bool stamp_on, int b) {
+    constexpr int OFF_AMN = 16 * 4096, OFF_AD = 16 * 4096 + 16 * 512;
+    constexpr int HT = 2 * TK_G32_MTW; /* 16-row M-tiles of a row half */
+    const int h = lane >> 5;
+    const uint8_t* ap = blk + half * (HT * 4096) + ((lane >> 4) & 1) * 4096 + (h * 32 + (lane & 15)) * 16;            /* + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256 */
+    const uint8_t* mp = blk + OFF_AMN + half * (HT * 512) + ((lane >> 4) & 1) * 512 + h * 256 + (lane & 15) * 16;   /* + t * 1024 */
+    const uint8_t* dp = blk + OFF_AD + half * (HT * 64) + h * 16;                                                  /* + t * 128 + b * 32 */
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < TK_G32_MTW; ++t) {
+        v4i A[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) A[u] = *(const v4i*)(ap + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256);
+#ifdef TK_G32_STAMPS
+        __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): stamp the arrival of the A operands */
+        TK_STAMP(2 + 3 * t);
+#endif
+        v16i pl = zero, ph = zero;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            pl = TK_MFMA32(A[u], o.bl[u], pl, 0, 0, 0);
+            ph = TK_MFMA32(A[u], o.bh[u], ph, 0, 0, 0);
+        }
+#ifdef TK_G32_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        TK_STAMP(3 + 3 * t); /* the MFMAs have ISSUED (the stamp does not wait for their results) */
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        v16f cm;
+        if (Q4) {
+            const v8h mn = *(const v8h*)(mp + t * 1024);
+            const v16f fz = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(mn, o.bm16, fz, 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { /* accumulator register 4 b + i = row 8 b + 4 h + i of the M-tile */
+            const v4f da = *(const v4f*)(dp + t * 128 + b * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * b + i;
+                acc[t][r] = tk_fmaf(o.dw * da[i], (float)((ph[r] << (Q4 ? 3 : 6)) + pl[r]), acc[t][r]);
+                if (Q4) acc[t][r] = tk_fmaf(-(o.dmin * da[i]), cm[r], acc[t][r]);
+            }
+        }
+#ifdef TK_G32_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" :: "v"(acc[t][15]));
+        TK_STAMP(4 + 3 * t);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
+template <int TYPES>
+__global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups, int total_row_tiles) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int MT = 16;                        /* 16-row M-tiles staged per block: all 256 rows */
+    constexpr int CH = MT * TK_RING_TILE_BYTES;   /* one block of the ring */
+    constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 512;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = a.K / a.ks / 256;
+    const int nblk_total = a.K / 256;
+    const int ksi = blockIdx.x % a.ks;
+    const int blk0 = ksi * nb;
+    const int pair = wave & 3, half = wave >> 2; /* waves w and w + 4 share a SIMD: same weight rows, the two row halves */
+    const bool stamp_on = blockIdx.x == 0 && pair == 0 && lane == 0;
+    (void)stamp_on;
+
+    int rt = 2 * (blockIdx.x / a.ks + pair * groups); /* first of this wave's two adjacent row tiles */
+    const bool active = rt < total_row_tiles;
+    if (!active) rt = 0;
+    int seg = 0, row_base = 0;
+    while (seg < a.nseg - 1 && rt >= a.seg[seg].row_tiles) {
+        rt -= a.seg[seg].row_tiles;
+        row_base += a.seg[seg].row_tiles * TK_TILE_ROWS;
+        ++seg;
+    }
+    const int type = a.seg[seg].type;
+    constexpr bool HAS4 = (TYPES & 1) != 0, HAS6 = (TYPES & 2) != 0;
+    const bool is4 = HAS4 && (!HAS6 || type == TK_TYPE_Q4_K);
+    const size_t tile_bytes = is4 ? (size_t)TK_Q4K_TILE_BYTES : (size_t)TK_Q6K_TILE_BYTES;
+    const size_t tile_pitch = (size_t)nblk_total * tile_bytes;
+    const uint8_t* tile = a.seg[seg].tiles + ((size_t)rt * nblk_total + blk0) * tile_bytes;
+
+    float acc[TK_G32_MTW][16];
+#pragma unroll
+    for (int t = 0; t < TK_G32_MTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    /* ring staging as in k_gemm_w4a8: whole 16-row M-tiles dealt round-robin to the eight waves */
+    auto stage = [&](int c, int slot) {
+        uint8_t* dst = lds + slot * CH;
+#if TK_G32_STAGE_UPPER
+        if (wave < 4) return;
+        for (int m = wave - 4; m < MT; m += 4) {
+#else
+        for (int m = wave; m < MT; m += 8) {
+#endif
+            const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)(blk0 + c) * 4096 + lane * 16;
+            const auto gs = (const __attribute__((address_space(1))) void*)src;
+            const auto ls = (__attribute__((address_space(3))) void*)(dst + m * 4096);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 2048, 0);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 3072, 0);
+            const uint8_t* sm = (const uint8_t*)(a.abs16 + m * a.abs_ts + (size_t)(blk0 + c) * 256) + lane * 16;
+            if (lane < 32)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sm,
+                                                 (__attribute__((address_space(3))) void*)(dst + OFF_AMN + m * 512), 16, 0, 0);
+            const uint8_t* sd = (const uint8_t*)(a.ad + m * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS) + lane * 16;
+            if (lane < 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
+                                                 (__attribute__((address_space(3))) void*)(dst + OFF_AD + m * 64), 16, 0, 0);
+        }
+    };
+
+    if (HAS4 && is4) {
+        FragQ4 f0, f1;
+        if (active) { f0 = load_q4(tile, lane); f1 = load_q4(tile + tile_pitch, lane); }
+        stage(0, 0);
+#pragma unroll 1
+        for (int b = 0; b < nb; ++b) {
+            TK_STAMP(15);
+            __builtin_amdgcn_s_waitcnt(0);
+            TK_STAMP(14);
+            __syncthreads();
+            TK_STAMP(0);
+            if (b + 1 < nb) stage(b + 1, (b + 1) & 1);
+            if (!active) continue;
+#if TK_G32_STAGGER
+            if (half) __builtin_amdgcn_s_sleep(TK_G32_STAGGER);
+#endif
+            const uint8_t* next = tile + (size_t)(b + 1 < nb ? b + 1 : b) * tile_bytes; /* the last step re-requests its own tile: no branch around a load */
+            Ops32 o;
+            unpack_q4_x32(f0, f1, lane, o);
+            __builtin_amdgcn_sched_barrier(0);
+            f0 = load_q4(next, lane);
+            f1 = load_q4(next + tile_pitch, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            TK_STAMP(1);
+            gemm_block32<true>(o, lds + (b & 1) * CH, half, lane, acc, stamp_on, b);
+        }
+    }
+    if (HAS6 && !is4) {
+        FragQ6 f0, f1;
+        if (active) { f0 = load_q6(tile, lane); f1 = load_q6(tile + tile_pitch, lane); }
+        stage(0, 0);
+#pragma unroll 1
+        for (int b = 0; b < nb; ++b) {
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (b + 1 < nb) stage(b + 1, (b + 1) & 1);
+            if (!active) continue;
+#if TK_G32_STAGGER
+            if (half) __builtin_amdgcn_s_sleep(TK_G32_STAGGER);
+#endif
+            const uint8_t* next = tile + (size_t)(b + 1 < nb ? b + 1 : b) * tile_bytes;
+            Ops32 o;
+            unpack_q6_x32(f0, f1, lane, o);
+            __builtin_amdgcn_sched_barrier(0);
+            f0 = load_q6(next, lane);
+            f1 = load_q6(next + tile_pitch, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_block32<false>(o, lds + (b & 1) * CH, half, lane, acc, stamp_on, b);
+        }
+    }
+    if (!active) return;
+
+    const int n = a.col0 + row_base + rt * TK_TILE_ROWS + (lane & 31);
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TK_G32_MTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (half * TK_G32_MTW + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < a.nrows) __builtin_nontemporal_store(acc[t][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
+        }
+}
+
 /* s_waitcnt vmcnt(n) alone (expcnt / lgkmcnt untouched): until all but this wave's n youngest vector-memory operations are done.  The
  * LDS-DMA pieces of a chunk are invisible to the compiler's own wait insertion, so the ring is guarded by hand. */
 __device__ __forceinline__ void wait_vmcnt(int n) {
@@ -997,8 +1298,19 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     while (waves > 8) { groups *= 2; waves = (row_tiles + groups - 1) / groups; } /* tall matrices: more than one WG per CU */
     int types = 0;
     for (int i = 0; i < a.nseg; ++i) types |= a.seg[i].type == TK_TYPE_Q4_K ? 1 : 2;
+    if (a.nrows > 8 * TK_ROW_SLOTS) {
+        /* 129..256 rows: the 32x32x32 kernel, one type per wave (a mixed q / k / v launch needs no split): four (weight-tile pair) slots per
+         * workgroup, each served by two SIMD-partner waves (the two row halves) */
+        const int pairs = row_tiles / 2; /* every segment holds a multiple of 4 row tiles: pairs never straddle segments */
+        const int g32 = (pairs + 3) / 4;
+        const size_t ldsb = (size_t)2 * TK_MAX_TILES * TK_RING_TILE_BYTES;
+        if (types == 1) hipLaunchKernelGGL((k_gemm32_w4a8<1>), dim3(g32 * a.ks), dim3(512), ldsb, s, a, g32, row_tiles);
+        else if (types == 2) hipLaunchKernelGGL((k_gemm32_w4a8<2>), dim3(g32 * a.ks), dim3(512), ldsb, s, a, g32, row_tiles);
+        else hipLaunchKernelGGL((k_gemm32_w4a8<3>), dim3(g32 * a.ks), dim3(512), ldsb, s, a, g32, row_tiles);
+        return;
+    }
     if (a.nrows > 8 * TK_ROW_SLOTS && types == 3) {
-        /* 16 M-tiles: the two-type kernel does not fit the register file; a mixed matrix (q, k Q4_K + v Q6_K) goes as two 8-M-tile launches
+        /* (unreachable since the 32x32x32 kernel took the wide passes; kept for the 16-M-tile instantiation of k_gemm_w4a8) 16 M-tiles: the two-type kernel does not fit the register file; a mixed matrix (q, k Q4_K + v Q6_K) goes as two 8-M-tile launches
          * over the first 128 rows and the rest (M-tile images and output rows are simply offset) */
         TkGemvArgs lo = a, hi = a;
         lo.nrows = 8 * TK_ROW_SLOTS;
@@ -1482,6 +1794,7 @@ const char* tk_llm_prepare_device(int device) {
 #define TK_OPT(fn) do { if (e == hipSuccess) e = opt_in_lds(fn); } while (0)
 #define TK_OPT_GEMM(MTV) do { TK_OPT((k_gemm_w4a8<MTV, 1, 1>)); TK_OPT((k_gemm_w4a8<MTV, 2, 1>)); TK_OPT((k_gemm_w4a8<MTV, 3, 1>)); } while (0)
     TK_OPT_GEMM(4); TK_OPT_GEMM(8); TK_OPT_GEMM(16);
+    TK_OPT((k_gemm32_w4a8<1>)); TK_OPT((k_gemm32_w4a8<2>)); TK_OPT((k_gemm32_w4a8<3>));
 #define TK_OPT_GEMV(PFV, MTV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3>)); } while (0)
     TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
 #define TK_OPT_ATT_C(H, C) do { TK_OPT((k_attention<1, true, H, C>)); TK_OPT((k_attention<2, true, H, C>)); TK_OPT((k_attention<4, true, H, C>)); \

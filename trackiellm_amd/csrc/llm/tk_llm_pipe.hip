@@ -1,0 +1,361 @@
+/*
+ * tk_llm_pipe.hip — in-library stage hand-off of the layer-sharded LLM (protocol and rationale: tk_llm_pipe.h).
+ */
+#include "tk_llm_pipe.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../common/tk_exact_math.h"
+
+#define PQ(expr)                                                                                                   \
+    do {                                                                                                           \
+        hipError_t e__ = (expr);                                                                                   \
+        if (e__ != hipSuccess) {                                                                                   \
+            char b__[256];                                                                                         \
+            snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            error = b__;                                                                                           \
+            return false;                                                                                          \
+        }                                                                                                          \
+    } while (0)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+/* ---- device side ---------------------------------------------------------------------------------------------------------------- */
+
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+/* spin until *word >= want; bounded by TK_PIPE_TIMEOUT_S of the 100 MHz realtime counter.  Returns false on timeout. */
+__device__ bool spin_until(const unsigned long long* word, unsigned long long want) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (ld_sys(word) < want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)TK_PIPE_TIMEOUT_S * 100000000ull) return false;
+    }
+    return true;
+}
+
+/* consumer, first kernel of a pass: the next x message (sequence number recv_x + 1) has been published into my mailbox */
+__global__ void k_pipe_wait_x(TkPipeBlock* mine, TkPipeState* st) {
+    const unsigned long long seq = st->recv_x + 1;
+    if (!spin_until(&mine->x_flag[seq % TK_PIPE_SLOTS][0], seq)) st->status = 1;
+}
+
+/* consumer: slot -> the session's residual stream (fp32 as it is, f16 widened); the last workgroup returns the credit to the producer
+ * and advances recv_x */
+__global__ __launch_bounds__(256) void k_pipe_take_x(const TkPipeBlock* mine, TkPipeBlock* prev, TkPipeState* st, float* __restrict__ x, int n4 /* float4 groups */,
+                                                      int slot_floats, int f16) {
+    const unsigned long long seq = st->recv_x + 1;
+    const uint8_t* base = (const uint8_t*)mine + sizeof(TkPipeBlock) + (size_t)(seq % TK_PIPE_SLOTS) * slot_floats * 4;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        if (f16) {
+            const uint2 h = ((const uint2*)base)[i];
+            v4f v;
+            v[0] = tk_f16_to_f32((uint16_t)(h.x & 0xffffu)); v[1] = tk_f16_to_f32((uint16_t)(h.x >> 16));
+            v[2] = tk_f16_to_f32((uint16_t)(h.y & 0xffffu)); v[3] = tk_f16_to_f32((uint16_t)(h.y >> 16));
+            ((v4f*)x)[i] = v;
+        } else {
+            ((v4f*)x)[i] = ((const v4f*)base)[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int arrived = atomicAdd(&st->done_take, 1u);
+        if (arrived == gridDim.x - 1) {
+            st->done_take = 0;
+            st->recv_x = seq;
+            st_sys(&prev->credit_x[0], seq); /* the producer may reuse this slot once it wraps around */
+        }
+    }
+}
+
+/* producer, last kernel of a pass: x + (p_0 + ... + p_{ks-1}) — the pending residual update, slabs added in ascending order exactly as
+ * k_rmsnorm_q8 / k_residual_fold do — stored straight into a slot of the NEXT stage's mailbox; the last workgroup to arrive publishes the
+ * slot.  grid (d_model / 1024, nrows) */
+__global__ __launch_bounds__(256) void k_pipe_send_x(const float* __restrict__ x, const float* __restrict__ partial, int ks, int n_total, int D, TkPipeBlock* next,
+                                                      const TkPipeBlock* mine, TkPipeState* st, int slot_floats, int f16) {
+    const unsigned long long seq = st->sent_x + 1;
+    if (threadIdx.x == 0 && seq > TK_PIPE_SLOTS) { /* credit: the consumer has freed the slot this message reuses */
+        if (!spin_until(&mine->credit_x[0], seq - TK_PIPE_SLOTS)) st->status = 1;
+    }
+    __syncthreads();
+    const int r = blockIdx.y, g = blockIdx.x * 256 + threadIdx.x;
+    uint8_t* base = (uint8_t*)next + sizeof(TkPipeBlock) + (size_t)(seq % TK_PIPE_SLOTS) * slot_floats * 4;
+    if (4 * g < D) {
+        v4f v = *(const v4f*)(x + (int64_t)r * D + 4 * g);
+        if (partial) {
+            v4f o = *(const v4f*)(partial + (int64_t)r * n_total + 4 * g);
+            for (int s = 1; s < ks; ++s) o = o + *(const v4f*)(partial + ((int64_t)s * TK_MAX_ROWS + r) * n_total + 4 * g);
+            v = v + o;
+        }
+        const int64_t at = (int64_t)r * (D / 4) + g;
+        if (f16) {
+            uint2 h;
+            h.x = (uint32_t)tk_f32_to_f16(v[0]) | ((uint32_t)tk_f32_to_f16(v[1]) << 16);
+            h.y = (uint32_t)tk_f32_to_f16(v[2]) | ((uint32_t)tk_f32_to_f16(v[3]) << 16);
+            ((uint2*)base)[at] = h;
+        } else {
+            ((v4f*)base)[at] = v;
+        }
+    }
+    __threadfence_system(); /* this thread's payload stores are visible system-wide before the arrival below */
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int arrived = atomicAdd(&st->done_x, 1u);
+        if (arrived == gridDim.x * gridDim.y - 1) {
+            st->done_x = 0;
+            st->sent_x = seq;
+            __threadfence_system();
+            st_sys(&next->x_flag[seq % TK_PIPE_SLOTS][0], seq);
+        }
+    }
+}
+
+/* last stage: the ids just sampled (d_tok) -> stage 0's id mailbox.  One workgroup. */
+__global__ __launch_bounds__(256) void k_pipe_send_ids(const int32_t* __restrict__ tok, int nrows, TkPipeBlock* first, const TkPipeBlock* mine, TkPipeState* st) {
+    const unsigned long long seq = st->sent_ids + 1;
+    if (threadIdx.x == 0 && seq > TK_PIPE_SLOTS) {
+        if (!spin_until(&mine->credit_ids[0], seq - TK_PIPE_SLOTS)) st->status = 1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrows; i += 256) first->ids_payload[seq % TK_PIPE_SLOTS][i] = tok[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->sent_ids = seq;
+        st_sys(&first->ids_flag[seq % TK_PIPE_SLOTS][0], seq);
+    }
+}
+
+/* stage 0: wait for the ids of these rows' previous positions, make them the rows' tokens and note them in the session's history (what
+ * stage 0 feeds at decode step i = what the last stage sampled at step i - 1).  One workgroup. */
+__global__ __launch_bounds__(256) void k_pipe_take_ids(TkPipeBlock* mine, TkPipeBlock* last, TkPipeState* st, int32_t* __restrict__ tok, int nrows, int32_t* nsteps,
+                                                        int32_t* hist, int hist_stride, int hist_cap) {
+    __shared__ int ok;
+    const unsigned long long seq = st->recv_ids + 1;
+    if (threadIdx.x == 0) {
+        ok = spin_until(&mine->ids_flag[seq % TK_PIPE_SLOTS][0], seq) ? 1 : 0;
+        if (!ok) st->status = 1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrows; i += 256) {
+        const int32_t t = ok ? mine->ids_payload[seq % TK_PIPE_SLOTS][i] : 0;
+        tok[i] = t;
+        const int n = nsteps[i];
+        if (n < hist_cap) { hist[(int64_t)n * hist_stride + i] = t; nsteps[i] = n + 1; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->recv_ids = seq;
+        st_sys(&last->credit_ids[0], seq);
+    }
+}
+
+/* the rows' device-side positions move on by one (stages that do not sample: k_argmax does it on the last stage) */
+__global__ void k_pipe_advance(int32_t* pos, int nrows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrows) pos[r] = pos[r] + 1;
+}
+
+/* ---- host side ------------------------------------------------------------------------------------------------------------------ */
+
+static std::mutex g_pipe_capture_mu;
+
+TkLlmPipe::~TkLlmPipe() {
+    if (s_ && s_->model) (void)hipSetDevice(s_->model->device);
+    if (s_ && s_->stream) (void)hipStreamSynchronize(s_->stream);
+    for (auto& g : graph_) if (g) (void)hipGraphExecDestroy(g);
+    if (next_ && next_ipc_) (void)hipIpcCloseMemHandle(next_);
+    if (prev_ && prev_ipc_ && prev_ != next_) (void)hipIpcCloseMemHandle(prev_);
+    if (mine_) (void)hipFree(mine_);
+    if (st_) (void)hipFree(st_);
+    if (h_rows_) (void)hipHostFree(h_rows_);
+}
+
+bool TkLlmPipe::init(TkLlmSession* session, int stg, int n, int layer0, int layer1, bool payload_f16, TkPipeHandle* out_handle) {
+    if (!session || !session->model) { error = "no session"; return false; }
+    const TkLlmHParams& h = session->model->hp;
+    if (n < 1 || stg < 0 || stg >= n || layer0 < 0 || layer1 < layer0 || layer1 > h.n_layer) { error = "bad stage / layer range"; return false; }
+    if (stg == n - 1 && layer1 != h.n_layer) { error = "the last stage must end at the last layer"; return false; }
+    if (stg == 0 && layer0 != 0) { error = "stage 0 must start at layer 0"; return false; }
+    if (h.d_model % 4) { error = "d_model must be a multiple of 4"; return false; }
+    s_ = session; stage = stg; n_stages = n; l0 = layer0; l1 = layer1; f16_ = payload_f16;
+    PQ(hipSetDevice(s_->model->device));
+    block_bytes_ = sizeof(TkPipeBlock) + (size_t)TK_PIPE_SLOTS * TK_MAX_ROWS * h.d_model * 4;
+    PQ(hipMalloc((void**)&mine_, block_bytes_));
+    PQ(hipMemset(mine_, 0, sizeof(TkPipeBlock)));
+    PQ(hipMalloc((void**)&st_, sizeof(TkPipeState)));
+    PQ(hipMemset(st_, 0, sizeof(TkPipeState)));
+    PQ(hipHostMalloc((void**)&h_rows_, (size_t)64 * 3 * TK_MAX_ROWS * sizeof(int32_t), hipHostMallocDefault));
+    PQ(hipDeviceSynchronize());
+    if (out_handle) {
+        memset(out_handle, 0, sizeof *out_handle);
+        hipIpcMemHandle_t ih;
+        PQ(hipIpcGetMemHandle(&ih, mine_));
+        static_assert(sizeof(ih) <= sizeof(out_handle->ipc), "hipIpcMemHandle_t grew");
+        memcpy(out_handle->ipc, &ih, sizeof ih);
+        out_handle->bytes = block_bytes_;
+        out_handle->device = s_->model->device;
+        out_handle->pid = (int32_t)getpid();
+    }
+    return true;
+}
+
+bool TkLlmPipe::connect(const TkPipeHandle* next, const TkPipeHandle* prev) {
+    if (n_stages == 1) return true;
+    if (!next || !prev) { error = "both neighbours' handles are needed"; return false; }
+    if (next->bytes != block_bytes_ || prev->bytes != block_bytes_) { error = "a neighbour's mailbox has another geometry (model or build differ)"; return false; }
+    PQ(hipSetDevice(s_->model->device));
+    auto open = [&](const TkPipeHandle* hd, TkPipeBlock** out) -> bool {
+        if (hd->pid == (int32_t)getpid()) { error = "a handle of this process: use connect_local for stages that share a process"; return false; }
+        hipIpcMemHandle_t ih;
+        memcpy(&ih, hd->ipc, sizeof ih);
+        void* p = nullptr;
+        PQ(hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess));
+        *out = (TkPipeBlock*)p;
+        return true;
+    };
+    if (!open(next, &next_)) return false;
+    next_ipc_ = true;
+    if (memcmp(next->ipc, prev->ipc, sizeof next->ipc) == 0) { prev_ = next_; prev_ipc_ = false; } /* two stages: one neighbour, mapped once */
+    else { if (!open(prev, &prev_)) return false; prev_ipc_ = true; }
+    return true;
+}
+
+bool TkLlmPipe::connect_local(TkLlmPipe* next, TkLlmPipe* prev) {
+    if (n_stages == 1) return true;
+    if (!next || !prev || !next->mine_ || !prev->mine_) { error = "both neighbours are needed"; return false; }
+    if (next->block_bytes_ != block_bytes_ || prev->block_bytes_ != block_bytes_) { error = "a neighbour's mailbox has another geometry"; return false; }
+    PQ(hipSetDevice(s_->model->device));
+    for (TkLlmPipe* o : {next, prev}) {
+        const int od = o->s_->model->device;
+        if (od != s_->model->device) {
+            int can = 0;
+            PQ(hipDeviceCanAccessPeer(&can, s_->model->device, od));
+            if (!can) { error = "no peer access between the two stages' GPUs"; return false; }
+            const hipError_t e = hipDeviceEnablePeerAccess(od, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { error = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return false; }
+            (void)hipGetLastError();
+        }
+    }
+    next_ = next->mine_;
+    prev_ = prev->mine_;
+    return true;
+}
+
+/* one pass of this stage on the session's stream: [take the ids (stage 0) | wait for + take the stream] -> layers [l0, l1) -> [hand the
+ * stream on | sample and return the ids].  take_ids: stage 0 feeds the ids of the id mailbox instead of what d_tok holds;
+ * advance_pos: the rows' device-side positions move on by one afterwards (a sampling pass: k_argmax does it on the last stage, the
+ * other stages follow suit here, so every stage's positions agree when a decode loop starts) */
+void TkLlmPipe::enqueue_stage(int nrows, bool take_ids, bool head, bool advance_pos, bool fused_attn) {
+    const TkLlmHParams& h = s_->model->hp;
+    hipStream_t st = s_->stream;
+    const int D = h.d_model, slot_floats = TK_MAX_ROWS * D;
+    const bool first = stage == 0, last = stage == n_stages - 1;
+    if (first) {
+        if (take_ids && n_stages > 1)
+            hipLaunchKernelGGL(k_pipe_take_ids, dim3(1), dim3(256), 0, st, mine_, prev_, st_, s_->d_tok, nrows, s_->d_nsteps, s_->d_hist, TK_MAX_ROWS, s_->hist_cap);
+    } else {
+        hipLaunchKernelGGL(k_pipe_wait_x, dim3(1), dim3(1), 0, st, mine_, st_);
+        const int n4 = nrows * D / 4;
+        hipLaunchKernelGGL(k_pipe_take_x, dim3((n4 + 255) / 256), dim3(256), 0, st, mine_, prev_, st_, s_->x, n4, slot_floats, f16_ ? 1 : 0);
+    }
+    const bool sample = head && last;
+    s_->enqueue_range(nrows, l0, l1, first, false, sample, fused_attn);
+    if (!last) {
+        const float* partial = l1 > l0 ? s_->partial : nullptr;
+        hipLaunchKernelGGL(k_pipe_send_x, dim3((D / 4 + 255) / 256, nrows), dim3(256), 0, st, s_->x, partial, s_->last_ks_res, D, D, next_, mine_, st_, slot_floats,
+                           f16_ ? 1 : 0);
+    } else if (sample && n_stages > 1) {
+        hipLaunchKernelGGL(k_pipe_send_ids, dim3(1), dim3(256), 0, st, s_->d_tok, nrows, next_, mine_, st_);
+    }
+    if (advance_pos && !sample) hipLaunchKernelGGL(k_pipe_advance, dim3((nrows + 63) / 64), dim3(64), 0, st, s_->d_pos, nrows);
+}
+
+bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, bool head) {
+    const TkLlmHParams& h = s_->model->hp;
+    if (nrows <= 0 || nrows > TK_MAX_ROWS || !seq || !pos) { error = "nrows must be in [1, 256] and (seq, pos) given"; return false; }
+    if (n_stages > 1 && (!next_ || !prev_)) { error = "the pipe is not connected"; return false; }
+    bool distinct = true;
+    for (int r = 0; r < nrows; ++r) {
+        if (seq[r] < 0 || seq[r] >= s_->max_seq || pos[r] < 0 || pos[r] >= s_->max_ctx || (stage == 0 && tok && (tok[r] < 0 || tok[r] >= h.vocab))) { error = "row out of range (sequence id, position or token id)"; return false; }
+        for (int q = 0; q < r && distinct; ++q) distinct = seq[q] != seq[r];
+    }
+    PQ(hipSetDevice(s_->model->device));
+    int32_t* hb = h_rows_ + (size_t)(h_next_ % 64) * 3 * TK_MAX_ROWS; /* pinned: the copies below run when the stream gets there */
+    if (h_next_ >= 64) PQ(hipStreamSynchronize(s_->stream)); /* ring wrapped: rare (prompts of more than 64 passes) */
+    h_next_ = h_next_ >= 64 ? 1 : h_next_ + 1;
+    memcpy(hb, seq, nrows * 4);
+    memcpy(hb + TK_MAX_ROWS, pos, nrows * 4);
+    PQ(hipMemcpyAsync(s_->d_seq, hb, nrows * 4, hipMemcpyHostToDevice, s_->stream));
+    PQ(hipMemcpyAsync(s_->d_pos, hb + TK_MAX_ROWS, nrows * 4, hipMemcpyHostToDevice, s_->stream));
+    const bool from_tok = stage == 0 && tok != nullptr;
+    if (from_tok) {
+        memcpy(hb + 2 * TK_MAX_ROWS, tok, nrows * 4);
+        PQ(hipMemcpyAsync(s_->d_tok, hb + 2 * TK_MAX_ROWS, nrows * 4, hipMemcpyHostToDevice, s_->stream));
+    }
+    if (s_->mask_rows_dirty) { PQ(hipMemsetAsync(s_->d_mask_row, 0xFF, TK_MAX_ROWS * 4, s_->stream)); s_->mask_rows_dirty = false; }
+    s_->launch_error.clear();
+    /* host-described passes go eagerly (their row tables differ); distinct rows take the fused-attention form, as forward() does */
+    enqueue_stage(nrows, stage == 0 && !from_tok, head, head, distinct);
+    if (!s_->launch_error.empty()) { error = s_->launch_error; return false; }
+    PQ(hipGetLastError());
+    return true;
+}
+
+bool TkLlmPipe::decode(int nrows, int n_steps) {
+    if (nrows <= 0 || nrows > TK_MAX_ROWS || n_steps <= 0 || n_steps > s_->hist_cap) { error = "nrows must be in [1, 256] and n_steps within the session's context"; return false; }
+    if (n_stages > 1 && (!next_ || !prev_)) { error = "the pipe is not connected"; return false; }
+    PQ(hipSetDevice(s_->model->device));
+    if (s_->mask_rows_dirty) { PQ(hipMemsetAsync(s_->d_mask_row, 0xFF, TK_MAX_ROWS * 4, s_->stream)); s_->mask_rows_dirty = false; }
+    PQ(hipMemsetAsync(s_->d_nsteps, 0, TK_MAX_ROWS * 4, s_->stream));
+    const char* ng = getenv("TK_MI355X_NO_GRAPH");
+    const bool use_graph = !(ng && ng[0] == '1');
+    if (use_graph && !graph_[nrows]) {
+        std::lock_guard<std::mutex> lk(g_pipe_capture_mu);
+        hipGraph_t g = nullptr;
+        PQ(hipStreamBeginCapture(s_->stream, hipStreamCaptureModeRelaxed));
+        s_->launch_error.clear();
+        enqueue_stage(nrows, true, true, true, true);
+        const hipError_t e_end = hipStreamEndCapture(s_->stream, &g);
+        hipError_t e_inst = hipSuccess;
+        if (e_end == hipSuccess && s_->launch_error.empty()) e_inst = hipGraphInstantiate(&graph_[nrows], g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (e_end != hipSuccess || e_inst != hipSuccess || !s_->launch_error.empty()) {
+            graph_[nrows] = nullptr;
+            (void)hipGetLastError();
+            error = !s_->launch_error.empty() ? s_->launch_error : std::string("graph capture of a pipeline pass failed: ") + hipGetErrorString(e_end != hipSuccess ? e_end : e_inst);
+            return false;
+        }
+    }
+    for (int i = 0; i < n_steps; ++i) {
+        if (use_graph) PQ(hipGraphLaunch(graph_[nrows], s_->stream));
+        else { s_->launch_error.clear(); enqueue_stage(nrows, true, true, true, true); if (!s_->launch_error.empty()) { error = s_->launch_error; return false; } }
+    }
+    PQ(hipGetLastError());
+    return true;
+}
+
+bool TkLlmPipe::sync(int32_t* out_tokens, int n_steps) {
+    PQ(hipSetDevice(s_->model->device));
+    if (out_tokens && n_steps > 0) {
+        if (n_steps > s_->hist_cap) { error = "n_steps exceeds the session's history"; return false; }
+        PQ(hipMemcpyAsync(out_tokens, s_->d_hist, (size_t)n_steps * TK_MAX_ROWS * 4, hipMemcpyDeviceToHost, s_->stream));
+    }
+    TkPipeState hs{};
+    PQ(hipMemcpyAsync(&hs, st_, sizeof hs, hipMemcpyDeviceToHost, s_->stream));
+    PQ(hipStreamSynchronize(s_->stream));
+    h_next_ = 0;
+    if (hs.status != 0) {
+        PQ(hipMemsetAsync(&st_->status, 0, sizeof(int), s_->stream));
+        error = "a pipeline wait timed out: a neighbouring stage never published (peer process gone, or the stages walk different pass orders)";
+        return false;
+    }
+    return true;
+}

@@ -10,7 +10,10 @@
  *   kernel), Relu / Clip / LeakyRelu / Sigmoid / HardSigmoid / HardSwish, Add / Mul / ... with numpy broadcasting, Concat, Resize / Upsample
  *   (nearest, linear; half_pixel, pytorch_half_pixel, align_corners, asymmetric), MaxPool, AveragePool, GlobalAveragePool,
  *   BatchNormalization, MatMul, Gemm, Softmax, and the layout-only ops.
- * Anything else fails at load time with the op's name (a DPT / Swin transformer export needs ops outside this list and is reported so).
+ *   token-sequence graphs (DPT / Swin-transformer depth models, the class the reference names: src/vision/tk_depth_midas.c:8,
+ *   tests/tk_cortex_test.cpp:42): LayerNormalization, Erf / Gelu, batched MatMul, Gather, ReduceSum / ReduceL2 / ReduceMax / ReduceMin, Expand,
+ *   Max / Min / Where, ConvTranspose, strided Slice, Shape and integer shape arithmetic, rank-6 Transpose / Reshape (tk_onnx_exec_seq.hip).
+ * Anything else fails at load time with the op's name.
  * Arithmetic: fp32; every contraction is one k-ascending fma chain per output element (input channel outer, kernel row, kernel column
  * inner; the bias enters last), the exact-math exp / tanh / sigmoid / sqrt of common/tk_exact_math.h.
  */
@@ -55,6 +58,7 @@ public:
 private:
     bool exec(const TkOnnxNode& nd, std::map<std::string, Val>& v);
     bool exec_image_op(const TkOnnxNode& nd, std::map<std::string, Val>& v, bool* handled);
+    bool exec_seq_op(const TkOnnxNode& nd, std::map<std::string, Val>& v, bool* handled); /* tk_onnx_exec_seq.hip: the transformer (DPT / Swin) ops */
     float* alloc(int64_t n);
     bool add_const(const std::string& name, const TkOnnxTensor& t);
     TkOnnxGraph g_;
@@ -63,6 +67,7 @@ private:
     std::map<std::string, Val> consts_;  /* initialisers + Constant nodes, resident */
     std::map<std::string, Val> vals_;
     std::map<std::string, float*> packed_; /* per Conv node: [M][K + 1] weights with the bias as the last column (dense convolutions) */
+    std::vector<std::vector<int32_t>> staging_; /* host sources of this run's small uploads (Gather indices, masks): alive until the next begin() */
     float* arena_ = nullptr;
     size_t arena_cap_ = 0, arena_used_ = 0, arena_peak_ = 0;
 };

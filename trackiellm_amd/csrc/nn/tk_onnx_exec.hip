@@ -39,13 +39,14 @@ __global__ void k_vg_unary(int op, const float* x, float* y, int64_t n) {
     y[i] = r;
 }
 
-struct VgIdx { int64_t dim[4], sa[4], sb[4]; };
+#define TK_VG_RANK 6 /* window partition / merge of a Swin block is a rank-6 transpose */
+struct VgIdx { int64_t dim[TK_VG_RANK], sa[TK_VG_RANK], sb[TK_VG_RANK]; };
 
 __global__ void k_vg_binary(int op, const float* a, const float* b, float* y, VgIdx ix, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int64_t r = i, oa = 0, ob = 0;
-    for (int d = 3; d >= 0; --d) {
+    for (int d = TK_VG_RANK - 1; d >= 0; --d) {
         const int64_t c = r % ix.dim[d];
         r /= ix.dim[d];
         oa += c * ix.sa[d];
@@ -70,7 +71,7 @@ __global__ void k_vg_gather(const float* x, float* y, VgIdx ix, int64_t off, int
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int64_t r = i, oa = off, oo = y_off;
-    for (int d = 3; d >= 0; --d) {
+    for (int d = TK_VG_RANK - 1; d >= 0; --d) {
         const int64_t c = r % ix.dim[d];
         r /= ix.dim[d];
         oa += c * ix.sa[d];
@@ -357,7 +358,10 @@ float* TkOnnxExec::alloc(int64_t n) {
 static const char* kSupported[] = {"Conv", "Relu", "Sigmoid", "Tanh", "Sqrt", "Abs", "Neg", "Exp", "Log", "Add", "Sub", "Mul", "Div", "Pow", "Slice", "Concat",
                                    "Pad", "Transpose", "ReduceMean", "LSTM", "Unsqueeze", "Squeeze", "Reshape", "Flatten", "Identity", "Cast", "Constant",
                                    "Clip", "LeakyRelu", "HardSigmoid", "HardSwish", "Resize", "Upsample", "MaxPool", "AveragePool", "GlobalAveragePool",
-                                   "BatchNormalization", "MatMul", "Gemm", "Softmax", "Dropout"};
+                                   "BatchNormalization", "MatMul", "Gemm", "Softmax", "Dropout",
+                                   /* tk_onnx_exec_seq.hip */
+                                   "LayerNormalization", "Erf", "Gelu", "Gather", "ReduceSum", "ReduceL2", "ReduceMax", "ReduceMin", "Expand", "Max", "Min", "Where",
+                                   "ConvTranspose", "Shape"};
 
 bool TkOnnxExec::ops_supported(const TkOnnxGraph& g, std::string* err) {
     for (const auto& nd : g.nodes) {
@@ -408,6 +412,8 @@ bool TkOnnxExec::load(const char* path, int device, hipStream_t stream, size_t a
 }
 
 void TkOnnxExec::begin() {
+    if (!staging_.empty() && stream_) (void)hipStreamSynchronize(stream_); /* an upload of the previous run may still read its host source */
+    staging_.clear();
     arena_used_ = 0;
     vals_ = consts_;
 }
@@ -457,7 +463,9 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
     if (nd.out.empty()) { error = "node without outputs"; return false; }
     {
         bool handled = false;
-        const bool ok = exec_image_op(nd, v, &handled);
+        bool ok = exec_seq_op(nd, v, &handled);
+        if (handled) return ok;
+        ok = exec_image_op(nd, v, &handled);
         if (handled) return ok;
     }
 
@@ -479,7 +487,7 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         if (!a || !b) return false;
         const Val ac = *a, bc = *b;
         const size_t r = std::max(ac.shape.size(), bc.shape.size());
-        if (r > 4) { error = "rank > 4"; return false; }
+        if (r > TK_VG_RANK) { error = "rank > 6"; return false; }
         std::vector<int64_t> as(r, 1), bs(r, 1), os(r, 1);
         for (size_t i = 0; i < ac.shape.size(); ++i) as[r - ac.shape.size() + i] = ac.shape[i];
         for (size_t i = 0; i < bc.shape.size(); ++i) bs[r - bc.shape.size() + i] = bc.shape[i];
@@ -489,9 +497,9 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         }
         const std::vector<int64_t> sa = strides_of(as), sb = strides_of(bs);
         VgIdx ix{};
-        for (int d = 0; d < 4; ++d) { ix.dim[d] = 1; ix.sa[d] = ix.sb[d] = 0; }
+        for (int d = 0; d < TK_VG_RANK; ++d) { ix.dim[d] = 1; ix.sa[d] = ix.sb[d] = 0; }
         for (size_t i = 0; i < r; ++i) {
-            const size_t d = 4 - r + i;
+            const size_t d = TK_VG_RANK - r + i;
             ix.dim[d] = os[i];
             ix.sa[d] = as[i] == 1 ? 0 : sa[i];
             ix.sb[d] = bs[i] == 1 ? 0 : sb[i];
@@ -552,7 +560,7 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         if (!x) return false;
         const Val xc = *x;
         const size_t r = xc.shape.size();
-        if (r > 4) { error = "rank > 4"; return false; }
+        if (r > TK_VG_RANK) { error = "rank > 6"; return false; }
         std::vector<int64_t> perm;
         if (const auto* p = nd.aints("perm")) perm = *p;
         else for (size_t i = 0; i < r; ++i) perm.push_back((int64_t)(r - 1 - i));
@@ -560,10 +568,10 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         const std::vector<int64_t> sx = strides_of(xc.shape);
         std::vector<int64_t> os(r);
         VgIdx ix{}, oy{};
-        for (int d = 0; d < 4; ++d) { ix.dim[d] = 1; ix.sa[d] = 0; oy.sa[d] = 0; }
+        for (int d = 0; d < TK_VG_RANK; ++d) { ix.dim[d] = 1; ix.sa[d] = 0; oy.sa[d] = 0; }
         for (size_t i = 0; i < r; ++i) { if (perm[i] < 0 || perm[i] >= (int64_t)r) { error = "bad perm"; return false; } os[i] = xc.shape[(size_t)perm[i]]; }
         const std::vector<int64_t> so = strides_of(os);
-        for (size_t i = 0; i < r; ++i) { const size_t d = 4 - r + i; ix.dim[d] = os[i]; ix.sa[d] = sx[(size_t)perm[i]]; oy.sa[d] = so[i]; }
+        for (size_t i = 0; i < r; ++i) { const size_t d = TK_VG_RANK - r + i; ix.dim[d] = os[i]; ix.sa[d] = sx[(size_t)perm[i]]; oy.sa[d] = so[i]; }
         Val* y = out_f(0, os);
         if (!y) return false;
         hipLaunchKernelGGL(k_vg_gather, grid_for(y->count()), dim3(128), 0, stream_, xc.d, y->d, ix, (int64_t)0, y->count(), (int64_t)0, oy);
@@ -574,7 +582,7 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         if (!x) return false;
         const Val xc = *x;
         const size_t r = xc.shape.size();
-        if (r > 4) { error = "rank > 4"; return false; }
+        if (r > TK_VG_RANK) { error = "rank > 6"; return false; }
         std::vector<int64_t> starts, ends, axes, steps;
         if (!ints_arg("starts", 1, &starts) || !ints_arg("ends", 2, &ends)) { error = "starts / ends are missing"; return false; }
         if (!ints_arg("axes", 3, &axes)) for (size_t i = 0; i < starts.size(); ++i) axes.push_back((int64_t)i);
@@ -593,9 +601,9 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         }
         const std::vector<int64_t> sx = strides_of(xc.shape), so = strides_of(os);
         VgIdx ix{}, oy{};
-        for (int d = 0; d < 4; ++d) { ix.dim[d] = 1; ix.sa[d] = 0; oy.sa[d] = 0; }
+        for (int d = 0; d < TK_VG_RANK; ++d) { ix.dim[d] = 1; ix.sa[d] = 0; oy.sa[d] = 0; }
         int64_t off = 0;
-        for (size_t i = 0; i < r; ++i) { const size_t d = 4 - r + i; ix.dim[d] = os[i]; ix.sa[d] = sx[i]; oy.sa[d] = so[i]; off += begin[i] * sx[i]; }
+        for (size_t i = 0; i < r; ++i) { const size_t d = TK_VG_RANK - r + i; ix.dim[d] = os[i]; ix.sa[d] = sx[i]; oy.sa[d] = so[i]; off += begin[i] * sx[i]; }
         Val* y = out_f(0, os);
         if (!y) return false;
         if (y->count() > 0) hipLaunchKernelGGL(k_vg_gather, grid_for(y->count()), dim3(128), 0, stream_, xc.d, y->d, ix, off, y->count(), (int64_t)0, oy);
@@ -606,7 +614,7 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         for (size_t i = 0; i < nd.in.size(); ++i) { Val* x = need(i, false); if (!x) return false; parts.push_back(*x); }
         if (parts.empty()) { error = "no inputs"; return false; }
         const size_t r = parts[0].shape.size();
-        if (r > 4) { error = "rank > 4"; return false; }
+        if (r > TK_VG_RANK) { error = "rank > 6"; return false; }
         int64_t ax = nd.ai("axis", 0);
         if (ax < 0) ax += (int64_t)r;
         if (ax < 0 || ax >= (int64_t)r) { error = "Concat axis outside the rank of its inputs"; return false; }
@@ -624,8 +632,8 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         for (const Val& p : parts) {
             const std::vector<int64_t> sp = strides_of(p.shape);
             VgIdx ix{}, oy{};
-            for (int d = 0; d < 4; ++d) { ix.dim[d] = 1; ix.sa[d] = 0; oy.sa[d] = 0; }
-            for (size_t i = 0; i < r; ++i) { const size_t d = 4 - r + i; ix.dim[d] = p.shape[i]; ix.sa[d] = sp[i]; oy.sa[d] = so[i]; }
+            for (int d = 0; d < TK_VG_RANK; ++d) { ix.dim[d] = 1; ix.sa[d] = 0; oy.sa[d] = 0; }
+            for (size_t i = 0; i < r; ++i) { const size_t d = TK_VG_RANK - r + i; ix.dim[d] = p.shape[i]; ix.sa[d] = sp[i]; oy.sa[d] = so[i]; }
             if (p.count() > 0) hipLaunchKernelGGL(k_vg_gather, grid_for(p.count()), dim3(128), 0, stream_, p.d, y->d, ix, (int64_t)0, p.count(), at * so[(size_t)ax], oy);
             at += p.shape[(size_t)ax];
         }

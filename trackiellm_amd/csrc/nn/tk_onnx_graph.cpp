@@ -83,7 +83,11 @@ bool parse_tensor(Span s, std::string* name, TkOnnxTensor* t) {
         if (rawn == count * 4) { t->i.resize((size_t)count); for (int64_t i = 0; i < count; ++i) { int32_t x; memcpy(&x, raw.p + 4 * i, 4); t->i[(size_t)i] = x; } }
         else if ((int64_t)idata.size() == count) { t->i.resize((size_t)count); for (int64_t i = 0; i < count; ++i) t->i[(size_t)i] = (int32_t)idata[(size_t)i]; }
         else return count == 0;
-    } /* other types (bool, double, ...) are kept as shape-only entries: a node that needs them fails by name */
+    } else if (t->dtype == 9) { /* bool (attention masks of Where nodes): one byte per element in raw_data, or int32_data */
+        if (rawn == count) { t->i.resize((size_t)count); for (int64_t i = 0; i < count; ++i) t->i[(size_t)i] = raw.p[i] ? 1 : 0; }
+        else if ((int64_t)idata.size() == count) { t->i.resize((size_t)count); for (int64_t i = 0; i < count; ++i) t->i[(size_t)i] = idata[(size_t)i] ? 1 : 0; }
+        else return count == 0;
+    } /* other types (double, ...) are kept as shape-only entries: a node that needs them fails by name */
     return true;
 }
 

@@ -149,6 +149,59 @@ class LlmSession:
             pass
 
 
+class PipeHandle(C.Structure):
+    _fields_ = [("ipc", C.c_uint8 * 64), ("bytes", C.c_uint64), ("device", C.c_int32), ("pid", C.c_int32)]
+
+    def to_bytes(self):
+        return bytes(memoryview(self))
+
+    @classmethod
+    def from_bytes(cls, b):
+        return cls.from_buffer_copy(b)
+
+
+class LlmPipe:
+    """one stage of the layer-sharded LLM with the hand-off inside the library (tk_mi355x_pipe_*)"""
+
+    def __init__(self, session, stage, n_stages, layer0, layer1, payload_f16=False):
+        self.session, self.stage, self.n_stages = session, stage, n_stages
+        self.h = C.c_void_p()
+        self.handle = PipeHandle()
+        check(lib().tk_mi355x_pipe_create(C.byref(self.h), session.h, stage, n_stages, layer0, layer1, 1 if payload_f16 else 0, C.byref(self.handle)))
+
+    def connect(self, next_handle, prev_handle):
+        check(lib().tk_mi355x_pipe_connect(self.h, C.byref(next_handle), C.byref(prev_handle)))
+
+    def connect_local(self, nxt, prv):
+        check(lib().tk_mi355x_pipe_connect_local(self.h, nxt.h, prv.h))
+
+    def enqueue(self, seq, pos, tok=None, head=False):
+        seq = np.ascontiguousarray(seq, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        if tok is not None:
+            tok = np.ascontiguousarray(tok, dtype=np.int32)
+        check(lib().tk_mi355x_pipe_pass(self.h, len(seq), _p(seq), _p(pos), _p(tok), 1 if head else 0))
+
+    def decode(self, nrows, n_steps):
+        check(lib().tk_mi355x_pipe_decode(self.h, nrows, n_steps))
+
+    def sync(self, nrows=0, n_steps=0):
+        out = np.zeros((max(n_steps, 1), lib().tk_mi355x_llm_max_rows()), dtype=np.int32) if n_steps else None
+        check(lib().tk_mi355x_pipe_sync(self.h, _p(out), n_steps))
+        return out[:n_steps, :nrows].copy() if n_steps else None
+
+    def close(self):
+        if self.h:
+            lib().tk_mi355x_pipe_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- reference surface (what trackie-core links against) ------------------------------------
 
 class _Path(C.Structure):
