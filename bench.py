@@ -169,6 +169,12 @@ def weight_bytes_per_shape(hp):
             "qkv_q6": (qd + kvd) * D * Q4K_BPW + kvd * D * Q6K_BPW, "qkv_q4": (qd + 2 * kvd) * D * Q4K_BPW, "o": D * qd * Q4K_BPW, "lm_head": V * D * Q6K_BPW}
 
 
+def w_step_of(hp):
+    """weights (= int8 multiply-adds per row) of one decode step"""
+    qd, kvd = hp.n_head * hp.head_dim, hp.n_kv_head * hp.head_dim
+    return hp.n_layer * (hp.d_model * (qd + 2 * kvd) + qd * hp.d_model + 3 * hp.d_model * hp.d_ff) + hp.vocab * hp.d_model
+
+
 def gemv_roofline(sess, hp, rows, model_weight_bytes, iters=50):
     """W4A8 launch set of one decode step at `rows` rows per pass.  frac = WEIGHT bytes of the set / sum of launch durations / 8 TB/s —
     SURVEY.md §8d's bytes; the activation images and fp32 K-split partial outputs the launches also move are reported separately."""
@@ -190,12 +196,22 @@ def gemv_roofline(sess, hp, rows, model_weight_bytes, iters=50):
         launches += cnt
     assert abs(total_w - model_weight_bytes) < 1e-6 * model_weight_bytes, (total_w, model_weight_bytes)  # = the bytes a decode step streams
     achieved = total_w / total_ms / 1e6
-    kernel = "k_gemm_w4a8" if rows > 32 else "k_gemv_w4a8"  # > 32 rows: the K-streamed batched variant of the same arithmetic
+    # > 32 rows: the K-streamed batched variants of the same arithmetic (16x16x64 MFMAs up to 128 rows, 32x32x32 above)
+    kernel = "k_gemm32_w4a8" if rows > 128 else "k_gemm_w4a8" if rows > 32 else "k_gemv_w4a8"
     qd, kvd = hp.n_head * hp.head_dim, hp.n_kv_head * hp.head_dim
     w_step = hp.n_layer * (hp.d_model * (qd + 2 * kvd) + qd * hp.d_model + 3 * hp.d_model * hp.d_ff) + hp.vocab * hp.d_model
     tops = 2.0 * rows * w_step / (total_ms * 1e-3) / 1e12
-    out = {"bound": "hbm", "kernel": kernel, "rows_per_pass": rows, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "waste_ratio": None,
+    # which roof: a launch does 2 * rows int8 ops per weight and streams 0.5625 - 0.82 B per weight; the machine balance is 5000 TOP/s / 8 TB/s =
+    # 625 op/B, so passes of more than ~190 rows are bound by the matrix cores (the 256-row headline), narrower ones by HBM
+    ops_per_byte = 2.0 * rows * w_step_of(hp) / total_w
+    mfma_bound = ops_per_byte > INT8_PEAK_TOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    tops_now = 2.0 * rows * w_step_of(hp) / (total_ms * 1e-3) / 1e12
+    out = {"bound": "mfma" if mfma_bound else "hbm", "kernel": kernel, "rows_per_pass": rows,
+           "achieved": round(tops_now, 1) if mfma_bound else round(achieved, 1), "peak": INT8_PEAK_TOPS if mfma_bound else HBM_PEAK_GBS,
+           "unit": "TOP/s (int8, dense)" if mfma_bound else "GB/s",
+           "frac": round(tops_now / INT8_PEAK_TOPS, 4) if mfma_bound else round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "waste_ratio": None,
+           "hbm_view": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "what": "weight bytes of the launch set / sum of launch durations (SURVEY.md 8d's formula)"},
            "algorithmic_bytes_per_launch": round(total_w / launches), "avg_launch_ms": round(total_ms / launches, 5),
            "launches_per_decode_step": launches, "per_shape": shapes,
            "with_activations_and_partials": {"bytes_per_launch": round(total_all / launches), "achieved": round(total_all / total_ms / 1e6, 1),
@@ -204,7 +220,7 @@ def gemv_roofline(sess, hp, rows, model_weight_bytes, iters=50):
            "int8_ops_per_weight_byte": round(2.0 * rows * w_step / total_w, 1)}
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction applied): only a
     # summary collected from THIS kernel source counts; anything else would be a stale number
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_%s_b%d.json" % ("gemm" if rows > 32 else "gemv", rows))
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_%s_b%d.json" % ("gemm" if rows > 32 else "gemv", rows))
     if os.path.exists(pmc):
         pj = json.load(open(pmc))
         if pj.get("rows_per_pass") == rows and pj.get("kernel_source_sha") == kernel_source_sha():
@@ -217,9 +233,17 @@ def gemv_roofline(sess, hp, rows, model_weight_bytes, iters=50):
 def attention_roofline(sess, hp, rows, ctx, iters=64):
     ms, kvb = sess.time_attention(rows, ctx, iters)
     ach = kvb / ms / 1e6
-    return {"bound": "hbm", "kernel": "k_attention", "rows_per_pass": rows, "cached_positions": ctx, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": round(kvb), "avg_launch_ms": round(ms, 5),
-            "launches_per_decode_step": hp.n_layer, "traffic": None}
+    out = {"bound": "hbm", "kernel": "k_attention", "rows_per_pass": rows, "cached_positions": ctx, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": round(kvb), "avg_launch_ms": round(ms, 5),
+           "launches_per_decode_step": hp.n_layer, "traffic": None, "waste_ratio": None}
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_attention_b%d.json" % rows)  # tools/pmc_gemv.py <fetch> <write> <rows> <out> k_attention <ctx>
+    if os.path.exists(pmc):
+        pj = json.load(open(pmc))
+        if pj.get("rows_per_pass") == rows and pj.get("cached_positions") == ctx and pj.get("kernel_source_sha") == kernel_source_sha():
+            out["traffic"] = pj.get("hbm_bytes_per_average_launch")
+            out["waste_ratio"] = round(out["traffic"] / out["algorithmic_bytes_per_launch"], 3)
+            out["traffic_source"] = os.path.relpath(pmc, ROOT)
+    return out
 
 
 def omp_threads(n):
@@ -390,6 +414,22 @@ def reference_abi_runners(tk, K, N):
             "widest_pass": int(widest)}
 
 
+def reference_abi_runners_c_host(K, N):
+    """the same leg driven by a C program (tools/abi_runners_host.c: pthreads, no interpreter): what part of the Python leg's loss against
+    direct sessions is the driver.  Built in place with gcc (the GPU box runs this image); None when that fails."""
+    import subprocess
+    exe = os.path.join(ROOT, "build", "abi_runners_host")
+    libdir = os.path.join(ROOT, "trackiellm_amd")
+    try:
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "abi_runners_host.c"), "-L" + libdir,
+                               "-ltrackie_mi355x", "-lpthread", "-Wl,-rpath," + libdir, "-o", exe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out = subprocess.run([exe, str(K), str(N)], capture_output=True, text=True, timeout=300)
+        return json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 else {"error": (out.stderr or "rc %d" % out.returncode)[-200:]}
+    except Exception as e:
+        return {"error": str(e)[:200]}
+
+
 def hp_weight_bytes(tk, handle):
     tk.lib().tk_mi355x_llm_model_weight_bytes.restype = __import__("ctypes").c_uint64
     return tk.lib().tk_mi355x_llm_model_weight_bytes(handle)
@@ -413,9 +453,11 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="opt-in: the ranks form ONE layer-sharded LLM pipeline (RCCL send / recv of the residual stream between consecutive "
                          "GPUs, SURVEY.md 8e) instead of independent replicas; LLM stream only; --sessions row groups keep the stages busy")
-    ap.add_argument("--placement", choices=["replicas", "model-per-gpu"], default="replicas",
+    ap.add_argument("--pipe-f16", action="store_true", help="pipeline hand-off payload in IEEE f16 (SURVEY.md 8e's 8 KiB per row) instead of exact fp32")
+    ap.add_argument("--placement", choices=["replicas", "model-per-gpu", "combined"], default="replicas",
                     help="model-per-gpu (SURVEY.md 8e): rank 0 runs the LLM for ALL cycles of the job, the other ranks run the detector / ASR / VAD "
-                         "streams for them; results travel as bytes through the host (no data-path collective)")
+                         "streams for them; results travel as bytes through the host (no data-path collective).  combined (BASELINE configs[4]): the "
+                         "LLM layer-sharded over the first ranks, detector and VAD + ASR on the spare GPUs (D.combined_roles)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the isolated per-shape timing of the dominant kernel (the roofline objects); profile THIS command with "
                          "rocprofv3 --kernel-trace to compare its kernel durations with the HIP-event numbers (tools/roofline_check.py)")
@@ -449,8 +491,8 @@ def main():
         if dist is not None:
             D.barrier(dist, cuda=True)
 
-    if args.pipeline:
-        return run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N)
+    if args.pipeline or (args.placement == "combined" and world > 1):
+        return run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, combined=args.placement == "combined" and world > 1)
     if args.placement == "model-per-gpu" and world > 1:
         return run_model_per_gpu(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N)
 
@@ -558,6 +600,8 @@ def main():
         s1.close()
         out["reference_abi_b1"] = reference_abi_b1(tk, hp, N, roof1)
         out["reference_abi_batched"] = [reference_abi_runners(tk, K, N) for K in (16, 64, 256)]
+        # the same runners from a C host: the difference is the Python driver (GIL hand-offs between K threads that each make one ctypes call per token)
+        out["reference_abi_batched_c_host"] = [reference_abi_runners_c_host(K, N) for K in (16, 256)]
     if extras and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(tk, model, hp, P, N, args.asr_steps)
     print(json.dumps(out))
@@ -565,38 +609,64 @@ def main():
         dist.destroy_process_group()
 
 
-def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N):
-    # one model, layers split over the ranks; every rank builds the same weights and walks the same pass order
+def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, combined=False):
+    """--pipeline: every rank is one LLM stage.  --placement combined (BASELINE configs[4]): D.combined_roles(world) — the first ranks
+    form the pipeline, the spare GPUs run the detector and VAD + ASR for the same cycles.  The stage hand-off is the library's own
+    (device mailboxes mapped with hipIpc, hipGraph replays, no host synchronisation per pass: csrc/llm/tk_llm_pipe.h); torch.distributed
+    only carries the 80-byte mailbox handles once, the barrier and the max-over-ranks time."""
     f16 = args.weights == "f16"  # BASELINE configs[4]: the fp16 checkpoint layer-sharded over the node
-    model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4, f16=f16)
-    hp = model.hparams
+    roles = D.combined_roles(world) if combined else {"llm": list(range(world)), "vision": [], "audio": []}
     if dist is None:
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist = D.init("gloo")
     cuda_t = world > 1
-    big = tk.LlmSession(model, G * B, P + N + 8)
-    pipe = D.LlmPipeline(dist, big, hp.n_layer, hp.d_model, cuda_tensors=cuda_t)
+    cycles = G * B
+    in_llm = rank in roles["llm"]
+    model = pipe = cb = None
+    if in_llm:
+        model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4, f16=f16)  # every stage builds the same weights and runs only its layers
+        hp = model.hparams
+        make = D.gpu_pipe_factory(tk, model, B, P + N + 8, payload_f16=args.pipe_f16)
+        pipe = D.LibPipeline(dist, roles["llm"], hp.n_layer, G, make)
+    else:
+        D.LibPipeline(dist, roles["llm"], hp.n_layer, G, None)  # takes part in the handle exchange, owns no stage
+        share_v = -(-cycles // len(roles["vision"])) if rank in roles["vision"] else 0
+        share_a = -(-cycles // len(roles["audio"])) if rank in roles["audio"] else 0
+        cb = PerceptionBench(tk, share_v, share_a, rank, local_rank, args.perception_batch, args.asr_steps)
     same = [np.stack([splitmix_tokens(3 + 1000 * (g * B + s_), P, 3, hp.vocab) for s_ in range(B)]) for g in range(G)]
     for pr in same:
         pr[:, 0] = 1
+
+    def step():
+        if in_llm:
+            return pipe.generate(same, N)
+        cb.step()
+        return None
+
     for _ in range(args.warmup):
-        pipe.generate(same, N)
+        step()
     D.barrier(dist, cuda=cuda_t)
     t0 = time.time()
     for _ in range(args.steps):
-        pipe.generate(same, N)
+        step()
     D.barrier(dist, cuda=cuda_t)
     elapsed = D.max_over_ranks(dist, time.time() - t0, cuda=cuda_t)
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": round(G * B * args.steps / elapsed, 3), "unit": "cycles/s",
+        n_st = len(roles["llm"])
+        bounds = D.stage_bounds(hp.n_layer, n_st)
+        par = "pipeline x%d (in-library hand-off of [rows, 4096] %s through peer-mapped device mailboxes, hipGraph replays)" % (n_st, "f16" if args.pipe_f16 else "fp32")
+        if combined:
+            par += "; detector on ranks %s; VAD+ASR on ranks %s" % (roles["vision"], roles["audio"])
+        wl = ("configs[4]: Mistral-7B fp16" if f16 else "configs[1] weights (Q4_K_M)") + " layer-sharded, 64-token prefill + 128-token greedy decode per cycle, %d row groups of %d" % (G, B)
+        if combined:
+            wl += ", fused with YOLOv8n 640x640 + VAD / Whisper-tiny.en (1 s PCM) on the spare GPUs"
+        print(json.dumps({"metric": METRIC, "value": round(cycles * args.steps / elapsed, 3), "unit": "cycles/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 2),
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                           "dtype": "f16 weights x f16-rounded f32 activations, fp32 MFMA chain" if f16 else DTYPE, "data": "synthetic",
-                          "config": {"workload": ("configs[4] LLM stream, layer-sharded: Mistral-7B fp16" if f16 else "configs[1] LLM stream only, layer-sharded: Mistral-7B Q4_K_M") +
-                                                 ", 64-token prefill + 128-token greedy decode per cycle, host-driven passes (no hipGraph), %d row groups of %d" % (G, B),
-                                     "concurrent_cycles": G * B, "layers_per_rank": [pipe.bounds[r + 1] - pipe.bounds[r] for r in range(world)],
-                                     "parallelism": "pipeline x%d (RCCL send/recv of [rows, 4096] fp32 between consecutive stages)" % world},
-                          "llm_tok_per_s": round(G * B * N * args.steps / elapsed, 1)}))
+                          "config": {"workload": wl, "concurrent_cycles": cycles, "layers_per_stage": [bounds[r + 1] - bounds[r] for r in range(n_st)],
+                                     "roles": roles, "parallelism": par},
+                          "llm_tok_per_s": round(cycles * N * args.steps / elapsed, 1)}))
     dist.destroy_process_group()
 
 

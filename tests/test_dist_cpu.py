@@ -47,3 +47,101 @@ def test_model_per_gpu_roles_cover_every_stream():
     assert bench.model_per_gpu_roles(4) == ([1, 3], [2])
     vis, aud = bench.model_per_gpu_roles(8)
     assert vis == [1, 3, 5, 7] and aud == [2, 4, 6] and 0 not in vis + aud and sorted(vis + aud) == list(range(1, 8))
+
+
+def test_combined_roles_and_stage_bounds():
+    """BASELINE configs[4] / SURVEY.md 8e row "8": k pipeline ranks + a detector rank + a VAD / ASR rank; every rank has exactly one role
+    above two GPUs, the stages cover the layers without gaps"""
+    from trackiellm_amd import dist as D
+    assert D.combined_roles(1) == {"llm": [0], "vision": [0], "audio": [0]}
+    assert D.combined_roles(2) == {"llm": [0], "vision": [1], "audio": [1]}
+    assert D.combined_roles(3) == {"llm": [0, 1], "vision": [2], "audio": [2]}
+    assert D.combined_roles(4) == {"llm": [0, 1], "vision": [2], "audio": [3]}
+    r8 = D.combined_roles(8)
+    assert r8 == {"llm": [0, 1, 2, 3, 4, 5], "vision": [6], "audio": [7]}
+    for w in (4, 5, 6, 7, 8):
+        r = D.combined_roles(w)
+        assert sorted(r["llm"] + r["vision"] + r["audio"]) == list(range(w))
+    b = D.stage_bounds(32, 6)
+    assert b[0] == 0 and b[-1] == 32 and all(y > x for x, y in zip(b, b[1:])) and max(y - x for x, y in zip(b, b[1:])) - min(y - x for x, y in zip(b, b[1:])) <= 1
+    assert D.stage_bounds(32, 8) == list(range(0, 33, 4)) and D.stage_bounds(32, 1) == [0, 32]
+    with pytest.raises(ValueError):
+        D.stage_bounds(4, 5)
+
+
+class _RecorderPipe:
+    """what LibPipeline drives, without a GPU: records the calls"""
+
+    def __init__(self, rank, g, stage, n_stages, l0, l1):
+        self.handle_bytes = ("mailbox r%d g%d" % (rank, g)).encode().ljust(80, b".")
+        self.meta = (stage, n_stages, l0, l1)
+        self.calls = []
+        self.links = None
+
+    def connect(self, nxt, prv):
+        self.links = (nxt, prv)
+
+    def enqueue(self, seq, pos, tok, head):
+        self.calls.append(("pass", list(map(int, seq)), list(map(int, pos)), None if tok is None else list(map(int, tok)), bool(head)))
+
+    def decode(self, nrows, n_steps):
+        self.calls.append(("decode", nrows, n_steps))
+
+    def sync(self, nrows, n_steps):
+        import numpy as np
+        self.calls.append(("sync", nrows, n_steps))
+        return np.zeros((n_steps, nrows), np.int32) if n_steps else None
+
+
+def _combined_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    from trackiellm_amd import dist as D
+    dist = D.init("gloo")
+    roles = D.combined_roles(world)
+    made = []
+
+    def make(g, stage, n_stages, l0, l1):
+        made.append(_RecorderPipe(rank, g, stage, n_stages, l0, l1))
+        return made[-1]
+
+    pipe = D.LibPipeline(dist, roles["llm"], 32, 2, make if rank in roles["llm"] else None)
+    rng = np.random.default_rng(1)
+    prompts = [rng.integers(3, 100, (3, 6)).astype(np.int32) for _ in range(2)]
+    out = pipe.generate(prompts, 4, rows_per_pass=8)
+    D.barrier(dist, cuda=False)
+    q.put((rank, pipe.stage, [(p.meta, p.links, p.calls) for p in made], None if out is None else [o.shape for o in out]))
+    dist.destroy_process_group()
+
+
+def test_world_size_3_combined_job_two_stages_plus_perception_rank():
+    """3 ranks over gloo: ranks 0 and 1 are the two LLM stages, rank 2 the perception rank.  The mailbox handles reach the right
+    neighbours, both stages enqueue the SAME pass list (tokens only on stage 0), the perception rank owns no stage but takes part in the
+    exchange"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_combined_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=120) for _ in range(3))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[2][1] is None and res[2][2] == [] and res[2][3] is None          # the perception rank
+    s0, s1 = res[0][2], res[1][2]
+    assert [m for m, _, _ in s0] == [(0, 2, 0, 16)] * 2 and [m for m, _, _ in s1] == [(1, 2, 16, 32)] * 2
+    for g in range(2):                                                           # two stages: the other one is both next and previous
+        assert s0[g][1] == (("mailbox r1 g%d" % g).encode().ljust(80, b"."),) * 2
+        assert s1[g][1] == (("mailbox r0 g%d" % g).encode().ljust(80, b"."),) * 2
+    strip = lambda calls: [(c[0], c[1], c[2], c[4]) if c[0] == "pass" else c for c in calls]
+    for g in range(2):
+        assert strip(s0[g][2]) == strip(s1[g][2])                               # the same passes in the same order
+        passes0 = [c for c in s0[g][2] if c[0] == "pass"]
+        passes1 = [c for c in s1[g][2] if c[0] == "pass"]
+        assert all(c[3] is not None for c in passes0) and all(c[3] is None for c in passes1)   # tokens enter at stage 0 only
+        assert [c[4] for c in passes0] == [False, False, True]                  # 15 prompt rows in chunks of 8, then the sampling pass
+        assert ("decode", 3, 4) in s0[g][2] and s0[g][2][-1] == ("sync", 3, 4)
+    assert res[0][3] == [(4, 3), (4, 3)] and res[1][3] == [(4, 3), (4, 3)]

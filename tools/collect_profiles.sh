@@ -1,31 +1,52 @@
 #!/bin/bash
-# Collects the round's judged measurements on an MI355X box (run through gpurun from the repo root):
-#   1. PMC traffic of the W4A8 kernels (FETCH_SIZE and WRITE_SIZE in separate passes, eager launches) at 256 and 16 rows per pass
-#   2. rocprofv3 --kernel-trace --stats of the headline bench command and of --roofline-only (eager: see DESIGN.md "Profiling")
-#   3. the default bench.py line (hipGraph replay, the shipped path)
+# Collects everything under profiles/rNN_* in one GPU call (run through gpurun from the repo root):
+#   1. PMC traffic (FETCH_SIZE, WRITE_SIZE: separate passes) of the W4A8 launch set at 256 and 16 rows and of k_attention at 256 rows x 128 positions
+#   2. kernel traces of the roofline-only run and of the fused default run — of the GRAPH path (the shipped one): rocprofv3's queue
+#      interceptor walks a multi-packet submission linearly and runs off the end of the 16384-packet AQL ring when a hipGraphLaunch
+#      batch straddles it (profiles/r03_rocprofv3_hipgraph_crash_symbolised.txt), so the ring is made large enough never to wrap inside a
+#      profiled run (ROC_AQL_QUEUE_SIZE)
+#   3. the default bench.py line (unprofiled)
 # Everything lands under gpurun_out/; copy what should be judged into profiles/.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 O=gpurun_out
-export TK_MI355X_NO_GRAPH=1
+one_csv() { # exactly one counter file per pass, or stop: a stale directory must never feed a freshly stamped summary
+  local n; n=$(find "$1" -name '*counter_collection.csv' | wc -l)
+  [ "$n" = 1 ] || { echo "expected one counter_collection.csv under $1, found $n" >&2; exit 1; }
+  find "$1" -name '*counter_collection.csv'
+}
+export TK_MI355X_NO_GRAPH=1   # PMC passes: eager launches (one dispatch record per kernel)
 for B in 256 16; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf "/tmp/pmc_${B}_${C}"
-    timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_${B}_$C -o p -- python3 bench.py --llm-only --no-extras --batch $B --sessions 1 --steps 1 --warmup 0 --prompt 4 --decode 8 > $O/${R}_pmc_${B}_$C.log 2>&1 || { echo "pmc $B $C failed"; tail -5 $O/${R}_pmc_${B}_$C.log; exit 1; }
+    timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d "/tmp/pmc_${B}_${C}" -o p -- python3 tools/time_gemv.py --rows $B --iters 10 > $O/${R}_pmc_${B}_$C.log 2>&1 || { echo "pmc $B $C failed"; tail -5 $O/${R}_pmc_${B}_$C.log; exit 1; }
     echo "pmc $B $C done"
   done
   fam=gemm; [ $B -le 32 ] && fam=gemv
-  python3 tools/pmc_gemv.py $(find /tmp/pmc_${B}_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_${B}_WRITE_SIZE -name '*counter_collection.csv' | head -1) $B $O/${R}_pmc_${fam}_b$B.json > $O/${R}_pmc_${fam}_b$B.txt || exit 1
+  python3 tools/pmc_gemv.py "$(one_csv /tmp/pmc_${B}_FETCH_SIZE)" "$(one_csv /tmp/pmc_${B}_WRITE_SIZE)" $B $O/${R}_pmc_${fam}_b$B.json > $O/${R}_pmc_${fam}_b$B.txt || exit 1
   tail -1 $O/${R}_pmc_${fam}_b$B.txt
 done
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf "/tmp/pmc_att_${C}"
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d "/tmp/pmc_att_${C}" -o p -- python3 tools/time_attention.py 256 128 > $O/${R}_pmc_att_$C.log 2>&1 || { echo "pmc attention $C failed"; tail -5 $O/${R}_pmc_att_$C.log; exit 1; }
+done
+python3 tools/pmc_gemv.py "$(one_csv /tmp/pmc_att_FETCH_SIZE)" "$(one_csv /tmp/pmc_att_WRITE_SIZE)" 256 $O/${R}_pmc_attention_b256.json k_attention 128 > $O/${R}_pmc_attention_b256.txt || exit 1
+tail -1 $O/${R}_pmc_attention_b256.txt
+unset TK_MI355X_NO_GRAPH
+export ROC_AQL_QUEUE_SIZE=131072   # kernel traces of the graph path (see the header)
 rm -rf /tmp/kt_rl
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_rl -o rl -- python3 bench.py --roofline-only > $O/${R}_roofline_only_run.json 2> $O/${R}_roofline_only.err || { echo "roofline-only trace failed"; exit 1; }
-cp $(find /tmp/kt_rl -name '*kernel_stats.csv' | head -1) $O/${R}_roofline_only_kernel_stats.csv
-python3 tools/roofline_check.py $(find /tmp/kt_rl -name '*kernel_trace.csv' | head -1) $O/${R}_roofline_only_run.json > $O/${R}_roofline_check.txt 2>&1; tail -12 $O/${R}_roofline_check.txt
+cp "$(find /tmp/kt_rl -name '*kernel_stats.csv' | head -1)" $O/${R}_roofline_only_kernel_stats.csv
+python3 tools/roofline_check.py "$(find /tmp/kt_rl -name '*kernel_trace.csv' | head -1)" $O/${R}_roofline_only_run.json > $O/${R}_roofline_check.txt 2>&1; tail -12 $O/${R}_roofline_check.txt
 rm -rf /tmp/kt_f
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_f -o f -- python3 bench.py --steps 1 --warmup 1 --no-extras > $O/${R}_fused_3x256_rocprof_run.json 2> $O/${R}_fused_rocprof.err || { echo "fused trace failed"; exit 1; }
-cp $(find /tmp/kt_f -name '*kernel_stats.csv' | head -1) $O/${R}_fused_3x256_kernel_stats.csv
+cp "$(find /tmp/kt_f -name '*kernel_stats.csv' | head -1)" $O/${R}_fused_3x256_kernel_stats.csv
+for B in 256 16; do
+  rm -rf /tmp/kt_b
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_b -o b -- python3 bench.py --llm-only --batch $B --sessions 1 --steps 1 --warmup 1 --no-extras > $O/${R}_llm_b${B}_solo_run.json 2> $O/${R}_llm_b${B}_solo.err || { echo "solo trace $B failed"; exit 1; }
+  cp "$(find /tmp/kt_b -name '*kernel_stats.csv' | head -1)" $O/${R}_llm_b${B}_solo_kernel_stats.csv
+done
 echo "traces done"
-unset TK_MI355X_NO_GRAPH
+unset ROC_AQL_QUEUE_SIZE
 timeout -k 10 900 python3 bench.py > $O/${R}_bench_default.json 2> $O/${R}_bench_default.err; echo "bench rc=$?"; tail -c 1500 $O/${R}_bench_default.json

@@ -27,7 +27,11 @@ __device__ __forceinline__ void mfma_phase(const v4i (&A)[8], const v4i (&Bl)[8]
     const v16f fz = {};
     cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(mn, bm, fz, 0, 0, 0);
 }
-__device__ __forceinline__ void valu_phase(const v16i& pl, const v16i& ph, const v16f& cm, float dw, float dmin, const float* da, float (&acc)[16]) {
+__device__ __forceinline__ void valu_phase(v16i& pl, v16i& ph, v16f& cm, float& dw, float& dmin, float* da, float (&acc)[16]) {
+    /* every input is opaque to the optimiser each tile (no instruction is emitted): nothing of the 96-instruction finishing can be hoisted */
+    asm volatile("" : "+v"(dw), "+v"(dmin));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(pl[r]), "+v"(ph[r]), "+v"(cm[r]), "+v"(da[r]));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         acc[r] = __builtin_fmaf(dw * da[r], (float)((ph[r] << 3) + pl[r]), acc[r]);
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(512, 2) void k(int tiles, float* out, const float* 
     float da[16], acc[16], acc2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { da[r] = dain[(lane + r) & 63]; acc[r] = 0.0f; acc2[r] = 0.0f; }
-    const float dw = dain[lane] * 0.5f, dmin = dain[63 - lane];
+    float dw = dain[lane] * 0.5f, dmin = dain[63 - lane];
     v16i pl = {}, ph = {}; v16f cm = {};
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same command) to HBM bytes per launch of the
 W4A8 kernels, per GEMV shape.  Usage: tools/pmc_gemv.py <fetch counter_collection.csv> <write counter_collection.csv> <rows> profiles/rNN_pmc_{gemm|gemv}_b<rows>.json
+   [family [cached_positions]]   (family k_attention: the decode attention launches of tools/time_attention.py at that context length)
 The summary is stamped with the sha of the kernel source it was collected from (bench.py reports `traffic` only on a match).
 
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts 64 B per 128 B request for 16 B/lane streams
@@ -28,7 +29,9 @@ def load(path, counter, family):
 
 def main():
     rows = int(sys.argv[3])
-    family = "k_gemm_w4a8" if rows > 32 else "k_gemv_w4a8"  # passes of more than 32 rows run the batched variant
+    family = "k_gemm32_w4a8" if rows > 128 else "k_gemm_w4a8" if rows > 32 else "k_gemv_w4a8"  # passes of more than 32 rows run the batched variants
+    if len(sys.argv) > 5:
+        family = sys.argv[5]
     fetch, write = load(sys.argv[1], "FETCH_SIZE", family), load(sys.argv[2], "WRITE_SIZE", family)
     per, tot_b, tot_n = {}, 0.0, 0
     for key in sorted(fetch):
@@ -40,7 +43,7 @@ def main():
         tot_n += len(f)
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the same eager bench command; "
                    "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction for 16 B/lane streams)",
-           "rows_per_pass": rows, "kernel": family, "kernel_source_sha": kernel_source_sha(), "per_variant": per, "hbm_bytes_per_average_launch": round(tot_b / max(tot_n, 1)), "launches": tot_n}
+           "rows_per_pass": rows, "kernel": family, **({"cached_positions": int(sys.argv[6])} if len(sys.argv) > 6 else {}), "kernel_source_sha": kernel_source_sha(), "per_variant": per, "hbm_bytes_per_average_launch": round(tot_b / max(tot_n, 1)), "launches": tot_n}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in per.items()}, indent=1))
     print("average per launch:", out["hbm_bytes_per_average_launch"])

@@ -11,7 +11,10 @@ hp.n_layer = 2
 model = tk.LlmModel(hp).fill_synthetic(4)
 sess = tk.LlmSession(model, 256, 520)
 out = []
-for rows, ctx in [(256, 64), (256, 128), (256, 192), (256, 500), (16, 128), (16, 500), (1, 128)]:
+cases = [(256, 64), (256, 128), (256, 192), (256, 500), (16, 128), (16, 500), (1, 128)]
+if len(sys.argv) > 2:  # tools/time_attention.py ROWS CTX: one case (the PMC passes of tools/collect_profiles.sh)
+    cases = [(int(sys.argv[1]), int(sys.argv[2]))]
+for rows, ctx in cases:
     ms, kvb = sess.time_attention(rows, ctx, 64)
     out.append(f"{rows}x{ctx}: {1000 * ms:.1f} us ({kvb / ms / 1e6:.0f} GB/s)")
 print(os.environ.get("TK_MI355X_LIB", "default").split("/")[-1], " | ".join(out), flush=True)

@@ -71,7 +71,7 @@ void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t*
 
 size_t tk_gemv_lds_bytes(int K, int ks, int mtiles);
 /* dynamic LDS of one k_attention workgroup; must stay below 160 KiB (the session checks it against its max_ctx) */
-size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk /* positions per ring slot: 32 or 64 */);
+size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk /* positions per ring slot: 32 or 64 */, int slots = 2 /* ring depth: 2 or 5 */);
 /* opts every kernel of this file into 160 KiB of dynamic LDS on `device` (which must be the calling thread's current device); idempotent,
  * thread-safe; returns nullptr or an error string.  Sessions call it at creation: launches never change function attributes. */
 const char* tk_llm_prepare_device(int device);

@@ -6,10 +6,10 @@
  * inside a 256-block, float accumulation across blocks in ascending order, canonical
  * reduction trees elsewhere.  Results are bit-identical to the oracle.
  *
- * Roofline: the dominant kernels are k_gemv_w4a8 (passes of <= 32 rows) and k_gemm_w4a8 (33..256 rows): weights
- * streamed once per pass, 0.5625 / 0.8203 B per weight; MFMA carries the int8 contraction
- * [16 row slots x 64 k] x [64 k x 16 weight rows], so one weight pass serves up to 256 (sequence, position) rows.
- * Measured fractions and where the time goes: DESIGN.md §6.
+ * Roofline: the dominant kernels are k_gemv_w4a8 (passes of <= 32 rows), k_gemm_w4a8 (33..128 rows) and k_gemm32_w4a8 (129..256 rows):
+ * weights streamed once per pass, 0.5625 / 0.8203 B per weight; MFMA carries the int8 contraction
+ * [16 row slots x 64 k] x [64 k x 16 weight rows] (32 x 32 x 32 in the widest kernel), so one weight pass serves up to 256
+ * (sequence, position) rows.  Measured fractions and where the time goes: DESIGN.md §7.
  */
 #include "tk_llm_kernels.h"
 
@@ -680,7 +680,10 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m * TK_ROW_SLOTS + 4 * g + r;
-            if (row < a.nrows) __builtin_nontemporal_store(acc[m][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
+            /* default-policy stores: the <= 1 MB of slabs of a narrow pass stay in L2 / the Infinity Cache for the consumer kernel, which is one
+             * load latency long (decode step 2.277 -> 2.207 ms at 16 rows, 2.108 -> 2.038 ms at 1 row against non-temporal stores,
+             * profiles/r03_smallbatch_variants.txt); the wide kernels keep non-temporal stores (29 MB per launch would only evict) */
+            if (row < a.nrows) a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n] = acc[m][r];
         }
 }
 
@@ -1070,69 +1073,91 @@ __device__ __forceinline__ void unpack_q6_x32(const FragQ6& f0, const FragQ6& f1
 #ifndef TK_G32_STAGGER
 #define TK_G32_STAGGER 0 /* s_sleep units (64 clocks each) waves 4..7 wait after every block barrier: their VALU phases then face their SIMD partner's MFMA phases */
 #endif
-#ifdef TK_G32_STAMPS /* diagnostic build: s_memtime stamps of workgroup 0's waves 0 and 4 (tools/build_variant.sh stamps -DTK_G32_STAMPS), read back by tk_mi355x_debug_stamps */
-__device__ unsigned long long g_tk_stamps[2][16][16];
-#define TK_STAMP(slot) do { if (stamp_on && b < 16) g_tk_stamps[half][b][slot] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" __attribute__((visibility("default"))) int tk_mi355x_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tk_stamps), sizeof(g_tk_stamps)); }
-#else
-#define TK_STAMP(slot) do { } while (0)
+#ifndef TK_G32_PRIO
+#define TK_G32_PRIO 0 /* diagnostic: 1 = s_setprio 1 while a tile is finished on the VALU, 2 = s_setprio 1 while its MFMAs issue */
 #endif
 #ifndef TK_G32_STAGE_UPPER
 #define TK_G32_STAGE_UPPER 0 /* 1: waves 4..7 issue the whole ring staging (a stagger made of useful work) */
 #endif
 
-/* one 256-k block: this wave's 32 weight rows x its four 32-row M-tiles (row half `half` of the ring block `blk`) */
-template <bool Q4>
-__device__ __forceinline__ void gemm_block32(const Ops32& o, const uint8_t* blk, int half, int lane, float (&acc)[TK_G32_MTW][16], bool stamp_on, int b) {
+/* A-side operands of one 32-row M-tile of one ring block that are requested a tile AHEAD: the first four of the eight 16-byte reads of
+ * the int8 MFMAs and the min-term operand; the other four are requested when the tile starts and land under its first MFMAs */
+struct ATile32 { v4i a[4]; v8h mn; };
+struct Ptrs32 { const uint8_t *ap, *mp, *dp; };
+
+__device__ __forceinline__ Ptrs32 block_ptrs32(const uint8_t* blk, int half, int lane) {
     constexpr int OFF_AMN = 16 * 4096, OFF_AD = 16 * 4096 + 16 * 512;
     constexpr int HT = 2 * TK_G32_MTW; /* 16-row M-tiles of a row half */
     const int h = lane >> 5;
-    const uint8_t* ap = blk + half * (HT * 4096) + ((lane >> 4) & 1) * 4096 + (h * 32 + (lane & 15)) * 16;            /* + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256 */
-    const uint8_t* mp = blk + OFF_AMN + half * (HT * 512) + ((lane >> 4) & 1) * 512 + h * 256 + (lane & 15) * 16;   /* + t * 1024 */
-    const uint8_t* dp = blk + OFF_AD + half * (HT * 64) + h * 16;                                                  /* + t * 128 + b * 32 */
+    Ptrs32 p;
+    p.ap = blk + half * (HT * 4096) + ((lane >> 4) & 1) * 4096 + (h * 32 + (lane & 15)) * 16;            /* + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256 */
+    p.mp = blk + OFF_AMN + half * (HT * 512) + ((lane >> 4) & 1) * 512 + h * 256 + (lane & 15) * 16;   /* + t * 1024 */
+    p.dp = blk + OFF_AD + half * (HT * 64) + h * 16;                                                  /* + t * 128 + b * 32 */
+    return p;
+}
+
+template <bool Q4>
+__device__ __forceinline__ void load_atile32(ATile32& T, const Ptrs32& p, int t) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) T.a[u] = *(const v4i*)(p.ap + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256);
+    if (Q4) T.mn = *(const v8h*)(p.mp + t * 1024);
+}
+
+/* one 256-k block: this wave's 32 weight rows x its four 32-row M-tiles.  T arrives holding tile 0's operands (requested before the
+ * weight unpack, so their LDS latency hides under it); the operands of tile t + 1 are requested as soon as the MFMAs of tile t have
+ * issued — into the same registers — and land while tile t is finished on the VALU. */
+template <bool Q4, typename Hook>
+__device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const Ptrs32& p, float (&acc)[TK_G32_MTW][16], Hook&& after_mfmas) {
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < TK_G32_MTW; ++t) {
+        /* P = 8 Ph + Pl (64 Ph + Pl for Q6_K) inside ONE accumulator: the high-digit chain first, its result shifted on the VALU, then the
+         * low-digit chain on top of it (sixteen live registers fewer than two accumulators, and the finishing below needs no shift-add);
+         * the independent min-term MFMA sits where the shift waits for the last high-digit MFMA */
         v4i A[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) A[u] = *(const v4i*)(ap + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256);
-#ifdef TK_G32_STAMPS
-        __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): stamp the arrival of the A operands */
-        TK_STAMP(2 + 3 * t);
-#endif
-        v16i pl = zero, ph = zero;
+        for (int u = 0; u < 4; ++u) A[u] = T.a[u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            pl = TK_MFMA32(A[u], o.bl[u], pl, 0, 0, 0);
-            ph = TK_MFMA32(A[u], o.bh[u], ph, 0, 0, 0);
-        }
-#ifdef TK_G32_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-        TK_STAMP(3 + 3 * t); /* the MFMAs have ISSUED (the stamp does not wait for their results) */
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        for (int u = 4; u < 8; ++u) A[u] = *(const v4i*)(p.ap + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256);
+        v16i ph = zero;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ph = TK_MFMA32(A[u], o.bh[u], ph, 0, 0, 0);
         v16f cm;
         if (Q4) {
-            const v8h mn = *(const v8h*)(mp + t * 1024);
             const v16f fz = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(mn, o.bm16, fz, 0, 0, 0);
+            cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(T.mn, o.bm16, fz, 0, 0, 0);
         }
+        v16i pl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pl[r] = ph[r] << (Q4 ? 3 : 6);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pl = TK_MFMA32(A[u], o.bl[u], pl, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < TK_G32_MTW) load_atile32<Q4>(T, p, t + 1);
+        after_mfmas(t); /* a quarter of this wave's ring staging for the next block: LDS-DMA issue costs 60-180 cycles a piece, here they pass while
+                         * the tile's MFMAs are still in the matrix pipe */
+        __builtin_amdgcn_sched_barrier(0);
+#if TK_G32_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#elif TK_G32_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int b = 0; b < 4; ++b) { /* accumulator register 4 b + i = row 8 b + 4 h + i of the M-tile */
-            const v4f da = *(const v4f*)(dp + t * 128 + b * 32);
+            const v4f da = *(const v4f*)(p.dp + t * 128 + b * 32);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * b + i;
-                acc[t][r] = tk_fmaf(o.dw * da[i], (float)((ph[r] << (Q4 ? 3 : 6)) + pl[r]), acc[t][r]);
+                acc[t][r] = tk_fmaf(o.dw * da[i], (float)pl[r], acc[t][r]);
                 if (Q4) acc[t][r] = tk_fmaf(-(o.dmin * da[i]), cm[r], acc[t][r]);
             }
         }
-#ifdef TK_G32_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" :: "v"(acc[t][15]));
-        TK_STAMP(4 + 3 * t);
-        __builtin_amdgcn_sched_barrier(0);
+#if TK_G32_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif TK_G32_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
 #endif
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -1149,8 +1174,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
     const int ksi = blockIdx.x % a.ks;
     const int blk0 = ksi * nb;
     const int pair = wave & 3, half = wave >> 2; /* waves w and w + 4 share a SIMD: same weight rows, the two row halves */
-    const bool stamp_on = blockIdx.x == 0 && pair == 0 && lane == 0;
-    (void)stamp_on;
 
     int rt = 2 * (blockIdx.x / a.ks + pair * groups); /* first of this wave's two adjacent row tiles */
     const bool active = rt < total_row_tiles;
@@ -1174,22 +1197,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    /* ring staging as in k_gemm_w4a8: whole 16-row M-tiles dealt round-robin to the eight waves */
-    auto stage = [&](int c, int slot) {
+    /* ring staging: the 16-row M-tiles `wave` and `wave + 8` belong to this wave.  The int8 image (4 x 1 KiB pieces per tile, every lane
+     * takes part: no exec masking, so the issue can sit between the MFMA phases of the tile loop) in four parts of two pieces; the f16
+     * sub-block sums (32 lanes) and the block scales (4 lanes) separately at the top of a block */
+    auto stage_part = [&](int c, int slot, int part) {
+        const int m = wave + 8 * (part >> 1);
+        const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)(blk0 + c) * 4096 + (part & 1) * 2048 + lane * 16;
+        const auto gs = (const __attribute__((address_space(1))) void*)src;
+        const auto ls = (__attribute__((address_space(3))) void*)(lds + slot * CH + m * 4096 + (part & 1) * 2048);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
+    };
+    auto stage_small = [&](int c, int slot) {
         uint8_t* dst = lds + slot * CH;
-#if TK_G32_STAGE_UPPER
-        if (wave < 4) return;
-        for (int m = wave - 4; m < MT; m += 4) {
-#else
         for (int m = wave; m < MT; m += 8) {
-#endif
-            const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)(blk0 + c) * 4096 + lane * 16;
-            const auto gs = (const __attribute__((address_space(1))) void*)src;
-            const auto ls = (__attribute__((address_space(3))) void*)(dst + m * 4096);
-            __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
-            __builtin_amdgcn_global_load_lds(gs, ls, 16, 2048, 0);
-            __builtin_amdgcn_global_load_lds(gs, ls, 16, 3072, 0);
             const uint8_t* sm = (const uint8_t*)(a.abs16 + m * a.abs_ts + (size_t)(blk0 + c) * 256) + lane * 16;
             if (lane < 32)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sm,
@@ -1200,6 +1221,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
                                                  (__attribute__((address_space(3))) void*)(dst + OFF_AD + m * 64), 16, 0, 0);
         }
     };
+    auto stage = [&](int c, int slot) { stage_small(c, slot); for (int part = 0; part < 4; ++part) stage_part(c, slot, part); };
 
     if (HAS4 && is4) {
         FragQ4 f0, f1;
@@ -1207,25 +1229,27 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
         stage(0, 0);
 #pragma unroll 1
         for (int b = 0; b < nb; ++b) {
-            TK_STAMP(15);
             __builtin_amdgcn_s_waitcnt(0);
-            TK_STAMP(14);
             __syncthreads();
-            TK_STAMP(0);
-            if (b + 1 < nb) stage(b + 1, (b + 1) & 1);
-            if (!active) continue;
+            const bool more = b + 1 < nb;
+            if (!active) { if (more) stage(b + 1, (b + 1) & 1); continue; }
+            if (more) stage_small(b + 1, (b + 1) & 1);
 #if TK_G32_STAGGER
             if (half) __builtin_amdgcn_s_sleep(TK_G32_STAGGER);
 #endif
             const uint8_t* next = tile + (size_t)(b + 1 < nb ? b + 1 : b) * tile_bytes; /* the last step re-requests its own tile: no branch around a load */
+            const Ptrs32 bp = block_ptrs32(lds + (b & 1) * CH, half, lane);
+            ATile32 T;
+            load_atile32<true>(T, bp, 0);
+            __builtin_amdgcn_sched_barrier(0);
             Ops32 o;
             unpack_q4_x32(f0, f1, lane, o);
             __builtin_amdgcn_sched_barrier(0);
             f0 = load_q4(next, lane);
             f1 = load_q4(next + tile_pitch, lane);
             __builtin_amdgcn_sched_barrier(0);
-            TK_STAMP(1);
-            gemm_block32<true>(o, lds + (b & 1) * CH, half, lane, acc, stamp_on, b);
+            /* the last block restages itself into the slot nobody reads any more: no branch around the DMA issue */
+            gemm_block32<true>(o, T, bp, acc, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
         }
     }
     if (HAS6 && !is4) {
@@ -1236,19 +1260,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
         for (int b = 0; b < nb; ++b) {
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            if (b + 1 < nb) stage(b + 1, (b + 1) & 1);
-            if (!active) continue;
+            const bool more = b + 1 < nb;
+            if (!active) { if (more) stage(b + 1, (b + 1) & 1); continue; }
+            if (more) stage_small(b + 1, (b + 1) & 1);
 #if TK_G32_STAGGER
             if (half) __builtin_amdgcn_s_sleep(TK_G32_STAGGER);
 #endif
             const uint8_t* next = tile + (size_t)(b + 1 < nb ? b + 1 : b) * tile_bytes;
+            const Ptrs32 bp = block_ptrs32(lds + (b & 1) * CH, half, lane);
+            ATile32 T;
+            load_atile32<false>(T, bp, 0);
+            __builtin_amdgcn_sched_barrier(0);
             Ops32 o;
             unpack_q6_x32(f0, f1, lane, o);
             __builtin_amdgcn_sched_barrier(0);
             f0 = load_q6(next, lane);
             f1 = load_q6(next + tile_pitch, lane);
             __builtin_amdgcn_sched_barrier(0);
-            gemm_block32<false>(o, lds + (b & 1) * CH, half, lane, acc, stamp_on, b);
+            gemm_block32<false>(o, T, bp, acc, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
         }
     }
     if (!active) return;
@@ -1420,13 +1449,9 @@ void tk_launch_qkv_rope_append(const float* partial, int ks, int n_total, int n_
  * ------------------------------------------------------------------------------------------ */
 #define TK_ATT_MAX_GRP 4
 #define TK_ATT_TSPLIT 4 /* canonical: 4 interleaved partial sums over positions (t mod 4), added in order */
-#ifndef TK_ATT_SLOTS
-#define TK_ATT_SLOTS 2
-#endif
-/* TK_ATT_SLOTS 2: ring slots: the next chunk lands while the current one is used.  Measured on MI355X (256 rows x 128 cached
-                         * positions, profiles/r02_attention_variants.txt): 2 x 64 rows 53.5 us, 8 x 32 rows 86 us — a workgroup's life is a
-                         * chain of short dependent phases, so what pays is workgroups per CU (LDS footprint), not bytes in flight per workgroup */
-
+/* ring slots (template parameter SLOTS, 2 everywhere): the next chunk lands while the current one is used.  Wide passes (256 rows x 128
+ * cached positions, profiles/r02_attention_variants.txt: 2 x 64 rows 53.5 us, 8 x 32 rows 86 us) want a small LDS footprint — workgroups per
+ * CU pay, not bytes in flight per workgroup; narrow ones gain nothing from a deeper ring either (profiles/r03_attention_slots.txt) */
 __device__ __forceinline__ float sum_partials_wide(const float* partial, int ks, int n_total, int row, int col) {
     float p[TK_RMS_MAX_KS];
 #pragma unroll
@@ -1456,7 +1481,7 @@ __device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int las
     }
 }
 
-template <int GQ, bool FUSED, int HD /* head_dim when it is 64 or 128 (loops unroll, LDS reads batch), 0 = any */, int CH /* positions per ring slot */>
+template <int GQ, bool FUSED, int HD /* head_dim when it is 64 or 128 (loops unroll, LDS reads batch), 0 = any */, int CH /* positions per ring slot */, int SLOTS = 2>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbuf, const float* __restrict__ partial, int ks, int n_total,
                                                     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                                     uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache, const int32_t* __restrict__ seq,
@@ -1476,7 +1501,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     const int slot_bytes = CH * rb;
     /* LDS: the ring (K chunks, then V chunks: one stream), then the float arrays */
     uint8_t* ring = att_lds;
-    float* qs = (float*)(att_lds + TK_ATT_SLOTS * slot_bytes); /* [GQ][head_dim] */
+    float* qs = (float*)(att_lds + SLOTS * slot_bytes); /* [GQ][head_dim] */
     float* sc = qs + W;                                   /* [GQ][max_ctx] */
     float* red = sc + (size_t)GQ * max_ctx;               /* [4 waves][GQ] */
     uint16_t* own = (uint16_t*)(red + 4 * TK_ATT_MAX_GRP); /* [2][head_dim]: this row's own K and V (FUSED) */
@@ -1496,18 +1521,18 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     auto issue = [&](int j) { /* chunk j of the stream into slot j % SLOTS; always issued (a chunk with nothing cached yet re-reads clamped rows) */
         const bool is_k = j < nchunk;
         const int c = is_k ? j : j - nchunk;
-        att_stage(is_k ? krun : vrun, c * CH, last_row, rb, ring + (j % TK_ATT_SLOTS) * slot_bytes, is_k, wave, lane, CH);
+        att_stage(is_k ? krun : vrun, c * CH, last_row, rb, ring + (j % SLOTS) * slot_bytes, is_k, wave, lane, CH);
     };
     /* before touching chunk j: all but the chunks issued after it have landed; everybody is done with chunk j - 1, whose slot takes
      * chunk j + SLOTS - 1 */
     auto acquire = [&](int j) {
-        const int ahead = total - 1 - j < TK_ATT_SLOTS - 2 ? total - 1 - j : TK_ATT_SLOTS - 2;
+        const int ahead = total - 1 - j < SLOTS - 2 ? total - 1 - j : SLOTS - 2;
         wait_vmcnt(ahead * ppw);
         __syncthreads();
-        if (j + TK_ATT_SLOTS - 1 < total) issue(j + TK_ATT_SLOTS - 1);
+        if (j + SLOTS - 1 < total) issue(j + SLOTS - 1);
     };
 
-    for (int j = 0; j < TK_ATT_SLOTS - 1 && j < total; ++j) issue(j); /* in flight under the q / k / v prologue */
+    for (int j = 0; j < SLOTS - 1 && j < total; ++j) issue(j); /* in flight under the q / k / v prologue */
     if (FUSED) {
         const float* cs = rope_cos + (int64_t)p * half;
         const float* sn = rope_sin + (int64_t)p * half;
@@ -1542,7 +1567,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     float mx = -INFINITY;
     for (int c = 0; c < nchunk; ++c) {
         acquire(c); /* the first barrier also publishes qs and own */
-        uint8_t* slot = ring + (c % TK_ATT_SLOTS) * slot_bytes;
+        uint8_t* slot = ring + (c % SLOTS) * slot_bytes;
         if (FUSED && c == nchunk - 1) { /* the row's own key (position p, always in the last chunk) comes from LDS, swizzled like the rest */
             const int rr = p - c * CH;
             if (t < ppr) *(uint4*)(slot + rr * rb + ((t ^ (rr & (ppr - 1))) * 16)) = *(const uint4*)((const uint8_t*)own + t * 16);
@@ -1593,7 +1618,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     for (int h = 0; h < GQ; ++h) { l[h] = 0.0f; acc[h][0][0] = acc[h][0][1] = acc[h][1][0] = acc[h][1][1] = 0.0f; }
     for (int c = 0; c < nchunk; ++c) {
         acquire(nchunk + c); /* the first barrier also publishes the probabilities */
-        uint8_t* slot = ring + ((nchunk + c) % TK_ATT_SLOTS) * slot_bytes;
+        uint8_t* slot = ring + ((nchunk + c) % SLOTS) * slot_bytes;
         if (FUSED && c == nchunk - 1) {
             const int rr = p - c * CH;
             if (t < ppr) *(uint4*)(slot + rr * rb + t * 16) = *(const uint4*)((const uint8_t*)(own + head_dim) + t * 16);
@@ -1666,9 +1691,9 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbu
     }
 }
 
-size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk) {
+size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk, int slots) {
     const size_t W = (size_t)gq * head_dim;
-    const size_t ring = (size_t)TK_ATT_SLOTS * chunk * head_dim * 2;
+    const size_t ring = (size_t)slots * chunk * head_dim * 2;
     const size_t epilogue = ((size_t)TK_ATT_TSPLIT * W + TK_ATT_TSPLIT * TK_ATT_MAX_GRP + W) * sizeof(float); /* aliases the ring */
     return (ring > epilogue ? ring : epilogue) + (W + (size_t)gq * max_ctx + 4 * TK_ATT_MAX_GRP) * sizeof(float) + (size_t)2 * head_dim * 2;
 }
@@ -1680,15 +1705,22 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
     /* few rows: two workgroups per KV head (two query heads each) — twice the workgroups, half the dependent work in each; K / V are then
      * read twice, which costs nothing while the launch is latency-bound (16 rows: 15.9 -> see profiles/r02_attention_variants.txt) */
     if (gq == 4 && (2 * head_dim) % 256 == 0 && nrows * n_kv_head < 2 * TK_NUM_CU) gq = 2;
+#ifdef TK_ATT_GQ1_ROWS /* diagnostic: one query head per workgroup below this many rows */
+    if (gq == 2 && head_dim % 256 == 0 && nrows <= TK_ATT_GQ1_ROWS) gq = 1;
+#endif
     /* positions per ring slot: 64 while the launch is a latency chain of few workgroups (fewer, longer phases), 32 once several
      * workgroups per CU are resident (16 KiB less LDS each: more of them fit; 256 rows: 47.9 -> 43.3 us, 16 rows would lose 24 %;
      * profiles/r02_attention_variants.txt) */
     const int chunk = (n_head / gq) * nrows > 4 * TK_NUM_CU ? 32 : 64;
-    const size_t lds = tk_attention_lds_bytes(gq, head_dim, max_ctx, chunk);
-#define TK_ATT_LAUNCH_CH(G, F, H, C)                                                                                                          \
-    hipLaunchKernelGGL((k_attention<G, F, H, C>), dim3(n_head / gq, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin, kcache, \
+    /* ring depth 2 at every pass width: with few workgroups a five-slot ring (every K and V chunk of a 128-position context in flight at
+     * once) measured no faster — 16 rows x 128 positions 10.7 us against 11.1, decode step unchanged (profiles/r03_attention_slots.txt): a
+     * one-row launch already takes 9.8 us, the launch is a chain of ~10 barrier-separated phases, not of DMA latencies */
+    const int slots = 2;
+    const size_t lds = tk_attention_lds_bytes(gq, head_dim, max_ctx, chunk, slots);
+#define TK_ATT_LAUNCH_CH(G, F, H, C, S)                                                                                                       \
+    hipLaunchKernelGGL((k_attention<G, F, H, C, S>), dim3(n_head / gq, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin, kcache, \
                        vcache, seq, pos, n_head, n_kv_head, head_dim, layer, max_seq, max_ctx, out)
-#define TK_ATT_LAUNCH_HD(G, F, H) do { if (chunk == 32) TK_ATT_LAUNCH_CH(G, F, H, 32); else TK_ATT_LAUNCH_CH(G, F, H, 64); } while (0)
+#define TK_ATT_LAUNCH_HD(G, F, H) do { if (chunk == 32) TK_ATT_LAUNCH_CH(G, F, H, 32, 2); else TK_ATT_LAUNCH_CH(G, F, H, 64, 2); } while (0)
 #define TK_ATT_LAUNCH(G, F) do { if (head_dim == 128) TK_ATT_LAUNCH_HD(G, F, 128); else if (head_dim == 64) TK_ATT_LAUNCH_HD(G, F, 64); else TK_ATT_LAUNCH_HD(G, F, 0); } while (0)
     if (fused) {
         if (gq == 4) TK_ATT_LAUNCH(4, true); else if (gq == 2) TK_ATT_LAUNCH(2, true); else TK_ATT_LAUNCH(1, true);
@@ -1797,9 +1829,9 @@ const char* tk_llm_prepare_device(int device) {
     TK_OPT((k_gemm32_w4a8<1>)); TK_OPT((k_gemm32_w4a8<2>)); TK_OPT((k_gemm32_w4a8<3>));
 #define TK_OPT_GEMV(PFV, MTV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3>)); } while (0)
     TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
-#define TK_OPT_ATT_C(H, C) do { TK_OPT((k_attention<1, true, H, C>)); TK_OPT((k_attention<2, true, H, C>)); TK_OPT((k_attention<4, true, H, C>)); \
-                              TK_OPT((k_attention<1, false, H, C>)); TK_OPT((k_attention<2, false, H, C>)); TK_OPT((k_attention<4, false, H, C>)); } while (0)
-#define TK_OPT_ATT(H) do { TK_OPT_ATT_C(H, 32); TK_OPT_ATT_C(H, 64); } while (0)
+#define TK_OPT_ATT_C(H, C, S) do { TK_OPT((k_attention<1, true, H, C, S>)); TK_OPT((k_attention<2, true, H, C, S>)); TK_OPT((k_attention<4, true, H, C, S>)); \
+                                 TK_OPT((k_attention<1, false, H, C, S>)); TK_OPT((k_attention<2, false, H, C, S>)); TK_OPT((k_attention<4, false, H, C, S>)); } while (0)
+#define TK_OPT_ATT(H) do { TK_OPT_ATT_C(H, 32, 2); TK_OPT_ATT_C(H, 64, 2); } while (0)
     TK_OPT_ATT(0); TK_OPT_ATT(64); TK_OPT_ATT(128);
 #undef TK_OPT_ATT
 #undef TK_OPT_GEMV

@@ -170,3 +170,146 @@ class LlmPipeline:
                     owed[gi] = self._post_recv_ids(nseq)
         self._drain()
         return out
+
+
+# ---- BASELINE configs[4]: the LLM layer-sharded over k GPUs, "fused with vision + ASR on spare GPUs" (SURVEY.md §8e row "8") --------------
+
+def combined_roles(world):
+    """who does what in a job of `world` ranks (one per GPU): {"llm": the pipeline's ranks in stage order, "vision": detector ranks,
+    "audio": VAD + ASR ranks}.
+      1: everything on rank 0            2: LLM on 0, both perception streams on 1      3: two LLM stages, perception on 2
+      4 and more: ranks 0 .. world - 3 form the pipeline, rank world - 2 runs the detector, rank world - 1 VAD + ASR
+      (8: six stages of 5 - 6 layers + detector + ASR — the row SURVEY.md §8e names)"""
+    if world <= 1:
+        return {"llm": [0], "vision": [0], "audio": [0]}
+    if world == 2:
+        return {"llm": [0], "vision": [1], "audio": [1]}
+    if world == 3:
+        return {"llm": [0, 1], "vision": [2], "audio": [2]}
+    return {"llm": list(range(world - 2)), "vision": [world - 2], "audio": [world - 1]}
+
+
+def stage_bounds(n_layer, n_stages):
+    """layers [bounds[s], bounds[s + 1]) belong to stage s: as even as integer division allows, every stage at least one layer"""
+    if not 1 <= n_stages <= n_layer:
+        raise ValueError("a pipeline needs between 1 and n_layer stages")
+    return [(n_layer * s) // n_stages for s in range(n_stages + 1)]
+
+
+def stage_schedule(prompts, n_steps, rows_per_pass):
+    """the pass list EVERY stage enqueues, in this order, for its row groups: per group the prompt chunks (no sampling), the sampling pass
+    and the decode loop.  prompts: list of int arrays [nseq_g][n_prompt_g].  Entries: ("pass", g, seq, pos, tok, head) / ("decode", g, nseq, n_steps).
+    Sequences are numbered inside their group (each group has a session of its own on every stage)."""
+    import numpy as np
+    out = []
+    for gi, g in enumerate(prompts):
+        g = np.ascontiguousarray(g, np.int32)
+        nseq, n_prompt = g.shape
+        seq = np.repeat(np.arange(nseq, dtype=np.int32), n_prompt - 1)
+        pos = np.tile(np.arange(n_prompt - 1, dtype=np.int32), nseq)
+        tok = g[:, :-1].reshape(-1)
+        for i in range(0, len(seq), rows_per_pass):
+            out.append(("pass", gi, seq[i:i + rows_per_pass], pos[i:i + rows_per_pass], tok[i:i + rows_per_pass], False))
+        out.append(("pass", gi, np.arange(nseq, dtype=np.int32), np.full(nseq, n_prompt - 1, np.int32), g[:, -1].copy(), True))
+    for gi, g in enumerate(prompts):
+        out.append(("decode", gi, int(np.asarray(g).shape[0]), n_steps))
+    return out
+
+
+class LibPipeline:
+    """One LLM stage of a layer-sharded job, driven through the library's own hand-off (tk_mi355x_pipe_*: device mailboxes mapped with
+    hipIpc, csrc/llm/tk_llm_pipe.h).  The host only (1) exchanges the 80-byte mailbox handles once, over `dist` (any backend: they are
+    plain bytes), and (2) enqueues the same schedule on every stage; no tensor ever goes through torch.distributed and nothing
+    synchronises with the host between a prompt and its last decoded token.
+
+    make_pipe(group_index, stage, n_stages, l0, l1) -> an object with .handle_bytes, .connect(next_bytes, prev_bytes), .enqueue(seq, pos,
+    tok, head), .decode(nrows, n_steps), .sync(nrows, n_steps); the GPU one wraps tk.LlmPipe (below), tests inject a recorder."""
+
+    def __init__(self, dist, llm_ranks, n_layer, n_groups, make_pipe):
+        self.dist = dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.llm_ranks = list(llm_ranks)
+        self.n_stages = len(self.llm_ranks)
+        self.stage = self.llm_ranks.index(self.rank) if self.rank in self.llm_ranks else None
+        self.bounds = stage_bounds(n_layer, self.n_stages)
+        self.pipes = []
+        mine = []
+        if self.stage is not None:
+            for g in range(n_groups):
+                self.pipes.append(make_pipe(g, self.stage, self.n_stages, self.bounds[self.stage], self.bounds[self.stage + 1]))
+            mine = [p.handle_bytes for p in self.pipes]
+        # every rank of the job takes part in the exchange (perception ranks contribute nothing), so any process group works
+        if dist is not None and dist.get_world_size() > 1:
+            table = [None] * dist.get_world_size()
+            dist.all_gather_object(table, mine)
+        else:
+            table = [mine]
+        if self.stage is not None and self.n_stages > 1:
+            nxt = table[self.llm_ranks[(self.stage + 1) % self.n_stages]]
+            prv = table[self.llm_ranks[(self.stage - 1) % self.n_stages]]
+            for g, p in enumerate(self.pipes):
+                p.connect(nxt[g], prv[g])
+
+    @property
+    def first(self):
+        return self.stage == 0
+
+    @property
+    def last(self):
+        return self.stage is not None and self.stage == self.n_stages - 1
+
+    def generate(self, prompts, n_steps, rows_per_pass=256):
+        """enqueue the whole job of this stage, then wait once.  Returns the per-group [n_steps][nseq] ids: sampled ones on the last
+        stage, fed ones on stage 0, None on the others (and on ranks outside the pipeline)."""
+        if self.stage is None:
+            return None
+        for item in stage_schedule(prompts, n_steps, rows_per_pass):
+            if item[0] == "pass":
+                _, g, seq, pos, tok, head = item
+                self.pipes[g].enqueue(seq, pos, tok if self.first else None, head)
+            else:
+                _, g, nseq, steps = item
+                self.pipes[g].decode(nseq, steps)
+        out = []
+        for g, p in enumerate(self.pipes):
+            nseq = len(prompts[g])
+            toks = p.sync(nseq, n_steps if (self.first or self.last) else 0)
+            out.append(toks)
+        return out if (self.first or self.last) else None
+
+
+class _GpuPipe:
+    """adapter of tk.LlmPipe to what LibPipeline drives"""
+
+    def __init__(self, tk, session, stage, n_stages, l0, l1, payload_f16):
+        self.tk = tk
+        self.pipe = tk.LlmPipe(session, stage, n_stages, l0, l1, payload_f16=payload_f16)
+        self.handle_bytes = self.pipe.handle.to_bytes()
+
+    def connect(self, nxt, prv):
+        self.pipe.connect(self.tk.PipeHandle.from_bytes(nxt), self.tk.PipeHandle.from_bytes(prv))
+
+    def enqueue(self, seq, pos, tok, head):
+        self.pipe.enqueue(seq, pos, tok, head)
+
+    def decode(self, nrows, n_steps):
+        self.pipe.decode(nrows, n_steps)
+
+    def sync(self, nrows, n_steps):
+        return self.pipe.sync(nrows, n_steps)
+
+    def close(self):
+        self.pipe.close()
+
+
+def gpu_pipe_factory(tk, model, rows_per_group, max_ctx, payload_f16=False):
+    """make_pipe for LibPipeline on a GPU rank: one session (own stream, own KV cache) and one pipe per row group"""
+    sessions = []
+
+    def make(g, stage, n_stages, l0, l1):
+        s = tk.LlmSession(model, rows_per_group, max_ctx)
+        sessions.append(s)
+        return _GpuPipe(tk, s, stage, n_stages, l0, l1, payload_f16)
+
+    make.sessions = sessions
+    return make
