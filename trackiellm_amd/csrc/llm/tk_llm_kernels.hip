@@ -1119,6 +1119,9 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
         for (int u = 0; u < 4; ++u) A[u] = T.a[u];
 #pragma unroll
         for (int u = 4; u < 8; ++u) A[u] = *(const v4i*)(p.ap + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256);
+        v4f da[4]; /* the block scales of this tile's rows: requested here, used after the MFMAs (a read issued in the finishing loop is waited for at once) */
+#pragma unroll
+        for (int b = 0; b < 4; ++b) da[b] = *(const v4f*)(p.dp + t * 128 + b * 32);
         v16i ph = zero;
 #pragma unroll
         for (int u = 0; u < 8; ++u) ph = TK_MFMA32(A[u], o.bh[u], ph, 0, 0, 0);
@@ -1143,15 +1146,13 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
         __builtin_amdgcn_s_setprio(0);
 #endif
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { /* accumulator register 4 b + i = row 8 b + 4 h + i of the M-tile */
-            const v4f da = *(const v4f*)(p.dp + t * 128 + b * 32);
+        for (int b = 0; b < 4; ++b) /* accumulator register 4 b + i = row 8 b + 4 h + i of the M-tile */
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * b + i;
-                acc[t][r] = tk_fmaf(o.dw * da[i], (float)pl[r], acc[t][r]);
-                if (Q4) acc[t][r] = tk_fmaf(-(o.dmin * da[i]), cm[r], acc[t][r]);
+                acc[t][r] = tk_fmaf(o.dw * da[b][i], (float)pl[r], acc[t][r]);
+                if (Q4) acc[t][r] = tk_fmaf(-(o.dmin * da[b][i]), cm[r], acc[t][r]);
             }
-        }
 #if TK_G32_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #elif TK_G32_PRIO == 2
