@@ -100,6 +100,16 @@ def attr_float(name, v):
     return _ld(1, name.encode()) + _varint((2 << 3) | 5) + struct.pack("<f", v) + _vi(20, 1)
 
 
+def attr_graph(name, graph_bytes):
+    """a sub-graph attribute (AttributeProto.g = 6, type GRAPH = 5): the then_branch / else_branch of If"""
+    return _ld(1, name.encode()) + _ld(6, graph_bytes) + _vi(20, 5)
+
+
+def graph_proto(nodes, initialisers, inputs, outputs, name=b"g"):
+    g = b"".join(_ld(1, n) for n in nodes) + _ld(2, name) + b"".join(_ld(5, t) for t in initialisers)
+    return g + b"".join(_ld(11, i) for i in inputs) + b"".join(_ld(12, o) for o in outputs)
+
+
 def attr_str(name, s):
     return _ld(1, name.encode()) + _ld(4, s.encode()) + _vi(20, 3)
 
@@ -141,8 +151,11 @@ def vad_weights(seed, n_bins=33, n_fft=64, hidden=32):
     return W
 
 
-def vad_model(W, window=480, hop=32, hidden=32, extra_op=None):
-    """A VAD graph of the Silero class: reflect pad -> STFT as a strided Conv with a fixed (windowed cos | -sin) basis -> magnitude ->
+def vad_model(W, window=480, hop=32, hidden=32, extra_op=None, with_if=False, neg_head=False):
+    """with_if: the head sits inside an If on Equal(sr, 16000) — the way published silero_vad.onnx exports select their per-sample-rate
+    sub-network (to my knowledge of those files; none is available offline): then_branch = the head below, else_branch = the same head on
+    the negated features (an initialiser of its own inside the branch).  neg_head: the else-branch's arithmetic as a plain graph.
+    A VAD graph of the Silero class: reflect pad -> STFT as a strided Conv with a fixed (windowed cos | -sin) basis -> magnitude ->
     three Conv + ReLU (two strided) -> LSTM with recurrent inputs h, c -> ReLU -> 1x1 Conv -> Sigmoid -> mean over time.
     Inputs: input [1, window] f32, sr [] i64, h [1, 1, hidden], c [1, 1, hidden]; outputs: output [1, 1], hn, cn."""
     n_bins = W["stft"].shape[0] // 2
@@ -169,15 +182,28 @@ def vad_model(W, window=480, hop=32, hidden=32, extra_op=None):
         node("Squeeze", ["y"], ["y3"], [attr_ints("axes", [1])]),
         node("Transpose", ["y3"], ["yt"], [attr_ints("perm", [1, 2, 0])]),
         node("Relu", ["yt"], ["yr"]),
-        node("Conv", ["yr", "head.w", "head.b"], ["logit"]),
-        node("Sigmoid", ["logit"], ["p"]),
-        node("ReduceMean", ["p"], ["output"], [attr_ints("axes", [2]), attr_int("keepdims", 0)]),
     ]
+    neg = [node("Mul", ["yr", "minus_one"], ["yn"]), node("Conv", ["yn", "head.w", "head.b"], ["logit_e"]), node("Sigmoid", ["logit_e"], ["p_e"])]
+    if with_if:
+        then_g = graph_proto([node("Conv", ["yr", "head.w", "head.b"], ["logit_t"]), node("Sigmoid", ["logit_t"], ["p_t"])], [], [],
+                             [value_info("p_t", 1, [1, 1, -1])], b"then")
+        else_g = graph_proto(neg, [tensor("minus_one", np.array([-1.0], np.float32))], [], [value_info("p_e", 1, [1, 1, -1])], b"else")
+        nodes += [node("Equal", ["sr", "sr16k"], ["is16k"]),
+                  node("If", ["is16k"], ["p"], [attr_graph("then_branch", then_g), attr_graph("else_branch", else_g)], name="rate_switch")]
+    elif neg_head:
+        nodes += neg[:2] + [node("Sigmoid", ["logit_e"], ["p"])]
+    else:
+        nodes += [node("Conv", ["yr", "head.w", "head.b"], ["logit"]), node("Sigmoid", ["logit"], ["p"])]
+    nodes.append(node("ReduceMean", ["p"], ["output"], [attr_ints("axes", [2]), attr_int("keepdims", 0)]))
     if extra_op:
         nodes.append(node(extra_op, ["output"], ["unused"], name="extra"))
     inits = [tensor(k, v) for k, v in W.items()]
     inits += [int_tensor("pads", [0, 0, n_fft // 2, 0, 0, n_fft // 2]), int_tensor("s0", [0]), int_tensor("s1", [n_bins]), int_tensor("s2", [2 * n_bins]),
               int_tensor("ax1", [1])]
+    if with_if:
+        inits.append(int_tensor("sr16k", [16000], []))
+    if neg_head:
+        inits.append(tensor("minus_one", np.array([-1.0], np.float32)))
     inputs = [value_info("input", 1, [1, window]), value_info("sr", 7, []), value_info("h", 1, [1, 1, hidden]), value_info("c", 1, [1, 1, hidden])]
     outputs = [value_info("output", 1, [1, 1]), value_info("hn", 1, [1, 1, hidden]), value_info("cn", 1, [1, 1, hidden])]
     return model(nodes, inits, inputs, outputs)

@@ -313,8 +313,24 @@ def test_vad_onnx_graph_on_the_gpu_matches_torch(gpu, tmp_path):
     a, b = vad.probability(pcm[:480]), vad.probability(pcm[:480])
     assert a == b and abs(a - got[0]) < 1e-3     # the same first window, up to the int16 round trip
     vad.close()
-    bad = tmp_path / "vad_if.onnx"
-    bad.write_bytes(onnx_util.vad_model(W, extra_op="If"))
+    bad = tmp_path / "vad_loop.onnx"
+    bad.write_bytes(onnx_util.vad_model(W, extra_op="Loop"))
     with pytest.raises(gpu.TkError) as e:
         gpu.Vad(model=str(bad))
-    assert e.value.code == 4000 and "If" in e.value.detail
+    assert e.value.code == 4000 and "Loop" in e.value.detail
+    # the per-sample-rate switch of Silero-class exports: If on Equal(sr, 16000) with the head inside the branches.  At 16 kHz the then
+    # branch runs — the torch fixture's arithmetic; at 8 kHz the else branch — the same numbers as that arithmetic written as a plain graph
+    sw = tmp_path / "vad_if.onnx"
+    sw.write_bytes(onnx_util.vad_model(W, with_if=True))
+    v16 = gpu.Vad(model=str(sw))
+    assert np.array_equal(v16.probabilities(wins), got)
+    v16.close()
+    sw8 = tmp_path / "vad_if_8k.onnx"
+    sw8.write_bytes(onnx_util.vad_model(W, window=240, with_if=True))
+    plain8 = tmp_path / "vad_neg_8k.onnx"
+    plain8.write_bytes(onnx_util.vad_model(W, window=240, neg_head=True))
+    w8 = wins.reshape(-1, 240)
+    a8, b8 = gpu.Vad(model=str(sw8), sample_rate=8000), gpu.Vad(model=str(plain8), sample_rate=8000)
+    pa, pb = a8.probabilities(w8), b8.probabilities(w8)
+    assert np.array_equal(pa, pb) and pa.std() > 1e-4
+    a8.close(); b8.close()

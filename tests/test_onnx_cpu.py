@@ -59,10 +59,18 @@ def test_vad_graph_probe_accepts_the_silero_class_and_names_unsupported_ops(tmp_
     n, ni, ns = C.c_int32(), C.c_int32(), C.c_int32()
     assert tk.lib().tk_mi355x_vad_onnx_probe(str(ok).encode(), C.byref(n), C.byref(ni), C.byref(ns)) == 0
     assert n.value == 24 and ni.value == len(W) + 5 and ns.value == 2          # h and c are recurrent inputs
-    bad = tmp_path / "vad_if.onnx"
-    bad.write_bytes(X.vad_model(W, extra_op="If"))
+    bad = tmp_path / "vad_loop.onnx"
+    bad.write_bytes(X.vad_model(W, extra_op="Loop"))
     assert tk.lib().tk_mi355x_vad_onnx_probe(str(bad).encode(), None, None, None) == 4001   # TK_ERROR_MODEL_VERIFICATION_FAILED
-    assert b"'If'" in tk.lib().tk_error_get_detail()
+    assert b"'Loop'" in tk.lib().tk_error_get_detail()
+    # If with its two branch graphs (what per-sample-rate exports use) is read, its branches' ops are checked too
+    sw = tmp_path / "vad_if.onnx"
+    sw.write_bytes(X.vad_model(W, with_if=True))
+    assert tk.lib().tk_mi355x_vad_onnx_probe(str(sw).encode(), C.byref(n), C.byref(ni), C.byref(ns)) == 0
+    assert n.value == 24 and ns.value == 2                                      # Equal + If replace the two head nodes of the plain graph
+    naked = tmp_path / "vad_if_nobranch.onnx"
+    naked.write_bytes(X.vad_model(W, extra_op="If"))                             # an If without branch graphs
+    assert tk.lib().tk_mi355x_vad_onnx_probe(str(naked).encode(), None, None, None) == 4001 and b"then_branch" in tk.lib().tk_error_get_detail()
     assert tk.lib().tk_mi355x_vad_onnx_probe(str(tmp_path / "none.onnx").encode(), None, None, None) == 3001
     junk = tmp_path / "junk.onnx"
     junk.write_bytes(b"\x3a\xff\xff\xff\xff\x0f" + b"\0" * 16)                   # a graph field longer than the file

@@ -13,6 +13,9 @@
  *   token-sequence graphs (DPT / Swin-transformer depth models, the class the reference names: src/vision/tk_depth_midas.c:8,
  *   tests/tk_cortex_test.cpp:42): LayerNormalization, Erf / Gelu, batched MatMul, Gather, ReduceSum / ReduceL2 / ReduceMax / ReduceMin, Expand,
  *   Max / Min / Where, ConvTranspose, strided Slice, Shape and integer shape arithmetic, rank-6 Transpose / Reshape (tk_onnx_exec_seq.hip).
+ *   control flow: If whose condition is host data (Equal / Less / Greater / Not / And / Or on integer or bool tensors — the per-sample-rate
+ *   switch of Silero-class VAD exports): the chosen branch's nodes run in the same value map, its initialisers and Constant nodes are
+ *   resident like the outer graph's.  Loop / Scan are refused.
  * Anything else fails at load time with the op's name.
  * Arithmetic: fp32; every contraction is one k-ascending fma chain per output element (input channel outer, kernel row, kernel column
  * inner; the bias enters last), the exact-math exp / tanh / sigmoid / sqrt of common/tk_exact_math.h.

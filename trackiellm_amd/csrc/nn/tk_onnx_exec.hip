@@ -361,13 +361,21 @@ static const char* kSupported[] = {"Conv", "Relu", "Sigmoid", "Tanh", "Sqrt", "A
                                    "BatchNormalization", "MatMul", "Gemm", "Softmax", "Dropout",
                                    /* tk_onnx_exec_seq.hip */
                                    "LayerNormalization", "Erf", "Gelu", "Gather", "ReduceSum", "ReduceL2", "ReduceMax", "ReduceMin", "Expand", "Max", "Min", "Where",
-                                   "ConvTranspose", "Shape"};
+                                   "ConvTranspose", "Shape", "If", "Equal", "Less", "Greater", "Not", "And", "Or"};
 
 bool TkOnnxExec::ops_supported(const TkOnnxGraph& g, std::string* err) {
-    for (const auto& nd : g.nodes) {
+    std::vector<const TkOnnxNode*> all;
+    g.all_nodes(&all); /* the branches of If nodes included */
+    for (const TkOnnxNode* ndp : all) {
+        const TkOnnxNode& nd = *ndp;
         bool ok = false;
         for (const char* s : kSupported) ok = ok || nd.op == s;
         if (!ok) { *err = "ONNX op '" + nd.op + "' (node '" + nd.name + "') is outside the graph classes this path runs (tk_onnx_exec.h)"; return false; }
+        if (nd.op == "If") {
+            auto tb = nd.attr.find("then_branch"), eb = nd.attr.find("else_branch");
+            if (tb == nd.attr.end() || eb == nd.attr.end() || !tb->second.g || !eb->second.g) { *err = "If node '" + nd.name + "' lacks a then_branch / else_branch graph"; return false; }
+            if (tb->second.g->outputs.size() != nd.out.size() || eb->second.g->outputs.size() != nd.out.size()) { *err = "If node '" + nd.name + "': its branches declare another number of outputs than the node"; return false; }
+        }
     }
     if (g.outputs.empty()) { *err = "the graph declares no outputs"; return false; }
     return true;
@@ -399,7 +407,14 @@ bool TkOnnxExec::load(const char* path, int device, hipStream_t stream, size_t a
     if (!tk_nn_prepare_device()) { error = "tk_nn_prepare_device failed"; return false; }
     for (const auto& kv : g_.init)
         if (!add_const(kv.first, kv.second)) return false;
-    for (const auto& nd : g_.nodes) {
+    std::vector<const TkOnnxNode*> all;
+    g_.all_nodes(&all);
+    for (const TkOnnxNode* ndp : all) { /* the initialisers and Constant nodes of If branches live in the same name space (ONNX names are unique per model) */
+        const TkOnnxNode& nd = *ndp;
+        for (const auto& kv : nd.attr)
+            if (kv.second.g)
+                for (const auto& iv : kv.second.g->init)
+                    if (!add_const(iv.first, iv.second)) return false;
         if (nd.op != "Constant" || nd.out.empty()) continue;
         auto it = nd.attr.find("value");
         if (it == nd.attr.end() || !it->second.has_t) { error = "Constant node without a tensor value"; return false; }

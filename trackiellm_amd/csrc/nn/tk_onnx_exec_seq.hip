@@ -206,6 +206,55 @@ bool TkOnnxExec::exec_seq_op(const TkOnnxNode& nd, std::map<std::string, Val>& v
         out_i({e - s}, std::vector<int64_t>(x->shape.begin() + s, x->shape.begin() + e));
         return true;
     }
+    if (op == "If") {
+        /* the condition is host data here (a comparison of the integer sample-rate input in VAD graphs of the Silero class; a bool
+         * initialiser): the chosen branch's nodes run in this value map — a sub-graph sees the outer scope's names, ONNX IR "Graphs",
+         * name scoping — and its declared outputs become the node's */
+        Val* c = in(0);
+        if (!c) { error = "condition is missing"; return false; }
+        bool take;
+        if (c->is_int && c->ints.size() == 1) take = c->ints[0] != 0;
+        else if (!c->is_int && c->host.size() == 1) take = c->host[0] != 0.0f;
+        else { error = "the condition must be a scalar known on the host (an integer / bool tensor or a small float constant)"; return false; }
+        auto br = nd.attr.find(take ? "then_branch" : "else_branch");
+        if (br == nd.attr.end() || !br->second.g) { error = "branch graph missing"; return false; }
+        const TkOnnxGraph& sub = *br->second.g;
+        if (sub.outputs.size() != nd.out.size()) { error = "the branch declares another number of outputs than the node"; return false; }
+        for (const auto& sn : sub.nodes) {
+            if (sn.op == "Constant") continue;
+            if (!exec(sn, v)) { if (error.find(sn.op) == std::string::npos) error = sn.op + " (node '" + sn.name + "' of a branch): " + error; return false; }
+        }
+        for (size_t i = 0; i < nd.out.size(); ++i) {
+            auto it = v.find(sub.outputs[i].name);
+            if (it == v.end()) { error = "branch output '" + sub.outputs[i].name + "' was not produced"; return false; }
+            const Val o = it->second;
+            v[nd.out[i]] = o;
+        }
+        return true;
+    }
+    if (op == "Equal" || op == "Less" || op == "Greater" || op == "And" || op == "Or" || op == "Not") {
+        Val* a = in(0);
+        if (!a || !a->is_int) { error = "comparisons and logic run on host integer / bool tensors only"; return false; }
+        const Val ac = *a;
+        std::vector<int64_t> o(ac.ints.size());
+        if (op == "Not") {
+            for (size_t i = 0; i < o.size(); ++i) o[i] = ac.ints[i] ? 0 : 1;
+            out_i(ac.shape, std::move(o));
+            return true;
+        }
+        Val* b = in(1);
+        if (!b || !b->is_int) { error = "comparisons and logic run on host integer / bool tensors only"; return false; }
+        const Val bc = *b;
+        const size_t na = ac.ints.size(), nb = bc.ints.size();
+        if (na != nb && na != 1 && nb != 1) { error = "integer operands do not broadcast"; return false; }
+        o.resize(std::max(na, nb));
+        for (size_t i = 0; i < o.size(); ++i) {
+            const int64_t x = ac.ints[na == 1 ? 0 : i], y = bc.ints[nb == 1 ? 0 : i];
+            o[i] = op == "Equal" ? x == y : op == "Less" ? x < y : op == "Greater" ? x > y : op == "And" ? (x && y) : (x || y);
+        }
+        out_i(na >= nb ? ac.shape : bc.shape, std::move(o));
+        return true;
+    }
     /* integer tensors (shape sub-graphs): evaluated on the host */
     if ((op == "Add" || op == "Sub" || op == "Mul" || op == "Div") && in(0) && in(1) && in(0)->is_int && in(1)->is_int) {
         const Val a = *in(0), b = *in(1);

@@ -91,7 +91,9 @@ bool parse_tensor(Span s, std::string* name, TkOnnxTensor* t) {
     return true;
 }
 
-bool parse_attr(Span s, std::string* name, TkOnnxAttr* a) {
+bool parse_graph(Span g, TkOnnxGraph* out, int depth, std::string* err);
+
+bool parse_attr(Span s, std::string* name, TkOnnxAttr* a, int depth) {
     uint32_t num, wt;
     Span sub;
     uint64_t v;
@@ -102,7 +104,12 @@ bool parse_attr(Span s, std::string* name, TkOnnxAttr* a) {
         else if (num == 3 && wt == 0) a->i = (int64_t)v;
         else if (num == 4 && wt == 2) a->s = str(sub);
         else if (num == 5 && wt == 2) { std::string tn; if (!parse_tensor(sub, &tn, &a->t)) return false; a->has_t = true; }
-        else if (num == 7) {
+        else if (num == 6 && wt == 2) {
+            if (depth >= 4) return false; /* If inside If inside ...: four levels are more than any model of these classes nests */
+            a->g = std::make_shared<TkOnnxGraph>();
+            std::string err;
+            if (!parse_graph(sub, a->g.get(), depth + 1, &err)) return false;
+        } else if (num == 7) {
             if (wt == 5) { float f; uint32_t u = (uint32_t)v; memcpy(&f, &u, 4); a->floats.push_back(f); }
             else if (wt == 2) { const size_t n = (size_t)(sub.e - sub.p) / 4, o = a->floats.size(); a->floats.resize(o + n); memcpy(a->floats.data() + o, sub.p, n * 4); }
         } else if (num == 8) {
@@ -151,6 +158,48 @@ bool parse_value_info(Span s, TkOnnxValueInfo* vi) {
     }
     return true;
 }
+
+bool parse_graph(Span g, TkOnnxGraph* out, int depth, std::string* err) {
+    uint32_t num, wt;
+    Span sub;
+    uint64_t v;
+    std::vector<TkOnnxValueInfo> all_in;
+    while (g.p < g.e) {
+        if (!field(g, &num, &wt, &sub, &v)) { *err = "corrupt GraphProto"; return false; }
+        if (num == 1 && wt == 2) {
+            TkOnnxNode nd;
+            Span ns = sub, f2;
+            uint32_t fn, fw;
+            uint64_t fv;
+            while (ns.p < ns.e) {
+                if (!field(ns, &fn, &fw, &f2, &fv)) { *err = "corrupt NodeProto"; return false; }
+                if (fn == 1 && fw == 2) nd.in.push_back(str(f2));
+                else if (fn == 2 && fw == 2) nd.out.push_back(str(f2));
+                else if (fn == 3 && fw == 2) nd.name = str(f2);
+                else if (fn == 4 && fw == 2) nd.op = str(f2);
+                else if (fn == 5 && fw == 2) {
+                    std::string an;
+                    TkOnnxAttr a;
+                    if (!parse_attr(f2, &an, &a, depth)) { *err = "corrupt AttributeProto in node " + nd.name; return false; }
+                    nd.attr[an] = std::move(a);
+                }
+            }
+            out->nodes.push_back(std::move(nd));
+        } else if (num == 5 && wt == 2) {
+            std::string name;
+            TkOnnxTensor t;
+            if (!parse_tensor(sub, &name, &t)) { *err = "corrupt or oversized initialiser " + name; return false; }
+            out->init[name] = std::move(t);
+        } else if ((num == 11 || num == 12) && wt == 2) {
+            TkOnnxValueInfo vi;
+            if (!parse_value_info(sub, &vi)) { *err = "corrupt ValueInfoProto"; return false; }
+            (num == 11 ? all_in : out->outputs).push_back(std::move(vi));
+        }
+    }
+    for (auto& vi : all_in)
+        if (!out->init.count(vi.name)) out->inputs.push_back(vi); /* old exporters list initialisers among the inputs */
+    return true;
+}
 }  // namespace
 
 bool TkOnnxGraph::load(const char* path) {
@@ -175,46 +224,19 @@ bool TkOnnxGraph::load(const char* path) {
             if (num == 7 && wt == 2) graph = sub;
         }
         if (!graph.p) { error = "no graph in the ONNX file"; return false; }
-        std::vector<TkOnnxValueInfo> all_in;
-        Span g = graph;
-        while (g.p < g.e) {
-            if (!field(g, &num, &wt, &sub, &v)) { error = "corrupt GraphProto"; return false; }
-            if (num == 1 && wt == 2) {
-                TkOnnxNode nd;
-                Span ns = sub, f2;
-                uint32_t fn, fw;
-                uint64_t fv;
-                while (ns.p < ns.e) {
-                    if (!field(ns, &fn, &fw, &f2, &fv)) { error = "corrupt NodeProto"; return false; }
-                    if (fn == 1 && fw == 2) nd.in.push_back(str(f2));
-                    else if (fn == 2 && fw == 2) nd.out.push_back(str(f2));
-                    else if (fn == 3 && fw == 2) nd.name = str(f2);
-                    else if (fn == 4 && fw == 2) nd.op = str(f2);
-                    else if (fn == 5 && fw == 2) {
-                        std::string an;
-                        TkOnnxAttr a;
-                        if (!parse_attr(f2, &an, &a)) { error = "corrupt AttributeProto in node " + nd.name; return false; }
-                        nd.attr[an] = std::move(a);
-                    }
-                }
-                nodes.push_back(std::move(nd));
-            } else if (num == 5 && wt == 2) {
-                std::string name;
-                TkOnnxTensor t;
-                if (!parse_tensor(sub, &name, &t)) { error = "corrupt or oversized initialiser " + name; return false; }
-                init[name] = std::move(t);
-            } else if ((num == 11 || num == 12) && wt == 2) {
-                TkOnnxValueInfo vi;
-                if (!parse_value_info(sub, &vi)) { error = "corrupt ValueInfoProto"; return false; }
-                (num == 11 ? all_in : outputs).push_back(std::move(vi));
-            }
-        }
-        for (auto& vi : all_in)
-            if (!init.count(vi.name)) inputs.push_back(vi); /* old exporters list initialisers among the inputs */
+        if (!parse_graph(graph, this, 0, &error)) return false;
         if (nodes.empty()) { error = "the ONNX graph has no nodes"; return false; }
         return true;
     } catch (const std::exception& e) {
         error = std::string("corrupt ONNX file (") + e.what() + ")";
         return false;
+    }
+}
+
+void TkOnnxGraph::all_nodes(std::vector<const TkOnnxNode*>* out) const {
+    for (const auto& nd : nodes) {
+        out->push_back(&nd);
+        for (const auto& kv : nd.attr)
+            if (kv.second.g) kv.second.g->all_nodes(out);
     }
 }

@@ -4,8 +4,8 @@
  *   ModelProto.graph = 7
  *   GraphProto.node = 1, .initializer = 5, .input = 11, .output = 12
  *   NodeProto.input = 1, .output = 2, .name = 3, .op_type = 4, .attribute = 5
- *   AttributeProto.name = 1, .f = 2, .i = 3, .s = 4, .t = 5, .floats = 7, .ints = 8, .type = 20
- *   TensorProto.dims = 1, .data_type = 2 (1 FLOAT, 6 INT32, 7 INT64, 10 FLOAT16), .float_data = 4, .int32_data = 5, .int64_data = 7,
+ *   AttributeProto.name = 1, .f = 2, .i = 3, .s = 4, .t = 5, .g = 6 (a sub-graph: the branches of If), .floats = 7, .ints = 8, .type = 20
+ *   TensorProto.dims = 1, .data_type = 2 (1 FLOAT, 6 INT32, 7 INT64, 9 BOOL, 10 FLOAT16), .float_data = 4, .int32_data = 5, .int64_data = 7,
  *               .name = 8, .raw_data = 9
  *   ValueInfoProto.name = 1, .type = 2 -> TypeProto.tensor_type = 1 -> {elem_type = 1, shape = 2 -> dim = 1 -> {dim_value = 1, dim_param = 2}}
  * The reference hands silero_vad.onnx (src/sensors/tk_vad_silero.c:110-280) and the MiDaS depth model (src/vision/tk_depth_midas.c:231-283)
@@ -17,8 +17,11 @@
 #include <stdint.h>
 
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
+
+struct TkOnnxGraph;
 
 struct TkOnnxTensor {
     std::vector<int64_t> dims;
@@ -36,6 +39,7 @@ struct TkOnnxAttr {
     std::vector<float> floats;
     TkOnnxTensor t;
     bool has_t = false;
+    std::shared_ptr<TkOnnxGraph> g; /* then_branch / else_branch of an If node (nesting depth limited by the reader) */
 };
 
 struct TkOnnxNode {
@@ -62,6 +66,8 @@ struct TkOnnxGraph {
     std::vector<TkOnnxValueInfo> inputs, outputs; /* inputs exclude initialisers */
     std::string error;
     bool load(const char* path);
+    /* every node of the graph and of its sub-graphs, outer ones first (op checks, Constant collection) */
+    void all_nodes(std::vector<const TkOnnxNode*>* out) const;
 };
 
 #endif
