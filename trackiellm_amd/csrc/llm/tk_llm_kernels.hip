@@ -22,6 +22,7 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define TK_WAVE 64
 
@@ -1073,6 +1074,15 @@ __device__ __forceinline__ void unpack_q6_x32(const FragQ6& f0, const FragQ6& f1
 #ifndef TK_G32_STAGGER
 #define TK_G32_STAGGER 0 /* s_sleep units (64 clocks each) waves 4..7 wait after every block barrier: their VALU phases then face their SIMD partner's MFMA phases */
 #endif
+#ifndef TK_G32_PK
+#define TK_G32_PK 0 /* 1 = finish two outputs per VALU instruction (packed fp32) */
+#endif
+#ifndef TK_G32_CLOCK
+#define TK_G32_CLOCK 0 /* diagnostic build: one (s_memtime, s_memrealtime) pair around a workgroup's whole K loop -> in-kernel clock and cycles per block */
+#endif
+#ifndef TK_G32_ABL
+#define TK_G32_ABL 0 /* diagnostic, TIMING ONLY (results are wrong): 1 no MFMAs, 2 no finishing, 4 no unpack, 8 no ring staging, 16 no barrier, 32 no LDS operand reads */
+#endif
 #ifndef TK_G32_PRIO
 #define TK_G32_PRIO 0 /* diagnostic: 1 = s_setprio 1 while a tile is finished on the VALU, 2 = s_setprio 1 while its MFMAs issue */
 #endif
@@ -1109,6 +1119,9 @@ __device__ __forceinline__ void load_atile32(ATile32& T, const Ptrs32& p, int t)
 template <bool Q4, typename Hook>
 __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const Ptrs32& p, float (&acc)[TK_G32_MTW][16], Hook&& after_mfmas) {
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if TK_G32_PK
+    const v2f dwv = {o.dw, o.dw}, dmv = {-o.dmin, -o.dmin};
+#endif
 #pragma unroll
     for (int t = 0; t < TK_G32_MTW; ++t) {
         /* P = 8 Ph + Pl (64 Ph + Pl for Q6_K) inside ONE accumulator: the high-digit chain first, its result shifted on the VALU, then the
@@ -1117,26 +1130,46 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
         v4i A[8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) A[u] = T.a[u];
+#if TK_G32_ABL & 32
+#pragma unroll
+        for (int u = 4; u < 8; ++u) A[u] = T.a[u - 4];
+        v4f da[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { da[b] = (v4f){1.0f, 2.0f, 3.0f, 4.0f}; asm volatile("" : "+v"(da[b])); }
+#else
 #pragma unroll
         for (int u = 4; u < 8; ++u) A[u] = *(const v4i*)(p.ap + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256);
         v4f da[4]; /* the block scales of this tile's rows: requested here, used after the MFMAs (a read issued in the finishing loop is waited for at once) */
 #pragma unroll
         for (int b = 0; b < 4; ++b) da[b] = *(const v4f*)(p.dp + t * 128 + b * 32);
+#endif
         v16i ph = zero;
+        v16f cm;
+        v16i pl;
+#if TK_G32_ABL & 1
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" :: "v"(A[u]), "v"(o.bh[u]), "v"(o.bl[u]));
+        asm volatile("" :: "v"(T.mn), "v"(o.bm16));
+        asm volatile("" : "=v"(ph));
+        asm volatile("" : "=v"(cm));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pl[r] = ph[r] << (Q4 ? 3 : 6);
+#else
 #pragma unroll
         for (int u = 0; u < 8; ++u) ph = TK_MFMA32(A[u], o.bh[u], ph, 0, 0, 0);
-        v16f cm;
         if (Q4) {
             const v16f fz = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(T.mn, o.bm16, fz, 0, 0, 0);
         }
-        v16i pl;
 #pragma unroll
         for (int r = 0; r < 16; ++r) pl[r] = ph[r] << (Q4 ? 3 : 6);
 #pragma unroll
         for (int u = 0; u < 8; ++u) pl = TK_MFMA32(A[u], o.bl[u], pl, 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#if !(TK_G32_ABL & 32)
         if (t + 1 < TK_G32_MTW) load_atile32<Q4>(T, p, t + 1);
+#endif
         after_mfmas(t); /* a quarter of this wave's ring staging for the next block: LDS-DMA issue costs 60-180 cycles a piece, here they pass while
                          * the tile's MFMAs are still in the matrix pipe */
         __builtin_amdgcn_sched_barrier(0);
@@ -1145,6 +1178,29 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
 #elif TK_G32_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
+#if TK_G32_ABL & 2
+        asm volatile("" :: "v"(pl), "v"(cm));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(da[b]));
+#elif TK_G32_PK
+        /* the same IEEE operations two outputs at a time (v_pk_mul_f32 / v_pk_fma_f32): (-dmin) * da == -(dmin * da) exactly */
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const int r = 4 * b + i;
+                const v2f dav = {da[b][i], da[b][i + 1]};
+                const v2f pf = {(float)pl[r], (float)pl[r + 1]};
+                v2f a2 = {acc[t][r], acc[t][r + 1]};
+                a2 = __builtin_elementwise_fma(dwv * dav, pf, a2);
+                if (Q4) {
+                    const v2f cmv = {cm[r], cm[r + 1]};
+                    a2 = __builtin_elementwise_fma(dmv * dav, cmv, a2);
+                }
+                acc[t][r] = a2[0];
+                acc[t][r + 1] = a2[1];
+            }
+#else
 #pragma unroll
         for (int b = 0; b < 4; ++b) /* accumulator register 4 b + i = row 8 b + 4 h + i of the M-tile */
 #pragma unroll
@@ -1153,6 +1209,7 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
                 acc[t][r] = tk_fmaf(o.dw * da[b][i], (float)pl[r], acc[t][r]);
                 if (Q4) acc[t][r] = tk_fmaf(-(o.dmin * da[b][i]), cm[r], acc[t][r]);
             }
+#endif
 #if TK_G32_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
 #elif TK_G32_PRIO == 2
@@ -1161,6 +1218,20 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+
+#if TK_G32_CLOCK
+__device__ unsigned long long g_g32_stamps[1024][4];
+__device__ unsigned long long g_g32_seg[1024][8][4]; /* per wave, summed over the blocks: unpack, tile loop, s_waitcnt(0), barrier */
+extern "C" __attribute__((visibility("default"))) int tk_debug_g32_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g32_stamps), (size_t)n * 32);
+}
+extern "C" __attribute__((visibility("default"))) int tk_debug_g32_seg(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g32_seg), (size_t)n * 8 * 32);
+}
+#define TK_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define TK_STAMP(v)
+#endif
 
 template <int TYPES>
 __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups, int total_row_tiles) {
@@ -1224,34 +1295,86 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
     };
     auto stage = [&](int c, int slot) { stage_small(c, slot); for (int part = 0; part < 4; ++part) stage_part(c, slot, part); };
 
+#if TK_G32_CLOCK
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (HAS4 && is4) {
         FragQ4 f0, f1;
         if (active) { f0 = load_q4(tile, lane); f1 = load_q4(tile + tile_pitch, lane); }
         stage(0, 0);
+#if TK_G32_CLOCK == 2
+        unsigned long long seg_u = 0, seg_t = 0, seg_w = 0, seg_b = 0;
+#endif
 #pragma unroll 1
         for (int b = 0; b < nb; ++b) {
+#if TK_G32_CLOCK == 2
+            TK_STAMP(s_w0);
             __builtin_amdgcn_s_waitcnt(0);
+            TK_STAMP(s_w1);
             __syncthreads();
+            TK_STAMP(s_top);
+            seg_w += s_w1 - s_w0; seg_b += s_top - s_w1;
+#else
+            __builtin_amdgcn_s_waitcnt(0);
+#if !(TK_G32_ABL & 16)
+            __syncthreads();
+#endif
+#endif
             const bool more = b + 1 < nb;
             if (!active) { if (more) stage(b + 1, (b + 1) & 1); continue; }
+#if !(TK_G32_ABL & 8)
             if (more) stage_small(b + 1, (b + 1) & 1);
+#endif
 #if TK_G32_STAGGER
             if (half) __builtin_amdgcn_s_sleep(TK_G32_STAGGER);
 #endif
             const uint8_t* next = tile + (size_t)(b + 1 < nb ? b + 1 : b) * tile_bytes; /* the last step re-requests its own tile: no branch around a load */
             const Ptrs32 bp = block_ptrs32(lds + (b & 1) * CH, half, lane);
             ATile32 T;
+#if TK_G32_ABL & 32
+            for (int u = 0; u < 4; ++u) { T.a[u] = (v4i){lane, b, u, 3}; asm volatile("" : "+v"(T.a[u])); }
+            asm volatile("" : "=v"(T.mn));
+#else
             load_atile32<true>(T, bp, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             Ops32 o;
+#if TK_G32_ABL & 4
+            for (int u = 0; u < 8; ++u) {
+                o.bl[u] = (v4i){(int)f0.q0.x, (int)f0.q0.y, (int)f1.q0.z, (int)f1.q0.w};
+                o.bh[u] = (v4i){(int)f0.q1.x, (int)f0.q1.y, (int)f1.q1.z, (int)f1.q1.w};
+                asm volatile("" : "+v"(o.bl[u]), "+v"(o.bh[u]));
+            }
+            asm volatile("" : "=v"(o.bm16));
+            o.dw = __int_as_float(f0.h.x); o.dmin = __int_as_float(f1.h.x);
+#else
             unpack_q4_x32(f0, f1, lane, o);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#if TK_G32_CLOCK == 2
+            TK_STAMP(s_un);
+            seg_u += s_un - s_top;
+#endif
             f0 = load_q4(next, lane);
             f1 = load_q4(next + tile_pitch, lane);
             __builtin_amdgcn_sched_barrier(0);
             /* the last block restages itself into the slot nobody reads any more: no branch around the DMA issue */
+#if TK_G32_ABL & 8
+            gemm_block32<true>(o, T, bp, acc, [&](int) {});
+#else
             gemm_block32<true>(o, T, bp, acc, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
+#endif
+#if TK_G32_CLOCK == 2
+            TK_STAMP(s_end);
+            seg_t += s_end - s_un;
+#endif
         }
+#if TK_G32_CLOCK == 2
+        if (lane == 0 && blockIdx.x < 1024) {
+            g_g32_seg[blockIdx.x][wave][0] = seg_u; g_g32_seg[blockIdx.x][wave][1] = seg_t;
+            g_g32_seg[blockIdx.x][wave][2] = seg_w; g_g32_seg[blockIdx.x][wave][3] = seg_b;
+        }
+#endif
     }
     if (HAS6 && !is4) {
         FragQ6 f0, f1;
@@ -1281,6 +1404,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
             gemm_block32<false>(o, T, bp, acc, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
         }
     }
+#if TK_G32_CLOCK
+    if (tid == 0 && blockIdx.x < 1024) {
+        g_g32_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st0;
+        g_g32_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
+        g_g32_stamps[blockIdx.x][2] = (unsigned long long)nb;
+        g_g32_stamps[blockIdx.x][3] = (unsigned long long)gridDim.x;
+    }
+#endif
     if (!active) return;
 
     const int n = a.col0 + row_base + rt * TK_TILE_ROWS + (lane & 31);
