@@ -55,7 +55,7 @@ def main():
             import ctypes
             import numpy as np
             L = ctypes.CDLL(os.environ["TK_MI355X_LIB"])
-            st = np.zeros((1024, 4), np.uint64)
+            st = np.zeros((1024, 8), np.uint64)
             assert L.tk_debug_g32_stamps(st.ctypes.data_as(ctypes.c_void_p), 1024) == 0
             st = st[: int(st[0, 3])] if 0 < st[0, 3] <= 1024 else st[:0]
             if len(st):
@@ -65,9 +65,19 @@ def main():
                     assert L.tk_debug_g32_seg(sg.ctypes.data_as(ctypes.c_void_p), 1024) == 0
                     sg = sg[: len(st)].astype(float) / nb
                     if sg.sum() > 0:
-                        m = np.median(sg, axis=0)  # [wave][segment], cycles per block
+                        m = np.zeros((8, 4))  # [wave slot: pair + 4 * row half][segment], cycles per block; a workgroup fills the four slots of its half
+                        for w in range(8):
+                            rows = sg[:, w][sg[:, w].sum(axis=1) > 0]
+                            if len(rows):
+                                m[w] = np.median(rows, axis=0)
                         for w in range(8):
                             print(f"         wave {w}: unpack {m[w, 0]:6.0f}  tiles {m[w, 1]:6.0f}  s_waitcnt(0) {m[w, 2]:6.0f}  barrier {m[w, 3]:6.0f}  = {m[w].sum():6.0f} cycles per block")
+                ab = st[:, 4:8].astype(float)
+                t0 = ab[:, 0].min()
+                us = (ab - t0) / 100.0
+                print(f"         timeline of the last launch (us after the first workgroup's entry): entry median {np.median(us[:, 0]):.1f} max {us[:, 0].max():.1f}; loop start median "
+                      f"{np.median(us[:, 1]):.1f}; loop end median {np.median(us[:, 2]):.1f} p90 {np.percentile(us[:, 2], 90):.1f} max {us[:, 2].max():.1f}; exit median {np.median(us[:, 3]):.1f} "
+                      f"max {us[:, 3].max():.1f}; K loop us min {(us[:, 2] - us[:, 1]).min():.1f} median {np.median(us[:, 2] - us[:, 1]):.1f} max {(us[:, 2] - us[:, 1]).max():.1f}")
                 print(f"         K loop per workgroup (median of {len(st)}): {cyc:.0f} cycles, {real / 100:.2f} us -> in-kernel clock {cyc / real * 100:.0f} MHz, "
                       f"{cyc / nb:.0f} cycles per 256-k block ({nb:.0f} blocks)")
     print(f"step     {tot_ms * 1e3:8.1f} us  {tot_b / tot_ms / 1e6:8.1f} GB/s  frac {tot_b / tot_ms / 1e6 / 8000:.4f}", flush=True)

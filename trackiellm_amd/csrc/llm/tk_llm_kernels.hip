@@ -1069,25 +1069,30 @@ __device__ __forceinline__ void unpack_q6_x32(const FragQ6& f0, const FragQ6& f1
     o.dmin = 0.0f;
 }
 
+/* s_waitcnt vmcnt(n) alone (expcnt / lgkmcnt untouched): until all but this wave's n youngest vector-memory operations are done.  The
+ * LDS-DMA pieces of a chunk are invisible to the compiler's own wait insertion, so the ring is guarded by hand. */
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define TK_VMW(k) case k: __builtin_amdgcn_s_waitcnt(0x0F70 | ((k) & 15) | (((k) >> 4) << 14)); break;
+    switch (n) {
+        TK_VMW(0) TK_VMW(1) TK_VMW(2) TK_VMW(3) TK_VMW(4) TK_VMW(5) TK_VMW(6) TK_VMW(7) TK_VMW(8) TK_VMW(9) TK_VMW(10) TK_VMW(11) TK_VMW(12)
+        TK_VMW(13) TK_VMW(14) TK_VMW(15) TK_VMW(16) TK_VMW(17) TK_VMW(18) TK_VMW(19) TK_VMW(20) TK_VMW(21) TK_VMW(22) TK_VMW(23) TK_VMW(24)
+        TK_VMW(25) TK_VMW(26) TK_VMW(27) TK_VMW(28)
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+#undef TK_VMW
+}
+
 #define TK_MFMA32 __builtin_amdgcn_mfma_i32_32x32x32_i8
 #define TK_G32_MTW 4 /* 32-row M-tiles per wave */
-#ifndef TK_G32_STAGGER
-#define TK_G32_STAGGER 0 /* s_sleep units (64 clocks each) waves 4..7 wait after every block barrier: their VALU phases then face their SIMD partner's MFMA phases */
-#endif
 #ifndef TK_G32_PK
-#define TK_G32_PK 0 /* 1 = finish two outputs per VALU instruction (packed fp32) */
-#endif
-#ifndef TK_G32_CLOCK
-#define TK_G32_CLOCK 0 /* diagnostic build: one (s_memtime, s_memrealtime) pair around a workgroup's whole K loop -> in-kernel clock and cycles per block */
+#define TK_G32_PK 0 /* 1 = finish two outputs per VALU instruction (v_pk_mul_f32 / v_pk_fma_f32; bit-identical) */
 #endif
 #ifndef TK_G32_ABL
-#define TK_G32_ABL 0 /* diagnostic, TIMING ONLY (results are wrong): 1 no MFMAs, 2 no finishing, 4 no unpack, 8 no ring staging, 16 no barrier, 32 no LDS operand reads */
+#define TK_G32_ABL 0 /* diagnostic, TIMING ONLY (results are wrong): 1 no MFMAs, 2 no finishing, 4 no unpack, 8 no ring staging, 32 no LDS operand reads */
 #endif
-#ifndef TK_G32_PRIO
-#define TK_G32_PRIO 0 /* diagnostic: 1 = s_setprio 1 while a tile is finished on the VALU, 2 = s_setprio 1 while its MFMAs issue */
-#endif
-#ifndef TK_G32_STAGE_UPPER
-#define TK_G32_STAGE_UPPER 0 /* 1: waves 4..7 issue the whole ring staging (a stagger made of useful work) */
+#ifndef TK_G32_CLOCK
+#define TK_G32_CLOCK 0 /* diagnostic builds (tools/time_gemv.py --stamps): 1 = one (s_memtime, s_memrealtime) pair around a workgroup's K loop -> in-kernel
+                        * clock and cycles per block; 2 = also cycles per block by segment, stamped only where the wave is drained anyway */
 #endif
 
 /* A-side operands of one 32-row M-tile of one ring block that are requested a tile AHEAD: the first four of the eight 16-byte reads of
@@ -1095,14 +1100,14 @@ __device__ __forceinline__ void unpack_q6_x32(const FragQ6& f0, const FragQ6& f1
 struct ATile32 { v4i a[4]; v8h mn; };
 struct Ptrs32 { const uint8_t *ap, *mp, *dp; };
 
-__device__ __forceinline__ Ptrs32 block_ptrs32(const uint8_t* blk, int half, int lane) {
-    constexpr int OFF_AMN = 16 * 4096, OFF_AD = 16 * 4096 + 16 * 512;
-    constexpr int HT = 2 * TK_G32_MTW; /* 16-row M-tiles of a row half */
+#define TK_G32_MT 8 /* 16-row M-tiles of one ring block: a workgroup's 128 rows */
+__device__ __forceinline__ Ptrs32 block_ptrs32(const uint8_t* blk, int lane) {
+    constexpr int OFF_AMN = TK_G32_MT * 4096, OFF_AD = TK_G32_MT * 4096 + TK_G32_MT * 512;
     const int h = lane >> 5;
     Ptrs32 p;
-    p.ap = blk + half * (HT * 4096) + ((lane >> 4) & 1) * 4096 + (h * 32 + (lane & 15)) * 16;            /* + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256 */
-    p.mp = blk + OFF_AMN + half * (HT * 512) + ((lane >> 4) & 1) * 512 + h * 256 + (lane & 15) * 16;   /* + t * 1024 */
-    p.dp = blk + OFF_AD + half * (HT * 64) + h * 16;                                                  /* + t * 128 + b * 32 */
+    p.ap = blk + ((lane >> 4) & 1) * 4096 + (h * 32 + (lane & 15)) * 16;            /* + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256 */
+    p.mp = blk + OFF_AMN + ((lane >> 4) & 1) * 512 + h * 256 + (lane & 15) * 16;   /* + t * 1024 */
+    p.dp = blk + OFF_AD + h * 16;                                                  /* + t * 128 + b * 32 */
     return p;
 }
 
@@ -1113,9 +1118,8 @@ __device__ __forceinline__ void load_atile32(ATile32& T, const Ptrs32& p, int t)
     if (Q4) T.mn = *(const v8h*)(p.mp + t * 1024);
 }
 
-/* one 256-k block: this wave's 32 weight rows x its four 32-row M-tiles.  T arrives holding tile 0's operands (requested before the
- * weight unpack, so their LDS latency hides under it); the operands of tile t + 1 are requested as soon as the MFMAs of tile t have
- * issued — into the same registers — and land while tile t is finished on the VALU. */
+/* one 256-k block: this wave's 32 weight rows x its four 32-row M-tiles.  T arrives holding tile 0's operands; the operands of tile
+ * t + 1 are requested as soon as the MFMAs of tile t have issued — into the same registers — and land while tile t is finished on the VALU. */
 template <bool Q4, typename Hook>
 __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const Ptrs32& p, float (&acc)[TK_G32_MTW][16], Hook&& after_mfmas) {
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1130,16 +1134,15 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
         v4i A[8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) A[u] = T.a[u];
+        v4f da[4]; /* the block scales of this tile's rows: requested here, used after the MFMAs (a read issued in the finishing loop is waited for at once) */
 #if TK_G32_ABL & 32
 #pragma unroll
         for (int u = 4; u < 8; ++u) A[u] = T.a[u - 4];
-        v4f da[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) { da[b] = (v4f){1.0f, 2.0f, 3.0f, 4.0f}; asm volatile("" : "+v"(da[b])); }
 #else
 #pragma unroll
         for (int u = 4; u < 8; ++u) A[u] = *(const v4i*)(p.ap + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256);
-        v4f da[4]; /* the block scales of this tile's rows: requested here, used after the MFMAs (a read issued in the finishing loop is waited for at once) */
 #pragma unroll
         for (int b = 0; b < 4; ++b) da[b] = *(const v4f*)(p.dp + t * 128 + b * 32);
 #endif
@@ -1173,17 +1176,12 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
         after_mfmas(t); /* a quarter of this wave's ring staging for the next block: LDS-DMA issue costs 60-180 cycles a piece, here they pass while
                          * the tile's MFMAs are still in the matrix pipe */
         __builtin_amdgcn_sched_barrier(0);
-#if TK_G32_PRIO == 1
-        __builtin_amdgcn_s_setprio(1);
-#elif TK_G32_PRIO == 2
-        __builtin_amdgcn_s_setprio(0);
-#endif
 #if TK_G32_ABL & 2
         asm volatile("" :: "v"(pl), "v"(cm));
 #pragma unroll
         for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(da[b]));
 #elif TK_G32_PK
-        /* the same IEEE operations two outputs at a time (v_pk_mul_f32 / v_pk_fma_f32): (-dmin) * da == -(dmin * da) exactly */
+        /* the same IEEE operations two outputs at a time: (-dmin) * da == -(dmin * da) exactly */
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -1210,44 +1208,137 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
                 if (Q4) acc[t][r] = tk_fmaf(-(o.dmin * da[b][i]), cm[r], acc[t][r]);
             }
 #endif
-#if TK_G32_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#elif TK_G32_PRIO == 2
-        __builtin_amdgcn_s_setprio(1);
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
+template <bool Q4> struct G32Frag { typedef FragQ4 type; };
+template <> struct G32Frag<false> { typedef FragQ6 type; };
+template <bool Q4>
+__device__ __forceinline__ typename G32Frag<Q4>::type g32_load(const uint8_t* tile, int lane) {
+    if constexpr (Q4) return load_q4(tile, lane);
+    else return load_q6(tile, lane);
+}
+template <bool Q4>
+__device__ __forceinline__ void g32_unpack(const typename G32Frag<Q4>::type& f0, const typename G32Frag<Q4>::type& f1, int lane, Ops32& o) {
+    if constexpr (Q4) unpack_q4_x32(f0, f1, lane, o);
+    else unpack_q6_x32(f0, f1, lane, o);
+}
+
 #if TK_G32_CLOCK
-__device__ unsigned long long g_g32_stamps[1024][4];
-__device__ unsigned long long g_g32_seg[1024][8][4]; /* per wave, summed over the blocks: unpack, tile loop, s_waitcnt(0), barrier */
+__device__ unsigned long long g_g32_stamps[1024][8]; /* K-loop cycles, K-loop 100 MHz ticks, blocks, grid, absolute 100 MHz time at kernel entry / loop start / loop end / exit */
+__device__ unsigned long long g_g32_seg[1024][8][4]; /* per wave, summed over the blocks: unpack, tile loop, s_waitcnt, barrier */
 extern "C" __attribute__((visibility("default"))) int tk_debug_g32_stamps(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g32_stamps), (size_t)n * 32);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g32_stamps), (size_t)n * 64);
 }
 extern "C" __attribute__((visibility("default"))) int tk_debug_g32_seg(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g32_seg), (size_t)n * 8 * 32);
 }
+#endif
+#if TK_G32_CLOCK == 2
 #define TK_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define TK_SEG(i, d) seg[i] += (d) /* 0 unpack, 1 tiles, 2 the wait (+ the early wave's barrier) before the unpack, 3 the late wave's wait + barrier */
 #else
 #define TK_STAMP(v)
+#define TK_SEG(i, d)
 #endif
 
+/* The K loop of one wave: its two weight tiles (32 weight rows) against its four 32-row M-tiles, block by block through the ring. */
+template <bool Q4, typename StageSmall, typename StagePart>
+__device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_bytes, size_t tile_pitch, int nb, const uint8_t* ring, int slot_bytes, int lane,
+                                           float (&acc)[TK_G32_MTW][16], unsigned long long* seg, StageSmall&& stage_small, StagePart&& stage_part) {
+    typedef typename G32Frag<Q4>::type F;
+    F f0 = g32_load<Q4>(tile, lane), f1 = g32_load<Q4>(tile + tile_pitch, lane);
+    stage_small(0, 0);
+    for (int part = 0; part < 4; ++part) stage_part(0, 0, part);
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+        TK_STAMP(s_w0);
+        __builtin_amdgcn_s_waitcnt(0);
+        TK_STAMP(s_w1);
+        __syncthreads();
+        TK_STAMP(s_top);
+        const bool more = b + 1 < nb;
+#if !(TK_G32_ABL & 8)
+        if (more) stage_small(b + 1, (b + 1) & 1);
+#endif
+        const uint8_t* next = tile + (size_t)(more ? b + 1 : b) * tile_bytes; /* the last step re-requests its own tile: no branch around a load */
+        const Ptrs32 bp = block_ptrs32(ring + (b & 1) * slot_bytes, lane);
+        ATile32 T;
+#if TK_G32_ABL & 32
+        for (int u = 0; u < 4; ++u) { T.a[u] = (v4i){lane, b, u, 3}; asm volatile("" : "+v"(T.a[u])); }
+        asm volatile("" : "=v"(T.mn));
+#else
+        load_atile32<Q4>(T, bp, 0); /* tile 0's operands: their LDS latency hides under the unpack */
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        Ops32 o;
+#if TK_G32_ABL & 4
+        for (int u = 0; u < 8; ++u) {
+            o.bl[u] = (v4i){(int)f0.q0.x, (int)f0.q0.y, (int)f1.q0.z, (int)f1.q0.w};
+            o.bh[u] = (v4i){(int)f0.q1.x, (int)f0.q1.y, (int)f1.q1.z, (int)f1.q1.w};
+            asm volatile("" : "+v"(o.bl[u]), "+v"(o.bh[u]));
+        }
+        asm volatile("" : "=v"(o.bm16));
+        o.dw = __int_as_float(f0.q0.x); o.dmin = __int_as_float(f1.q0.y);
+#else
+        g32_unpack<Q4>(f0, f1, lane, o);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        TK_STAMP(s_un);
+        f0 = g32_load<Q4>(next, lane);
+        f1 = g32_load<Q4>(next + tile_pitch, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        /* the last block restages itself into the slot nobody reads any more: no branch around the DMA issue */
+#if TK_G32_ABL & 8
+        gemm_block32<Q4>(o, T, bp, acc, [&](int) {});
+#else
+        gemm_block32<Q4>(o, T, bp, acc, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        TK_STAMP(s_end);
+        TK_SEG(0, s_un - s_top); TK_SEG(1, s_end - s_un); TK_SEG(2, s_w1 - s_w0); TK_SEG(3, s_top - s_w1);
+    }
+}
+
+/* 129..256 rows (and one row half alone).  A workgroup = 4 waves, one per SIMD = four pairs of weight tiles (128 weight rows) x ONE half
+ * of the pass's rows (128 rows = four 32-row M-tiles per wave); the two row halves of the same weights are two workgroups that share a CU
+ * (73 KiB of ring each) and nothing else.  The SIMD's two resident waves therefore belong to DIFFERENT workgroups: no barrier couples
+ * them, so one's weight unpack (190 VALU instructions, no MFMA) drifts under the other's MFMA phases.  With both halves in one 8-wave
+ * workgroup the block barrier re-aligned the partners every 256 k — both unpacked at once, then the later one finished alone:
+ * 8750 cycles per block against 4352 of matrix pipe (profiles/r03_gemm32_segments.txt).
+ * blockIdx -> (half, unit): consecutive workgroup ids go round the 8 XCDs, so the two halves of a unit are 8 ids apart: same XCD, same
+ * L2 — the second half's weight requests hit the lines the first one brought in. */
 template <int TYPES>
-__global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups, int total_row_tiles) {
+__global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups, int total_row_tiles, int n_halves) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int MT = 16;                        /* 16-row M-tiles staged per block: all 256 rows */
+#if TK_G32_CLOCK
+    const unsigned long long sr_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+    constexpr int MT = TK_G32_MT;
     constexpr int CH = MT * TK_RING_TILE_BYTES;   /* one block of the ring */
     constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 512;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = a.K / a.ks / 256;
     const int nblk_total = a.K / 256;
-    const int ksi = blockIdx.x % a.ks;
+    int half = 0, unit = blockIdx.x;
+    if (n_halves == 2) {
+        const int units = gridDim.x >> 1, body = (units >> 3) << 4; /* ids below `body`: XCD-aligned pairs; the rest (units not a multiple of 8) adjacent */
+        if ((int)blockIdx.x < body) {
+            const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            half = idx & 1;
+            unit = (idx >> 1) * 8 + x;
+        } else {
+            const int r = blockIdx.x - body;
+            half = r & 1;
+            unit = (body >> 1) + (r >> 1);
+        }
+    }
+    const int ksi = unit % a.ks;
     const int blk0 = ksi * nb;
-    const int pair = wave & 3, half = wave >> 2; /* waves w and w + 4 share a SIMD: same weight rows, the two row halves */
 
-    int rt = 2 * (blockIdx.x / a.ks + pair * groups); /* first of this wave's two adjacent row tiles */
+    int rt = 2 * (unit / a.ks + pair * groups); /* first of this wave's two adjacent row tiles */
     const bool active = rt < total_row_tiles;
     if (!active) rt = 0;
     int seg = 0, row_base = 0;
@@ -1269,12 +1360,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    /* ring staging: the 16-row M-tiles `wave` and `wave + 8` belong to this wave.  The int8 image (4 x 1 KiB pieces per tile, every lane
-     * takes part: no exec masking, so the issue can sit between the MFMA phases of the tile loop) in four parts of two pieces; the f16
-     * sub-block sums (32 lanes) and the block scales (4 lanes) separately at the top of a block */
+    /* ring staging: of the half's eight 16-row M-tiles, `pair` and `pair + 4` belong to this wave.  The int8 image (4 x 1 KiB pieces per
+     * tile, every lane takes part: no exec masking, so the issue can sit between the MFMA phases of the tile loop) in four parts of two
+     * pieces; the f16 sub-block sums (32 lanes) and the block scales (4 lanes) separately at the top of a block */
+    const int m0 = half * MT; /* the half's first M-tile in the pass's activation images */
     auto stage_part = [&](int c, int slot, int part) {
-        const int m = wave + 8 * (part >> 1);
-        const uint8_t* src = (const uint8_t*)a.aq + m * a.aq_ts + (size_t)(blk0 + c) * 4096 + (part & 1) * 2048 + lane * 16;
+        const int m = pair + 4 * (part >> 1);
+        const uint8_t* src = (const uint8_t*)a.aq + (size_t)(m0 + m) * a.aq_ts + (size_t)(blk0 + c) * 4096 + (part & 1) * 2048 + lane * 16;
         const auto gs = (const __attribute__((address_space(1))) void*)src;
         const auto ls = (__attribute__((address_space(3))) void*)(lds + slot * CH + m * 4096 + (part & 1) * 2048);
         __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
@@ -1282,137 +1374,48 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
     };
     auto stage_small = [&](int c, int slot) {
         uint8_t* dst = lds + slot * CH;
-        for (int m = wave; m < MT; m += 8) {
-            const uint8_t* sm = (const uint8_t*)(a.abs16 + m * a.abs_ts + (size_t)(blk0 + c) * 256) + lane * 16;
+        for (int m = pair; m < MT; m += 4) {
+            const uint8_t* sm = (const uint8_t*)(a.abs16 + (size_t)(m0 + m) * a.abs_ts + (size_t)(blk0 + c) * 256) + lane * 16;
             if (lane < 32)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sm,
                                                  (__attribute__((address_space(3))) void*)(dst + OFF_AMN + m * 512), 16, 0, 0);
-            const uint8_t* sd = (const uint8_t*)(a.ad + m * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS) + lane * 16;
+            const uint8_t* sd = (const uint8_t*)(a.ad + (size_t)(m0 + m) * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS) + lane * 16;
             if (lane < 4)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
                                                  (__attribute__((address_space(3))) void*)(dst + OFF_AD + m * 64), 16, 0, 0);
         }
     };
-    auto stage = [&](int c, int slot) { stage_small(c, slot); for (int part = 0; part < 4; ++part) stage_part(c, slot, part); };
 
 #if TK_G32_CLOCK
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (HAS4 && is4) {
-        FragQ4 f0, f1;
-        if (active) { f0 = load_q4(tile, lane); f1 = load_q4(tile + tile_pitch, lane); }
-        stage(0, 0);
-#if TK_G32_CLOCK == 2
-        unsigned long long seg_u = 0, seg_t = 0, seg_w = 0, seg_b = 0;
-#endif
-#pragma unroll 1
-        for (int b = 0; b < nb; ++b) {
-#if TK_G32_CLOCK == 2
-            TK_STAMP(s_w0);
-            __builtin_amdgcn_s_waitcnt(0);
-            TK_STAMP(s_w1);
-            __syncthreads();
-            TK_STAMP(s_top);
-            seg_w += s_w1 - s_w0; seg_b += s_top - s_w1;
-#else
-            __builtin_amdgcn_s_waitcnt(0);
-#if !(TK_G32_ABL & 16)
-            __syncthreads();
-#endif
-#endif
-            const bool more = b + 1 < nb;
-            if (!active) { if (more) stage(b + 1, (b + 1) & 1); continue; }
-#if !(TK_G32_ABL & 8)
-            if (more) stage_small(b + 1, (b + 1) & 1);
-#endif
-#if TK_G32_STAGGER
-            if (half) __builtin_amdgcn_s_sleep(TK_G32_STAGGER);
-#endif
-            const uint8_t* next = tile + (size_t)(b + 1 < nb ? b + 1 : b) * tile_bytes; /* the last step re-requests its own tile: no branch around a load */
-            const Ptrs32 bp = block_ptrs32(lds + (b & 1) * CH, half, lane);
-            ATile32 T;
-#if TK_G32_ABL & 32
-            for (int u = 0; u < 4; ++u) { T.a[u] = (v4i){lane, b, u, 3}; asm volatile("" : "+v"(T.a[u])); }
-            asm volatile("" : "=v"(T.mn));
-#else
-            load_atile32<true>(T, bp, 0);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            Ops32 o;
-#if TK_G32_ABL & 4
-            for (int u = 0; u < 8; ++u) {
-                o.bl[u] = (v4i){(int)f0.q0.x, (int)f0.q0.y, (int)f1.q0.z, (int)f1.q0.w};
-                o.bh[u] = (v4i){(int)f0.q1.x, (int)f0.q1.y, (int)f1.q1.z, (int)f1.q1.w};
-                asm volatile("" : "+v"(o.bl[u]), "+v"(o.bh[u]));
-            }
-            asm volatile("" : "=v"(o.bm16));
-            o.dw = __int_as_float(f0.h.x); o.dmin = __int_as_float(f1.h.x);
-#else
-            unpack_q4_x32(f0, f1, lane, o);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#if TK_G32_CLOCK == 2
-            TK_STAMP(s_un);
-            seg_u += s_un - s_top;
-#endif
-            f0 = load_q4(next, lane);
-            f1 = load_q4(next + tile_pitch, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            /* the last block restages itself into the slot nobody reads any more: no branch around the DMA issue */
-#if TK_G32_ABL & 8
-            gemm_block32<true>(o, T, bp, acc, [&](int) {});
-#else
-            gemm_block32<true>(o, T, bp, acc, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
-#endif
-#if TK_G32_CLOCK == 2
-            TK_STAMP(s_end);
-            seg_t += s_end - s_un;
-#endif
-        }
-#if TK_G32_CLOCK == 2
-        if (lane == 0 && blockIdx.x < 1024) {
-            g_g32_seg[blockIdx.x][wave][0] = seg_u; g_g32_seg[blockIdx.x][wave][1] = seg_t;
-            g_g32_seg[blockIdx.x][wave][2] = seg_w; g_g32_seg[blockIdx.x][wave][3] = seg_b;
-        }
-#endif
-    }
-    if (HAS6 && !is4) {
-        FragQ6 f0, f1;
-        if (active) { f0 = load_q6(tile, lane); f1 = load_q6(tile + tile_pitch, lane); }
-        stage(0, 0);
+    unsigned long long segc[4] = {0, 0, 0, 0};
+    if (!active) { /* a workgroup's spare wave slots (row tiles beyond the matrix) still stage their share of the ring */
+        stage_small(0, 0);
+        for (int part = 0; part < 4; ++part) stage_part(0, 0, part);
 #pragma unroll 1
         for (int b = 0; b < nb; ++b) {
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            const bool more = b + 1 < nb;
-            if (!active) { if (more) stage(b + 1, (b + 1) & 1); continue; }
-            if (more) stage_small(b + 1, (b + 1) & 1);
-#if TK_G32_STAGGER
-            if (half) __builtin_amdgcn_s_sleep(TK_G32_STAGGER);
-#endif
-            const uint8_t* next = tile + (size_t)(b + 1 < nb ? b + 1 : b) * tile_bytes;
-            const Ptrs32 bp = block_ptrs32(lds + (b & 1) * CH, half, lane);
-            ATile32 T;
-            load_atile32<false>(T, bp, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            Ops32 o;
-            unpack_q6_x32(f0, f1, lane, o);
-            __builtin_amdgcn_sched_barrier(0);
-            f0 = load_q6(next, lane);
-            f1 = load_q6(next + tile_pitch, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            gemm_block32<false>(o, T, bp, acc, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
+            if (b + 1 < nb) { stage_small(b + 1, (b + 1) & 1); for (int part = 0; part < 4; ++part) stage_part(b + 1, (b + 1) & 1, part); }
         }
+        return;
     }
+    if (HAS4 && is4) g32_k_loop<true>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, segc, stage_small, stage_part);
+    if (HAS6 && !is4) g32_k_loop<false>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, segc, stage_small, stage_part);
 #if TK_G32_CLOCK
     if (tid == 0 && blockIdx.x < 1024) {
         g_g32_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st0;
         g_g32_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
         g_g32_stamps[blockIdx.x][2] = (unsigned long long)nb;
         g_g32_stamps[blockIdx.x][3] = (unsigned long long)gridDim.x;
+        g_g32_stamps[blockIdx.x][4] = sr_entry;
+        g_g32_stamps[blockIdx.x][5] = sr0;
+        g_g32_stamps[blockIdx.x][6] = __builtin_amdgcn_s_memrealtime();
     }
+    if (lane == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 4; ++i) g_g32_seg[blockIdx.x][pair + 4 * half][i] = segc[i];
 #endif
-    if (!active) return;
 
     const int n = a.col0 + row_base + rt * TK_TILE_ROWS + (lane & 31);
     const int h = lane >> 5;
@@ -1423,19 +1426,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
             const int row = (half * TK_G32_MTW + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row < a.nrows) __builtin_nontemporal_store(acc[t][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
         }
-}
-
-/* s_waitcnt vmcnt(n) alone (expcnt / lgkmcnt untouched): until all but this wave's n youngest vector-memory operations are done.  The
- * LDS-DMA pieces of a chunk are invisible to the compiler's own wait insertion, so the ring is guarded by hand. */
-__device__ __forceinline__ void wait_vmcnt(int n) {
-#define TK_VMW(k) case k: __builtin_amdgcn_s_waitcnt(0x0F70 | ((k) & 15) | (((k) >> 4) << 14)); break;
-    switch (n) {
-        TK_VMW(0) TK_VMW(1) TK_VMW(2) TK_VMW(3) TK_VMW(4) TK_VMW(5) TK_VMW(6) TK_VMW(7) TK_VMW(8) TK_VMW(9) TK_VMW(10) TK_VMW(11) TK_VMW(12)
-        TK_VMW(13) TK_VMW(14) TK_VMW(15) TK_VMW(16) TK_VMW(17) TK_VMW(18) TK_VMW(19) TK_VMW(20) TK_VMW(21) TK_VMW(22) TK_VMW(23) TK_VMW(24)
-        TK_VMW(25) TK_VMW(26) TK_VMW(27) TK_VMW(28)
-        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-    }
-#undef TK_VMW
+#if TK_G32_CLOCK
+    __builtin_amdgcn_s_waitcnt(0);
+    if (tid == 0 && blockIdx.x < 1024) g_g32_stamps[blockIdx.x][7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 #define TK_NUM_CU 256
@@ -1459,15 +1453,20 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     while (waves > 8) { groups *= 2; waves = (row_tiles + groups - 1) / groups; } /* tall matrices: more than one WG per CU */
     int types = 0;
     for (int i = 0; i < a.nseg; ++i) types |= a.seg[i].type == TK_TYPE_Q4_K ? 1 : 2;
-    if (a.nrows > 8 * TK_ROW_SLOTS) {
+#ifndef TK_G32_MIN_ROWS
+#define TK_G32_MIN_ROWS (8 * TK_ROW_SLOTS + 1)
+#endif
+    if (a.nrows >= TK_G32_MIN_ROWS) {
         /* 129..256 rows: the 32x32x32 kernel, one type per wave (a mixed q / k / v launch needs no split): four (weight-tile pair) slots per
-         * workgroup, each served by two SIMD-partner waves (the two row halves) */
+         * workgroup, one workgroup per row half */
         const int pairs = row_tiles / 2; /* every segment holds a multiple of 4 row tiles: pairs never straddle segments */
         const int g32 = (pairs + 3) / 4;
-        const size_t ldsb = (size_t)2 * TK_MAX_TILES * TK_RING_TILE_BYTES;
-        if (types == 1) hipLaunchKernelGGL((k_gemm32_w4a8<1>), dim3(g32 * a.ks), dim3(512), ldsb, s, a, g32, row_tiles);
-        else if (types == 2) hipLaunchKernelGGL((k_gemm32_w4a8<2>), dim3(g32 * a.ks), dim3(512), ldsb, s, a, g32, row_tiles);
-        else hipLaunchKernelGGL((k_gemm32_w4a8<3>), dim3(g32 * a.ks), dim3(512), ldsb, s, a, g32, row_tiles);
+        const int n_halves = a.nrows > 8 * TK_ROW_SLOTS ? 2 : 1;
+        const size_t ldsb = (size_t)2 * TK_G32_MT * TK_RING_TILE_BYTES;
+        const dim3 grid(g32 * a.ks * n_halves);
+        if (types == 1) hipLaunchKernelGGL((k_gemm32_w4a8<1>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
+        else if (types == 2) hipLaunchKernelGGL((k_gemm32_w4a8<2>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
+        else hipLaunchKernelGGL((k_gemm32_w4a8<3>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
         return;
     }
     if (a.nrows > 8 * TK_ROW_SLOTS && types == 3) {
@@ -1614,7 +1613,10 @@ __device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int las
 }
 
 template <int GQ, bool FUSED, int HD /* head_dim when it is 64 or 128 (loops unroll, LDS reads batch), 0 = any */, int CH /* positions per ring slot */, int SLOTS = 2>
-__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qbuf, const float* __restrict__ partial, int ks, int n_total,
+#ifndef TK_ATT_WAVES
+#define TK_ATT_WAVES 1
+#endif
+__global__ __launch_bounds__(256, TK_ATT_WAVES) void k_attention(const float* __restrict__ qbuf, const float* __restrict__ partial, int ks, int n_total,
                                                     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                                     uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache, const int32_t* __restrict__ seq,
                                                     const int32_t* __restrict__ pos, int n_head, int n_kv_head, int head_dim_rt, int layer, int max_seq,
