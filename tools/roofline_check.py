@@ -5,7 +5,8 @@
     tools/roofline_check.py D/rl_kernel_trace.csv run.log
 
 The HIP-event figure is wall time per launch of back-to-back launches (it includes the inter-kernel gap); rocprofv3 reports
-begin-to-end of each dispatch.  Shapes are matched by (kernel family, grid size, workgroup size).
+begin-to-end of each dispatch.  Shapes are matched by (kernel instantiation, grid size, workgroup size); at 256 rows gate|up and the Q4_K
+down projection are the same launch shape (k_gemm32_w4a8<1>, 448 workgroups): their rocprofv3 line is the mixture of the two.
 """
 import csv
 import json
@@ -22,13 +23,13 @@ def main():
         name = r["Kernel_Name"]
         if "w4a8" not in name:
             continue
-        fam = "k_gemm_w4a8" if "k_gemm_w4a8" in name else "k_gemv_w4a8"
+        fam = name.split("(")[0].replace("void ", "")  # with the template arguments: k_gemm32_w4a8<1> (Q4_K), <2> (Q6_K), <3> (mixed q / k / v)
         dur[(fam, int(r["Grid_Size_X"] if "Grid_Size_X" in r else r["Grid_Size"]), int(r["Workgroup_Size_X"] if "Workgroup_Size_X" in r else r["Workgroup_Size"]))].append(
             (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("rocprofv3 kernel durations by launch shape (us):")
     for k in sorted(dur):
         v = dur[k]
-        print(f"  {k[0]} grid={k[1]:7d} wg={k[2]:4d}  n={len(v):5d}  mean={sum(v) / len(v):8.2f}  min={min(v):8.2f}")
+        print(f"  {k[0]:24s} grid={k[1]:7d} wg={k[2]:4d}  n={len(v):5d}  mean={sum(v) / len(v):8.2f}  min={min(v):8.2f}")
     print("bench.py HIP-event per-launch times (us):")
     for name, d in rl["per_shape"].items():
         print(f"  {name:8s} {d['ms'] * 1e3:8.2f}")
