@@ -1087,6 +1087,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #ifndef TK_G32_PK
 #define TK_G32_PK 0 /* 1 = finish two outputs per VALU instruction (v_pk_mul_f32 / v_pk_fma_f32; bit-identical) */
 #endif
+#ifndef TK_G32_BALANCE
+#define TK_G32_BALANCE 1 /* 0 = diagnostic: no progress-based issue priority */
+#endif
 #ifndef TK_G32_ABL
 #define TK_G32_ABL 0 /* diagnostic, TIMING ONLY (results are wrong): 1 no MFMAs, 2 no finishing, 4 no unpack, 8 no ring staging, 32 no LDS operand reads */
 #endif
@@ -1259,6 +1262,17 @@ __device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_byte
         __syncthreads();
         TK_STAMP(s_top);
         const bool more = b + 1 < nb;
+#if TK_G32_BALANCE
+        { /* a CU's two workgroups share its SIMDs under oldest-first arbitration: the older one runs near its solo rate, the younger one on what
+           * is left and finishes alone (K loop 58 / 74 us for gate|up).  Issue priority that falls with progress lets the one that is behind
+           * catch up: 63 / 71 us, launch set - 1..3 % (profiles/r03_gemm32_balance.txt) */
+            const int q = 4 * b / nb;
+            if (q == 0) __builtin_amdgcn_s_setprio(3);
+            else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
 #if !(TK_G32_ABL & 8)
         if (more) stage_small(b + 1, (b + 1) & 1);
 #endif
