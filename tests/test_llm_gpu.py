@@ -134,7 +134,7 @@ def test_mistral_shaped_layer_bit_exact(gpu):
         assert np.array_equal(gam, wam)
 
 
-@pytest.mark.parametrize("nrows", [33, 48, 64, 65, 100, 128, 129, 200, 256])
+@pytest.mark.parametrize("nrows", [33, 48, 64, 65, 100, 128, 129, 161, 200, 255, 256])  # 129..256: k_gemm32_w4a8, the second row half partly or barely filled
 def test_tiny_batched_pass_rows(gpu, nrows):
     """passes of more than 32 rows take the K-streamed batched kernel (4, 8 or 16 M-tiles per weight tile, folded Q6_K):
     ragged rows over several sequences, then one decode row per sequence — bit-exact logits"""

@@ -33,14 +33,22 @@ __device__ __forceinline__ void tile_step(const uint8_t* lp, int t, const Opa& c
     }
     const v16i z = {};
     now.pl = z; now.ph = z;
+    if (SCHED != 9) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        now.pl = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a[u], Bl[u], now.pl, 0, 0, 0);
-        now.ph = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a[u], Bh[u], now.ph, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) {
+            now.pl = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a[u], Bl[u], now.pl, 0, 0, 0);
+            now.ph = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a[u], Bh[u], now.ph, 0, 0, 0);
+        }
+        const v16f fz = {};
+        now.cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.mn, bm, fz, 0, 0, 0);
+    } else { /* no MFMAs: the operands stay live */
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" :: "v"(cur.a[u]));
+        asm volatile("" :: "v"(cur.mn));
+        asm volatile("" : "+v"(now.pl), "+v"(now.ph));
     }
-    const v16f fz = {};
-    now.cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.mn, bm, fz, 0, 0, 0);
-    // finishing of the previous tile
+    // finishing of the previous tile (UNP < 0: none)
+    if (UNP >= 0)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -51,7 +59,7 @@ __device__ __forceinline__ void tile_step(const uint8_t* lp, int t, const Opa& c
         }
     // the unpack's share: UNP integer VALU instructions on values the optimiser cannot fold
 #pragma unroll
-    for (int i = 0; i < UNP; ++i) junk[i & 7] = __builtin_amdgcn_perm(junk[i & 7], junk[(i + 5) & 7], 0x07020500u + i); /* one full-rate VALU instruction each */
+    for (int i = 0; i < (UNP > 0 ? UNP : 0); ++i) junk[i & 7] = __builtin_amdgcn_perm(junk[i & 7], junk[(i + 5) & 7], 0x07020500u + i); /* one full-rate VALU instruction each */
     if (SCHED == 1) {
 #pragma unroll
         for (int i = 0; i < 17; ++i) {
@@ -149,15 +157,13 @@ static void run(const char* name) {
 int main() {
     run<0, 0, false, 0>("(warm-up)");
     for (int rep = 0; rep < 2; ++rep) {
-        run<0, 0, false, 0>("compiler order: 17 MFMA + 96 finishing VALU");
-        run<0, 24, false, 0>("compiler order: + 24 unpack VALU");
-        run<1, 24, false, 0>("grouped 1 MFMA : 7 VALU: + 24 unpack VALU");
-        run<0, 24, true, 0>("compiler order: + 24 unpack VALU + 13 ds_read_b128");
-        run<1, 24, true, 0>("grouped (read first): + 24 unpack VALU + 13 ds_read_b128");
-        run<2, 24, true, 0>("grouped (read mid): + 24 unpack VALU + 13 ds_read_b128");
-        run<0, 0, true, 0>("compiler order: + 13 ds_read_b128 only");
-        run<0, 24, true, 2>("compiler order: + 24 unpack VALU + 13 ds_read_b128 + 1.5 LDS-DMA pieces");
-        run<2, 24, true, 2>("grouped (read mid): the same");
+        run<0, 0, false, 0>("17 MFMA + 96 finishing VALU");
+        run<0, -1, false, 0>("17 MFMA only");
+        run<0, -1, true, 0>("17 MFMA + 13 ds_read_b128 (no VALU)");
+        run<0, 0, true, 0>("17 MFMA + 96 VALU + 13 ds_read_b128");
+        run<9, 0, true, 0>("96 VALU + 13 ds_read_b128 (no MFMA)");
+        run<9, 0, false, 0>("96 VALU only");
+        run<9, -1, true, 0>("13 ds_read_b128 only");
     }
     return 0;
 }

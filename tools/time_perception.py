@@ -32,10 +32,17 @@ def vad_pass():
         vad.process_with_events(pcm[b])
 
 
-timed("detector (32 frames)", lambda: det.detect_batch(frames))
-timed("vad (32 x 1 s)", vad_pass)
-timed("asr 16 steps (32 x 1 s)", lambda: asr.transcribe_tokens(pcm, 16, want_aux=False))
-timed("asr 1 step (32 x 1 s)", lambda: asr.transcribe_tokens(pcm, 1, want_aux=False))
+ONLY = os.environ.get("TK_PERC_ONLY", "")  # "det", "vad", "asr16", "asr1": one stream only (kernel traces)
+if ONLY in ("", "det"):
+    timed("detector (32 frames)", lambda: det.detect_batch(frames))
+if ONLY in ("", "vad"):
+    timed("vad (32 x 1 s)", vad_pass)
+if ONLY in ("", "asr16"):
+    timed("asr 16 steps (32 x 1 s)", lambda: asr.transcribe_tokens(pcm, 16, want_aux=False))
+if ONLY in ("", "asr1"):
+    timed("asr 1 step (32 x 1 s)", lambda: asr.transcribe_tokens(pcm, 1, want_aux=False))
+if ONLY:
+    sys.exit(0)
 
 # depth: a graph of the convolutional MiDaS class (tests/onnx_util.depth_spec at 4x the fixture's channel counts), one 640x480 frame -> 256x256 map
 import tempfile  # noqa: E402

@@ -1627,6 +1627,9 @@ __device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int las
 }
 
 template <int GQ, bool FUSED, int HD /* head_dim when it is 64 or 128 (loops unroll, LDS reads batch), 0 = any */, int CH /* positions per ring slot */, int SLOTS = 2>
+#ifndef TK_ATT_ABL
+#define TK_ATT_ABL 0 /* diagnostic, TIMING ONLY: 1 no QK dot products, 2 one PV batch per chunk */
+#endif
 #ifndef TK_ATT_WAVES
 #define TK_ATT_WAVES 1
 #endif
@@ -1728,7 +1731,12 @@ __global__ __launch_bounds__(256, TK_ATT_WAVES) void k_attention(const float* __
                 const float* qh = qs + h * head_dim;
                 float a = 0.0f;
                 constexpr int KB = HD ? HD / 8 : 1; /* key pieces read per batch: the whole row when head_dim is known */
+#if TK_ATT_ABL & 1
+                a = (float)kr[t & 15] + qh[t & 31];
+                for (int i0 = 0; i0 < 0; i0 += KB) {
+#else
                 for (int i0 = 0; i0 < ppr; i0 += KB) {
+#endif
                     uint4 kv[KB];
 #pragma unroll
                     for (int u = 0; u < KB; ++u) kv[u] = *(const uint4*)(kr + (((i0 + u) ^ (rr & (ppr - 1))) * 16));
@@ -1776,7 +1784,11 @@ __global__ __launch_bounds__(256, TK_ATT_WAVES) void k_attention(const float* __
         /* positions in batches of PB: every LDS read of a batch is issued before its first fma (out-of-range slots of the last batch
          * read a clamped row and enter with probability 0: fma(0, v, acc) == acc and l + 0 == l exactly, the canonical order is untouched) */
         constexpr int PB = 4;
+#if TK_ATT_ABL & 2
+        for (int rr0 = wave; rr0 < (t_end < 1 ? t_end : 1); rr0 += PB * TK_ATT_TSPLIT) {
+#else
         for (int rr0 = wave; rr0 < t_end; rr0 += PB * TK_ATT_TSPLIT) {
+#endif
             float pr[PB][GQ];
             uint32_t vv[PB][2];
 #pragma unroll
@@ -1863,12 +1875,15 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
     /* ring depth 2 at every pass width: with few workgroups a five-slot ring (every K and V chunk of a 128-position context in flight at
      * once) measured no faster — 16 rows x 128 positions 10.7 us against 11.1, decode step unchanged (profiles/r03_attention_slots.txt): a
      * one-row launch already takes 9.8 us, the launch is a chain of ~10 barrier-separated phases, not of DMA latencies */
-    const int slots = 2;
+#ifndef TK_ATT_WIDE_SLOTS
+#define TK_ATT_WIDE_SLOTS 2 /* ring depth of the many-workgroup (32-position chunk) form */
+#endif
+    const int slots = chunk == 32 ? TK_ATT_WIDE_SLOTS : 2;
     const size_t lds = tk_attention_lds_bytes(gq, head_dim, max_ctx, chunk, slots);
 #define TK_ATT_LAUNCH_CH(G, F, H, C, S)                                                                                                       \
     hipLaunchKernelGGL((k_attention<G, F, H, C, S>), dim3(n_head / gq, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin, kcache, \
                        vcache, seq, pos, n_head, n_kv_head, head_dim, layer, max_seq, max_ctx, out)
-#define TK_ATT_LAUNCH_HD(G, F, H) do { if (chunk == 32) TK_ATT_LAUNCH_CH(G, F, H, 32, 2); else TK_ATT_LAUNCH_CH(G, F, H, 64, 2); } while (0)
+#define TK_ATT_LAUNCH_HD(G, F, H) do { if (chunk == 32) TK_ATT_LAUNCH_CH(G, F, H, 32, TK_ATT_WIDE_SLOTS); else TK_ATT_LAUNCH_CH(G, F, H, 64, 2); } while (0)
 #define TK_ATT_LAUNCH(G, F) do { if (head_dim == 128) TK_ATT_LAUNCH_HD(G, F, 128); else if (head_dim == 64) TK_ATT_LAUNCH_HD(G, F, 64); else TK_ATT_LAUNCH_HD(G, F, 0); } while (0)
     if (fused) {
         if (gq == 4) TK_ATT_LAUNCH(4, true); else if (gq == 2) TK_ATT_LAUNCH(2, true); else TK_ATT_LAUNCH(1, true);
@@ -1979,7 +1994,7 @@ const char* tk_llm_prepare_device(int device) {
     TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
 #define TK_OPT_ATT_C(H, C, S) do { TK_OPT((k_attention<1, true, H, C, S>)); TK_OPT((k_attention<2, true, H, C, S>)); TK_OPT((k_attention<4, true, H, C, S>)); \
                                  TK_OPT((k_attention<1, false, H, C, S>)); TK_OPT((k_attention<2, false, H, C, S>)); TK_OPT((k_attention<4, false, H, C, S>)); } while (0)
-#define TK_OPT_ATT(H) do { TK_OPT_ATT_C(H, 32, 2); TK_OPT_ATT_C(H, 64, 2); } while (0)
+#define TK_OPT_ATT(H) do { TK_OPT_ATT_C(H, 32, TK_ATT_WIDE_SLOTS); TK_OPT_ATT_C(H, 64, 2); } while (0)
     TK_OPT_ATT(0); TK_OPT_ATT(64); TK_OPT_ATT(128);
 #undef TK_OPT_ATT
 #undef TK_OPT_GEMV
