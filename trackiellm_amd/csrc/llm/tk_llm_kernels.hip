@@ -1142,6 +1142,9 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
 #pragma unroll
         for (int u = 4; u < 8; ++u) A[u] = T.a[u - 4];
 #pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(A[u])); /* opaque per tile: identical operands would let the compiler merge the four tiles' MFMAs */
+        if (Q4) asm volatile("" : "+v"(T.mn));
+#pragma unroll
         for (int b = 0; b < 4; ++b) { da[b] = (v4f){1.0f, 2.0f, 3.0f, 4.0f}; asm volatile("" : "+v"(da[b])); }
 #else
 #pragma unroll
