@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256) void k_pipe_take_x(const TkPipeBlock* mine, Tk
     const unsigned long long seq = st->recv_x + 1;
     const uint8_t* base = (const uint8_t*)mine + sizeof(TkPipeBlock) + (size_t)(seq % TK_PIPE_SLOTS) * slot_floats * 4;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    /* k_pipe_wait_x's acquire dropped stale lines of this slot only from the caches of the ONE workgroup that polled; this kernel's
+     * workgroups sit behind other L2s (one per XCD) that may still hold the slot's contents of eight passes ago, and the slot was written
+     * by a peer, not through them: acquire at system scope before the first payload read, whatever the launch boundary did */
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     if (i < n4) {
         if (f16) {
             const uint2 h = ((const uint2*)base)[i];
