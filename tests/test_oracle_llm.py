@@ -48,6 +48,35 @@ def test_oracle_decode_matches_hf_kv_cache_fixture():
     assert np.array_equal(g32.argmax(1)[:-1], ids[1:])
 
 
+def test_oracle_matches_hf_at_mistral_geometry():
+    """llm_mistral_shape.npz: two layers at Mistral-7B's geometry — d_model 4096, 32 heads of 128, GQA 4 : 1, d_ff 14336, vocab 32000,
+    the canonical K-split plan (4, 4, 1, 7) — against transformers.MistralForCausalLM on the de-quantised synthetic checkpoint: a 40-token
+    prefill and 6 greedy steps from HF's own KV cache.  fp32-activation mode: HF's logits (at 512 fixed vocabulary columns) to 2e-3 of the
+    logit scale and HF's ids step by step; int8-activation mode (what the product computes): within activation-quantisation noise."""
+    g = np.load(os.path.join(GOLD, "llm_mistral_shape.npz"))
+    toks, cols, ids = g["tokens"], g["cols"], g["hf_ids"]
+    hf, hf_steps, scale = g["hf_logits_cols"], g["hf_step_logits_cols"], float(g["hf_scale"])
+    P, S = len(toks), len(ids)
+    orc = O.OracleLlm(O.mistral7b_config(n_layer=int(g["n_layer"]), max_ctx=64, max_seq=1), seed=int(g["seed"]))
+    res = {}
+    try:
+        for mode in (1, 0):
+            O.lib().orc_set_fp32_activations(mode)
+            orc.reset()
+            pl, pam = orc.forward(np.zeros(P, np.int32), np.arange(P, dtype=np.int32), toks)
+            st = np.stack([orc.forward([0], [P + i], [ids[i]])[0][0] for i in range(S)])
+            res[mode] = (pl, pam, st)
+    finally:
+        O.lib().orc_set_fp32_activations(0)
+    pl, pam, st = res[1]
+    assert max(np.abs(pl[:, cols] - hf).max(), np.abs(st[:, cols] - hf_steps).max()) < 2e-3 * scale
+    assert int(pam[-1]) == int(ids[0]) and np.array_equal(st.argmax(1)[:-1], ids[1:])
+    assert (pam == g["hf_argmax"]).mean() >= 0.95  # near-ties of a random-weight model may fall the other way
+    pl, pam, st = res[0]
+    assert max(np.abs(pl[:, cols] - hf).max(), np.abs(st[:, cols] - hf_steps).max()) < 0.05 * scale
+    assert (pam == g["hf_argmax"]).mean() >= 0.9
+
+
 def test_prefill_equals_incremental_decode():
     orc = O.OracleLlm(O.tiny_config(), seed=7)
     toks = np.array([5, 17, 300, 42, 9, 260], dtype=np.int32)
