@@ -58,6 +58,10 @@ TK_API void tk_mi355x_llm_model_destroy(tk_mi355x_llm_model_t** m);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_set_runner_slots(void* model_handle, int slots);
 /* what the schedulers of a model have done so far: passes run, rows processed, the widest pass */
 TK_API void tk_mi355x_llm_model_batch_stats(void* model_handle, uint64_t* passes, uint64_t* rows, int32_t* max_rows_in_a_pass);
+/* run-ahead rows (csrc/llm/tk_llm_batcher.h) that no owner came back for: the scheduler feeds a sequence's sampled id one position ahead
+ * of its owner's next tk_llm_runner_generate_next_token; a runner that stops or changes course costs one such row.  `rows` above counts
+ * only rows an owner asked for. */
+TK_API uint64_t tk_mi355x_llm_model_run_ahead_wasted(void* model_handle);
 
 /* sessions --------------------------------------------------------------------------------- */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_session_create(tk_mi355x_llm_session_t** out, tk_mi355x_llm_model_t* m, int max_seq,

@@ -584,6 +584,61 @@ def test_runners_on_one_model_share_decode_passes(gpu):
     loader.close()
 
 
+def test_run_ahead_rows_are_invisible(gpu):
+    """the scheduler feeds a sequence's sampled id one position AHEAD of its owner's next generate_next_token (csrc/llm/tk_llm_batcher.h).
+    Whatever the owner does next, it sees the tokens of a runner nobody ran ahead of: (a) it comes back late (the row is done and waiting),
+    (b) it comes back at once (the row is in flight), (c) it stops and starts a new prompt (the row is wasted, its cache row overwritten).  A tool response fed at the position a wasted
+    row wrote is test_runner_add_tool_response_continues_the_context.  Reference: the oracle's greedy ids."""
+    import time
+    loader = gpu.ModelLoader()
+    h = loader.load("synthetic://tiny?seed=4")
+    model = _BorrowedModel(gpu, h)
+    orc = O.OracleLlm(oracle_cfg_from(model.hparams, 96, 1), seed=4)
+
+    def oracle_ids(text_ids, n, then=()):
+        orc.reset()
+        _, am = orc.forward([0] * len(text_ids), list(range(len(text_ids))), text_ids, want_logits=False)
+        cur, out, pos = int(am[-1]), [], len(text_ids)
+        for _ in range(n):
+            out.append(cur)
+            _, am = orc.forward([0], [pos], [cur], want_logits=False)
+            cur, pos = int(am[0]), pos + 1
+        return out, pos, cur
+
+    def ids_of_prompt(p):
+        return [1] + [3 + b for b in p.encode()]
+
+    r = gpu.LlmRunner(h, context_size=96)
+    w0 = gpu.ModelLoader.run_ahead_wasted(h)
+    # (a) a slow owner: every row is finished before it is asked for
+    r.prepare("late owner")
+    got = []
+    for _ in range(6):
+        time.sleep(0.02)
+        got.append(r.next_token())
+    assert None not in got
+    want, _, _ = oracle_ids(ids_of_prompt("late owner"), 6)
+    assert _ids_of(got) == want
+    # (b) + (c): a fast owner, then a new prompt in the middle of a generation — the row that ran ahead of the abandoned one is wasted
+    r.prepare("second prompt, longer than the first")
+    got = [r.next_token() for _ in range(5)]
+    assert None not in got
+    want, _, _ = oracle_ids(ids_of_prompt("second prompt, longer than the first"), 5)
+    assert _ids_of(got) == want
+    r.prepare("x")   # shorter than what the cache holds: stale rows beyond it, one of them written by a run-ahead row
+    got = [r.next_token() for _ in range(8)]
+    assert None not in got
+    want, _, _ = oracle_ids(ids_of_prompt("x"), 8)
+    assert _ids_of(got) == want
+    assert gpu.ModelLoader.run_ahead_wasted(h) >= w0 + 2
+    # rows an owner asked for: 3 prompts + 6 + 5 + 8 decode rows — the run-ahead rows that were taken count once, the wasted ones never
+    _, rows, _ = gpu.ModelLoader.batch_stats(h)
+    assert rows == len(ids_of_prompt("late owner")) + len(ids_of_prompt("second prompt, longer than the first")) + len(ids_of_prompt("x")) + 6 + 5 + 8
+    r.close()
+    loader.unload(h)
+    loader.close()
+
+
 def test_f16_weights_bit_exact_and_pipeline_split(gpu):
     """fp16 checkpoints (BASELINE configs[4]): every matrix IEEE f16, run on the exact fp32 MFMA GEMM over f16-rounded activations.
     Logits bit-identical to the oracle (one fma chain per output over k ascending); a decode loop through the captured graphs; the

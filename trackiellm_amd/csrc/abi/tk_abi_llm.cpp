@@ -376,6 +376,20 @@ void tk_mi355x_llm_model_batch_stats(void* model_handle, uint64_t* passes, uint6
     if (max_rows_in_a_pass) *max_rows_in_a_pass = mx;
 }
 
+uint64_t tk_mi355x_llm_model_run_ahead_wasted(void* model_handle) {
+    uint64_t w = 0;
+    if (model_handle) {
+        tk_mi355x_llm_model_t* m = (tk_mi355x_llm_model_t*)model_handle;
+        std::lock_guard<std::mutex> lk(m->batch_mu);
+        for (auto& b : m->batchers) {
+            uint64_t bw = 0;
+            b->stats(nullptr, nullptr, nullptr, &bw);
+            w += bw;
+        }
+    }
+    return w;
+}
+
 /* grammar engine entry points (no GPU involved): used by the CPU tests and by hosts that want the tool-call text */
 tk_error_code_t tk_mi355x_grammar_check(const char* gbnf, const char* text, int32_t* n_accepted, int32_t* complete) {
     if (!text || !n_accepted || !complete) return TK_ERROR_INVALID_ARGUMENT;
@@ -586,7 +600,7 @@ tk_error_code_t tk_llm_runner_create(tk_llm_runner_t** out_runner, void* model_h
             if (slots <= 0) slots = 16;
             std::unique_ptr<TkLlmBatcher> b(new TkLlmBatcher());
             std::string err;
-            if (!b->init(&r->model->model, slots, r->n_ctx, &err)) return fail(TK_ERROR_GPU_MEMORY, err);
+            if (!b->init(&r->model->model, slots, r->n_ctx, r->model->tok.eos, &err)) return fail(TK_ERROR_GPU_MEMORY, err);
             r->slot = b->acquire_slot();
             r->batcher = b.get();
             r->model->batchers.push_back(std::move(b));

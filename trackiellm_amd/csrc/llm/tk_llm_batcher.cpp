@@ -12,12 +12,14 @@ TkLlmBatcher::~TkLlmBatcher() {
     if (worker_.joinable()) worker_.join();
 }
 
-bool TkLlmBatcher::init(TkLlmModel* model, int slots, int n_ctx, std::string* err) {
+bool TkLlmBatcher::init(TkLlmModel* model, int slots, int n_ctx, int32_t eos, std::string* err) {
     if (slots < 1) slots = 1;
     if (slots > TK_MAX_ROWS) slots = TK_MAX_ROWS; /* one decode row per runner must fit one pass */
     if (!session_.init(model, slots, n_ctx)) { *err = session_.error; return false; }
     n_ctx_ = n_ctx;
     slot_used_.assign((size_t)slots, 0);
+    ahead_.assign((size_t)slots, Ahead());
+    eos_ = eos;
     worker_ = std::thread([this] { loop(); });
     return true;
 }
@@ -31,14 +33,33 @@ int TkLlmBatcher::acquire_slot() {
 
 void TkLlmBatcher::release_slot(int slot) {
     std::lock_guard<std::mutex> lk(mu_);
-    if (slot >= 0 && slot < (int)slot_used_.size()) slot_used_[(size_t)slot] = 0;
+    if (slot >= 0 && slot < (int)slot_used_.size()) { slot_used_[(size_t)slot] = 0; drop_ahead(slot); }
 }
 
-void TkLlmBatcher::stats(uint64_t* passes, uint64_t* rows, int* max_rows) {
+void TkLlmBatcher::stats(uint64_t* passes, uint64_t* rows, int* max_rows, uint64_t* wasted) {
     std::lock_guard<std::mutex> lk(mu_);
     if (passes) *passes = passes_;
     if (rows) *rows = rows_;
     if (max_rows) *max_rows = max_rows_;
+    if (wasted) *wasted = wasted_;
+}
+
+/* the owner of `slot` has just been handed `sampled` for position pos_done: feed it at pos_done + 1 in the next pass */
+void TkLlmBatcher::plan_ahead(int slot, int pos_done, int32_t sampled, bool masked) {
+    Ahead& a = ahead_[(size_t)slot];
+    if (masked || sampled < 0 || sampled == eos_ || pos_done + 2 >= n_ctx_ || a.st != Ahead::NONE) return; /* the runner stops at n_past + 1 >= n_ctx */
+    a = Ahead();
+    a.st = Ahead::PLANNED;
+    a.pos = pos_done + 1;
+    a.tok = sampled;
+}
+
+void TkLlmBatcher::drop_ahead(int slot) {
+    Ahead& a = ahead_[(size_t)slot];
+    if (a.st == Ahead::NONE) return;
+    if (a.st == Ahead::INFLIGHT) { a.discard = true; a.waiter = nullptr; return; } /* the pass that carries it retires it */
+    if (a.st == Ahead::DONE) wasted_++;
+    a = Ahead();
 }
 
 bool TkLlmBatcher::submit(int slot, int pos0, const int32_t* toks, int n, const uint32_t* mask, int32_t* sampled, std::string* err) {
@@ -48,6 +69,29 @@ bool TkLlmBatcher::submit(int slot, int pos0, const int32_t* toks, int n, const 
     r.slot = slot; r.pos0 = pos0; r.n = n; r.toks = toks; r.mask = mask;
     std::unique_lock<std::mutex> lk(mu_);
     if (stop_) { *err = "scheduler stopped"; return false; }
+    Ahead& a = ahead_[(size_t)slot];
+    if (a.st != Ahead::NONE && !a.discard) {
+        if (n == 1 && !mask && pos0 == a.pos && toks[0] == a.tok) { /* the row this call asks for is the one that ran (or runs) ahead */
+            if (a.st == Ahead::DONE) {
+                const bool ok = a.ok;
+                const int32_t got = a.sampled;
+                a = Ahead();
+                if (!ok) { *err = last_error_; return false; }
+                rows_++;
+                *sampled = got;
+                plan_ahead(slot, pos0, got, false);
+                cv_.notify_all();
+                return true;
+            }
+            a.waiter = &r; /* PLANNED or INFLIGHT: the pass that carries the row finishes this request */
+            cv_.notify_all();
+            r.cv.wait(lk, [&] { return r.finished; });
+            if (!r.ok) { *err = r.error; return false; }
+            *sampled = r.sampled;
+            return true;
+        }
+        drop_ahead(slot); /* the owner went another way (a tool response, a new prompt, a masked step) */
+    }
     queue_.push_back(&r);
     cv_.notify_all();
     r.cv.wait(lk, [&] { return r.finished; });
@@ -60,21 +104,28 @@ void TkLlmBatcher::loop() {
     std::vector<int32_t> sq, ps, tk, am;
     std::vector<const uint32_t*> masks;
     std::vector<Request*> in_pass, completing;
+    std::vector<int> ahead_rows; /* slots whose run-ahead row rides this pass, in row order after the queued requests' rows */
+    auto any_planned = [&] {
+        for (const Ahead& a : ahead_) if (a.st == Ahead::PLANNED) return true;
+        return false;
+    };
     for (;;) {
-        in_pass.clear(); completing.clear();
+        in_pass.clear(); completing.clear(); ahead_rows.clear();
         sq.clear(); ps.clear(); tk.clear(); masks.clear();
         bool any_mask = false;
         {
             std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+            cv_.wait(lk, [&] { return stop_ || !queue_.empty() || any_planned(); });
             if (stop_) {
                 for (Request* r : queue_) { r->ok = false; r->error = "scheduler stopped"; r->finished = true; r->cv.notify_all(); }
                 queue_.clear();
+                for (Ahead& a : ahead_)
+                    if (a.waiter) { a.waiter->ok = false; a.waiter->error = "scheduler stopped"; a.waiter->finished = true; a.waiter->cv.notify_all(); a.waiter = nullptr; }
                 return;
             }
-            /* the owners of the requests the last pass finished are about to ask for their next token: give them a moment so that K
-             * runners decoding in lock step share every pass (a late one simply rides the next pass) */
-            if (queue_.size() < expect_) {
+            /* the owners of the requests the last pass finished WITHOUT a run-ahead row (masked steps) are about to ask for their next
+             * token: give them a moment so that K runners decoding in lock step share every pass (a late one simply rides the next pass) */
+            if (queue_.size() < expect_ && !any_planned()) {
                 /* the window grows with the number of owners expected back (waking K host threads takes time) and stays well under the cost
                  * of the pass it fills: 200 us + 8 us per expected request, at most 2.5 ms (a 256-row pass is ~8 ms, a 16-row pass ~2.3 ms) */
                 const int64_t us = std::min<int64_t>(2500, 200 + 8 * (int64_t)expect_);
@@ -98,31 +149,69 @@ void TkLlmBatcher::loop() {
                     any_mask = any_mask || r->mask != nullptr;
                 }
             }
+            /* then the run-ahead rows, one per sequence whose owner holds the id they feed */
+            for (size_t s = 0; s < ahead_.size() && (int)sq.size() < TK_MAX_ROWS; ++s) {
+                Ahead& a = ahead_[s];
+                if (a.st != Ahead::PLANNED) continue;
+                a.st = Ahead::INFLIGHT;
+                sq.push_back((int32_t)s);
+                ps.push_back(a.pos);
+                tk.push_back(a.tok);
+                masks.push_back(nullptr);
+                ahead_rows.push_back((int)s);
+            }
         }
         const int nrows = (int)sq.size();
+        if (nrows == 0) continue;
         am.assign((size_t)nrows, -1);
-        const bool head = !completing.empty();
+        const bool head = !completing.empty() || !ahead_rows.empty();
         const bool ok = session_.forward(nrows, sq.data(), ps.data(), tk.data(), nullptr, head ? am.data() : nullptr, head, head && any_mask ? masks.data() : nullptr);
         {
             std::lock_guard<std::mutex> lk(mu_);
             passes_++;
-            rows_ += (uint64_t)nrows;
             if (nrows > max_rows_) max_rows_ = nrows;
+            if (!ok) last_error_ = session_.error;
             int row = 0;
+            size_t held = 0; /* completing requests that got no run-ahead row: their owners are waited for */
             for (Request* r : in_pass) {
                 const int take = std::min(r->n - r->done_rows, TK_MAX_ROWS - row);
                 row += take;
+                rows_ += (uint64_t)take;
                 r->done_rows += take;
                 if (!ok) { r->ok = false; r->error = session_.error; r->done_rows = r->n; }
                 if (r->done_rows == r->n) {
                     r->sampled = ok ? am[(size_t)row - 1] : -1;
                     for (auto it = queue_.begin(); it != queue_.end(); ++it)
                         if (*it == r) { queue_.erase(it); break; }
+                    if (ok) plan_ahead(r->slot, r->pos0 + r->n - 1, r->sampled, r->mask != nullptr);
+                    if (!ok || ahead_[(size_t)r->slot].st != Ahead::PLANNED) held++;
                     r->finished = true;
                     r->cv.notify_all();
                 }
             }
-            expect_ = completing.size();
+            for (int s : ahead_rows) {
+                Ahead& a = ahead_[(size_t)s];
+                const int32_t got = ok ? am[(size_t)row] : -1;
+                ++row;
+                if (a.discard) { wasted_++; a = Ahead(); continue; }
+                if (a.waiter) { /* the owner is already waiting for exactly this row */
+                    Request* w = a.waiter;
+                    const int pos = a.pos;
+                    a = Ahead();
+                    w->ok = ok;
+                    if (!ok) w->error = session_.error;
+                    w->sampled = got;
+                    rows_++;
+                    if (ok) plan_ahead(s, pos, got, false);
+                    w->finished = true;
+                    w->cv.notify_all();
+                } else {
+                    a.st = Ahead::DONE;
+                    a.sampled = got;
+                    a.ok = ok;
+                }
+            }
+            expect_ = held;
         }
     }
 }

@@ -9,6 +9,14 @@
  * K host threads that each drive "their" runner read the 4.3 GB of weights once per step instead of K times.
  * A row's result does not depend on which other rows share its pass (bit-identical logits at any pass width:
  * tests/test_llm_gpu.py::test_full_7b_pass_width_invariance), so a runner sees exactly the tokens it would see alone.
+ *
+ * Run-ahead.  generate_next_token is a host round trip per token: the owner wakes, turns the id into a piece, returns to its caller and
+ * comes back with the id it was just given — while the GPU waits.  So when a sequence's sampled id has been handed to its owner, the
+ * scheduler feeds that id at the next position in its very next pass WITHOUT waiting for the owner (one position ahead, never more); the
+ * owner's next call then finds its row in flight or already done.  Not for rows sampled under a grammar mask (the next mask depends on
+ * the accepted token), not after EOS, not at the end of the context.  An owner that comes back with something else (a tool response, a
+ * new prompt) or not at all costs one wasted row: the cache row it wrote is overwritten before anything attends to it, because positions
+ * are fed in order.  Tokens are unchanged — a row's result does not depend on when or with whom it runs.
  */
 #ifndef TK_LLM_BATCHER_H
 #define TK_LLM_BATCHER_H
@@ -26,7 +34,7 @@ class TkLlmBatcher {
 public:
     ~TkLlmBatcher();
     /* one session with `slots` sequences of `n_ctx` positions on the model's device; starts the scheduler thread */
-    bool init(TkLlmModel* model, int slots, int n_ctx, std::string* err);
+    bool init(TkLlmModel* model, int slots, int n_ctx, int32_t eos, std::string* err);
     int acquire_slot();            /* -1 when every slot is taken */
     void release_slot(int slot);
     int n_ctx() const { return n_ctx_; }
@@ -34,8 +42,9 @@ public:
     /* Blocking: feed `n` tokens of sequence `slot` at positions pos0, pos0 + 1, ...; *sampled = arg max after the last one (over the
      * tokens `mask` allows, when given: (vocab + 31) / 32 words, bit t = token t).  Thread-safe; one outstanding call per slot. */
     bool submit(int slot, int pos0, const int32_t* toks, int n, const uint32_t* mask, int32_t* sampled, std::string* err);
-    /* counters for tests and bench: passes run, rows processed, the widest pass so far */
-    void stats(uint64_t* passes, uint64_t* rows, int* max_rows);
+    /* counters for tests and bench: passes run, rows processed FOR AN OWNER (a run-ahead row counts when its owner takes it; wasted ones
+     * are in *wasted), the widest pass so far */
+    void stats(uint64_t* passes, uint64_t* rows, int* max_rows, uint64_t* wasted = nullptr);
 
 private:
     struct Request {
@@ -47,7 +56,21 @@ private:
         std::string error;
         std::condition_variable cv;
     };
+    /* one run-ahead row per sequence slot */
+    struct Ahead {
+        enum State { NONE, PLANNED, INFLIGHT, DONE } st = NONE;
+        int pos = 0;
+        int32_t tok = 0, sampled = -1;
+        bool ok = true, discard = false;
+        Request* waiter = nullptr;
+    };
     void loop();
+    void plan_ahead(int slot, int pos_done, int32_t sampled, bool masked); /* mu_ held */
+    void drop_ahead(int slot);                                              /* mu_ held */
+    std::vector<Ahead> ahead_;
+    int32_t eos_ = -1;
+    uint64_t wasted_ = 0;
+    std::string last_error_;
     TkLlmSession session_;
     int n_ctx_ = 0;
     std::vector<char> slot_used_;

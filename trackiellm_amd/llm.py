@@ -254,6 +254,14 @@ class ModelLoader:
         lib().tk_mi355x_llm_model_batch_stats(handle, C.byref(p), C.byref(r), C.byref(m))
         return p.value, r.value, m.value
 
+    @staticmethod
+    def run_ahead_wasted(handle):
+        """run-ahead rows of this model's schedulers that no owner came back for"""
+        f = lib().tk_mi355x_llm_model_run_ahead_wasted
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p]
+        return int(f(handle))
+
     def close(self):
         if self.h:
             lib().tk_model_loader_destroy(C.byref(self.h))
