@@ -435,6 +435,9 @@ def hp_weight_bytes(tk, handle):
     return tk.lib().tk_mi355x_llm_model_weight_bytes(handle)
 
 
+COLL_CUDA = True  # collectives on device tensors (RCCL); False in the one-GPU rehearsal (gloo)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -474,8 +477,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     from trackiellm_amd import dist as D
+    # TK_BENCH_SHARE_GPU=1: a REHEARSAL of the N > 1 paths on a box with one GPU — every rank drives device 0, gloo lines the ranks up.
+    # It exercises the launch contract, the handle exchange and the in-library stage hand-off across processes (hipIpc); the value it
+    # prints says nothing about scaling and is marked so.
+    share = os.environ.get("TK_BENCH_SHARE_GPU") == "1" and world > 1
     if world > 1:
-        dist = D.init("nccl", local_rank)
+        dist = D.init("gloo" if share else "nccl", local_rank)
+    if share:
+        local_rank = 0
+    global COLL_CUDA
+    COLL_CUDA = not share
 
     import trackiellm_amd as tk
     if tk.lib().tk_mi355x_device_count() <= local_rank:
@@ -489,7 +500,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            D.barrier(dist, cuda=True)
+            D.barrier(dist, cuda=COLL_CUDA)
 
     if args.pipeline or (args.placement == "combined" and world > 1):
         return run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, combined=args.placement == "combined" and world > 1)
@@ -513,7 +524,7 @@ def main():
     r = cb.run(args.steps, args.warmup, barrier) if args.steps > 0 else None
     elapsed = r["elapsed"] if r else 0.0
     if dist is not None and r:
-        elapsed = D.max_over_ranks(dist, elapsed, cuda=True)
+        elapsed = D.max_over_ranks(dist, elapsed, cuda=COLL_CUDA)
     if rank != 0:
         cb.close()
         if dist is not None:
@@ -571,6 +582,8 @@ def main():
                              "detections_last_batch": cb.n_dets, "overlapped_with_llm": True, "dtype": "f32 (exact fp32 MFMA chain)"}
     if args.layers != 32:
         out["invalid"] = "debug run with fewer layers"
+    if not COLL_CUDA:
+        out["rehearsal"] = "TK_BENCH_SHARE_GPU=1: all ranks share ONE GPU; not a scaling measurement"
     extras = not args.no_extras and args.layers == 32 and world == 1
     roof16 = None
     if extras and not (G == 3 and B == 16):
@@ -619,7 +632,7 @@ def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, com
     if dist is None:
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist = D.init("gloo")
-    cuda_t = world > 1
+    cuda_t = world > 1 and COLL_CUDA
     cycles = G * B
     in_llm = rank in roles["llm"]
     model = pipe = cb = None
@@ -662,6 +675,7 @@ def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, com
             wl += ", fused with YOLOv8n 640x640 + VAD / Whisper-tiny.en (1 s PCM) on the spare GPUs"
         print(json.dumps({"metric": METRIC, "value": round(cycles * args.steps / elapsed, 3), "unit": "cycles/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 2),
+                          **({} if COLL_CUDA else {"rehearsal": "TK_BENCH_SHARE_GPU=1: all ranks share ONE GPU; not a scaling measurement"}),
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                           "dtype": "f16 weights x f16-rounded f32 activations, fp32 MFMA chain" if f16 else DTYPE, "data": "synthetic",
                           "config": {"workload": wl, "concurrent_cycles": cycles, "layers_per_stage": [bounds[r + 1] - bounds[r] for r in range(n_st)],
@@ -689,7 +703,7 @@ def run_model_per_gpu(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N
     vis, aud = model_per_gpu_roles(world)
 
     def barrier():
-        D.barrier(dist, cuda=True)
+        D.barrier(dist, cuda=COLL_CUDA)
 
     if rank == 0:
         model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4)
@@ -702,9 +716,9 @@ def run_model_per_gpu(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N
         cb = PerceptionBench(tk, share_v, share_a, rank, local_rank, args.perception_batch, args.asr_steps)
         r = cb.run(args.steps, args.warmup, barrier)
         role = "perception"
-    elapsed = D.max_over_ranks(dist, r["elapsed"], cuda=True)
+    elapsed = D.max_over_ranks(dist, r["elapsed"], cuda=COLL_CUDA)
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": round(cycles * args.steps / elapsed, 3), "unit": "cycles/s", "n_gpus": world, "steps": args.steps,
+        print(json.dumps({"metric": METRIC, "value": round(cycles * args.steps / elapsed, 3), "unit": "cycles/s", "n_gpus": world, **({} if COLL_CUDA else {"rehearsal": "TK_BENCH_SHARE_GPU=1: all ranks share ONE GPU; not a scaling measurement"}), "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "strong",
                           "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                           "config": {"workload": "configs[3]/[4] fused cycle, one model per GPU (SURVEY.md 8e)", "concurrent_cycles": cycles, "decode_groups": G,
