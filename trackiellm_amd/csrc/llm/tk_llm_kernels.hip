@@ -1901,6 +1901,9 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
 /* ------------------------------------------------------------------------------------------
  * SwiGLU + Q8 quantise:  act = silu(gate) * up ; gate = cols [0,FF), up = cols [FF,2FF)
  * ------------------------------------------------------------------------------------------ */
+/* KSM = the most K-split slabs an instantiation handles: the slab loads are held in registers before the first add, and the gate | up
+ * projection of the canonical plan has ONE slab — with room for eight the kernel needs 130 registers (3 waves per SIMD), with one 40 */
+template <int KSM>
 __global__ __launch_bounds__(256) void k_swiglu_q8(const float* partial, int ks, int FF, TkActQ8 out) {
     const int r = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -1908,9 +1911,9 @@ __global__ __launch_bounds__(256) void k_swiglu_q8(const float* partial, int ks,
     /* 8 gate and 8 up values as 16-byte loads, every K-split slab requested before the first add (slabs added in ascending order) */
     v4f g[2], u[2];
     {
-        v4f pg[TK_RMS_MAX_KS][2], pu[TK_RMS_MAX_KS][2];
+        v4f pg[KSM][2], pu[KSM][2];
 #pragma unroll
-        for (int s = 0; s < TK_RMS_MAX_KS; ++s)
+        for (int s = 0; s < KSM; ++s)
             if (s < ks) {
                 const float* row = partial + ((int64_t)s * TK_MAX_ROWS + r) * (2 * (int64_t)FF);
                 pg[s][0] = *(const v4f*)(row + 8 * c); pg[s][1] = *(const v4f*)(row + 8 * c + 4);
@@ -1918,7 +1921,7 @@ __global__ __launch_bounds__(256) void k_swiglu_q8(const float* partial, int ks,
             }
         g[0] = pg[0][0]; g[1] = pg[0][1]; u[0] = pu[0][0]; u[1] = pu[0][1];
 #pragma unroll
-        for (int s = 1; s < TK_RMS_MAX_KS; ++s)
+        for (int s = 1; s < KSM; ++s)
             if (s < ks) { g[0] = g[0] + pg[s][0]; g[1] = g[1] + pg[s][1]; u[0] = u[0] + pu[s][0]; u[1] = u[1] + pu[s][1]; }
     }
     float v[8];
@@ -1928,7 +1931,8 @@ __global__ __launch_bounds__(256) void k_swiglu_q8(const float* partial, int ks,
 }
 
 void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ8 out, hipStream_t s) {
-    hipLaunchKernelGGL(k_swiglu_q8, dim3((FF / 8 + 255) / 256, nrows), dim3(256), 0, s, partial, ks, FF, out);
+    if (ks == 1) hipLaunchKernelGGL((k_swiglu_q8<1>), dim3((FF / 8 + 255) / 256, nrows), dim3(256), 0, s, partial, ks, FF, out);
+    else hipLaunchKernelGGL((k_swiglu_q8<TK_RMS_MAX_KS>), dim3((FF / 8 + 255) / 256, nrows), dim3(256), 0, s, partial, ks, FF, out);
 }
 
 /* ------------------------------------------------------------------------------------------
