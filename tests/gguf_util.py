@@ -61,8 +61,8 @@ def expected_piece(vocab, tid):
     return test_vocab(vocab)[tid].replace("▁", " ").encode()
 
 
-def write_llama_gguf(path, orc, cfg, with_vocab=True):
-    """serialise an OracleLlm (tests/oracle_lib.py) as a llama-architecture GGUF"""
+def write_llama_gguf(path, orc, cfg, with_vocab=True, drop=()):
+    """serialise an OracleLlm (tests/oracle_lib.py) as a llama-architecture GGUF; `drop` = tensor names to leave out (damaged-file tests)"""
     import oracle_lib as O
     names = ["attn_norm", "attn_q", "attn_k", "attn_v", "attn_output", "ffn_norm", "ffn_gate", "ffn_up", "ffn_down"]
     kv = [("general.architecture", GGUF_STRING, "llama"), ("llama.block_count", GGUF_U32, cfg.n_layer),
@@ -93,4 +93,4 @@ def write_llama_gguf(path, orc, cfg, with_vocab=True):
     for l in range(cfg.n_layer):
         for w, (r, c) in enumerate(shapes):
             add(f"blk.{l}.{names[w]}.weight", l, w, r, c)
-    write_gguf(path, kv, tensors)
+    write_gguf(path, kv, [t for t in tensors if t[0] not in drop])

@@ -406,6 +406,26 @@ def test_gguf_checkpoint_end_to_end(gpu, tmp_path):
         gpu.ModelLoader().load(str(tmp_path / "nope.gguf"))
 
 
+@pytest.mark.timeout(120)
+def test_gguf_with_a_missing_tensor_fails_the_load_instead_of_hanging(gpu, tmp_path):
+    """the loader holds its registry lock across the GGUF load; the failure path must not take it again (a file with a missing
+    tensor hung tk_model_loader_load_model).  TK_ERROR_MODEL_LOAD_FAILED = 4000, and the loader stays usable afterwards."""
+    import gguf_util
+    cfg = O.tiny_config()
+    orc = O.OracleLlm(cfg, seed=4)
+    bad = str(tmp_path / "missing.gguf")
+    gguf_util.write_llama_gguf(bad, orc, cfg, drop=("blk.1.ffn_up.weight",))
+    loader = gpu.ModelLoader()
+    with pytest.raises(gpu.TkError) as ei:
+        loader.load(bad)
+    assert ei.value.code == 4000 and "blk.1.ffn_up.weight" in str(ei.value)
+    good = str(tmp_path / "whole.gguf")
+    gguf_util.write_llama_gguf(good, orc, cfg)
+    h = loader.load(good)                                             # the registry lock was released
+    loader.unload(h)
+    loader.close()
+
+
 class _BorrowedModel:
     """a tk_mi355x_llm_model_t* owned by a tk_model_loader (the handle tk_model_loader_load_model returns) seen as a LlmModel"""
 

@@ -1,6 +1,6 @@
-"""The LLM layer-sharded over ranks: stage execution is bit-identical to the unsplit pass, and a 2-rank pipeline
-(two processes sharing the one GPU of the test box, gloo transport through host memory — on an 8-GPU node the same code moves the
-stream with RCCL send / recv) generates the ids of a single session."""
+"""The LLM layer-sharded over ranks: stage execution is bit-identical to the unsplit pass, and the in-library hand-off
+(device mailboxes, csrc/llm/tk_llm_pipe.h) — three stages in one process, two processes over hipIpc on the one GPU of the test box —
+generates the ids of a single session, generation after generation on the same pipes; a missing peer fails fast."""
 import os
 import sys
 
@@ -33,56 +33,6 @@ def test_stage_split_is_bit_identical_to_one_pass(gpu):
         split.forward_stage([0], [9], 0, 2, tok=[5], head=True)           # the head belongs to the last layer
     with pytest.raises(gpu.TkError):
         split.forward_stage([0], [9], 0, 2, tok=[5])                      # no head and nowhere to put the stream
-
-
-def _pipeline_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import trackiellm_amd as tk
-    from trackiellm_amd import dist as D
-    dist = D.init("gloo")
-    hp = tk.TINY()
-    hp.n_layer = 4
-    model = tk.LlmModel(hp).fill_synthetic(31)
-    hp = model.hparams
-    sess = tk.LlmSession(model, 6, 32)
-    pipe = D.LlmPipeline(dist, sess, hp.n_layer, hp.d_model, cuda_tensors=False)
-    rng = np.random.default_rng(5)
-    prompts = [rng.integers(3, hp.vocab, (2, 5)).astype(np.int32) for _ in range(3)]
-    out = pipe.generate(prompts, 6, rows_per_pass=3)
-    q.put((rank, (pipe.l0, pipe.l1), [o.tolist() for o in out]))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_two_rank_pipeline_matches_single_session(gpu):
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29800 + (os.getpid() % 150)
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=240) for _ in range(2))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    assert res[0][1] == (0, 2) and res[1][1] == (2, 4)
-    assert res[0][2] == res[1][2]                     # stage 0 got every id back from the last stage
-    # single session, same model / prompts: prefill + greedy decode per group
-    hp = gpu.TINY()
-    hp.n_layer = 4
-    model = gpu.LlmModel(hp).fill_synthetic(31)
-    hp = model.hparams
-    rng = np.random.default_rng(5)
-    prompts = [rng.integers(3, hp.vocab, (2, 5)).astype(np.int32) for _ in range(3)]
-    for gi, pr in enumerate(prompts):
-        sess = gpu.LlmSession(model, 2, 32)
-        first = sess.prefill(pr)
-        toks, _ = sess.decode(2, 5)
-        want = np.concatenate([first[None, :], toks])
-        assert np.array_equal(np.array(res[0][2][gi]), want), gi
-        sess.close()
 
 
 # ---- the stage hand-off inside the library (csrc/llm/tk_llm_pipe.h): device mailboxes, no host synchronisation per pass, graph replays ----
@@ -201,21 +151,75 @@ def test_in_library_handoff_two_processes_ipc_mapped_mailboxes(gpu):
     assert np.array_equal(toks[1], want[1:]) and np.array_equal(toks[0], want[:9])
 
 
-def test_pipe_wait_is_bounded_and_reports_a_missing_peer(gpu):
-    """a stage whose producer never publishes must not hang: the device-side wait gives up (TK_PIPE_TIMEOUT_S) and sync() returns
-    TK_ERROR_TIMEOUT — exercised through argument errors only here (the 20 s wait itself is not spent in the suite)"""
+def test_second_generation_on_the_same_pipes_takes_fresh_ids(gpu):
+    """a generation sends one id message more than stage 0 takes (the last step's sample); the next generation's decode loop
+    must start from ITS prompt's sample, not from that leftover.  Three generations with different prompts on one set of pipes, each
+    compared with a single session; the third continues decoding with a second decode() call (the FIFO hands the last sample on)."""
     hp = gpu.TINY()
     hp.n_layer = 4
     model = gpu.LlmModel(hp).fill_synthetic(31)
-    sess = gpu.LlmSession(model, 2, 16)
+    hp = model.hparams
+    bounds = [0, 2, 4]
+    sess = [gpu.LlmSession(model, 3, 48) for _ in range(2)]
+    pipes = [gpu.LlmPipe(sess[s], s, 2, bounds[s], bounds[s + 1]) for s in range(2)]
+    for s in range(2):
+        pipes[s].connect_local(pipes[1 - s], pipes[1 - s])
+    rng = np.random.default_rng(11)
+    for gen, (n_prompt, n_dec) in enumerate(((6, 5), (9, 7), (4, 6))):
+        prompts = rng.integers(3, hp.vocab, (3, n_prompt)).astype(np.int32)
+        for s in range(2):
+            _drive_stage(pipes[s], prompts, n_dec, rows_per_pass=4)
+        fed = pipes[0].sync(3, n_dec)
+        sampled = pipes[1].sync(3, n_dec)
+        want = _single_session_reference(gpu, model, [prompts], n_dec + 3)[0]
+        assert np.array_equal(sampled, want[1:n_dec + 1]), "generation %d: samples differ from a single session's" % gen
+        assert np.array_equal(fed, want[:n_dec]), "generation %d: stage 0 fed stale ids" % gen
+    for s in range(2):                                                # continuation: three more steps of the last generation
+        pipes[s].decode(3, 3)
+    fed = pipes[0].sync(3, 3)
+    sampled = pipes[1].sync(3, 3)
+    assert np.array_equal(sampled, want[n_dec + 1:n_dec + 4]) and np.array_equal(fed, want[n_dec:n_dec + 3])
+    for p in pipes:
+        p.close()
+    for s in sess:
+        s.close()
+
+
+@pytest.mark.timeout(120)
+def test_pipe_wait_is_bounded_fails_fast_and_stays_failed(gpu, monkeypatch):
+    """a stage whose producer never publishes must not hang: the first device-side wait gives up after the pipe's timeout
+    ($TK_MI355X_PIPE_TIMEOUT_S = 1 s here), every wait still enqueued behind it — the rest of the prompt, 40 graph replays — returns at
+    once, sync() reports TK_ERROR_TIMEOUT (1005) within seconds, and the pipe stays failed."""
+    import time
+    hp = gpu.TINY()
+    hp.n_layer = 4
+    model = gpu.LlmModel(hp).fill_synthetic(31)
+    sess = [gpu.LlmSession(model, 2, 64) for _ in range(2)]
     with pytest.raises(gpu.TkError):
-        gpu.LlmPipe(sess, 0, 2, 1, 2)                                 # stage 0 must start at layer 0
+        gpu.LlmPipe(sess[0], 0, 2, 1, 2)                              # stage 0 must start at layer 0
     with pytest.raises(gpu.TkError):
-        gpu.LlmPipe(sess, 1, 2, 2, 3)                                 # the last stage must end at the last layer
-    p = gpu.LlmPipe(sess, 0, 2, 0, 2)
+        gpu.LlmPipe(sess[0], 1, 2, 2, 3)                              # the last stage must end at the last layer
+    monkeypatch.setenv("TK_MI355X_PIPE_TIMEOUT_S", "1")
+    p0 = gpu.LlmPipe(sess[0], 0, 2, 0, 2)
+    p1 = gpu.LlmPipe(sess[1], 1, 2, 2, 4)
     with pytest.raises(gpu.TkError):
-        p.enqueue([0], [0], [5])                                      # not connected
+        p0.enqueue([0], [0], [5])                                     # not connected
     with pytest.raises(gpu.TkError):
-        p.connect(p.handle, p.handle)                                 # a handle of this very process: connect_local is the way
-    p.close()
-    sess.close()
+        p0.connect(p0.handle, p0.handle)                              # a handle of this very process: connect_local is the way
+    p0.connect_local(p1, p1)
+    p1.connect_local(p0, p0)
+    prompts = np.random.default_rng(3).integers(3, model.hparams.vocab, (2, 6)).astype(np.int32)
+    t0 = time.time()
+    _drive_stage(p1, prompts, 40, rows_per_pass=4)                    # stage 1 alone: stage 0 never enqueues anything
+    with pytest.raises(gpu.TkError) as ei:
+        p1.sync(2, 40)
+    took = time.time() - t0
+    assert ei.value.code == 1005 and took < 20.0, (ei.value.code, took)   # one timeout, not one per wait (44 waits x 1 s)
+    with pytest.raises(gpu.TkError):
+        p1.decode(2, 1)                                               # failed for good
+    with pytest.raises(gpu.TkError):
+        p1.sync()
+    for p in (p0, p1):
+        p.close()
+    for s in sess:
+        s.close()

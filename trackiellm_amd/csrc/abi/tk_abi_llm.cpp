@@ -223,7 +223,9 @@ tk_error_code_t tk_mi355x_llm_model_load_gguf(tk_mi355x_llm_model_t** out, const
             snprintf(nm, sizeof nm, "blk.%d.%s.weight", l, names[w]);
             ok = put(l, w, nm, nullptr);
         }
-    if (!ok) { tk_mi355x_llm_model_destroy(&m); return TK_ERROR_MODEL_LOAD_FAILED; }
+    /* `m` is private to this call (never registered, no runner holds it): freed directly.  NOT tk_mi355x_llm_model_destroy — that takes
+     * g_models_mu, which tk_model_loader_load_model holds across this call (a GGUF with a missing tensor hung the loader) */
+    if (!ok) { delete m; return TK_ERROR_MODEL_LOAD_FAILED; }
     if (!f.tokens.empty()) m->tok.init_spm(f.tokens, f.scores, f.token_type, (int)f.get("tokenizer.ggml.bos_token_id", 1), (int)f.get("tokenizer.ggml.eos_token_id", 2));
     auto it = f.str.find("general.architecture");
     m->context_length = (int)f.get((it == f.str.end() ? std::string("llama") : it->second) + ".context_length", 4096);

@@ -15,8 +15,37 @@
  * hipGraph that is replayed once per decode step with NO host synchronisation, host copy or collective call per pass.
  * Payload: exact fp32 (default: the pipeline's tokens and logits are bit-identical to one GPU) or IEEE f16 (SURVEY §8e's 8 KiB per
  * row; the residual stream is rounded once per boundary — a tolerance mode).
- * Every wait is bounded (TK_PIPE_TIMEOUT_S seconds of s_memrealtime): a peer that never publishes sets the pipe's status word and
- * the pass drains; the host sees the error at its next synchronisation, nothing hangs.
+ * Every wait is bounded (TK_PIPE_TIMEOUT_S seconds of s_memrealtime, or $TK_MI355X_PIPE_TIMEOUT_S): a peer that never publishes sets
+ * the pipe's status word; from then on every wait of this stage returns at once and no counter, slot or credit moves, so whatever is
+ * still enqueued drains in microseconds, the host sees TK_ERROR_TIMEOUT at its next sync and the pipe stays failed (re-create it).
+ *
+ * Coherence (who caches what; ADVICE r03 / VERDICT r03 item 4).  The protocol needs visibility BETWEEN AGENTS IN THE MIDDLE OF KERNELS:
+ * a peer GPU stores into this GPU's mailbox over xGMI while a kernel resident here polls a flag word of it.
+ *  - Memory type.  HIP guarantees coherence of plain hipMalloc ("coarse-grained") memory between agents only at kernel boundaries: its
+ *    pages are mapped so that the HOME GPU's L2s may keep lines of it on the assumption that nobody else writes them while a kernel
+ *    runs, and a system-scope acquire (buffer_inv sc0 sc1) is not required to drop such lines.  A peer's write lands in HBM behind those
+ *    L2s: a poller could spin on a stale flag for ever, a reader could get a slot's contents of eight passes ago.  On ONE device (every test
+ *    of this build, profiles/r03_multirank_rehearsal.txt) all stages sit behind the same L2s and HBM, which hides that.  So the mailbox —
+ *    flags, credits, id payload AND the x payload slots (one allocation, one IPC handle) — is FINE-GRAINED device memory
+ *    (hipExtMallocWithFlags(hipDeviceMallocFinegrained)), the type HIP documents as coherent between agents at system-scope
+ *    synchronisation points inside a running kernel: it is mapped so that neither the home GPU's nor a peer's L2 holds a line of it
+ *    past a system-scope release / acquire.  The per-stage private state (TkPipeState) is only ever touched by its own GPU and stays
+ *    coarse-grained.
+ *  - Producer (k_pipe_send_x / k_pipe_send_ids, runs on the PEER of the mailbox's home): plain payload stores into the mapped slot ->
+ *    __threadfence_system() by every storing thread (release at system scope: write-back of this GPU's L2 lines of remote fine-grained
+ *    memory, s_waitcnt vmcnt(0)) -> workgroup barrier -> arrival counter in the producer's own memory -> the LAST workgroup fences again
+ *    and stores the slot's sequence number with a system-scope release store.  The flag can therefore not overtake any workgroup's
+ *    payload: each fenced its stores before it arrived.
+ *  - Consumer (k_pipe_wait_x / k_pipe_take_x / k_pipe_take_ids, on the home GPU): ONE lane polls the flag with system-scope acquire loads
+ *    (they bypass the L1 and, on fine-grained memory, the L2), then EVERY workgroup that reads payload executes a system-scope acquire
+ *    fence before its first payload load (it invalidates that CU's L1 and the non-coherent lines of its XCD's L2) — the poller's acquire
+ *    covers only the poller's own CU and XCD, and a launch boundary does not invalidate peer-written lines.  This is the fix of commit
+ *    919aa78 (stale slot contents behind other XCDs' L2s were seen ON ONE DEVICE with coarse-grained memory); with fine-grained memory
+ *    the fence is still required for the L1.
+ *  - Credits flow the other way under the same two rules (system-scope release store by the consumer, acquire poll by the producer).
+ * Status: the fine-grained mailbox passes the one-process (pointer) and two-process (hipIpc) tests on one GPU; NO run has crossed a
+ * device boundary yet (the GPU boxes of this build have one GPU) — multi-GPU numbers and claims stay unverified until
+ * tests/test_pipeline_gpu.py::test_in_library_handoff_two_processes_ipc_mapped_mailboxes has passed once with one stage per device.
  */
 #ifndef TK_LLM_PIPE_H
 #define TK_LLM_PIPE_H
@@ -50,8 +79,9 @@ struct TkPipeState {
     unsigned long long sent_x, recv_x, sent_ids, recv_ids;
     unsigned int done_x;   /* arrival counter of k_pipe_send_x's workgroups */
     unsigned int done_take;
-    int status;            /* 0 ok, 1 a wait timed out */
+    int status;            /* 0 ok, 1 a wait timed out: sticky — every later wait returns at once, no counter moves any more */
     int pad;
+    unsigned long long timeout_ticks; /* bound of one wait in s_memrealtime ticks (100 MHz): TK_PIPE_TIMEOUT_S, or $TK_MI355X_PIPE_TIMEOUT_S */
 };
 
 struct TkPipeHandle { /* what the host exchanges between stages: 64 handle bytes + the block size + who made it */
@@ -93,6 +123,9 @@ private:
     TkPipeBlock *next_ = nullptr, *prev_ = nullptr; /* the neighbours' mailboxes as mapped here */
     bool next_ipc_ = false, prev_ipc_ = false;
     TkPipeState* st_ = nullptr;
+    bool fine_grained_ = true;         /* mailbox in fine-grained device memory (see "Coherence" above) */
+    bool failed_ = false;              /* a wait timed out: sticky until the pipe is destroyed */
+    int ids_outstanding_ = 0;          /* id messages the last stage has been asked to send minus those stage 0 has been asked to take */
     int32_t* h_rows_ = nullptr;        /* pinned staging ring for (seq, pos, tok) of host-described passes */
     int h_next_ = 0;
     hipGraphExec_t graph_[TK_MAX_ROWS + 1] = {};

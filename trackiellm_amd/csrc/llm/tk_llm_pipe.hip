@@ -30,12 +30,15 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-/* spin until *word >= want; bounded by TK_PIPE_TIMEOUT_S of the 100 MHz realtime counter.  Returns false on timeout. */
-__device__ bool spin_until(const unsigned long long* word, unsigned long long want) {
+/* spin until *word >= want; bounded by the pipe's timeout (st->timeout_ticks of the 100 MHz realtime counter).  Returns false on timeout
+ * — and at once when the pipe has failed already: after the first timeout every wait still enqueued (the rest of a prompt, the decode
+ * loop's graph replays) drains in microseconds instead of spinning its own full timeout. */
+__device__ bool spin_until(const unsigned long long* word, unsigned long long want, const TkPipeState* st) {
+    if (st->status != 0) return false;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (ld_sys(word) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)TK_PIPE_TIMEOUT_S * 100000000ull) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > st->timeout_ticks) return false;
     }
     return true;
 }
@@ -43,19 +46,22 @@ __device__ bool spin_until(const unsigned long long* word, unsigned long long wa
 /* consumer, first kernel of a pass: the next x message (sequence number recv_x + 1) has been published into my mailbox */
 __global__ void k_pipe_wait_x(TkPipeBlock* mine, TkPipeState* st) {
     const unsigned long long seq = st->recv_x + 1;
-    if (!spin_until(&mine->x_flag[seq % TK_PIPE_SLOTS][0], seq)) st->status = 1;
+    if (!spin_until(&mine->x_flag[seq % TK_PIPE_SLOTS][0], seq, st)) st->status = 1;
 }
 
 /* consumer: slot -> the session's residual stream (fp32 as it is, f16 widened); the last workgroup returns the credit to the producer
- * and advances recv_x */
+ * and advances recv_x.  A failed pipe (status set by this pass's wait or any earlier one) moves nothing and keeps its counters: the
+ * protocol state stays what it was when the peer went missing. */
 __global__ __launch_bounds__(256) void k_pipe_take_x(const TkPipeBlock* mine, TkPipeBlock* prev, TkPipeState* st, float* __restrict__ x, int n4 /* float4 groups */,
                                                       int slot_floats, int f16) {
+    if (st->status != 0) return; /* uniform over the grid: written by an earlier kernel of this stream */
     const unsigned long long seq = st->recv_x + 1;
     const uint8_t* base = (const uint8_t*)mine + sizeof(TkPipeBlock) + (size_t)(seq % TK_PIPE_SLOTS) * slot_floats * 4;
     const int i = blockIdx.x * 256 + threadIdx.x;
     /* k_pipe_wait_x's acquire dropped stale lines of this slot only from the caches of the ONE workgroup that polled; this kernel's
      * workgroups sit behind other L2s (one per XCD) that may still hold the slot's contents of eight passes ago, and the slot was written
-     * by a peer, not through them: acquire at system scope before the first payload read, whatever the launch boundary did */
+     * by a peer, not through them: acquire at system scope before the first payload read, whatever the launch boundary did
+     * (tk_llm_pipe.h, "Coherence") */
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     if (i < n4) {
         if (f16) {
@@ -84,11 +90,14 @@ __global__ __launch_bounds__(256) void k_pipe_take_x(const TkPipeBlock* mine, Tk
  * slot.  grid (d_model / 1024, nrows) */
 __global__ __launch_bounds__(256) void k_pipe_send_x(const float* __restrict__ x, const float* __restrict__ partial, int ks, int n_total, int D, TkPipeBlock* next,
                                                       const TkPipeBlock* mine, TkPipeState* st, int slot_floats, int f16) {
+    __shared__ int ok;
     const unsigned long long seq = st->sent_x + 1;
-    if (threadIdx.x == 0 && seq > TK_PIPE_SLOTS) { /* credit: the consumer has freed the slot this message reuses */
-        if (!spin_until(&mine->credit_x[0], seq - TK_PIPE_SLOTS)) st->status = 1;
+    if (threadIdx.x == 0) { /* credit: the consumer has freed the slot this message reuses */
+        ok = st->status == 0;
+        if (ok && seq > TK_PIPE_SLOTS && !spin_until(&mine->credit_x[0], seq - TK_PIPE_SLOTS, st)) { st->status = 1; ok = 0; }
     }
     __syncthreads();
+    if (!ok) return; /* failed pipe: nothing is stored into a slot the consumer may still own, no counter moves */
     const int r = blockIdx.y, g = blockIdx.x * 256 + threadIdx.x;
     uint8_t* base = (uint8_t*)next + sizeof(TkPipeBlock) + (size_t)(seq % TK_PIPE_SLOTS) * slot_floats * 4;
     if (4 * g < D) {
@@ -123,11 +132,14 @@ __global__ __launch_bounds__(256) void k_pipe_send_x(const float* __restrict__ x
 
 /* last stage: the ids just sampled (d_tok) -> stage 0's id mailbox.  One workgroup. */
 __global__ __launch_bounds__(256) void k_pipe_send_ids(const int32_t* __restrict__ tok, int nrows, TkPipeBlock* first, const TkPipeBlock* mine, TkPipeState* st) {
+    __shared__ int ok;
     const unsigned long long seq = st->sent_ids + 1;
-    if (threadIdx.x == 0 && seq > TK_PIPE_SLOTS) {
-        if (!spin_until(&mine->credit_ids[0], seq - TK_PIPE_SLOTS)) st->status = 1;
+    if (threadIdx.x == 0) {
+        ok = st->status == 0;
+        if (ok && seq > TK_PIPE_SLOTS && !spin_until(&mine->credit_ids[0], seq - TK_PIPE_SLOTS, st)) { st->status = 1; ok = 0; }
     }
     __syncthreads();
+    if (!ok) return;
     for (int i = threadIdx.x; i < nrows; i += 256) first->ids_payload[seq % TK_PIPE_SLOTS][i] = tok[i];
     __threadfence_system();
     __syncthreads();
@@ -144,18 +156,33 @@ __global__ __launch_bounds__(256) void k_pipe_take_ids(TkPipeBlock* mine, TkPipe
     __shared__ int ok;
     const unsigned long long seq = st->recv_ids + 1;
     if (threadIdx.x == 0) {
-        ok = spin_until(&mine->ids_flag[seq % TK_PIPE_SLOTS][0], seq) ? 1 : 0;
+        ok = spin_until(&mine->ids_flag[seq % TK_PIPE_SLOTS][0], seq, st) ? 1 : 0;
         if (!ok) st->status = 1;
     }
     __syncthreads();
+    if (!ok) return; /* failed pipe: the rows keep their tokens (the pass computes on them and its result is discarded with the error) */
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); /* the payload was written by a peer: every reading lane acquires, not only the poller */
     for (int i = threadIdx.x; i < nrows; i += 256) {
-        const int32_t t = ok ? mine->ids_payload[seq % TK_PIPE_SLOTS][i] : 0;
+        const int32_t t = mine->ids_payload[seq % TK_PIPE_SLOTS][i];
         tok[i] = t;
         const int n = nsteps[i];
         if (n < hist_cap) { hist[(int64_t)n * hist_stride + i] = t; nsteps[i] = n + 1; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        st->recv_ids = seq;
+        st_sys(&last->credit_ids[0], seq);
+    }
+}
+
+/* stage 0: consume and discard `count` id messages.  A generation ends with one more id message sent (the last decode step's sample)
+ * than stage 0 takes (it feeds the ids of steps 0 .. n - 1); when the host then describes new tokens itself, that message is stale and
+ * must leave the FIFO before the next decode loop takes "the ids of the previous position" (the skew grew by one id per
+ * generate() on one pipe).  One thread. */
+__global__ void k_pipe_drain_ids(TkPipeBlock* mine, TkPipeBlock* last, TkPipeState* st, int count) {
+    for (int c = 0; c < count; ++c) {
+        const unsigned long long seq = st->recv_ids + 1;
+        if (!spin_until(&mine->ids_flag[seq % TK_PIPE_SLOTS][0], seq, st)) { st->status = 1; return; }
         st->recv_ids = seq;
         st_sys(&last->credit_ids[0], seq);
     }
@@ -170,6 +197,9 @@ __global__ void k_pipe_advance(int32_t* pos, int nrows) {
 /* ---- host side ------------------------------------------------------------------------------------------------------------------ */
 
 static std::mutex g_pipe_capture_mu;
+static const char* const kFailedMsg =
+    "a pipeline wait timed out: a neighbouring stage never published (peer process gone, or the stages walk different pass orders); the pipe "
+    "is out of step with its neighbours and must be re-created";
 
 TkLlmPipe::~TkLlmPipe() {
     if (s_ && s_->model) (void)hipSetDevice(s_->model->device);
@@ -192,10 +222,19 @@ bool TkLlmPipe::init(TkLlmSession* session, int stg, int n, int layer0, int laye
     s_ = session; stage = stg; n_stages = n; l0 = layer0; l1 = layer1; f16_ = payload_f16;
     PQ(hipSetDevice(s_->model->device));
     block_bytes_ = sizeof(TkPipeBlock) + (size_t)TK_PIPE_SLOTS * TK_MAX_ROWS * h.d_model * 4;
-    PQ(hipMalloc((void**)&mine_, block_bytes_));
+    /* the mailbox is polled and written by OTHER agents while kernels of this one run: fine-grained device memory (tk_llm_pipe.h,
+     * "Coherence").  TK_MI355X_PIPE_COARSE=1 keeps plain hipMalloc memory for an A/B on one device. */
+    const char* coarse = getenv("TK_MI355X_PIPE_COARSE");
+    fine_grained_ = !(coarse && coarse[0] == '1');
+    if (fine_grained_) PQ(hipExtMallocWithFlags((void**)&mine_, block_bytes_, hipDeviceMallocFinegrained));
+    else PQ(hipMalloc((void**)&mine_, block_bytes_));
     PQ(hipMemset(mine_, 0, sizeof(TkPipeBlock)));
     PQ(hipMalloc((void**)&st_, sizeof(TkPipeState)));
-    PQ(hipMemset(st_, 0, sizeof(TkPipeState)));
+    TkPipeState st0{};
+    double tmo = TK_PIPE_TIMEOUT_S;
+    if (const char* e = getenv("TK_MI355X_PIPE_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0 && v < 3600.0) tmo = v; }
+    st0.timeout_ticks = (unsigned long long)(tmo * 1e8); /* s_memrealtime: 100 MHz */
+    PQ(hipMemcpy(st_, &st0, sizeof st0, hipMemcpyHostToDevice));
     PQ(hipHostMalloc((void**)&h_rows_, (size_t)64 * 3 * TK_MAX_ROWS * sizeof(int32_t), hipHostMallocDefault));
     PQ(hipDeviceSynchronize());
     if (out_handle) {
@@ -286,6 +325,7 @@ bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const in
     const TkLlmHParams& h = s_->model->hp;
     if (nrows <= 0 || nrows > TK_MAX_ROWS || !seq || !pos) { error = "nrows must be in [1, 256] and (seq, pos) given"; return false; }
     if (n_stages > 1 && (!next_ || !prev_)) { error = "the pipe is not connected"; return false; }
+    if (failed_) { error = kFailedMsg; return false; }
     bool distinct = true;
     for (int r = 0; r < nrows; ++r) {
         if (seq[r] < 0 || seq[r] >= s_->max_seq || pos[r] < 0 || pos[r] >= s_->max_ctx || (stage == 0 && tok && (tok[r] < 0 || tok[r] >= h.vocab))) { error = "row out of range (sequence id, position or token id)"; return false; }
@@ -306,8 +346,17 @@ bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const in
     }
     if (s_->mask_rows_dirty) { PQ(hipMemsetAsync(s_->d_mask_row, 0xFF, TK_MAX_ROWS * 4, s_->stream)); s_->mask_rows_dirty = false; }
     s_->launch_error.clear();
+    /* id FIFO bookkeeping (every stage enqueues the same schedule, so stage 0 can count the last stage's sends): host-given tokens make
+     * whatever the FIFO still holds stale — the previous generation's last sample — so it is drained before this pass */
+    const bool take = stage == 0 && !from_tok && n_stages > 1;
+    if (stage == 0 && from_tok && n_stages > 1 && ids_outstanding_ > 0) {
+        hipLaunchKernelGGL(k_pipe_drain_ids, dim3(1), dim3(1), 0, s_->stream, mine_, prev_, st_, ids_outstanding_);
+        ids_outstanding_ = 0;
+    }
+    if (take) --ids_outstanding_;
+    if (head && n_stages > 1) ++ids_outstanding_;
     /* host-described passes go eagerly (their row tables differ); distinct rows take the fused-attention form, as forward() does */
-    enqueue_stage(nrows, stage == 0 && !from_tok, head, head, distinct);
+    enqueue_stage(nrows, take, head, head, distinct);
     if (!s_->launch_error.empty()) { error = s_->launch_error; return false; }
     PQ(hipGetLastError());
     return true;
@@ -316,6 +365,8 @@ bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const in
 bool TkLlmPipe::decode(int nrows, int n_steps) {
     if (nrows <= 0 || nrows > TK_MAX_ROWS || n_steps <= 0 || n_steps > s_->hist_cap) { error = "nrows must be in [1, 256] and n_steps within the session's context"; return false; }
     if (n_stages > 1 && (!next_ || !prev_)) { error = "the pipe is not connected"; return false; }
+    if (failed_) { error = kFailedMsg; return false; }
+    if (stage == 0 && n_stages > 1 && ids_outstanding_ < 1) { error = "decode() without a sampling pass before it: the id mailbox would be empty"; return false; }
     PQ(hipSetDevice(s_->model->device));
     if (s_->mask_rows_dirty) { PQ(hipMemsetAsync(s_->d_mask_row, 0xFF, TK_MAX_ROWS * 4, s_->stream)); s_->mask_rows_dirty = false; }
     PQ(hipMemsetAsync(s_->d_nsteps, 0, TK_MAX_ROWS * 4, s_->stream));
@@ -356,9 +407,11 @@ bool TkLlmPipe::sync(int32_t* out_tokens, int n_steps) {
     PQ(hipMemcpyAsync(&hs, st_, sizeof hs, hipMemcpyDeviceToHost, s_->stream));
     PQ(hipStreamSynchronize(s_->stream));
     h_next_ = 0;
-    if (hs.status != 0) {
-        PQ(hipMemsetAsync(&st_->status, 0, sizeof(int), s_->stream));
-        error = "a pipeline wait timed out: a neighbouring stage never published (peer process gone, or the stages walk different pass orders)";
+    if (hs.status != 0 || failed_) {
+        /* the status word stays set and so does failed_: this stage's sequence numbers no longer agree with its neighbours', the pipe has to
+         * be re-created (all stages) — every further pass / decode / sync fails at once */
+        failed_ = true;
+        error = kFailedMsg;
         return false;
     }
     return true;
