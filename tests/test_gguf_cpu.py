@@ -58,7 +58,30 @@ def test_sentencepiece_bpe_tokenizer(tmp_path):
     assert tok("hello world") == [1, 263, 273]                     # score-ordered bigram merges: [bos, "▁hello", "▁world"]
     assert tok("hello", 0) == [263]
     assert tok("hé") == [1, 259, 267, 3 + 0xC3, 3 + 0xA9]          # "▁", "h", then <0xXX> byte fallback for the unknown character
-    assert tok("") == [1, 259]                                     # llama adds the space prefix even to empty text
+    assert tok("") == [1] and tok("", 0) == []                     # llama.cpp: empty text has no fragment to prefix — [bos] alone (ABI_NOTES.md)
+
+
+def test_tokenizer_reproduces_the_sentencepiece_library(tmp_path):
+    """independent pin: a BPE model trained by the `sentencepiece` library with the Llama / Mistral tokenizer settings
+    (tests/golden/make_spm_golden.py), its vocabulary stored the way llama.cpp's converter writes it into a GGUF, and the LIBRARY's ids of
+    56 strings — empty, leading / trailing / repeated spaces, multi-byte scripts, emoji, control bytes, byte fallback, the U+2581 marker
+    itself — as expected outputs of tk_mi355x_gguf_tokenize."""
+    import json
+    import trackiellm_amd as tk
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spm_bpe_tiny.json"), encoding="utf-8"))
+    G = gguf_util
+    kv = [("general.architecture", G.GGUF_STRING, "llama"), ("tokenizer.ggml.model", G.GGUF_STRING, "llama"),
+          ("tokenizer.ggml.tokens", G.GGUF_ARRAY, (G.GGUF_STRING, fx["tokens"])), ("tokenizer.ggml.scores", G.GGUF_ARRAY, (G.GGUF_F32, fx["scores"])),
+          ("tokenizer.ggml.token_type", G.GGUF_ARRAY, (G.GGUF_I32, fx["types"])), ("tokenizer.ggml.bos_token_id", G.GGUF_U32, fx["bos_id"]),
+          ("tokenizer.ggml.eos_token_id", G.GGUF_U32, fx["eos_id"])]
+    p = str(tmp_path / "vocab_only.gguf")                          # a vocabulary-only file, like llama.cpp's ggml-vocab-*.gguf
+    G.write_gguf(p, kv, [])
+    ids = np.zeros(256, np.int32)
+    assert len(fx["cases"]) >= 50
+    for c in fx["cases"]:
+        for bos in (0, 1):
+            n = tk.lib().tk_mi355x_gguf_tokenize(p.encode(), c["text"].encode(), bos, ids.ctypes.data_as(C.c_void_p), 256)
+            assert ids[:n].tolist() == [fx["bos_id"]] * bos + c["ids"], (c["text"], ids[:max(n, 0)].tolist(), c["ids"])
 
 
 def test_crafted_headers_are_rejected_not_crashed(tmp_path):

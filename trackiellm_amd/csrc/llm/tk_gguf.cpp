@@ -149,9 +149,13 @@ bool TkGgufFile::open_checked(const char* path) {
     uint64_t align = (uint64_t)get("general.alignment", 32);
     if (align == 0) align = 32;
     uint64_t pos = (uint64_t)(c.p - (const uint8_t*)map_);
-    if (align > (1u << 20) || pos > map_len_ || align - 1 > map_len_ - pos) { error = "corrupt GGUF alignment"; return false; }
-    uint64_t data0 = (pos + align - 1) / align * align;
-    if (data0 > map_len_) { error = "GGUF tensor data section is missing"; return false; }
+    if (align > (1u << 20) || pos > map_len_) { error = "corrupt GGUF alignment"; return false; }
+    uint64_t data0 = (pos + align - 1) / align * align; /* pos <= file size and align <= 2^20: no wrap */
+    if (data0 > map_len_) {
+        /* a vocabulary-only file (llama.cpp ships such ggml-vocab-*.gguf) may end before the padding of an empty data section */
+        if (!tensors.empty()) { error = "GGUF tensor data section is missing"; return false; }
+        data0 = map_len_;
+    }
     const uint64_t data_len = map_len_ - data0;
     for (auto& t : tensors) {
         uint64_t n = 1;

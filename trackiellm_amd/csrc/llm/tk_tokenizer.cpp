@@ -42,6 +42,9 @@ std::vector<int32_t> TkTokenizer::encode(const std::string& text, bool add_bos) 
         }
         return out;
     }
+    /* llama.cpp (and the sentencepiece library) turn EMPTY text into no tokens at all — [bos] alone with add_bos — not into the dummy-prefix
+     * piece: the space prefix belongs to the first text fragment, and empty text has none (include/tk/ABI_NOTES.md, "Tokenizer") */
+    if (text.empty()) return out;
     /* SentencePiece-BPE, llama flavour: prefix space, spaces -> U+2581 */
     std::string s = " " + text;
     std::string norm;
@@ -53,7 +56,8 @@ std::vector<int32_t> TkTokenizer::encode(const std::string& text, bool add_bos) 
     std::vector<Sym> syms;
     for (size_t i = 0; i < norm.size();) {
         unsigned char c = (unsigned char)norm[i];
-        size_t n = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 1;
+        static const uint8_t len_by_high_nibble[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 3, 4}; /* llama.cpp's utf8_len: by the lead byte's high nibble, also for malformed input */
+        size_t n = len_by_high_nibble[c >> 4];
         if (i + n > norm.size()) n = norm.size() - i;
         syms.push_back(Sym{(int)syms.size() - 1, (int)syms.size() + 1, i, n});
         i += n;
