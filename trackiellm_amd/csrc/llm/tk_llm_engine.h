@@ -29,8 +29,6 @@ struct TkLlmHParams {
 
 struct TkDevTensor {
     uint8_t* data = nullptr; /* tiles (matrices) or raw f32 / GGUF blocks */
-    uint8_t* planes = nullptr; /* k-quant matrices: the pre-expanded digit planes of the 129..256-row kernel (tk_llm_layout.h), or nullptr */
-    size_t plane_bytes = 0;
     int type = 0;
     int64_t rows = 0, cols = 0;
     size_t bytes = 0;
@@ -58,11 +56,6 @@ public:
     /* f16: the fp16 checkpoint recipe (every matrix and the embedding IEEE f16, norms f32) instead of Q4_K_M */
     bool fill_synthetic(uint64_t seed, bool f16 = false);
     bool has_f16 = false; /* some matrix is f16: sessions also keep f16-rounded f32 activations */
-    /* build the digit planes of every k-quant matrix (2.2 B per weight on top of the 0.56 / 0.82 B tiles: 15.6 GB for Mistral-7B) so that
-     * passes of more than 128 rows run k_gemm32p_w4a8; $TK_MI355X_PLANES=0 (read by init) leaves them out: such passes then unpack in the
-     * K loop (k_gemm32_w4a8) — same results bit for bit */
-    bool want_planes = true;
-    size_t plane_bytes_total = 0;
     /* `host_blocks` is the tensor in GGUF layout (F32 for norms) */
     bool set_tensor(int layer, int which, int type, const void* host_blocks, size_t nbytes);
     bool ready() const;

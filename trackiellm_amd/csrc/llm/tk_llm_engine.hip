@@ -79,14 +79,12 @@ bool TkLlmModel::init(const TkLlmHParams& h, int dev) {
         if (ksv[i] <= 0 || ksv[i] > 8 || (kk[i] / 256) % ksv[i]) return bad("K-split must be in [1, 8] and divide K/256");
     HIPQ(hipSetDevice(device));
     layers.assign(h.n_layer, TkLlmLayer());
-    const char* pe = getenv("TK_MI355X_PLANES");
-    want_planes = !(pe && pe[0] == '0');
     return true;
 }
 
 TkLlmModel::~TkLlmModel() {
     (void)hipSetDevice(device);
-    auto fr = [](TkDevTensor& t) { if (t.data) (void)hipFree(t.data); if (t.planes) (void)hipFree(t.planes); t.data = t.planes = nullptr; };
+    auto fr = [](TkDevTensor& t) { if (t.data) (void)hipFree(t.data); t.data = nullptr; };
     fr(token_embd); fr(out_norm); fr(output);
     for (auto& L : layers) { fr(L.attn_norm); fr(L.ffn_norm); fr(L.q); fr(L.k); fr(L.v); fr(L.o); fr(L.gate); fr(L.up); fr(L.down); }
 }
@@ -94,7 +92,6 @@ TkLlmModel::~TkLlmModel() {
 /* dev_blocks: tensor in GGUF layout already in device memory */
 bool TkLlmModel::install(TkDevTensor* t, int type, int64_t rows, int64_t cols, const void* dev_blocks, hipStream_t s) {
     if (t->data) { (void)hipFree(t->data); t->data = nullptr; }
-    if (t->planes) { (void)hipFree(t->planes); t->planes = nullptr; plane_bytes_total -= t->plane_bytes; t->plane_bytes = 0; }
     t->type = type; t->rows = rows; t->cols = cols;
     const bool is_matrix = rows > 1 && t != &token_embd;
     if (type == TK_TYPE_F32) {
@@ -126,18 +123,6 @@ bool TkLlmModel::install(TkDevTensor* t, int type, int64_t rows, int64_t cols, c
     }
     tk_launch_repack(type, dev_blocks, rows, cols, t->data, s);
     HIPQ(hipGetLastError());
-    if (want_planes && rows % 32 == 0) {
-        t->plane_bytes = tk_plane_bytes(type, rows, cols);
-        if (hipMalloc((void**)&t->planes, t->plane_bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            t->planes = nullptr; t->plane_bytes = 0;
-            error = "out of device memory for the pre-expanded weight planes (set TK_MI355X_PLANES=0 to run wide passes without them)";
-            return false;
-        }
-        plane_bytes_total += t->plane_bytes;
-        tk_launch_expand_planes(type, t->data, rows, cols, t->planes, s);
-        HIPQ(hipGetLastError());
-    }
     return true;
 }
 
@@ -342,7 +327,7 @@ static void set_act(TkGemvArgs& a, const TkActQ8& q) {
     a.aq = q.aq; a.ad = q.ad; a.abs = q.abs; a.abs16 = q.abs16; a.aq_ts = q.aq_ts; a.ad_ts = q.ad_ts; a.abs_ts = q.abs_ts;
 }
 
-static TkGemvSeg seg_of(const TkDevTensor& t) { return TkGemvSeg{t.data, t.type, (int)(t.rows / TK_TILE_ROWS), t.planes}; }
+static TkGemvSeg seg_of(const TkDevTensor& t) { return TkGemvSeg{t.data, t.type, (int)(t.rows / TK_TILE_ROWS)}; }
 
 void TkLlmSession::enqueue_pass(int nrows, bool lm_head, bool fused_attn) { enqueue_range(nrows, 0, model->hp.n_layer, true, false, lm_head, fused_attn); }
 

@@ -15,7 +15,6 @@ struct TkGemvSeg {
     const uint8_t* tiles; /* device tiles [row_tile][K/256][tile bytes] */
     int type;             /* TK_TYPE_Q4_K / TK_TYPE_Q6_K */
     int row_tiles;        /* rows / 16; must be a multiple of 4 */
-    const uint8_t* planes; /* pre-expanded digit planes [rows / 32][K/256][TK_PLANE4_BYTES | TK_PLANE6_BYTES] (tk_llm_layout.h), or nullptr */
 };
 
 struct TkGemvArgs {
@@ -51,9 +50,6 @@ struct TkActQ8 { /* quantised-activation buffers for one K */
 void tk_launch_synth_blocks(int type, uint64_t seed, uint64_t tensor_id, int64_t nblocks, float scale, void* out, hipStream_t s);
 void tk_launch_synth_f32(uint64_t seed, uint64_t tensor_id, int64_t n, float* out, hipStream_t s);
 void tk_launch_repack(int type, const void* blocks, int64_t rows, int64_t K, uint8_t* tiles, hipStream_t s);
-/* tiles -> the digit planes the 129..256-row kernel streams (rows % 32 == 0) */
-size_t tk_plane_bytes(int type, int64_t rows, int64_t K);
-void tk_launch_expand_planes(int type, const uint8_t* tiles, int64_t rows, int64_t K, uint8_t* planes, hipStream_t s);
 
 /* step kernels */
 void tk_launch_embed(const void* embd, int type /* TK_TYPE_Q4_K or TK_TYPE_F16 */, int D, const int32_t* tok, int nrows, float* x, hipStream_t s);

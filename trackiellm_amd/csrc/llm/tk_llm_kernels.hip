@@ -1449,284 +1449,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
 #endif
 }
 
-
-/* ------------------------------------------------------------------------------------------
- * Wide passes on PRE-EXPANDED weights ("digit planes", tk_llm_layout.h): the same arithmetic as k_gemm32_w4a8, bit for bit, with the
- * weight unpack taken out of the K loop.
- *
- * Why: at 129..256 rows the launch set does 848 int8 ops per weight byte and leaves ~90 % of HBM idle, while per 32 x 32 x 256 tile the
- * SIMD has to issue 17 MFMAs (544 cycles of matrix pipe), 96 finishing VALU instructions AND 47 VALU of weight unpack — twice, because
- * both row-half workgroups unpack the same weights.  A wave's VALU phase (143 instructions at 4 cycles, 25 % of the issue slots taken by
- * the partner wave's MFMAs) outlasts its partner's MFMA phase (544 cycles), so the two waves of a SIMD cannot keep the matrix pipe full:
- * it is 49 % busy in the K loop (profiles/r03_gemm32_sq_counters_split.txt), and removing the unpack alone takes 15 % off the launch
- * (profiles/r03_gemm32_split_ablation.txt, sabl4).  So the unpack's OUTPUT — the two int8 digit planes of every (32 weight rows x 256 k)
- * tile exactly as unpack_q4_x32 / unpack_q6_x32 leave them in registers, plus the f16 min operand and the f32 block scales — is stored
- * once at load time (k_expand_planes: the very same device functions) and the K loop loads it straight into the B-operand registers:
- * 2.19 B per weight instead of 0.5625, spent from the idle HBM bandwidth; no unpack VALU, no v_permlane16_swap, no packed fragments in
- * flight.
- *
- * Registers: the 64 digit registers are SINGLE-buffered.  Every M-tile of a block needs all of them, so the next block's planes are
- * requested inside the block's LAST M-tile, each half as soon as its last MFMA has issued (high digits after the high chain, low digits
- * after the low chain, scales after the finishing).  That leaves about one tile time between request and use — too little for HBM — so
- * every wave first pulls the next tile into L2 with three "touch" loads (one dword per 128-byte line, 64 lines per instruction) at the
- * top of the block, a whole block time ahead; the real loads then hit L2.
- * ------------------------------------------------------------------------------------------ */
-template <bool Q4> struct G32Plane { static constexpr int BYTES = Q4 ? TK_PLANE4_BYTES : TK_PLANE6_BYTES; };
-
-__device__ __forceinline__ v4i ldg_nt_v4i(const uint8_t* p) { return __builtin_nontemporal_load((const v4i*)p); }
-
-__device__ __forceinline__ void planes_load_h(Ops32& o, const uint8_t* pt, int lane) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) o.bh[u] = ldg_nt_v4i(pt + (2 * u) * 1024 + lane * 16);
-}
-__device__ __forceinline__ void planes_load_l(Ops32& o, const uint8_t* pt, int lane) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) o.bl[u] = ldg_nt_v4i(pt + (2 * u + 1) * 1024 + lane * 16);
-}
-template <bool Q4>
-__device__ __forceinline__ void planes_load_s(Ops32& o, const uint8_t* pt, int lane) {
-    if (Q4) {
-        o.bm16 = __builtin_nontemporal_load((const v8h*)(pt + 16384 + lane * 16));
-        const v2f d = __builtin_nontemporal_load((const v2f*)(pt + 17408 + lane * 8));
-        o.dw = d[0];
-        o.dmin = d[1];
-    } else {
-        o.dw = __builtin_nontemporal_load((const float*)(pt + 16384 + lane * 4));
-        o.dmin = 0.0f;
-    }
-}
-
-/* tiles (tk_llm_layout.h) -> digit planes: one wave per (pair of row tiles, 256-k block), running the K loop's own unpack */
-template <bool Q4>
-__global__ __launch_bounds__(64) void k_expand_planes(const uint8_t* __restrict__ tiles, int nblk, uint8_t* __restrict__ planes) {
-    const int lane = threadIdx.x;
-    const int64_t pr = blockIdx.y, blk = blockIdx.x;
-    const size_t tb = Q4 ? (size_t)TK_Q4K_TILE_BYTES : (size_t)TK_Q6K_TILE_BYTES;
-    const uint8_t* t0 = tiles + ((size_t)(2 * pr) * nblk + blk) * tb;
-    const uint8_t* t1 = tiles + ((size_t)(2 * pr + 1) * nblk + blk) * tb;
-    Ops32 o;
-    g32_unpack<Q4>(g32_load<Q4>(t0, lane), g32_load<Q4>(t1, lane), lane, o);
-    uint8_t* pt = planes + ((size_t)pr * nblk + blk) * G32Plane<Q4>::BYTES;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        *(v4i*)(pt + (2 * u) * 1024 + lane * 16) = o.bh[u];
-        *(v4i*)(pt + (2 * u + 1) * 1024 + lane * 16) = o.bl[u];
-    }
-    if (Q4) {
-        *(v8h*)(pt + 16384 + lane * 16) = o.bm16;
-        *(v2f*)(pt + 17408 + lane * 8) = (v2f){o.dw, o.dmin};
-    } else {
-        *(float*)(pt + 16384 + lane * 4) = o.dw;
-    }
-}
-
-size_t tk_plane_bytes(int type, int64_t rows, int64_t K) {
-    return (size_t)(rows / 32) * (size_t)(K / 256) * (type == TK_TYPE_Q4_K ? (size_t)TK_PLANE4_BYTES : (size_t)TK_PLANE6_BYTES);
-}
-
-void tk_launch_expand_planes(int type, const uint8_t* tiles, int64_t rows, int64_t K, uint8_t* planes, hipStream_t s) {
-    const dim3 grid((unsigned)(K / 256), (unsigned)(rows / 32));
-    if (type == TK_TYPE_Q4_K) hipLaunchKernelGGL((k_expand_planes<true>), grid, dim3(64), 0, s, tiles, (int)(K / 256), planes);
-    else hipLaunchKernelGGL((k_expand_planes<false>), grid, dim3(64), 0, s, tiles, (int)(K / 256), planes);
-}
-
-/* one 256-k block on planes: gemm_block32's tile loop; in the LAST tile the B-operand registers are refilled from `next` (the same
- * pair's planes of the next block) as they fall free */
-template <bool Q4, typename Hook>
-__device__ __forceinline__ void gemm_block32p(Ops32& o, ATile32& T, const Ptrs32& p, float (&acc)[TK_G32_MTW][16], const uint8_t* next, int lane, Hook&& after_mfmas) {
-    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int t = 0; t < TK_G32_MTW; ++t) {
-        constexpr int LAST = TK_G32_MTW - 1;
-        v4i A[8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) A[u] = T.a[u];
-        v4f da[4];
-#pragma unroll
-        for (int u = 4; u < 8; ++u) A[u] = *(const v4i*)(p.ap + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) da[b] = *(const v4f*)(p.dp + t * 128 + b * 32);
-        v16i ph = zero;
-        v16f cm;
-        v16i pl;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ph = TK_MFMA32(A[u], o.bh[u], ph, 0, 0, 0);
-        if (Q4) {
-            const v16f fz = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(T.mn, o.bm16, fz, 0, 0, 0);
-        }
-        if (t == LAST) { /* the high digits have been read by their last MFMA: their registers take the next block's */
-            __builtin_amdgcn_sched_barrier(0);
-            planes_load_h(o, next, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pl[r] = ph[r] << (Q4 ? 3 : 6);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) pl = TK_MFMA32(A[u], o.bl[u], pl, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t == LAST) planes_load_l(o, next, lane);
-        if (t + 1 < TK_G32_MTW) load_atile32<Q4>(T, p, t + 1);
-        after_mfmas(t);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) /* accumulator register 4 b + i = row 8 b + 4 h + i of the M-tile */
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * b + i;
-                acc[t][r] = tk_fmaf(o.dw * da[b][i], (float)pl[r], acc[t][r]);
-                if (Q4) acc[t][r] = tk_fmaf(-(o.dmin * da[b][i]), cm[r], acc[t][r]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t == LAST) {
-            planes_load_s<Q4>(o, next, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-#ifndef TK_G32P_TOUCH
-#define TK_G32P_TOUCH 1 /* 0 = diagnostic: no L2 touch loads ahead of the plane loads */
-#endif
-
-template <bool Q4, typename StageSmall, typename StagePart>
-__device__ __forceinline__ void g32p_k_loop(const uint8_t* pt, int nb, const uint8_t* ring, int slot_bytes, int lane, float (&acc)[TK_G32_MTW][16],
-                                            StageSmall&& stage_small, StagePart&& stage_part) {
-    constexpr size_t PB = G32Plane<Q4>::BYTES;
-    Ops32 o;
-    planes_load_h(o, pt, lane);
-    planes_load_l(o, pt, lane);
-    planes_load_s<Q4>(o, pt, lane);
-    stage_small(0, 0);
-    for (int part = 0; part < 4; ++part) stage_part(0, 0, part);
-    /* 140 (Q4_K) / 130 (Q6_K) 128-byte lines per tile: lanes x 128 B, three instructions, the third one folded back onto the tile's tail */
-    const int toff2 = 16384 + (lane % ((int)(PB - 16384) / 128)) * 128;
-#pragma unroll 1
-    for (int b = 0; b < nb; ++b) {
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        const bool more = b + 1 < nb;
-#if TK_G32_BALANCE
-        {
-            const int q = 4 * b / nb;
-            if (q == 0) __builtin_amdgcn_s_setprio(3);
-            else if (q == 1) __builtin_amdgcn_s_setprio(2);
-            else if (q == 2) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-#endif
-        const uint8_t* next = pt + (size_t)(more ? b + 1 : b) * PB; /* the last step re-requests its own tile: no branch around a load */
-#if TK_G32P_TOUCH
-        /* pull `next` into L2 now; the real loads come in this block's last tile.  The results are only kept alive until the next block's
-         * s_waitcnt (an un-waited load may not lose its destination register) */
-        const uint32_t j0 = *(const uint32_t*)(next + lane * 128), j1 = *(const uint32_t*)(next + 8192 + lane * 128), j2 = *(const uint32_t*)(next + toff2);
-#endif
-        if (more) stage_small(b + 1, (b + 1) & 1);
-        const Ptrs32 bp = block_ptrs32(ring + (b & 1) * slot_bytes, lane);
-        ATile32 T;
-        load_atile32<Q4>(T, bp, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        gemm_block32p<Q4>(o, T, bp, acc, next, lane, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
-        __builtin_amdgcn_sched_barrier(0);
-#if TK_G32P_TOUCH
-        asm volatile("" ::"v"(j0), "v"(j1), "v"(j2));
-#endif
-    }
-}
-
-template <int TYPES>
-__global__ __launch_bounds__(256, 2) void k_gemm32p_w4a8(TkGemvArgs a, int groups, int total_row_tiles, int n_halves) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int MT = TK_G32_MT;
-    constexpr int CH = MT * TK_RING_TILE_BYTES;
-    constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 512;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int pair = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nb = a.K / a.ks / 256;
-    const int nblk_total = a.K / 256;
-    int half = 0, unit = blockIdx.x;
-    if (n_halves == 2) { /* the two halves of a unit 8 workgroup ids apart: same XCD, same L2 (k_gemm32_w4a8) */
-        const int units = gridDim.x >> 1, body = (units >> 3) << 4;
-        if ((int)blockIdx.x < body) {
-            const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
-            half = idx & 1;
-            unit = (idx >> 1) * 8 + x;
-        } else {
-            const int r = blockIdx.x - body;
-            half = r & 1;
-            unit = (body >> 1) + (r >> 1);
-        }
-    }
-    const int ksi = unit % a.ks;
-    const int blk0 = ksi * nb;
-    int rt = 2 * (unit / a.ks + pair * groups);
-    const bool active = rt < total_row_tiles;
-    if (!active) rt = 0;
-    int seg = 0, row_base = 0;
-    while (seg < a.nseg - 1 && rt >= a.seg[seg].row_tiles) {
-        rt -= a.seg[seg].row_tiles;
-        row_base += a.seg[seg].row_tiles * TK_TILE_ROWS;
-        ++seg;
-    }
-    const int type = a.seg[seg].type;
-    constexpr bool HAS4 = (TYPES & 1) != 0, HAS6 = (TYPES & 2) != 0;
-    const bool is4 = HAS4 && (!HAS6 || type == TK_TYPE_Q4_K);
-    const size_t pb = is4 ? (size_t)TK_PLANE4_BYTES : (size_t)TK_PLANE6_BYTES;
-    const uint8_t* pt = a.seg[seg].planes + ((size_t)(rt >> 1) * nblk_total + blk0) * pb;
-
-    float acc[TK_G32_MTW][16];
-#pragma unroll
-    for (int t = 0; t < TK_G32_MTW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-    const int m0 = half * MT;
-    auto stage_part = [&](int c, int slot, int part) {
-        const int m = pair + 4 * (part >> 1);
-        const uint8_t* src = (const uint8_t*)a.aq + (size_t)(m0 + m) * a.aq_ts + (size_t)(blk0 + c) * 4096 + (part & 1) * 2048 + lane * 16;
-        const auto gs = (const __attribute__((address_space(1))) void*)src;
-        const auto ls = (__attribute__((address_space(3))) void*)(lds + slot * CH + m * 4096 + (part & 1) * 2048);
-        __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
-    };
-    auto stage_small = [&](int c, int slot) {
-        uint8_t* dst = lds + slot * CH;
-        for (int m = pair; m < MT; m += 4) {
-            const uint8_t* sm = (const uint8_t*)(a.abs16 + (size_t)(m0 + m) * a.abs_ts + (size_t)(blk0 + c) * 256) + lane * 16;
-            if (lane < 32)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sm,
-                                                 (__attribute__((address_space(3))) void*)(dst + OFF_AMN + m * 512), 16, 0, 0);
-            const uint8_t* sd = (const uint8_t*)(a.ad + (size_t)(m0 + m) * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS) + lane * 16;
-            if (lane < 4)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
-                                                 (__attribute__((address_space(3))) void*)(dst + OFF_AD + m * 64), 16, 0, 0);
-        }
-    };
-    if (!active) { /* spare wave slots still stage their share of the ring */
-        stage_small(0, 0);
-        for (int part = 0; part < 4; ++part) stage_part(0, 0, part);
-#pragma unroll 1
-        for (int b = 0; b < nb; ++b) {
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (b + 1 < nb) { stage_small(b + 1, (b + 1) & 1); for (int part = 0; part < 4; ++part) stage_part(b + 1, (b + 1) & 1, part); }
-        }
-        return;
-    }
-    if (HAS4 && is4) g32p_k_loop<true>(pt, nb, lds, CH, lane, acc, stage_small, stage_part);
-    if (HAS6 && !is4) g32p_k_loop<false>(pt, nb, lds, CH, lane, acc, stage_small, stage_part);
-
-    const int n = a.col0 + row_base + rt * TK_TILE_ROWS + (lane & 31);
-    const int h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < TK_G32_MTW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (half * TK_G32_MTW + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < a.nrows) __builtin_nontemporal_store(acc[t][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
-        }
-}
-
 #define TK_NUM_CU 256
 
 /* Dynamic LDS above 64 KiB is an opt-in that HIP keeps per (function, DEVICE): a process that drives several GPUs (the ABI takes a
@@ -1759,14 +1481,6 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
         const int n_halves = a.nrows > 8 * TK_ROW_SLOTS ? 2 : 1;
         const size_t ldsb = (size_t)2 * TK_G32_MT * TK_RING_TILE_BYTES;
         const dim3 grid(g32 * a.ks * n_halves);
-        bool planes = true;
-        for (int i = 0; i < a.nseg; ++i) planes = planes && a.seg[i].planes != nullptr;
-        if (planes) { /* pre-expanded digit planes (k_gemm32p_w4a8): the model builds them unless told not to */
-            if (types == 1) hipLaunchKernelGGL((k_gemm32p_w4a8<1>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
-            else if (types == 2) hipLaunchKernelGGL((k_gemm32p_w4a8<2>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
-            else hipLaunchKernelGGL((k_gemm32p_w4a8<3>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
-            return;
-        }
         if (types == 1) hipLaunchKernelGGL((k_gemm32_w4a8<1>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
         else if (types == 2) hipLaunchKernelGGL((k_gemm32_w4a8<2>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
         else hipLaunchKernelGGL((k_gemm32_w4a8<3>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
@@ -2283,7 +1997,6 @@ const char* tk_llm_prepare_device(int device) {
 #define TK_OPT_GEMM(MTV) do { TK_OPT((k_gemm_w4a8<MTV, 1, 1>)); TK_OPT((k_gemm_w4a8<MTV, 2, 1>)); TK_OPT((k_gemm_w4a8<MTV, 3, 1>)); } while (0)
     TK_OPT_GEMM(4); TK_OPT_GEMM(8); TK_OPT_GEMM(16);
     TK_OPT((k_gemm32_w4a8<1>)); TK_OPT((k_gemm32_w4a8<2>)); TK_OPT((k_gemm32_w4a8<3>));
-    TK_OPT((k_gemm32p_w4a8<1>)); TK_OPT((k_gemm32p_w4a8<2>)); TK_OPT((k_gemm32p_w4a8<3>));
 #define TK_OPT_GEMV(PFV, MTV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3>)); } while (0)
     TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
 #define TK_OPT_ATT_C(H, C, S) do { TK_OPT((k_attention<1, true, H, C, S>)); TK_OPT((k_attention<2, true, H, C, S>)); TK_OPT((k_attention<4, true, H, C, S>)); \

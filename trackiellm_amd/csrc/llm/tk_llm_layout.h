@@ -37,16 +37,6 @@
  *                                      the A operand of the MFMA that contracts them with the 6-bit mins
  *      abs16: f16   [K/256][2][16][8]  the same sums as sum = 2 hh + ll (|hh| <= 2032, ll in {0, 1}: exact in f16) — the batched kernel
  *                                      contracts them with (2 m_j, m_j) in ONE v_mfma_f32_16x16x32_f16 (exact: every partial sum < 2^24)
- *  Digit planes (the 129..256-row kernel k_gemm32p_w4a8; a SECOND copy of every k-quant matrix, built at load time by k_expand_planes):
- *  per (32 weight rows = two adjacent tiles) x (256-k block) the B operands of v_mfma_i32_32x32x32_i8 exactly as the K loop of
- *  k_gemm32_w4a8 holds them in registers after its unpack — lane (n32 = l & 31, h = l >> 5):
- *      [0    ,16384)  MFMA u = 0..7: high digits at (2 u) KiB, low digits at (2 u + 1) KiB, 16 B per lane (q * sh and q * sl for Q4_K with
- *                     the 6-bit sub-block scale 8 sh + sl; vh and vl for Q6_K with scale * (q - 32) = 64 vh + vl)
- *      Q4_K  [16384,17408) the f16 min-term operand (8 halves per lane), [17408,17920) {f32 d, f32 dmin} per lane
- *      Q6_K  [16384,16640) f32 d per lane
- *  2.19 / 2.03 B per weight instead of 0.5625 / 0.8203: wide passes do 848 int8 ops per weight byte and leave ~90 % of HBM idle, the
- *  unpack VALU work is what they are short of.  Planes of one pair are contiguous over k: planes[pair][block].
- *
  *  "row slot" b < 16 is a (sequence, position) row of the current pass; a pass holds up to TK_MAX_TILES such
  *  16-row M-tiles (row r lives in tile r / 16, slot r % 16), each with its own aq / ad / abs image.
  */
@@ -58,8 +48,6 @@
 #define TK_TILE_ROWS 16
 #define TK_Q4K_TILE_BYTES 2304
 #define TK_Q6K_TILE_BYTES 3360
-#define TK_PLANE4_BYTES 17920 /* digit planes of 32 rows x 256 k, Q4_K */
-#define TK_PLANE6_BYTES 16640 /* Q6_K */
 #define TK_ROW_SLOTS 16  /* rows of one MFMA M-tile */
 #define TK_MAX_TILES 16   /* M-tiles per pass: a weight tile is unpacked once and multiplied against all of them */
 #define TK_MAX_ROWS (TK_ROW_SLOTS * TK_MAX_TILES)
