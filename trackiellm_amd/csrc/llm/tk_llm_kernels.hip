@@ -1434,6 +1434,45 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
         for (int i = 0; i < 4; ++i) g_g32_seg[blockIdx.x][pair + 4 * half][i] = segc[i];
 #endif
 
+#ifndef TK_G32_NT_STORE
+#define TK_G32_NT_STORE 0 /* 1 = diagnostic: non-temporal slab stores.  Default policy: the 4..29 MB of slabs a launch writes are read back at once by
+                           * the norm / SwiGLU / attention kernel behind it and fit the 256 MiB Infinity Cache (LLM-only 3 x 256: 213.8 -> 218.0
+                           * cycles/s, profiles/r04_gemm32_stores.txt); the weight stream keeps its non-temporal loads and does not evict them */
+#endif
+#ifndef TK_G32_WIDE_STORE
+#define TK_G32_WIDE_STORE 1 /* 0 = diagnostic: one dword per lane and store instruction */
+#endif
+#if TK_G32_WIDE_STORE
+    /* Epilogue: 64 accumulator registers per lane.  Stored as they stand, a store instruction writes one dword per lane (two 128-byte row
+     * segments): 64 store instructions per wave, and the tail of the launch is store-ISSUE bound (exit - loop end 4 us of gate|up's 76).
+     * So each 32 x 32 tile goes through LDS once — into the 4 KiB ring regions THIS wave staged itself (M-tiles `pair` and `pair + 4` of
+     * the slot nobody reads any more: after the wave's own vmcnt(0) no DMA can land there, and LDS operations of one wave execute in order,
+     * so no barrier is needed) — and comes back as 16 bytes per lane: lane (row r8 = l >> 3, column group l & 7) holds four consecutive
+     * columns of one row, a store instruction writes eight whole 128-byte row segments, 16 instructions per wave instead of 64. */
+    {
+        __builtin_amdgcn_s_waitcnt(0);
+        uint8_t* scr[2] = {lds + (nb & 1) * CH + pair * 4096, lds + (nb & 1) * CH + (pair + 4) * 4096};
+        const int h = lane >> 5, n32 = lane & 31;
+        const int n0 = a.col0 + row_base + rt * TK_TILE_ROWS + 4 * (lane & 7);
+#pragma unroll
+        for (int t = 0; t < TK_G32_MTW; ++t) {
+            float* sp = (float*)scr[t & 1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + n32] = acc[t][r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rl = 8 * i + (lane >> 3);
+                const v4f v = *(const v4f*)(sp + rl * 32 + 4 * (lane & 7));
+                const int row = (half * TK_G32_MTW + t) * 32 + rl;
+#if TK_G32_NT_STORE
+                if (row < a.nrows) __builtin_nontemporal_store(v, (v4f*)&a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n0]);
+#else
+                if (row < a.nrows) *(v4f*)&a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n0] = v;
+#endif
+            }
+        }
+    }
+#else
     const int n = a.col0 + row_base + rt * TK_TILE_ROWS + (lane & 31);
     const int h = lane >> 5;
 #pragma unroll
@@ -1443,6 +1482,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
             const int row = (half * TK_G32_MTW + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row < a.nrows) __builtin_nontemporal_store(acc[t][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
         }
+#endif
 #if TK_G32_CLOCK
     __builtin_amdgcn_s_waitcnt(0);
     if (tid == 0 && blockIdx.x < 1024) g_g32_stamps[blockIdx.x][7] = __builtin_amdgcn_s_memrealtime();
