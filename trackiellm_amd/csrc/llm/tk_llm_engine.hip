@@ -377,8 +377,17 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         const int ks_o = enqueue_matmul(ot, 1, QD, h.ks_o, D, act_qd, partial, nrows);
         tk_launch_rmsnorm_q8(x, partial, ks_o, D, (const float*)L.ffn_norm.data, h.rms_eps, D, nrows, act_d, s);
         const TkDevTensor* gu[2] = {&L.gate, &L.up};
-        const int ks_gu = enqueue_matmul(gu, 2, D, h.ks_gateup, 2 * FF, act_d, partial, nrows);
-        tk_launch_swiglu_q8(partial, ks_gu, FF, nrows, act_ff, s);
+        if (tk_gemv_fuses_swiglu(nrows, h.ks_gateup, L.gate.type, L.up.type)) { /* wide pass: SwiGLU in the launch's epilogue, `partial` holds h [rows][FF] */
+            TkGemvArgs a{};
+            a.seg[0] = seg_of(L.gate); a.seg[1] = seg_of(L.up);
+            a.nseg = 2; a.K = D; a.ks = 1; a.n_total = FF; a.nrows = nrows; a.swiglu = 1;
+            set_act(a, act_d); a.out = partial;
+            tk_launch_gemv(a, s);
+            tk_launch_quant_q8(partial, FF, nrows, act_ff, s);
+        } else {
+            const int ks_gu = enqueue_matmul(gu, 2, D, h.ks_gateup, 2 * FF, act_d, partial, nrows);
+            tk_launch_swiglu_q8(partial, ks_gu, FF, nrows, act_ff, s);
+        }
         const TkDevTensor* dn[1] = {&L.down};
         ks_res = enqueue_matmul(dn, 1, FF, h.ks_down, D, act_ff, partial, nrows);
     }
@@ -608,6 +617,7 @@ bool TkLlmSession::time_gemv(int layer, int which, int nrows, int iters, float* 
         a.nrows = nrows;
         if (which == 0) { /* gate+up */
             a.seg[0] = seg_of(L.gate); a.seg[1] = seg_of(L.up); a.nseg = 2; a.K = h.d_model; a.ks = h.ks_gateup; a.n_total = 2 * h.d_ff;
+            if (tk_gemv_fuses_swiglu(nrows, h.ks_gateup, L.gate.type, L.up.type)) { a.swiglu = 1; a.n_total = h.d_ff; } /* the launch a wide pass makes */
             set_act(a, act_d); a.out = partial;
             *bytes = (double)L.gate.bytes + (double)L.up.bytes;
         } else if (which == 1) { /* down */

@@ -25,6 +25,7 @@ struct TkGemvArgs {
     int n_total;  /* row pitch of `out`: the sum of rows over all segments of the matrix */
     int col0;     /* column of `out` where segment 0 starts (non-zero when a launch carries only some of the matrix's segments) */
     int nrows;    /* live rows (<= TK_MAX_ROWS); rows 16.. use the second M-tile */
+    int swiglu;   /* 1 (only where tk_gemv_fuses_swiglu() says so): seg[0] = gate, seg[1] = up, out = h[nrows][n_total = d_ff] = silu(gate) * up */
     size_t aq_ts, ad_ts, abs_ts; /* M-tile strides of aq (bytes), ad (floats), abs (ints) */
     const int8_t* aq;
     const float* ad;
@@ -65,6 +66,9 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
                          uint16_t* kcache, uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows, int n_head, int n_kv_head,
                          int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, bool fused, hipStream_t s);
 void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ8 out, hipStream_t s);
+/* wide passes: the gate | up launch forms h = silu(gate) * up in its epilogue (half the slab bytes written and read back); then only the quantisation is left */
+bool tk_gemv_fuses_swiglu(int nrows, int ks, int type_gate, int type_up);
+void tk_launch_quant_q8(const float* hbuf, int FF, int nrows, TkActQ8 out, hipStream_t s);
 /* allow_base / allow_row (both optional): per-row allowed-token bit masks, allow_row[r] = mask index or -1 */
 void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow_base, const int32_t* allow_row, int32_t* tok, int32_t* pos,
                       int32_t* nsteps, int32_t* hist, int hist_stride, hipStream_t s);

@@ -1251,7 +1251,7 @@ extern "C" __attribute__((visibility("default"))) int tk_debug_g32_seg(unsigned 
 
 /* The K loop of one wave: its two weight tiles (32 weight rows) against its four 32-row M-tiles, block by block through the ring. */
 template <bool Q4, typename StageSmall, typename StagePart>
-__device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_bytes, size_t tile_pitch, int nb, const uint8_t* ring, int slot_bytes, int lane,
+__device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_bytes, ptrdiff_t tile_pitch, int nb, const uint8_t* ring, int slot_bytes, int lane,
                                            float (&acc)[TK_G32_MTW][16], unsigned long long* seg, StageSmall&& stage_small, StagePart&& stage_part) {
     typedef typename G32Frag<Q4>::type F;
     F f0 = g32_load<Q4>(tile, lane), f1 = g32_load<Q4>(tile + tile_pitch, lane);
@@ -1355,11 +1355,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
     const int ksi = unit % a.ks;
     const int blk0 = ksi * nb;
 
-    int rt = 2 * (unit / a.ks + pair * groups); /* first of this wave's two adjacent row tiles */
-    const bool active = rt < total_row_tiles;
+    /* a.swiglu (gate | up launches with one K range): the wave's 32 weight rows are gate tile i and up tile i — the same 16 hidden columns —
+     * so its epilogue can form silu(gate) * up; the four waves of a workgroup take adjacent tiles (their stores join to 256 B per row) */
+    int rt = a.swiglu ? 4 * (unit / a.ks) + pair : 2 * (unit / a.ks + pair * groups); /* first of this wave's two row tiles */
+    const bool active = rt < (a.swiglu ? a.seg[0].row_tiles : total_row_tiles);
     if (!active) rt = 0;
     int seg = 0, row_base = 0;
-    while (seg < a.nseg - 1 && rt >= a.seg[seg].row_tiles) {
+    while (!a.swiglu && seg < a.nseg - 1 && rt >= a.seg[seg].row_tiles) {
         rt -= a.seg[seg].row_tiles;
         row_base += a.seg[seg].row_tiles * TK_TILE_ROWS;
         ++seg;
@@ -1368,7 +1370,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
     constexpr bool HAS4 = (TYPES & 1) != 0, HAS6 = (TYPES & 2) != 0;
     const bool is4 = HAS4 && (!HAS6 || type == TK_TYPE_Q4_K);
     const size_t tile_bytes = is4 ? (size_t)TK_Q4K_TILE_BYTES : (size_t)TK_Q6K_TILE_BYTES;
-    const size_t tile_pitch = (size_t)nblk_total * tile_bytes;
+    const ptrdiff_t tile_pitch = a.swiglu ? a.seg[1].tiles - a.seg[0].tiles : (ptrdiff_t)((size_t)nblk_total * tile_bytes);
     const uint8_t* tile = a.seg[seg].tiles + ((size_t)rt * nblk_total + blk0) * tile_bytes;
 
     float acc[TK_G32_MTW][16];
@@ -1459,6 +1461,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
             float* sp = (float*)scr[t & 1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + n32] = acc[t][r];
+            if (a.swiglu) { /* columns 0..15 of the tile are gate, 16..31 up, of hidden columns 16 rt ..: h = silu(gate) * up, what k_swiglu_q8 evaluates */
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int rl = 16 * i + (lane >> 2), cg = 4 * (lane & 3);
+                    const v4f g = *(const v4f*)(sp + rl * 32 + cg), u = *(const v4f*)(sp + rl * 32 + 16 + cg);
+                    v4f hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = tk_siluf(g[j]) * u[j];
+                    const int row = (half * TK_G32_MTW + t) * 32 + rl;
+                    if (row < a.nrows) *(v4f*)&a.out[(size_t)row * a.n_total + rt * TK_TILE_ROWS + cg] = hv;
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rl = 8 * i + (lane >> 3);
@@ -1516,7 +1531,7 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     if (a.nrows >= TK_G32_MIN_ROWS) {
         /* 129..256 rows: the 32x32x32 kernel, one type per wave (a mixed q / k / v launch needs no split): four (weight-tile pair) slots per
          * workgroup, one workgroup per row half */
-        const int pairs = row_tiles / 2; /* every segment holds a multiple of 4 row tiles: pairs never straddle segments */
+        const int pairs = a.swiglu ? a.seg[0].row_tiles : row_tiles / 2; /* every segment holds a multiple of 4 row tiles: pairs never straddle segments */
         const int g32 = (pairs + 3) / 4;
         const int n_halves = a.nrows > 8 * TK_ROW_SLOTS ? 2 : 1;
         const size_t ldsb = (size_t)2 * TK_G32_MT * TK_RING_TILE_BYTES;
@@ -1968,6 +1983,25 @@ __global__ __launch_bounds__(256) void k_swiglu_q8(const float* partial, int ks,
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = tk_siluf(g[i >> 2][i & 3]) * u[i >> 2][i & 3];
     quantize_chunk8(v, c, r, out);
+}
+
+/* the Q8 quantisation alone, for h = silu(gate) * up that the wide gate | up launch has formed in its epilogue (TkGemvArgs::swiglu) */
+__global__ __launch_bounds__(256) void k_quant_q8(const float* __restrict__ hbuf, int FF, TkActQ8 out) {
+    const int r = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= FF / 8) return; /* FF/8 is a multiple of 32: whole half-waves drop out together */
+    const float* row = hbuf + (int64_t)r * FF + 8 * c;
+    const v4f a = *(const v4f*)row, b = *(const v4f*)(row + 4);
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    quantize_chunk8(v, c, r, out);
+}
+
+void tk_launch_quant_q8(const float* hbuf, int FF, int nrows, TkActQ8 out, hipStream_t s) {
+    hipLaunchKernelGGL(k_quant_q8, dim3((FF / 8 + 255) / 256, nrows), dim3(256), 0, s, hbuf, FF, out);
+}
+
+bool tk_gemv_fuses_swiglu(int nrows, int ks, int type_gate, int type_up) {
+    return nrows >= TK_G32_MIN_ROWS && ks == 1 && type_gate == type_up && (type_gate == TK_TYPE_Q4_K || type_gate == TK_TYPE_Q6_K);
 }
 
 void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ8 out, hipStream_t s) {
