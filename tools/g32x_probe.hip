@@ -103,9 +103,11 @@ __global__ __launch_bounds__(256, 1) void k1(int tiles, float* out, const float*
     Opa o0, o1;
     Res r0, r1;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { o0.a[u] = (v4i){lane + u, u, 3, 7}; o1.a[u] = o0.a[u]; }
+    /* the two ping-pong operand sets DIFFER: with identical sets (round 3) the compiler computed the two tile steps' MFMAs once — the modes
+     * without LDS reads issued 17 MFMAs per TWO tiles, which is what "17 MFMA only: 273 cycles per tile" and "17 MFMA + 96 VALU: 621" timed */
+    for (int u = 0; u < 8; ++u) { o0.a[u] = (v4i){lane + u, u, 3, 7}; o1.a[u] = (v4i){lane - u, u + 1, 5, 2}; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { o0.mn[e] = (_Float16)(float)(lane + e); o1.mn[e] = o0.mn[e]; }
+    for (int e = 0; e < 8; ++e) { o0.mn[e] = (_Float16)(float)(lane + e); o1.mn[e] = (_Float16)(float)(lane - e); }
     r0.pl = r0.ph = r1.pl = r1.ph = (v16i){};
     r0.cm = r1.cm = (v16f){};
 #pragma unroll
@@ -118,7 +120,9 @@ __global__ __launch_bounds__(256, 1) void k1(int tiles, float* out, const float*
         /* operand / result sets ping-pong; two of the real kernel's eight accumulator tiles (the count does not change the instruction stream) */
         tile_step<SCHED, UNP, LDSR, DMA, 0>(lp, t, o0, o1, Bl, Bh, bm, r0, r1, dw, dmin, acc[1], junk, gs, ldst);
         tile_step<SCHED, UNP, LDSR, DMA, 1>(lp, t + 1, o1, o0, Bl, Bh, bm, r1, r0, dw, dmin, acc[0], junk, gs, ldst);
-        Bl[0][0] += 1;
+        Bl[0][0] += 1; /* every operand set changes per iteration: a loop-invariant chain (round 3: the Bh chains and the min-term MFMA in the modes */
+        Bh[0][0] += 1; /* without finishing) is hoisted out of the loop by the compiler and the mode then times 8 MFMAs per tile, not 17 */
+        bm[0] = bm[0] + (_Float16)1.0f;
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.0f;
@@ -127,7 +131,10 @@ __global__ __launch_bounds__(256, 1) void k1(int tiles, float* out, const float*
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += acc[m][r];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += (float)r0.pl[r] + (float)r1.ph[r] + r0.cm[r] + r1.cm[r];
+    /* BOTH digit chains of BOTH result sets are consumed (round 3 read only r0.pl and r1.ph: in the modes without finishing the other two
+     * chains were dead code) — see also the operand updates in the loop: "17 MFMA only: 273 cycles per tile" of profiles/r03_g32x_probe2.txt
+     * timed 8 MFMAs per tile (8 x 32 + 17 cycles), the int8 32x32x32 MFMA takes 32 cycles (profiles/r04_g32x_probe_fixed.txt) */
+    for (int r = 0; r < 16; ++r) s += (float)r0.pl[r] + (float)r1.ph[r] + (float)r0.ph[r] + (float)r1.pl[r] + r0.cm[r] + r1.cm[r];
     for (int i = 0; i < 8; ++i) s += (float)junk[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;

@@ -78,16 +78,49 @@ __global__ __launch_bounds__(1024) void k_logmel_finish(float* mel, int per_b) {
  * + 0.0f (the GEMM epilogue's bias slot); softmax as k_softmax_rows evaluates it (256 strided partial maxima / sums, shuffle tree,
  * ((w0 + w1) + w2) + w3); output = one fp32 fma chain over the keys in ascending order, + 0.0f.  The decoder steps of 32 utterances were
  * sixteen 64x64-tile GEMM launches of one live row each per step; this is eight short launches. */
+#define TK_AT1_CK 64 /* keys per ring slot of the value stream */
+#define TK_AT1_NS 3  /* ring slots */
+/* s_waitcnt vmcnt(n) alone */
+__device__ __forceinline__ void at1_wait_vmcnt(int n) {
+#define TK_VMW(k) case k: __builtin_amdgcn_s_waitcnt(0x0F70 | ((k) & 15) | (((k) >> 4) << 14)); break;
+    switch (n) {
+        TK_VMW(0) TK_VMW(1) TK_VMW(2) TK_VMW(3) TK_VMW(4) TK_VMW(5) TK_VMW(6) TK_VMW(7) TK_VMW(8) TK_VMW(9) TK_VMW(10) TK_VMW(11) TK_VMW(12)
+        TK_VMW(13) TK_VMW(14) TK_VMW(15) TK_VMW(16)
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+#undef TK_VMW
+}
+/* The value contraction is ONE fp32 chain over the keys per output (the canonical order), carried by hd threads; what the other threads
+ * can do is move the values: all four waves stream V through a three-slot LDS ring by LDS-DMA (64 keys x hd floats per slot, 1 KiB pieces
+ * of four 256-byte rows), the first two slots requested before the scores are even computed, so the chain reads LDS instead of waiting
+ * for 32 global rows at a time (cross-attention over 1500 keys: the chain wave alone had 384 KB to pull through 32 loads in flight). */
 __global__ __launch_bounds__(256) void k_attend1(const float* q, const float* k, const float* v, float* out, int Tk, int64_t q_bstride, int64_t kv_bstride, int d,
                                                  int hd, float scale) {
-    extern __shared__ float att1_lds[];
+    extern __shared__ __attribute__((aligned(16))) float att1_lds[];
     __shared__ float red[4];
-    float* sc = att1_lds;      /* [Tk] */
-    float* qs = att1_lds + Tk; /* [hd] */
-    const int h = blockIdx.x, b = blockIdx.y, t0 = threadIdx.x;
+    float* vring = att1_lds;                                   /* [NS][CK][hd] */
+    float* sc = att1_lds + (size_t)TK_AT1_NS * TK_AT1_CK * hd; /* [Tk] */
+    float* qs = sc + Tk;                                       /* [hd] */
+    const int h = blockIdx.x, b = blockIdx.y, t0 = threadIdx.x, lane = t0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6);
     const float* qp = q + (int64_t)b * q_bstride + (int64_t)h * hd;
     const float* kp = k + (int64_t)b * kv_bstride + (int64_t)h * hd;
     const float* vp = v + (int64_t)b * kv_bstride + (int64_t)h * hd;
+    const int nchunk = (Tk + TK_AT1_CK - 1) / TK_AT1_CK;
+    const int upr = hd / 4;                       /* 16-byte units per row */
+    const int ppw = TK_AT1_CK * hd / 256 / 4;     /* DMA pieces per wave and chunk (the launcher admits hd % 16 == 0 only) */
+    auto issue = [&](int c) { /* rows past the last key re-read it: never used by the chain */
+        float* slot = vring + (size_t)(c % TK_AT1_NS) * TK_AT1_CK * hd;
+        for (int i = 0; i < ppw; ++i) {
+            const int p = wave + 4 * i, u = p * 64 + lane;
+            int row = c * TK_AT1_CK + u / upr;
+            row = row < Tk ? row : Tk - 1;
+            const auto gs = (const __attribute__((address_space(1))) void*)(vp + (int64_t)row * d + 4 * (u % upr));
+            const auto ls = (__attribute__((address_space(3))) void*)((uint8_t*)slot + p * 1024);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
+        }
+    };
+    for (int j = 0; j < TK_AT1_NS - 1 && j < nchunk; ++j) issue(j);
     for (int i = t0; i < hd; i += 256) qs[i] = qp[i];
     __syncthreads();
     float m = -INFINITY;
@@ -115,33 +148,30 @@ __global__ __launch_bounds__(256) void k_attend1(const float* q, const float* k,
     __syncthreads();
     const float tot = ((red[0] + red[1]) + red[2]) + red[3];
     for (int t = t0; t < Tk; t += 256) sc[t] = tk_divf(sc[t], tot);
-    __syncthreads();
-    if (t0 < hd) {
-        /* the chain over the keys is sequential; what can overlap is the value loads: four groups of eight rows stay in flight */
-        constexpr int PD = 4;
-        float vb[PD][8];
-        const int ngrp = Tk / 8;
-        auto vload = [&](int grp, float* dst) {
-            const int gg = grp < ngrp ? grp : (ngrp > 0 ? ngrp - 1 : 0);
+    float a = 0.0f;
+    for (int c = 0; c < nchunk; ++c) {
+        /* chunk c has landed once all but the chunks requested after it have; the barrier also says everybody is done with chunk c - 1,
+         * whose slot takes chunk c + NS - 1 (and, the first time, publishes the probabilities) */
+        const int ahead = nchunk - 1 - c < TK_AT1_NS - 2 ? nchunk - 1 - c : TK_AT1_NS - 2;
+        at1_wait_vmcnt(ahead * ppw);
+        __syncthreads();
+        if (c + TK_AT1_NS - 1 < nchunk) issue(c + TK_AT1_NS - 1);
+        if (t0 < hd) {
+            const float* vs = vring + (size_t)(c % TK_AT1_NS) * TK_AT1_CK * hd + t0;
+            const float* pc = sc + c * TK_AT1_CK;
+            const int n = Tk - c * TK_AT1_CK < TK_AT1_CK ? Tk - c * TK_AT1_CK : TK_AT1_CK;
+            int u = 0;
+            for (; u + 8 <= n; u += 8) {
+                float vv[8], pp[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dst[u] = ngrp > 0 ? vp[(int64_t)(8 * gg + u) * d + t0] : 0.0f;
-        };
+                for (int e = 0; e < 8; ++e) { vv[e] = vs[(u + e) * hd]; pp[e] = pc[u + e]; }
 #pragma unroll
-        for (int p = 0; p < PD; ++p) vload(p, vb[p]);
-        float a = 0.0f;
-        for (int gb = 0; gb < ngrp; gb += PD) {
-#pragma unroll
-            for (int p = 0; p < PD; ++p) {
-                if (gb + p < ngrp) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) a = tk_fmaf(sc[8 * (gb + p) + u], vb[p][u], a);
-                    vload(gb + p + PD, vb[p]);
-                }
+                for (int e = 0; e < 8; ++e) a = tk_fmaf(pp[e], vv[e], a);
             }
+            for (; u < n; ++u) a = tk_fmaf(pc[u], vs[u * hd], a);
         }
-        for (int t = 8 * ngrp; t < Tk; ++t) a = tk_fmaf(sc[t], vp[(int64_t)t * d + t0], a);
-        out[(int64_t)b * q_bstride + (int64_t)h * hd + t0] = a + 0.0f;
     }
+    if (t0 < hd) out[(int64_t)b * q_bstride + (int64_t)h * hd + t0] = a + 0.0f;
 }
 
 /* ---------------------------------------------------------------- GPU ops for the shared graph */
@@ -210,9 +240,9 @@ struct TkAudioGpuOps {
     bool attend1(const float* q, const float* k, const float* v, float* out, int B, int Tk, int64_t q_bstride, int64_t kv_bstride, int d, int nh) {
         drop_image();
         const int hd = d / nh;
-        if (hd > 256 || (hd & 3) || (size_t)Tk * 4 + (size_t)hd * 4 > 60 * 1024) return false;
-        hipLaunchKernelGGL(k_attend1, dim3(nh, B), dim3(256), (size_t)Tk * 4 + (size_t)hd * 4, s, q, k, v, out, Tk, q_bstride, kv_bstride, d, hd,
-                           tk_divf(1.0f, tk_sqrtf((float)hd)));
+        const size_t ldsb = ((size_t)TK_AT1_NS * TK_AT1_CK * hd + (size_t)Tk + (size_t)hd) * 4;
+        if (hd > 256 || (hd & 15) || (d & 3) || Tk < 1 || ldsb > 60 * 1024) return false; /* the three-launch form takes what does not fit */
+        hipLaunchKernelGGL(k_attend1, dim3(nh, B), dim3(256), ldsb, s, q, k, v, out, Tk, q_bstride, kv_bstride, d, hd, tk_divf(1.0f, tk_sqrtf((float)hd)));
         return true;
     }
     void add_rows(float* x, const float* add, int rows, int D, int add_rows) { drop_image(); tk_launch_add_rows(x, add, rows, D, add_rows, s); }

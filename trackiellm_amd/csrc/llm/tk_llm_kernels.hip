@@ -1504,7 +1504,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
 #endif
 }
 
-#define TK_NUM_CU 256
+/* compute units of the calling thread's current device (every launcher runs with the session's device current): read once per device */
+static int tk_num_cu() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+#define TK_NUM_CU tk_num_cu()
 
 /* Dynamic LDS above 64 KiB is an opt-in that HIP keeps per (function, DEVICE): a process that drives several GPUs (the ABI takes a
  * device ordinal per handle, SURVEY 8b "Threading") must raise it on each of them.  tk_llm_prepare_device() does that once per device
@@ -1541,31 +1552,15 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((k_gemm32_w4a8<3>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
         return;
     }
-    if (a.nrows > 8 * TK_ROW_SLOTS && types == 3) {
-        /* (unreachable since the 32x32x32 kernel took the wide passes; kept for the 16-M-tile instantiation of k_gemm_w4a8) 16 M-tiles: the two-type kernel does not fit the register file; a mixed matrix (q, k Q4_K + v Q6_K) goes as two 8-M-tile launches
-         * over the first 128 rows and the rest (M-tile images and output rows are simply offset) */
-        TkGemvArgs lo = a, hi = a;
-        lo.nrows = 8 * TK_ROW_SLOTS;
-        hi.nrows = a.nrows - 8 * TK_ROW_SLOTS;
-        hi.aq = a.aq + 8 * a.aq_ts;
-        hi.ad = a.ad + 8 * a.ad_ts;
-        hi.abs = a.abs + 8 * a.abs_ts;
-        hi.abs16 = a.abs16 + 8 * a.abs_ts;
-        hi.out = a.out + (size_t)8 * TK_ROW_SLOTS * a.n_total;
-        tk_launch_gemv(lo, s);
-        tk_launch_gemv(hi, s);
-        return;
-    }
-    if (a.nrows > 2 * TK_ROW_SLOTS) { /* batched passes: K-streamed activations, 4, 8 or 16 M-tiles per weight tile */
-        const int mtb = a.nrows > 8 * TK_ROW_SLOTS ? 16 : a.nrows > 4 * TK_ROW_SLOTS ? 8 : 4;
+    if (a.nrows > 2 * TK_ROW_SLOTS) { /* batched passes of 33..128 rows: K-streamed activations, 4 or 8 M-tiles per weight tile */
+        const int mtb = a.nrows > 4 * TK_ROW_SLOTS ? 8 : 4;
         const size_t ldsb = (size_t)2 * TK_RING_BLOCKS * mtb * TK_RING_TILE_BYTES;
         /* one weight tile per wave (two adjacent tiles per wave halve the LDS operand stream but leave one wave per SIMD: 25 % slower on
          * MI355X, profiles/r01_gemm_batched.txt) */
 #define TK_GEMM_LAUNCH(MTV, TYV) hipLaunchKernelGGL((k_gemm_w4a8<MTV, TYV, 1>), dim3(groups * a.ks), dim3(64 * waves), ldsb, s, a, groups, row_tiles)
 #define TK_GEMM_TY(MTV) do { if (types == 1) TK_GEMM_LAUNCH(MTV, 1); else if (types == 2) TK_GEMM_LAUNCH(MTV, 2); else TK_GEMM_LAUNCH(MTV, 3); } while (0)
         if (mtb == 4) TK_GEMM_TY(4);
-        else if (mtb == 8) TK_GEMM_TY(8);
-        else TK_GEMM_TY(16);
+        else TK_GEMM_TY(8);
 #undef TK_GEMM_TY
 #undef TK_GEMM_LAUNCH
         return;
@@ -2069,7 +2064,7 @@ const char* tk_llm_prepare_device(int device) {
     hipError_t e = hipSuccess;
 #define TK_OPT(fn) do { if (e == hipSuccess) e = opt_in_lds(fn); } while (0)
 #define TK_OPT_GEMM(MTV) do { TK_OPT((k_gemm_w4a8<MTV, 1, 1>)); TK_OPT((k_gemm_w4a8<MTV, 2, 1>)); TK_OPT((k_gemm_w4a8<MTV, 3, 1>)); } while (0)
-    TK_OPT_GEMM(4); TK_OPT_GEMM(8); TK_OPT_GEMM(16);
+    TK_OPT_GEMM(4); TK_OPT_GEMM(8);
     TK_OPT((k_gemm32_w4a8<1>)); TK_OPT((k_gemm32_w4a8<2>)); TK_OPT((k_gemm32_w4a8<3>));
 #define TK_OPT_GEMV(PFV, MTV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3>)); } while (0)
     TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
