@@ -52,6 +52,7 @@ private:
     friend struct TkAudioGpuOps;
     float* arena = nullptr;
     size_t arena_floats = 0, arena_used = 0;
+    std::string launch_error; /* a launcher refused its arguments while the graph was being enqueued (no HIP error is raised for that) */
     int16_t* pcm_dev = nullptr;
     size_t pcm_cap = 0;
 };

@@ -95,7 +95,7 @@ __device__ __forceinline__ void at1_wait_vmcnt(int n) {
  * of four 256-byte rows), the first two slots requested before the scores are even computed, so the chain reads LDS instead of waiting
  * for 32 global rows at a time (cross-attention over 1500 keys: the chain wave alone had 384 KB to pull through 32 loads in flight). */
 __global__ __launch_bounds__(256) void k_attend1(const float* q, const float* k, const float* v, float* out, int Tk, int64_t q_bstride, int64_t kv_bstride, int d,
-                                                 int hd, float scale) {
+                                                 int hd, float scale, float* img /* optional: out also as the tiled GEMM's operand image [B rows][K = d] */) {
     extern __shared__ __attribute__((aligned(16))) float att1_lds[];
     __shared__ float red[4];
     float* vring = att1_lds;                                   /* [NS][CK][hd] */
@@ -171,7 +171,14 @@ __global__ __launch_bounds__(256) void k_attend1(const float* q, const float* k,
             for (; u < n; ++u) a = tk_fmaf(pc[u], vs[u * hd], a);
         }
     }
-    if (t0 < hd) out[(int64_t)b * q_bstride + (int64_t)h * hd + t0] = a + 0.0f;
+    if (t0 < hd) {
+        const float r = a + 0.0f;
+        out[(int64_t)b * q_bstride + (int64_t)h * hd + t0] = r;
+        if (img) {
+            const int kk = h * hd + t0;
+            img[(int64_t)(b >> 4) * 16 * d + (int64_t)(kk >> 4) * 256 + (kk & 3) * 64 + (b & 15) * 4 + ((kk & 15) >> 2)] = r;
+        }
+    }
 }
 
 /* ---------------------------------------------------------------- GPU ops for the shared graph */
@@ -195,7 +202,20 @@ struct TkAudioGpuOps {
      * once.  It sits on top of the arena and is dropped — its space handed back — by every other op, by any allocation of the graph and
      * by a GEMM that writes into the matrix it was made from. */
     struct { const float* A = nullptr; int M = 0, K = 0, lda = 0; float* img = nullptr; size_t mark = 0; bool live = false; } pk;
+    /* linear layers of a short pass (<= 256 rows: the decoder steps) on the SAME packed input are collected — up to three — and go out as ONE
+     * launch with a destination per segment (q | k | v: the query buffer and row p of the two caches); anything else flushes the batch first */
+    struct { TkTiledGemm t{}; int n = 0; } pend;
+    void flush() {
+        if (pend.n == 0) return;
+        pend.t.nseg = pend.n;
+        int cols = 0;
+        for (int i = 0; i < pend.n; ++i) cols += pend.t.row_tiles[i] * 16;
+        pend.t.n_valid = cols;
+        if (!tk_launch_gemm_tiled(pend.t, s)) a->launch_error = "tiled GEMM launch refused (batched decoder layers)";
+        pend.n = 0;
+    }
     void drop_image() {
+        flush();
         if (pk.live) { a->arena_used = pk.mark; pk.live = false; }
     }
     float* alloc(size_t n) {
@@ -209,6 +229,17 @@ struct TkAudioGpuOps {
         return p;
     }
     int32_t* alloc_i32(size_t n) { return (int32_t*)alloc(n); }
+    static bool short_pass(int M) { return M <= TK_TW_MAX_BLOCK_ROWS; }
+    /* the packed image of a matrix a producer kernel is about to write (layer norm, decoder attention): lives on top of the arena like
+     * the image gemm() packs itself, and is found there by the linear layers that follow */
+    float* image_for(const float* A, int M, int K, int lda) {
+        pk.mark = a->arena_used;
+        TkGemm g{};
+        g.M = M; g.K = K;
+        pk.img = raw_alloc(tk_tiled_gemm_scratch(g));
+        pk.A = A; pk.M = M; pk.K = K; pk.lda = lda; pk.live = true;
+        return pk.img;
+    }
     /* a linear layer whose weights have tiles runs on the tiled GEMM (same k-ascending fp32 chain, bit-identical, ~3x the rate of the
      * LDS-staged kernel on these shapes and one short launch instead of a latency chain for the decoder's few rows) */
     void gemm(const TkGemm& g) {
@@ -221,12 +252,41 @@ struct TkAudioGpuOps {
             tk_launch_pack_a(g.A, g.M, g.K, g.lda, 0, pk.img, s);
             pk.A = g.A; pk.M = g.M; pk.K = g.K; pk.lda = g.lda; pk.live = true;
         }
+        const bool plain = short_pass(g.M) && !g.residual && !g.c_feeds_linear && g.N % 16 == 0;
+        if (plain) { /* joins (or opens) the batch of layers on this input */
+            if (pend.n > 0 && (pend.t.a_img != pk.img || pend.t.K != g.K || pend.t.nrows != g.M || pend.t.act != g.act)) flush();
+            TkTiledGemm& t = pend.t;
+            if (pend.n == 0) {
+                t = TkTiledGemm{};
+                t.wbytes = 4; t.K = g.K; t.ks = 1; t.nrows = g.M; t.slab_rows = 0; t.a_img = pk.img; t.a_ts = (size_t)g.K * 16;
+                t.act = g.act; t.add_zero_bias = 1; t.per_seg = 1;
+            }
+            const int i = pend.n++;
+            t.tiles[i] = a->model->wt[(size_t)idx]; t.row_tiles[i] = g.N / 16;
+            t.seg_out[i] = g.C; t.seg_ldc[i] = g.ldc; t.seg_bias[i] = g.bias; t.seg_n[i] = g.N;
+            if (pend.n == 3) flush();
+            return; /* none of these layers writes into its own input (q, k, v and the caches are buffers of their own) */
+        }
+        flush();
         TkTiledGemm t{};
         t.tiles[0] = a->model->wt[(size_t)idx]; t.row_tiles[0] = (g.N + 15) / 16; t.nseg = 1; t.wbytes = 4;
         t.K = g.K; t.ks = 1; t.ldc = g.ldc; t.n_valid = g.N; t.nrows = g.M; t.slab_rows = 0;
         t.a_img = pk.img; t.a_ts = (size_t)g.K * 16; t.out = g.C;
         t.bias = g.bias; t.residual = g.residual; t.ldr = g.ldr; t.act = g.act; t.add_zero_bias = 1;
+        /* fc1 of a short pass: its output is only ever the input of fc2 — written as fc2's operand image as well (on top of fc1's own) */
+        const bool emit_img = g.c_feeds_linear && short_pass(g.M) && g.N % 128 == 0 && g.ldc == g.N && !g.residual;
+        float* cimg = nullptr;
+        if (emit_img) {
+            TkGemm nx{};
+            nx.M = g.M; nx.K = g.N;
+            cimg = raw_alloc(tk_tiled_gemm_scratch(nx));
+            t.c_img = cimg;
+        }
         if (!tk_launch_gemm_tiled(t, s)) tk_launch_gemm(g, s); /* not reached: tk_tiled_gemm_applies() admits only shapes the launcher takes */
+        if (emit_img) { /* the image pair stays allocated from pk.mark up; the upper one is now the live image */
+            pk.img = cimg; pk.A = g.C; pk.M = g.M; pk.K = g.N; pk.lda = g.ldc; pk.live = true;
+            return;
+        }
         /* the output may overwrite the packed matrix (an in-place layer): the image is then stale */
         const float* c0 = g.C;
         const float* c1 = g.C + (size_t)(g.M - 1) * g.ldc + g.N;
@@ -235,14 +295,19 @@ struct TkAudioGpuOps {
         if (c0 < a1 && a0 < c1) drop_image();
     }
     void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) { drop_image(); tk_launch_im2col1d(x, B, T, C, ldx, kw, stride, pad, col, s); }
-    void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) { drop_image(); tk_launch_layernorm(x, rows, D, w, b, TK_WH_LN_EPS, y, s); }
+    void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) {
+        drop_image();
+        float* img = (short_pass(rows) && D % 128 == 0) ? image_for(y, rows, D, D) : nullptr; /* a short pass's norm feeds linear layers: packed on the way out */
+        tk_launch_layernorm(x, rows, D, w, b, TK_WH_LN_EPS, y, s, img);
+    }
     void softmax_rows(float* x, int rows, int cols, int ld) { drop_image(); tk_launch_softmax_rows(x, rows, cols, ld, s); }
     bool attend1(const float* q, const float* k, const float* v, float* out, int B, int Tk, int64_t q_bstride, int64_t kv_bstride, int d, int nh) {
         drop_image();
         const int hd = d / nh;
         const size_t ldsb = ((size_t)TK_AT1_NS * TK_AT1_CK * hd + (size_t)Tk + (size_t)hd) * 4;
         if (hd > 256 || (hd & 15) || (d & 3) || Tk < 1 || ldsb > 60 * 1024) return false; /* the three-launch form takes what does not fit */
-        hipLaunchKernelGGL(k_attend1, dim3(nh, B), dim3(256), ldsb, s, q, k, v, out, Tk, q_bstride, kv_bstride, d, hd, tk_divf(1.0f, tk_sqrtf((float)hd)));
+        float* img = (short_pass(B) && d % 128 == 0 && q_bstride == d) ? image_for(out, B, d, d) : nullptr; /* the output projection's input, packed on the way out */
+        hipLaunchKernelGGL(k_attend1, dim3(nh, B), dim3(256), ldsb, s, q, k, v, out, Tk, q_bstride, kv_bstride, d, hd, tk_divf(1.0f, tk_sqrtf((float)hd)), img);
         return true;
     }
     void add_rows(float* x, const float* add, int rows, int D, int add_rows) { drop_image(); tk_launch_add_rows(x, add, rows, D, add_rows, s); }
@@ -269,15 +334,23 @@ struct TkAudioSizeOps {
     size_t used = 0, peak = 0;
     float* alloc(size_t n) { used += (n + 63) & ~(size_t)63; if (used > peak) peak = used; return nullptr; }
     int32_t* alloc_i32(size_t n) { return (int32_t*)alloc(n); }
-    void gemm(const TkGemm& g) { /* the tiled path's activation image is scratch on top of the live allocations */
+    void gemm(const TkGemm& g) { /* the tiled path's activation image is scratch on top of the live allocations; fc1 of a short pass adds fc2's image */
         if (!tk_tiled_gemm_applies(g)) return;
+        size_t top = used + ((tk_tiled_gemm_scratch(g) + 63) & ~(size_t)63);
+        if (g.c_feeds_linear && g.M <= TK_TW_MAX_BLOCK_ROWS) { TkGemm nx{}; nx.M = g.M; nx.K = g.N; top += (tk_tiled_gemm_scratch(nx) + 63) & ~(size_t)63; }
+        if (top > peak) peak = top;
+    }
+    void image(int M, int K) { /* a producer's packed output (layer norm, decoder attention of a short pass) */
+        if (M > TK_TW_MAX_BLOCK_ROWS) return;
+        TkGemm g{};
+        g.M = M; g.K = K;
         const size_t top = used + ((tk_tiled_gemm_scratch(g) + 63) & ~(size_t)63);
         if (top > peak) peak = top;
     }
     void im2col1d(const float*, int, int, int, int, int, int, int, float*) {}
-    void layernorm(const float*, int, int, const float*, const float*, float*) {}
+    void layernorm(const float*, int rows, int D, const float*, const float*, float*) { image(rows, D); }
     void softmax_rows(float*, int, int, int) {}
-    bool attend1(const float*, const float*, const float*, float*, int, int, int64_t, int64_t, int, int) { return true; } /* needs no scratch */
+    bool attend1(const float*, const float*, const float*, float*, int B, int, int64_t, int64_t, int d, int) { image(B, d); return true; }
     void add_rows(float*, const float*, int, int, int) {}
     void embed_rows(const float*, const float*, const int32_t*, const int32_t*, int, int, float*) {}
     void argmax_rows(const float*, int, int, int, int32_t*) {}
@@ -432,6 +505,7 @@ bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* 
     }
     if (n_samples > 0) HIPQ(hipMemcpyAsync(pcm_dev, pcm, (size_t)B * n_samples * 2, hipMemcpyHostToDevice, stream));
     arena_used = 0;
+    launch_error.clear();
     TkAudioGpuOps ops{this, stream};
     TkWhisperGraph<TkAudioGpuOps> g{h, model->man, model->w.data()};
     float* ml = g.mel(ops, pcm_dev, B, n_samples, n_samples);
@@ -468,12 +542,14 @@ bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* 
             HIPQ(hipMemcpyAsync(first_logits->data(), st.logits, first_logits->size() * 4, hipMemcpyDeviceToHost, stream));
         }
     }
+    ops.flush();
     std::vector<int32_t> outs((size_t)n_steps * B);
     HIPQ(hipMemcpyAsync(outs.data(), out_tab + (size_t)(n_prompt - 1) * B, outs.size() * 4, hipMemcpyDeviceToHost, stream));
     HIPQ(hipStreamSynchronize(stream)); /* host_tab and outs live until here */
     for (int step = 0; step < n_steps; ++step)
         for (int b = 0; b < B; ++b) tokens_out[(size_t)b * n_steps + step] = outs[(size_t)step * B + b];
     HIPQ(hipGetLastError());
+    if (!launch_error.empty()) { error = launch_error; return false; }
     return true;
 }
 

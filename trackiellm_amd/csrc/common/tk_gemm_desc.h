@@ -24,6 +24,8 @@ struct TkGemm {
     /* B holds IEEE f16 values (2 bytes each, same [N][ldb] / [K][ldb] indexing in elements): each is widened to f32 exactly, the chain
      * arithmetic is unchanged — f16 checkpoints (LLM fp16 weights) stream half the bytes */
     int b_f16;
+    /* hint, no arithmetic: C is only read as the A operand of the next linear layer (fc1 -> fc2); a backend may emit it pre-packed */
+    int c_feeds_linear;
 };
 
 

@@ -249,7 +249,7 @@ struct TkWhisperGraph {
             attention(o, q, k, v, at, B, Tc, Tc, (int64_t)Tc * d, (int64_t)Tc * d, d, nh, sc);
             o.gemm(lin(at, R, d, d, W[L.o_w], W[L.o_b], d, x, d, 0, x, d));
             o.layernorm(x, R, d, W[L.ln2_w], W[L.ln2_b], hb);
-            o.gemm(lin(hb, R, d, d, W[L.fc1_w], W[L.fc1_b], 4 * d, ff, 4 * d, TK_ACT_GELU));
+            { TkGemm g1 = lin(hb, R, d, d, W[L.fc1_w], W[L.fc1_b], 4 * d, ff, 4 * d, TK_ACT_GELU); g1.c_feeds_linear = 1; o.gemm(g1); }
             o.gemm(lin(ff, R, 4 * d, 4 * d, W[L.fc2_w], W[L.fc2_b], d, x, d, 0, x, d));
         }
         float* y = o.alloc((size_t)R * d);
@@ -307,7 +307,7 @@ struct TkWhisperGraph {
             attention(o, s.q, s.xk[l], s.xv[l], s.at, B, 1, Tc, dt, (int64_t)Tc * dt, dt, nh, s.sc);
             o.gemm(lin(s.at, B, dt, dt, W[L.xo_w], W[L.xo_b], dt, s.x, dt, 0, s.x, dt));
             o.layernorm(s.x, B, dt, W[L.ln2_w], W[L.ln2_b], s.hb);
-            o.gemm(lin(s.hb, B, dt, dt, W[L.fc1_w], W[L.fc1_b], 4 * dt, s.ff, 4 * dt, TK_ACT_GELU));
+            { TkGemm g1 = lin(s.hb, B, dt, dt, W[L.fc1_w], W[L.fc1_b], 4 * dt, s.ff, 4 * dt, TK_ACT_GELU); g1.c_feeds_linear = 1; o.gemm(g1); }
             o.gemm(lin(s.ff, B, 4 * dt, 4 * dt, W[L.fc2_w], W[L.fc2_b], dt, s.x, dt, 0, s.x, dt));
         }
         o.layernorm(s.x, B, dt, W[m.dec_ln_w], W[m.dec_ln_b], s.hb);

@@ -45,6 +45,16 @@ struct TkTiledGemm {
     int ldr;
     int act;                 /* TkAct */
     int add_zero_bias;       /* k_gemm_f32 adds 0.0f when there is no bias (-0 + 0 = +0): reproduce it where results must match that kernel */
+    /* ks == 1 extras (zero = off):
+     * per_seg: every segment is a linear layer of its own on the same input — its own destination, pitch, bias and width (q | k | v of a
+     *   Whisper decoder step in ONE launch: q goes to the query buffer, k and v straight into row p of the caches) */
+    int per_seg;
+    float* seg_out[3];
+    int seg_ldc[3];
+    const float* seg_bias[3];
+    int seg_n[3];
+    /* c_img: the output is ALSO written as the operand image of the next linear layer (K = n_valid), so no pack launch follows */
+    float* c_img;
 };
 
 /* false (nothing launched): K / ks is not a multiple of the ring granularity (128 k; 64 k from 129 rows per block on) or a field is inconsistent */

@@ -37,7 +37,9 @@ __device__ __forceinline__ float tw_act(float v, int act) {
     }
 }
 
-/* WB = bytes per weight value (2: f16, 4: f32); MT = M-tiles per workgroup */
+/* WB = bytes per weight value (2: f16, 4: f32); MT = M-tiles per workgroup.  (Twelve weight pieces in flight for the Whisper decoder's
+ * K = 384 launches — one round trip to the weights instead of three — measured 20 % SLOWER per launch: the whole activation image must
+ * then land before the first MFMA, profiles/r04_perception.txt.) */
 template <int MT, int WB>
 __global__ __launch_bounds__(512) void k_gemm_tiled(TkTiledGemm a, int groups, int total_row_tiles, int rk /* k per ring slot */) {
     /* weight pieces in flight per wave; a ring slot holds a multiple of PF chunks (the launcher's rk), so piece c sits in register set c % PF */
@@ -175,7 +177,29 @@ __global__ __launch_bounds__(512) void k_gemm_tiled(TkTiledGemm a, int groups, i
             }
         return;
     }
+    if (a.per_seg) { /* the segment is a layer of its own: column inside it, its bias, its destination */
+        const int ns = rt * TK_TW_ROWS_PER_TILE + (lane & 15);
+        if (ns >= a.seg_n[seg]) return;
+        const float* bp = a.seg_bias[seg];
+        const float bias = bp ? bp[ns] : 0.0f;
+        float* outp = a.seg_out[seg];
+        const int ldc = a.seg_ldc[seg];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * TK_TW_ROWS_PER_TILE + 4 * g + r;
+                if (row < rows_here) {
+                    float v = acc[m][r];
+                    if (bp || a.add_zero_bias) v = v + bias;
+                    outp[(size_t)(row0 + row) * ldc + ns] = tw_act(v, a.act);
+                }
+            }
+        return;
+    }
     const float bias = a.bias ? a.bias[n] : 0.0f;
+    /* operand-image position of column n as k of the next layer: k = 16 j + 4 t + g2 -> [M-tile][j][g2][row][t] (tk_gemm_tiled.h) */
+    const size_t img_col = (size_t)(n >> 4) * 256 + (size_t)(n & 3) * 64 + ((n & 15) >> 2);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -187,6 +211,7 @@ __global__ __launch_bounds__(512) void k_gemm_tiled(TkTiledGemm a, int groups, i
                 v = tw_act(v, a.act);
                 if (a.residual) v = v + a.residual[(size_t)(row0 + row) * a.ldr + n];
                 a.out[(size_t)(row0 + row) * a.ldc + n] = v;
+                if (a.c_img) a.c_img[(size_t)((row0 + row) >> 4) * 16 * a.n_valid + img_col + (size_t)((row0 + row) & 15) * 4] = v;
             }
         }
 }
@@ -261,6 +286,9 @@ bool tk_gemm_tiled_prepare_device() {
 
 bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
     if (a.nseg < 1 || a.nseg > 3 || a.ks < 1 || a.K <= 0 || a.K % (32 * a.ks) || a.nrows <= 0 || (a.wbytes != 2 && a.wbytes != 4) || (a.ks > 1 && a.nrows > TK_TW_MAX_BLOCK_ROWS)) return false;
+    if ((a.per_seg || a.c_img) && (a.ks != 1 || a.nrows > TK_TW_MAX_BLOCK_ROWS)) return false;
+    if (a.per_seg && (a.residual || a.c_img)) return false;
+    if (a.c_img && (a.n_valid % 16 || a.nseg != 1)) return false;
     int row_tiles = 0;
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.row_tiles[i];
     const int rows_blk = a.nrows < TK_TW_MAX_BLOCK_ROWS ? a.nrows : TK_TW_MAX_BLOCK_ROWS;

@@ -429,7 +429,9 @@ __device__ __forceinline__ float nn_block_sum256(float v, float* red) {
 }
 
 /* y = ((x - mean) * rstd) * w + b ; sums in the canonical 256-partial order */
-__global__ __launch_bounds__(256) void k_layernorm(const float* x, int D, const float* w, const float* b, float eps, float* y) {
+/* img (optional): the rows are ALSO written as the tiled GEMM's operand image (csrc/nn/tk_gemm_tiled.h: element (row, k = 16 j + 4 t + g) at
+ * [row / 16][j][g][row % 16][t]) — the linear layer behind a norm then needs no pack launch */
+__global__ __launch_bounds__(256) void k_layernorm(const float* x, int D, const float* w, const float* b, float eps, float* y, float* img) {
     __shared__ float red[4];
     const int64_t r = blockIdx.x;
     const float* xr = x + r * D;
@@ -440,10 +442,15 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* x, int D, const 
     for (int i = threadIdx.x; i < D; i += 256) { const float d = xr[i] - mean; q = tk_fmaf(d, d, q); }
     const float var = tk_divf(nn_block_sum256(q, red), (float)D);
     const float rstd = tk_divf(1.0f, tk_sqrtf(var + eps));
-    for (int i = threadIdx.x; i < D; i += 256) y[r * D + i] = ((xr[i] - mean) * rstd) * w[i] + b[i];
+    float* ir = img ? img + (r >> 4) * 16 * (int64_t)D + (r & 15) * 4 : nullptr;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float v = ((xr[i] - mean) * rstd) * w[i] + b[i];
+        y[r * D + i] = v;
+        if (ir) ir[(int64_t)(i >> 4) * 256 + (i & 3) * 64 + ((i & 15) >> 2)] = v;
+    }
 }
-void tk_launch_layernorm(const float* x, int rows, int D, const float* w, const float* b, float eps, float* y, hipStream_t s) {
-    hipLaunchKernelGGL(k_layernorm, dim3(rows), dim3(256), 0, s, x, D, w, b, eps, y);
+void tk_launch_layernorm(const float* x, int rows, int D, const float* w, const float* b, float eps, float* y, hipStream_t s, float* img) {
+    hipLaunchKernelGGL(k_layernorm, dim3(rows), dim3(256), 0, s, x, D, w, b, eps, y, img);
 }
 
 /* in-place row softmax over the first `cols` entries of every row (row pitch ld) */
