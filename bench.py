@@ -58,9 +58,10 @@ def q6_layers(n_layer):
 
 
 class CycleBench:
-    """G decode groups x B cycles; one step() = every stream once over G x B cycles, software-pipelined: the LLM consumes the
-    perception results of THIS cycle batch (produced during the previous step) while the detector / ASR / VAD streams already work
-    on the next batch."""
+    """G decode groups x B cycles; one step() = every stream once over G x B cycles: the detector / ASR / VAD streams and the LLM groups
+    run side by side on one GPU, each on its own inputs.  The LLM's prompts are the fixed seeded ids of SURVEY.md 8d, NOT built from this
+    step's detections / transcripts — the streams share the GPU, not data (the multi-GPU placements add the hand-over explicitly:
+    trackiellm_amd/dist.py PerceptionExchange)."""
 
     def __init__(self, tk, model, G, B, P, N, fused, rank, device, perception_batch, asr_steps, vision_device=None, audio_device=None):
         self.tk, self.G, self.B, self.P, self.N, self.fused = tk, G, B, P, N, fused
@@ -136,20 +137,31 @@ class CycleBench:
             return None, 0.0, 0.0, 0.0
         return res[0][0], float(np.mean([r[1] for r in res])), float(np.mean([r[2] for r in res])), float(np.mean([r[3] for r in res]))
 
-    def run(self, steps, warmup, barrier=lambda: None):
+    def run(self, steps, warmup, barrier=lambda: None, exchange=None):
+        """exchange (model-per-gpu placement, LLM rank): every step ends with the hand-over of the perception ranks' results, and a step
+        only generates once the results of ITS batch (handed over at the end of the previous step) are here"""
         self.prime()
-        for _ in range(warmup):
+        need = self.G * self.B
+        for i in range(warmup):
+            if exchange is not None and i > 0:
+                exchange.require(need, need)
             self.step()
+            if exchange is not None:
+                exchange.hand_over(None)
         self.perc_ms["vision"].clear(); self.perc_ms["audio"].clear()
         barrier()
         t0 = time.time()
         pre_s = dec_s = 0.0
         ms_steps = []
-        for _ in range(steps):
+        for i in range(steps):
+            if exchange is not None and (warmup > 0 or i > 0):
+                exchange.require(need, need)
             _, a, b, ms = self.step()
             pre_s += a
             dec_s += b
             ms_steps.append(ms)
+            if exchange is not None:
+                exchange.hand_over(None)
         barrier()
         elapsed = time.time() - t0
         return {"elapsed": elapsed, "prefill_s": pre_s / max(steps, 1), "decode_s": dec_s / max(steps, 1), "decode_ms_per_step": float(np.mean(ms_steps)) if ms_steps else 0.0}
@@ -650,11 +662,22 @@ def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, com
     for pr in same:
         pr[:, 0] = 1
 
+    ex = D.PerceptionExchange(dist, dst=roles["llm"][0]) if combined else None
+    n_done = [0]
+
     def step():
+        """one cycle batch: stage 0 needs the perception results of THIS batch (handed over at the end of the previous step) before it
+        enqueues the batch's passes; every rank ends the step with the hand-over of the batch the perception ranks just finished"""
+        res = None
         if in_llm:
-            return pipe.generate(same, N)
-        cb.step()
-        return None
+            if ex is not None and rank == roles["llm"][0] and n_done[0] > 0:
+                ex.require(cycles, cycles)
+            pipe.generate(same, N)
+        else:
+            res = cb.step()
+        if ex is not None:
+            ex.hand_over(res)
+        n_done[0] += 1
 
     for _ in range(args.warmup):
         step()
@@ -680,6 +703,8 @@ def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, com
                           "dtype": "f16 weights x f16-rounded f32 activations, fp32 MFMA chain" if f16 else DTYPE, "data": "synthetic",
                           "config": {"workload": wl, "concurrent_cycles": cycles, "layers_per_stage": [bounds[r + 1] - bounds[r] for r in range(n_st)],
                                      "roles": roles, "parallelism": par},
+                          **({"perception_handover": {"what": "detections (<= 20 per frame) + ASR token ids of every batch gathered to the pipeline's stage 0 per step, required before its generate",
+                                                      "bytes_per_step": ex.bytes_last, "checksum": ex.checksum}} if ex is not None and rank == roles["llm"][0] else {}),
                           "llm_tok_per_s": round(cycles * N * args.steps / elapsed, 1)}))
     dist.destroy_process_group()
 
@@ -697,24 +722,26 @@ def run_model_per_gpu(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N
     """SURVEY.md §8e rows "2" / "4" / "8": rank 0's GPU holds the LLM and decodes ALL cycles of the job; ranks 1.. run the detector
     (odd ranks) and VAD + ASR (even ranks, all of them when world == 2) for those cycles.  One step = G x B cycles through every
     stream once; the job's value = those cycles / max-over-ranks time.  What crosses GPUs in the reference's design is <= 20 detections
-    and a text string per cycle (bytes, through the host): the bench hands nothing over inside the timed region — the software
-    pipeline of CycleBench (the LLM of batch k next to the perception of batch k + 1) is what the placement preserves."""
+    and a text string per cycle (src/cortex/tk_cortex_main.c:1224-1237, 1323-1345): every step ends with that hand-over
+    (D.PerceptionExchange: one gather to rank 0 inside the timed region) and rank 0 generates for a batch only once its results are there
+    — the software pipeline of CycleBench (the LLM of batch k next to the perception of batch k + 1) with its dependency in place."""
     cycles = G * B
     vis, aud = model_per_gpu_roles(world)
 
     def barrier():
         D.barrier(dist, cuda=COLL_CUDA)
 
+    ex = D.PerceptionExchange(dist, dst=0)
     if rank == 0:
         model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4)
         cb = CycleBench(tk, model, G, B, P, N, False, rank, local_rank, args.perception_batch, args.asr_steps)
-        r = cb.run(args.steps, args.warmup, barrier)
+        r = cb.run(args.steps, args.warmup, barrier, ex)
         role = "llm"
     else:
         share_v = -(-cycles // len(vis)) if rank in vis else 0
         share_a = -(-cycles // len(aud)) if rank in aud else 0
         cb = PerceptionBench(tk, share_v, share_a, rank, local_rank, args.perception_batch, args.asr_steps)
-        r = cb.run(args.steps, args.warmup, barrier)
+        r = cb.run(args.steps, args.warmup, barrier, ex)
         role = "perception"
     elapsed = D.max_over_ranks(dist, r["elapsed"], cuda=COLL_CUDA)
     if rank == 0:
@@ -724,7 +751,9 @@ def run_model_per_gpu(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N
                           "config": {"workload": "configs[3]/[4] fused cycle, one model per GPU (SURVEY.md 8e)", "concurrent_cycles": cycles, "decode_groups": G,
                                      "rows_per_llm_pass": B, "prompt_tokens": P, "decode_tokens": N,
                                      "parallelism": "model-per-gpu x%d: LLM on rank 0; detector on ranks %s; VAD+ASR on ranks %s" % (world, vis, aud)},
-                          "llm_rank_ms_per_step": round(1000.0 * r["elapsed"] / args.steps, 2), "role_of_rank0": role}))
+                          "llm_rank_ms_per_step": round(1000.0 * r["elapsed"] / args.steps, 2), "role_of_rank0": role,
+                          "perception_handover": {"what": "detections (<= 20 per frame) + ASR token ids of every batch gathered to rank 0 per step, required before its generate",
+                                                  "bytes_per_step": ex.bytes_last, "checksum": ex.checksum}}))
     cb.close()
     dist.destroy_process_group()
 
@@ -747,20 +776,25 @@ class PerceptionBench:
             self.pcm = np.clip(rng.normal(0, 3000, (min(n_utts, 4 * self.PB), 16000)), -32768, 32767).astype(np.int16)
 
     def _vision(self):
+        self.dets = []
         for i in range(0, self.n_frames, self.PB):
             n = min(self.PB, self.n_frames - i)
-            self.det.detect_batch([self.frames[(i + k) % len(self.frames)] for k in range(n)])
+            self.dets.extend(self.det.detect_batch([self.frames[(i + k) % len(self.frames)] for k in range(n)]))
 
     def _audio(self):
         for b in range(self.n_utts):
             self.vad.reset()
             self.vad.process_with_events(self.pcm[b % len(self.pcm)])
+        toks = []
         for i in range(0, self.n_utts, self.PB):
             n = min(self.PB, self.n_utts - i)
-            self.asr.transcribe_tokens(self.pcm[[(i + k) % len(self.pcm) for k in range(n)]], self.asr_steps, want_aux=False)
+            toks.append(self.asr.transcribe_tokens(self.pcm[[(i + k) % len(self.pcm) for k in range(n)]], self.asr_steps, want_aux=False)[0])
+        self.toks = np.concatenate(toks) if toks else None
 
     def step(self):
+        """one batch through this rank's streams; returns what the LLM's first rank needs of it (D.pack_perception)"""
         th = []
+        self.dets, self.toks = None, None
         if self.det:
             th.append(threading.Thread(target=self._vision))
         if self.asr:
@@ -769,14 +803,20 @@ class PerceptionBench:
             t.start()
         for t in th:
             t.join()
+        from trackiellm_amd import dist as D
+        return D.pack_perception(self.dets, self.toks)
 
-    def run(self, steps, warmup, barrier):
+    def run(self, steps, warmup, barrier, exchange=None):
         for _ in range(warmup):
-            self.step()
+            res = self.step()
+            if exchange is not None:
+                exchange.hand_over(res)
         barrier()
         t0 = time.time()
         for _ in range(steps):
-            self.step()
+            res = self.step()
+            if exchange is not None:
+                exchange.hand_over(res)  # the step's results travel to the LLM's first rank inside the timed region
         barrier()
         return {"elapsed": time.time() - t0}
 

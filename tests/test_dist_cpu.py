@@ -145,3 +145,56 @@ def test_world_size_3_combined_job_two_stages_plus_perception_rank():
         assert [c[4] for c in passes0] == [False, False, True]                  # 15 prompt rows in chunks of 8, then the sampling pass
         assert ("decode", 3, 4) in s0[g][2] and s0[g][2][-1] == ("sync", 3, 4)
     assert res[0][3] == [(4, 3), (4, 3)] and res[1][3] == [(4, 3), (4, 3)]
+
+
+def _handover_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    from trackiellm_amd import dist as D
+    dist = D.init("gloo")
+    ex = D.PerceptionExchange(dist, dst=0)
+    log = []
+    for step in range(3):
+        if rank == 0:                                   # the LLM's first rank: needs the batch's results before it generates
+            if step > 0:
+                ex.require(4, 4)
+            else:
+                try:
+                    ex.require(4, 4)
+                    log.append("no error")
+                except RuntimeError:
+                    log.append("missing before the first hand-over")
+            got = ex.hand_over(None)
+            log.append((len(got), ex.bytes_last, ex.checksum, [sorted(b.keys()) for b in got]))
+        elif rank == 1:                                 # detector rank: 4 frames, the detector wrapper's tuples, one frame over the cap
+            dets = [[(7, b"person", 0.9, (1 + step, 2, 30, 40))], [], [(k % 80, b"x", 0.5, (k, k, 5, 5)) for k in range(25)], [(1, b"a", 0.6, (0, 0, 1, 1))] * 2]
+            ex.hand_over(D.pack_perception(dets, None))
+        else:                                           # VAD + ASR rank: 4 utterances x 16 token ids
+            ex.hand_over(D.pack_perception(None, np.arange(64, dtype=np.int32).reshape(4, 16) + step))
+    D.barrier(dist, cuda=False)
+    q.put((rank, log))
+    dist.destroy_process_group()
+
+
+def test_perception_results_reach_the_llm_rank_every_step():
+    """bench.py --placement model-per-gpu / combined: every step ends with the gather of detections (<= 20 per frame) and ASR token ids
+    to the LLM's first rank, which refuses to generate for a batch whose results are not there (world size 3 over gloo)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29250 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_handover_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1] for r in (q.get(timeout=120) for _ in range(3))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    log = res[0]
+    assert log[0] == "missing before the first hand-over"
+    steps = log[1:]
+    assert len(steps) == 3 and all(s[0] == 2 for s in steps)                     # two perception ranks contributed each time
+    assert all(s[3] == [["dets", "n_dets"], ["tokens"]] for s in steps)
+    assert steps[0][1] == 4 * 20 * 6 * 4 + 4 * 4 + 4 * 16 * 4                    # frames x 20 x 6 floats + counts + token ids
+    assert len({s[2] for s in steps}) == 3                                       # the payload changed every step and was read

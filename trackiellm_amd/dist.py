@@ -57,6 +57,72 @@ def aggregate_throughput(cycles_per_rank, steps, world, elapsed_max):
     return cycles_per_rank * steps * world / elapsed_max
 
 
+MAX_DETS = 20  # detections per frame that reach the prompt (the reference's max_detected_objects, src/cortex/tk_cortex_main.c:781)
+
+
+def pack_perception(dets, tokens):
+    """what a perception rank hands to the LLM's first rank for its share of a cycle batch — the bytes the reference turns into the
+    prompt's context (src/cortex/tk_cortex_main.c:1224-1237, 1323-1345): per frame up to MAX_DETS (class, confidence, x, y, w, h) rows,
+    per utterance the decoded token ids.  dets: list (per frame) of detection lists / tuples, or None; tokens: int array [n][steps] or None."""
+    import numpy as np
+    out = {}
+    if dets is not None:
+        a = np.zeros((len(dets), MAX_DETS, 6), np.float32)
+        n = np.zeros(len(dets), np.int32)
+        for i, fr in enumerate(dets):
+            k = min(len(fr), MAX_DETS)
+            n[i] = k
+            for j in range(k):
+                d = fr[j]
+                # vision.ObjectDetector.detect_batch: (class id, label, confidence, (x, y, w, h)); or six plain numbers
+                a[i, j] = (d[0], d[2], *d[3]) if len(d) == 4 and isinstance(d[3], (tuple, list)) else tuple(d)[:6]
+        out["dets"], out["n_dets"] = a, n
+    if tokens is not None:
+        out["tokens"] = np.ascontiguousarray(tokens, np.int32)
+    return out
+
+
+class PerceptionExchange:
+    """The cycle's data dependency across ranks (model-per-gpu and combined placements): every step ends with ONE gather of the
+    perception ranks' results of the batch they just finished to the LLM's first rank (rank `dst`), which must hold them before it
+    generates for that batch — the software pipeline of the one-GPU bench (LLM of batch k beside the perception of batch k + 1) with its
+    hand-off made explicit.  Every rank of the job calls hand_over() once per step, in the same place; the payload is a few hundred
+    bytes per cycle and goes through torch.distributed (gather_object: any backend)."""
+
+    def __init__(self, dist, dst=0):
+        self.dist, self.dst = dist, dst
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self.received = None      # on dst: what the perception ranks produced last step
+        self.bytes_last = 0
+        self.checksum = 0
+
+    def hand_over(self, payload):
+        """payload: pack_perception(...) on perception ranks, None elsewhere.  On `dst` the gathered results become `received`."""
+        import numpy as np
+        box = [None] * self.world if self.rank == self.dst else None
+        self.dist.gather_object(payload, box, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        got = [b for b in box if b]
+        self.received = got
+        self.bytes_last = int(sum(v.nbytes for b in got for v in b.values()))
+        cs = 0
+        for b in got:  # consumed: every value is read once (the prompt builder's stand-in; the token ids of the prompt stay the fixed
+            for v in b.values():  # seeded ones of SURVEY.md 8d, so the numbers compare with the one-GPU run)
+                cs = (cs * 1000003 + int(np.asarray(v, np.float64).sum() * 16)) % (1 << 61)
+        self.checksum = cs
+        return got
+
+    def require(self, n_frames, n_utts):
+        """on dst, before generating for a batch: its perception results are here and complete"""
+        got = self.received or []
+        f = sum(len(b["n_dets"]) for b in got if "n_dets" in b)
+        u = sum(len(b["tokens"]) for b in got if "tokens" in b)
+        if f < n_frames or u < n_utts:
+            raise RuntimeError("perception results of this batch are missing: %d / %d frames, %d / %d utterances" % (f, n_frames, u, n_utts))
+
+
 def combined_roles(world):
     """who does what in a job of `world` ranks (one per GPU): {"llm": the pipeline's ranks in stage order, "vision": detector ranks,
     "audio": VAD + ASR ranks}.
