@@ -1084,19 +1084,6 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 
 #define TK_MFMA32 __builtin_amdgcn_mfma_i32_32x32x32_i8
 #define TK_G32_MTW 4 /* 32-row M-tiles per wave */
-#ifndef TK_G32_PK
-#define TK_G32_PK 0 /* 1 = finish two outputs per VALU instruction (v_pk_mul_f32 / v_pk_fma_f32; bit-identical) */
-#endif
-#ifndef TK_G32_BALANCE
-#define TK_G32_BALANCE 1 /* 0 = diagnostic: no progress-based issue priority */
-#endif
-#ifndef TK_G32_ABL
-#define TK_G32_ABL 0 /* diagnostic, TIMING ONLY (results are wrong): 1 no MFMAs, 2 no finishing, 4 no unpack, 8 no ring staging, 32 no LDS operand reads */
-#endif
-#ifndef TK_G32_CLOCK
-#define TK_G32_CLOCK 0 /* diagnostic builds (tools/time_gemv.py --stamps): 1 = one (s_memtime, s_memrealtime) pair around a workgroup's K loop -> in-kernel
-                        * clock and cycles per block; 2 = also cycles per block by segment, stamped only where the wave is drained anyway */
-#endif
 
 /* A-side operands of one 32-row M-tile of one ring block that are requested a tile AHEAD: the first four of the eight 16-byte reads of
  * the int8 MFMAs and the min-term operand; the other four are requested when the tile starts and land under its first MFMAs */
@@ -1126,9 +1113,6 @@ __device__ __forceinline__ void load_atile32(ATile32& T, const Ptrs32& p, int t)
 template <bool Q4, typename Hook>
 __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const Ptrs32& p, float (&acc)[TK_G32_MTW][16], Hook&& after_mfmas) {
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#if TK_G32_PK
-    const v2f dwv = {o.dw, o.dw}, dmv = {-o.dmin, -o.dmin};
-#endif
 #pragma unroll
     for (int t = 0; t < TK_G32_MTW; ++t) {
         /* P = 8 Ph + Pl (64 Ph + Pl for Q6_K) inside ONE accumulator: the high-digit chain first, its result shifted on the VALU, then the
@@ -1138,32 +1122,13 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
 #pragma unroll
         for (int u = 0; u < 4; ++u) A[u] = T.a[u];
         v4f da[4]; /* the block scales of this tile's rows: requested here, used after the MFMAs (a read issued in the finishing loop is waited for at once) */
-#if TK_G32_ABL & 32
-#pragma unroll
-        for (int u = 4; u < 8; ++u) A[u] = T.a[u - 4];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(A[u])); /* opaque per tile: identical operands would let the compiler merge the four tiles' MFMAs */
-        if (Q4) asm volatile("" : "+v"(T.mn));
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { da[b] = (v4f){1.0f, 2.0f, 3.0f, 4.0f}; asm volatile("" : "+v"(da[b])); }
-#else
 #pragma unroll
         for (int u = 4; u < 8; ++u) A[u] = *(const v4i*)(p.ap + t * 8192 + (u >> 1) * 1024 + (u & 1) * 256);
 #pragma unroll
         for (int b = 0; b < 4; ++b) da[b] = *(const v4f*)(p.dp + t * 128 + b * 32);
-#endif
         v16i ph = zero;
         v16f cm;
         v16i pl;
-#if TK_G32_ABL & 1
-#pragma unroll
-        for (int u = 0; u < 8; ++u) asm volatile("" :: "v"(A[u]), "v"(o.bh[u]), "v"(o.bl[u]));
-        asm volatile("" :: "v"(T.mn), "v"(o.bm16));
-        asm volatile("" : "=v"(ph));
-        asm volatile("" : "=v"(cm));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pl[r] = ph[r] << (Q4 ? 3 : 6);
-#else
 #pragma unroll
         for (int u = 0; u < 8; ++u) ph = TK_MFMA32(A[u], o.bh[u], ph, 0, 0, 0);
         if (Q4) {
@@ -1174,37 +1139,11 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
         for (int r = 0; r < 16; ++r) pl[r] = ph[r] << (Q4 ? 3 : 6);
 #pragma unroll
         for (int u = 0; u < 8; ++u) pl = TK_MFMA32(A[u], o.bl[u], pl, 0, 0, 0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
-#if !(TK_G32_ABL & 32)
         if (t + 1 < TK_G32_MTW) load_atile32<Q4>(T, p, t + 1);
-#endif
         after_mfmas(t); /* a quarter of this wave's ring staging for the next block: LDS-DMA issue costs 60-180 cycles a piece, here they pass while
                          * the tile's MFMAs are still in the matrix pipe */
         __builtin_amdgcn_sched_barrier(0);
-#if TK_G32_ABL & 2
-        asm volatile("" :: "v"(pl), "v"(cm));
-#pragma unroll
-        for (int b = 0; b < 4; ++b) asm volatile("" :: "v"(da[b]));
-#elif TK_G32_PK
-        /* the same IEEE operations two outputs at a time: (-dmin) * da == -(dmin * da) exactly */
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                const int r = 4 * b + i;
-                const v2f dav = {da[b][i], da[b][i + 1]};
-                const v2f pf = {(float)pl[r], (float)pl[r + 1]};
-                v2f a2 = {acc[t][r], acc[t][r + 1]};
-                a2 = __builtin_elementwise_fma(dwv * dav, pf, a2);
-                if (Q4) {
-                    const v2f cmv = {cm[r], cm[r + 1]};
-                    a2 = __builtin_elementwise_fma(dmv * dav, cmv, a2);
-                }
-                acc[t][r] = a2[0];
-                acc[t][r + 1] = a2[1];
-            }
-#else
 #pragma unroll
         for (int b = 0; b < 4; ++b) /* accumulator register 4 b + i = row 8 b + 4 h + i of the M-tile */
 #pragma unroll
@@ -1213,7 +1152,6 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
                 acc[t][r] = tk_fmaf(o.dw * da[b][i], (float)pl[r], acc[t][r]);
                 if (Q4) acc[t][r] = tk_fmaf(-(o.dmin * da[b][i]), cm[r], acc[t][r]);
             }
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -1231,41 +1169,20 @@ __device__ __forceinline__ void g32_unpack(const typename G32Frag<Q4>::type& f0,
     else unpack_q6_x32(f0, f1, lane, o);
 }
 
-#if TK_G32_CLOCK
-__device__ unsigned long long g_g32_stamps[1024][8]; /* K-loop cycles, K-loop 100 MHz ticks, blocks, grid, absolute 100 MHz time at kernel entry / loop start / loop end / exit */
-__device__ unsigned long long g_g32_seg[1024][8][4]; /* per wave, summed over the blocks: unpack, tile loop, s_waitcnt, barrier */
-extern "C" __attribute__((visibility("default"))) int tk_debug_g32_stamps(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g32_stamps), (size_t)n * 64);
-}
-extern "C" __attribute__((visibility("default"))) int tk_debug_g32_seg(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g32_seg), (size_t)n * 8 * 32);
-}
-#endif
-#if TK_G32_CLOCK == 2
-#define TK_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define TK_SEG(i, d) seg[i] += (d) /* 0 unpack, 1 tiles, 2 the wait (+ the early wave's barrier) before the unpack, 3 the late wave's wait + barrier */
-#else
-#define TK_STAMP(v)
-#define TK_SEG(i, d)
-#endif
 
 /* The K loop of one wave: its two weight tiles (32 weight rows) against its four 32-row M-tiles, block by block through the ring. */
 template <bool Q4, typename StageSmall, typename StagePart>
 __device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_bytes, ptrdiff_t tile_pitch, int nb, const uint8_t* ring, int slot_bytes, int lane,
-                                           float (&acc)[TK_G32_MTW][16], unsigned long long* seg, StageSmall&& stage_small, StagePart&& stage_part) {
+                                           float (&acc)[TK_G32_MTW][16], StageSmall&& stage_small, StagePart&& stage_part) {
     typedef typename G32Frag<Q4>::type F;
     F f0 = g32_load<Q4>(tile, lane), f1 = g32_load<Q4>(tile + tile_pitch, lane);
     stage_small(0, 0);
     for (int part = 0; part < 4; ++part) stage_part(0, 0, part);
 #pragma unroll 1
     for (int b = 0; b < nb; ++b) {
-        TK_STAMP(s_w0);
         __builtin_amdgcn_s_waitcnt(0);
-        TK_STAMP(s_w1);
         __syncthreads();
-        TK_STAMP(s_top);
         const bool more = b + 1 < nb;
-#if TK_G32_BALANCE
         { /* a CU's two workgroups share its SIMDs under oldest-first arbitration: the older one runs near its solo rate, the younger one on what
            * is left and finishes alone (K loop 58 / 74 us for gate|up).  Issue priority that falls with progress lets the one that is behind
            * catch up: 63 / 71 us, launch set - 1..3 % (profiles/r03_gemm32_balance.txt) */
@@ -1275,46 +1192,21 @@ __device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_byte
             else if (q == 2) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
-#endif
-#if !(TK_G32_ABL & 8)
         if (more) stage_small(b + 1, (b + 1) & 1);
-#endif
         const uint8_t* next = tile + (size_t)(more ? b + 1 : b) * tile_bytes; /* the last step re-requests its own tile: no branch around a load */
         const Ptrs32 bp = block_ptrs32(ring + (b & 1) * slot_bytes, lane);
         ATile32 T;
-#if TK_G32_ABL & 32
-        for (int u = 0; u < 4; ++u) { T.a[u] = (v4i){lane, b, u, 3}; asm volatile("" : "+v"(T.a[u])); }
-        asm volatile("" : "=v"(T.mn));
-#else
         load_atile32<Q4>(T, bp, 0); /* tile 0's operands: their LDS latency hides under the unpack */
-#endif
         __builtin_amdgcn_sched_barrier(0);
         Ops32 o;
-#if TK_G32_ABL & 4
-        for (int u = 0; u < 8; ++u) {
-            o.bl[u] = (v4i){(int)f0.q0.x, (int)f0.q0.y, (int)f1.q0.z, (int)f1.q0.w};
-            o.bh[u] = (v4i){(int)f0.q1.x, (int)f0.q1.y, (int)f1.q1.z, (int)f1.q1.w};
-            asm volatile("" : "+v"(o.bl[u]), "+v"(o.bh[u]));
-        }
-        asm volatile("" : "=v"(o.bm16));
-        o.dw = __int_as_float(f0.q0.x); o.dmin = __int_as_float(f1.q0.y);
-#else
         g32_unpack<Q4>(f0, f1, lane, o);
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        TK_STAMP(s_un);
         f0 = g32_load<Q4>(next, lane);
         f1 = g32_load<Q4>(next + tile_pitch, lane);
         __builtin_amdgcn_sched_barrier(0);
         /* the last block restages itself into the slot nobody reads any more: no branch around the DMA issue */
-#if TK_G32_ABL & 8
-        gemm_block32<Q4>(o, T, bp, acc, [&](int) {});
-#else
         gemm_block32<Q4>(o, T, bp, acc, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        TK_STAMP(s_end);
-        TK_SEG(0, s_un - s_top); TK_SEG(1, s_end - s_un); TK_SEG(2, s_w1 - s_w0); TK_SEG(3, s_top - s_w1);
     }
 }
 
@@ -1329,9 +1221,6 @@ __device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_byte
 template <int TYPES>
 __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups, int total_row_tiles, int n_halves) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-#if TK_G32_CLOCK
-    const unsigned long long sr_entry = __builtin_amdgcn_s_memrealtime();
-#endif
     constexpr int MT = TK_G32_MT;
     constexpr int CH = MT * TK_RING_TILE_BYTES;   /* one block of the ring */
     constexpr int OFF_AMN = MT * 4096, OFF_AD = MT * 4096 + MT * 512;
@@ -1405,10 +1294,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
         }
     };
 
-#if TK_G32_CLOCK
-    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    unsigned long long segc[4] = {0, 0, 0, 0};
     if (!active) { /* a workgroup's spare wave slots (row tiles beyond the matrix) still stage their share of the ring */
         stage_small(0, 0);
         for (int part = 0; part < 4; ++part) stage_part(0, 0, part);
@@ -1420,31 +1305,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
         }
         return;
     }
-    if (HAS4 && is4) g32_k_loop<true>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, segc, stage_small, stage_part);
-    if (HAS6 && !is4) g32_k_loop<false>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, segc, stage_small, stage_part);
-#if TK_G32_CLOCK
-    if (tid == 0 && blockIdx.x < 1024) {
-        g_g32_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st0;
-        g_g32_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
-        g_g32_stamps[blockIdx.x][2] = (unsigned long long)nb;
-        g_g32_stamps[blockIdx.x][3] = (unsigned long long)gridDim.x;
-        g_g32_stamps[blockIdx.x][4] = sr_entry;
-        g_g32_stamps[blockIdx.x][5] = sr0;
-        g_g32_stamps[blockIdx.x][6] = __builtin_amdgcn_s_memrealtime();
-    }
-    if (lane == 0 && blockIdx.x < 1024)
-        for (int i = 0; i < 4; ++i) g_g32_seg[blockIdx.x][pair + 4 * half][i] = segc[i];
-#endif
+    if (HAS4 && is4) g32_k_loop<true>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, stage_small, stage_part);
+    if (HAS6 && !is4) g32_k_loop<false>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, stage_small, stage_part);
 
-#ifndef TK_G32_NT_STORE
-#define TK_G32_NT_STORE 0 /* 1 = diagnostic: non-temporal slab stores.  Default policy: the 4..29 MB of slabs a launch writes are read back at once by
-                           * the norm / SwiGLU / attention kernel behind it and fit the 256 MiB Infinity Cache (LLM-only 3 x 256: 213.8 -> 218.0
-                           * cycles/s, profiles/r04_gemm32_stores.txt); the weight stream keeps its non-temporal loads and does not evict them */
-#endif
-#ifndef TK_G32_WIDE_STORE
-#define TK_G32_WIDE_STORE 1 /* 0 = diagnostic: one dword per lane and store instruction */
-#endif
-#if TK_G32_WIDE_STORE
     /* Epilogue: 64 accumulator registers per lane.  Stored as they stand, a store instruction writes one dword per lane (two 128-byte row
      * segments): 64 store instructions per wave, and the tail of the launch is store-ISSUE bound (exit - loop end 4 us of gate|up's 76).
      * So each 32 x 32 tile goes through LDS once — into the 4 KiB ring regions THIS wave staged itself (M-tiles `pair` and `pair + 4` of
@@ -1479,29 +1342,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
                 const int rl = 8 * i + (lane >> 3);
                 const v4f v = *(const v4f*)(sp + rl * 32 + 4 * (lane & 7));
                 const int row = (half * TK_G32_MTW + t) * 32 + rl;
-#if TK_G32_NT_STORE
-                if (row < a.nrows) __builtin_nontemporal_store(v, (v4f*)&a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n0]);
-#else
                 if (row < a.nrows) *(v4f*)&a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n0] = v;
-#endif
             }
         }
     }
-#else
-    const int n = a.col0 + row_base + rt * TK_TILE_ROWS + (lane & 31);
-    const int h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < TK_G32_MTW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (half * TK_G32_MTW + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < a.nrows) __builtin_nontemporal_store(acc[t][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
-        }
-#endif
-#if TK_G32_CLOCK
-    __builtin_amdgcn_s_waitcnt(0);
-    if (tid == 0 && blockIdx.x < 1024) g_g32_stamps[blockIdx.x][7] = __builtin_amdgcn_s_memrealtime();
-#endif
 }
 
 /* compute units of the calling thread's current device (every launcher runs with the session's device current): read once per device */
@@ -1680,9 +1524,6 @@ __device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int las
 }
 
 template <int GQ, bool FUSED, int HD /* head_dim when it is 64 or 128 (loops unroll, LDS reads batch), 0 = any */, int CH /* positions per ring slot */, int SLOTS = 2>
-#ifndef TK_ATT_ABL
-#define TK_ATT_ABL 0 /* diagnostic, TIMING ONLY: 1 no QK dot products, 2 one PV batch per chunk */
-#endif
 #ifndef TK_ATT_WAVES
 #define TK_ATT_WAVES 1
 #endif
@@ -1784,12 +1625,7 @@ __global__ __launch_bounds__(256, TK_ATT_WAVES) void k_attention(const float* __
                 const float* qh = qs + h * head_dim;
                 float a = 0.0f;
                 constexpr int KB = HD ? HD / 8 : 1; /* key pieces read per batch: the whole row when head_dim is known */
-#if TK_ATT_ABL & 1
-                a = (float)kr[t & 15] + qh[t & 31];
-                for (int i0 = 0; i0 < 0; i0 += KB) {
-#else
                 for (int i0 = 0; i0 < ppr; i0 += KB) {
-#endif
                     uint4 kv[KB];
 #pragma unroll
                     for (int u = 0; u < KB; ++u) kv[u] = *(const uint4*)(kr + (((i0 + u) ^ (rr & (ppr - 1))) * 16));
@@ -1837,11 +1673,7 @@ __global__ __launch_bounds__(256, TK_ATT_WAVES) void k_attention(const float* __
         /* positions in batches of PB: every LDS read of a batch is issued before its first fma (out-of-range slots of the last batch
          * read a clamped row and enter with probability 0: fma(0, v, acc) == acc and l + 0 == l exactly, the canonical order is untouched) */
         constexpr int PB = 4;
-#if TK_ATT_ABL & 2
-        for (int rr0 = wave; rr0 < (t_end < 1 ? t_end : 1); rr0 += PB * TK_ATT_TSPLIT) {
-#else
         for (int rr0 = wave; rr0 < t_end; rr0 += PB * TK_ATT_TSPLIT) {
-#endif
             float pr[PB][GQ];
             uint32_t vv[PB][2];
 #pragma unroll
