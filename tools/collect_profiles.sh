@@ -9,14 +9,24 @@
 # Everything lands under gpurun_out/; copy what should be judged into profiles/.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 O=gpurun_out
 one_csv() { # exactly one counter file per pass, or stop: a stale directory must never feed a freshly stamped summary
   local n; n=$(find "$1" -name '*counter_collection.csv' | wc -l)
   [ "$n" = 1 ] || { echo "expected one counter_collection.csv under $1, found $n" >&2; exit 1; }
   find "$1" -name '*counter_collection.csv'
 }
-export TK_MI355X_NO_GRAPH=1   # PMC passes: eager launches (one dispatch record per kernel)
+# PMC passes run the GRAPH path too (the shipped one): a counter pass yields one dispatch record per kernel node of a replayed graph.
+# ROC_AQL_QUEUE_SIZE: rocprofv3's queue interceptor walks a multi-packet submission linearly and runs off the end of the AQL ring when a
+# hipGraphLaunch batch straddles it (profiles/r03_rocprofv3_hipgraph_crash_symbolised.txt); the ring must therefore never wrap inside a
+# profiled process.  PACKET BUDGET: every profiled command below must submit fewer packets per queue than the ring holds — kernels + a
+# barrier packet per graph launch; bench.py --steps 1 --warmup 1 at 3 x 256 is ~100 k (64 prefill passes + 128 decode steps of ~260 kernels,
+# twice), the largest here.  More steps, warm-up or decode length need a larger ring FIRST, or the abort of round 2 comes back.
+export ROC_AQL_QUEUE_SIZE=131072
+check_budget() { # kernel-trace rows of a finished run against the ring
+  local n; n=$(($(cat "$1" | wc -l) - 1))
+  [ "$n" -lt $((ROC_AQL_QUEUE_SIZE * 9 / 10)) ] || { echo "packet budget: $n dispatches of $1 are within 10 % of ROC_AQL_QUEUE_SIZE=$ROC_AQL_QUEUE_SIZE: enlarge the ring" >&2; exit 1; }
+}
 for B in 256 16; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf "/tmp/pmc_${B}_${C}"
@@ -33,8 +43,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/pmc_gemv.py "$(one_csv /tmp/pmc_att_FETCH_SIZE)" "$(one_csv /tmp/pmc_att_WRITE_SIZE)" 256 $O/${R}_pmc_attention_b256.json k_attention 128 > $O/${R}_pmc_attention_b256.txt || exit 1
 tail -1 $O/${R}_pmc_attention_b256.txt
-unset TK_MI355X_NO_GRAPH
-export ROC_AQL_QUEUE_SIZE=131072   # kernel traces of the graph path (see the header)
+# kernel traces of the graph path
 rm -rf /tmp/kt_rl
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_rl -o rl -- python3 bench.py --roofline-only > $O/${R}_roofline_only_run.json 2> $O/${R}_roofline_only.err || { echo "roofline-only trace failed"; exit 1; }
 cp "$(find /tmp/kt_rl -name '*kernel_stats.csv' | head -1)" $O/${R}_roofline_only_kernel_stats.csv
@@ -42,6 +51,7 @@ python3 tools/roofline_check.py "$(find /tmp/kt_rl -name '*kernel_trace.csv' | h
 rm -rf /tmp/kt_f
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_f -o f -- python3 bench.py --steps 1 --warmup 1 --no-extras > $O/${R}_fused_3x256_rocprof_run.json 2> $O/${R}_fused_rocprof.err || { echo "fused trace failed"; exit 1; }
 cp "$(find /tmp/kt_f -name '*kernel_stats.csv' | head -1)" $O/${R}_fused_3x256_kernel_stats.csv
+check_budget "$(find /tmp/kt_f -name '*kernel_trace.csv' | head -1)"
 for B in 256 16; do
   rm -rf /tmp/kt_b
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_b -o b -- python3 bench.py --llm-only --batch $B --sessions 1 --steps 1 --warmup 1 --no-extras > $O/${R}_llm_b${B}_solo_run.json 2> $O/${R}_llm_b${B}_solo.err || { echo "solo trace $B failed"; exit 1; }
