@@ -53,6 +53,13 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def newest_pmc(name):
+    """the newest profiles/rNN_pmc_<name>.json (the round prefix sorts), or a path that does not exist"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s.json" % name)))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "none_pmc_%s.json" % name)
+
+
 def q6_layers(n_layer):
     return [l for l in range(n_layer) if l < n_layer // 8 or l >= 7 * n_layer // 8 or (l - n_layer // 8) % 3 == 2]
 
@@ -232,7 +239,7 @@ def gemv_roofline(sess, hp, rows, model_weight_bytes, iters=50):
            "int8_ops_per_weight_byte": round(2.0 * rows * w_step / total_w, 1)}
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction applied): only a
     # summary collected from THIS kernel source counts; anything else would be a stale number
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_%s_b%d.json" % ("gemm" if rows > 32 else "gemv", rows))
+    pmc = newest_pmc("%s_b%d" % ("gemm" if rows > 32 else "gemv", rows))
     if os.path.exists(pmc):
         pj = json.load(open(pmc))
         if pj.get("rows_per_pass") == rows and pj.get("kernel_source_sha") == kernel_source_sha():
@@ -248,7 +255,7 @@ def attention_roofline(sess, hp, rows, ctx, iters=64):
     out = {"bound": "hbm", "kernel": "k_attention", "rows_per_pass": rows, "cached_positions": ctx, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": round(kvb), "avg_launch_ms": round(ms, 5),
            "launches_per_decode_step": hp.n_layer, "traffic": None, "waste_ratio": None}
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_attention_b%d.json" % rows)  # tools/pmc_gemv.py <fetch> <write> <rows> <out> k_attention <ctx>
+    pmc = newest_pmc("attention_b%d" % rows)  # tools/pmc_gemv.py <fetch> <write> <rows> <out> k_attention <ctx>
     if os.path.exists(pmc):
         pj = json.load(open(pmc))
         if pj.get("rows_per_pass") == rows and pj.get("cached_positions") == ctx and pj.get("kernel_source_sha") == kernel_source_sha():

@@ -159,6 +159,95 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
 }
 
 /*
+ * Narrow outputs (N <= 32: the detector's high-resolution layers have 16 or 32 output channels and hundreds of thousands of rows): the
+ * 64x64 tile above spends half or three quarters of its MFMAs on columns that do not exist.  Here a workgroup covers 128 rows x 32
+ * columns, its four waves stacked in M; same slabs, same k-ordered chain per output element (bit-identical), A [M][lda] and B [N][ldb]
+ * with k contiguous only.
+ */
+#define NBM 128
+__global__ __launch_bounds__(256) void k_gemm_f32_n32(TkGemm g) {
+    __shared__ float As[NBM * LDS_LD];
+    __shared__ float Bs[32 * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * NBM;
+    const float* A = g.A;
+    const float* B = g.B;
+    float* C = g.C;
+    v16f acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
+    const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & 15) == 0;
+    float ra[4][4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { /* A: 128 rows x 32 k = 1024 groups of 4 k */
+            const int e = tid + 256 * h, row = e >> 3, kc = (e & 7) * 4;
+            const int m = m0 + row, k = k0 + kc;
+            ra[h][0] = ra[h][1] = ra[h][2] = ra[h][3] = 0.0f;
+            if (m < g.M) {
+                const float* p = A + (int64_t)m * g.lda + k;
+                if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; ra[h][0] = t.x; ra[h][1] = t.y; ra[h][2] = t.z; ra[h][3] = t.w; }
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (k + i < g.K) ra[h][i] = p[i];
+                }
+            }
+        }
+        { /* B: 32 rows x 32 k = 256 groups */
+            const int row = tid >> 3, kc = (tid & 7) * 4, k = k0 + kc;
+            rb[0] = rb[1] = rb[2] = rb[3] = 0.0f;
+            if (row < g.N) {
+                const float* p = B + (int64_t)row * g.ldb + k;
+                if (b_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; rb[0] = t.x; rb[1] = t.y; rb[2] = t.z; rb[3] = t.w; }
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[i] = p[i];
+                }
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int e = tid + 256 * h, row = e >> 3, kc = (e & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[row * LDS_LD + kc + i] = ra[h][i];
+        }
+        const int row = tid >> 3, kc = (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[row * LDS_LD + kc + i] = rb[i];
+    };
+    gload(0);
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < g.K) gload(k0 + BK);
+        const float* ap = As + (wave * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
+        const float* bp = Bs + (lane & 31) * LDS_LD + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int n = lane & 31;
+    if (n >= g.N) return;
+    const float bias = g.bias ? g.bias[n] : 0.0f;
+    const float* R = g.residual;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M) {
+            float v = acc[r];
+            if (g.alpha != 1.0f) v = v * g.alpha;
+            v = v + bias;
+            v = apply_act(v, g.act);
+            if (R) v = v + R[(int64_t)m * g.ldr + n];
+            C[(int64_t)m * g.ldc + n] = v;
+        }
+    }
+}
+
+/*
  * Large-shape variant: 128x128 output tile per workgroup, each of the 4 waves owns 64x64 = 2x2 MFMA tiles (4 accumulators),
  * k slabs of 32 double-buffered in LDS: the next slab's global loads are issued before the current slab's 64 MFMAs and
  * written to the other buffer afterwards, one barrier per slab.  Same k-ordered chain per output element as k_gemm_f32.
@@ -323,6 +412,10 @@ void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
         (void)tk_nn_prepare_device();
         dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
         hipLaunchKernelGGL(k_gemm_f32_big, grid, dim3(256), lds, s, g);
+        return;
+    }
+    if (g.N <= 32 && g.M >= 4 * NBM && !g.b_kn && !g.b_f16 && nz == 1 && g.batch_inner == 0) { /* narrow and tall: no MFMAs on absent columns */
+        hipLaunchKernelGGL(k_gemm_f32_n32, dim3(1, (g.M + NBM - 1) / NBM, 1), dim3(256), 0, s, g);
         return;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nz);
