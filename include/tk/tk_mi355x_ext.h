@@ -100,8 +100,13 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_decode(tk_mi355x_llm_session_t
  * with hipIpc across processes — one process per GPU — or by pointer inside one process: peer memory over xGMI), the last stage samples and
  * returns the ids to stage 0 the same way.  No host synchronisation, host copy or collective per pass; a stage's decode step is one captured
  * hipGraph.  payload_f16 = 0: the stream crosses as exact fp32 (tokens and logits bit-identical to one GPU); 1: IEEE f16, half the bytes, the
- * stream rounded once per boundary.  Every device-side wait is bounded (20 s): tk_mi355x_pipe_sync then returns TK_ERROR_TIMEOUT.
- * All stages must enqueue the same passes in the same order.  csrc/llm/tk_llm_pipe.h has the protocol. ---- */
+ * stream rounded once per boundary.  Every device-side wait is bounded (20 s; $TK_MI355X_PIPE_TIMEOUT_S seconds when set at create time):
+ * after a timeout every later wait of the stage returns at once, tk_mi355x_pipe_sync returns TK_ERROR_TIMEOUT and the pipe stays failed —
+ * pass / decode / sync keep failing until it is destroyed and re-created (its sequence numbers no longer agree with its neighbours').
+ * The mailbox is fine-grained device memory (peer writes while kernels poll; $TK_MI355X_PIPE_COARSE=1: plain hipMalloc, one-device A/B only).
+ * Any number of generations may run on one set of pipes: a pass with host-given tokens first discards the ids the previous generation left in
+ * the id mailbox; a decode() needs a sampling pass (head != 0) before it.
+ * All stages must enqueue the same passes in the same order.  csrc/llm/tk_llm_pipe.h has the protocol and the coherence argument. ---- */
 typedef struct tk_mi355x_pipe_s tk_mi355x_pipe_t;
 typedef struct { uint8_t ipc[64]; uint64_t bytes; int32_t device; int32_t pid; } tk_mi355x_pipe_handle_t; /* plain bytes: move them between processes any way */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_create(tk_mi355x_pipe_t** out, tk_mi355x_llm_session_t* s, int stage, int n_stages, int layer0, int layer1,
