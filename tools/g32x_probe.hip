@@ -171,6 +171,13 @@ int main() {
         run<9, 0, true, 0>("96 VALU + 13 ds_read_b128 (no MFMA)");
         run<9, 0, false, 0>("96 VALU only");
         run<9, -1, true, 0>("13 ds_read_b128 only");
+        /* the whole one-wave tile: + the unpack's share at 256 rows per wave (24 VALU) + two LDS-DMA pieces per tile, in compiler order and with
+         * the instruction stream grouped per MFMA by sched_group_barrier (1 MFMA : 1 LDS read : 7 VALU / 1 : 4 VALU : 1 read : 3 VALU) */
+        run<0, 24, true, 2>("compiler order: 17 MFMA + 96 + 24 VALU + 13 ds_read + 1.5 DMA");
+        run<1, 24, true, 2>("grouped (read first): the same");
+        run<2, 24, true, 2>("grouped (read mid): the same");
+        run<0, 24, false, 0>("compiler order: 17 MFMA + 96 + 24 VALU");
+        run<1, 24, false, 0>("grouped: 17 MFMA + 96 + 24 VALU");
     }
     return 0;
 }
