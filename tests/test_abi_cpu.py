@@ -90,3 +90,31 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split()[0]
+
+
+def test_module_executors_register_through_the_hosts_function():
+    """include/tk/tk_module_exec.h: the reference's plugin path (tk_module_register, src/ffi/src/ffi_bridge.rs:1298) gets one executor for
+    VISION / AUDIO / CORTEX through the host's own register function; unknown commands and null inputs come back as the reference's
+    TkStatus codes (src/ffi/c_api/tk_ffi_api.h:109-121).  No compute here."""
+    import trackiellm_amd
+    L = trackiellm_amd.lib()
+    EXEC = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_void_p)
+    REG = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_int32, EXEC)
+    seen = []
+
+    def host_register(module, fn):
+        seen.append((module, ctypes.cast(fn, ctypes.c_void_p).value))
+        return 0
+
+    L.tk_mi355x_register_modules.argtypes = [REG]
+    assert L.tk_mi355x_register_modules(REG(host_register)) == 0
+    addr = ctypes.cast(L.tk_mi355x_module_executor, ctypes.c_void_p).value
+    assert seen == [(10, addr), (20, addr), (0, addr)]                      # TK_MODULE_VISION, _AUDIO, _CORTEX
+    assert L.tk_mi355x_register_modules(REG(lambda m, f: -6)) == -6         # the host's refusal is passed on
+    L.tk_mi355x_module_executor.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_void_p]
+    buf = ctypes.create_string_buffer(128)
+    assert L.tk_mi355x_module_executor(None, 10, b"segment", buf) == -7     # TK_STATUS_ERROR_UNSUPPORTED_FEATURE
+    assert L.tk_mi355x_module_executor(None, 40, b"detect", buf) == -7      # navigation is not on this path
+    assert L.tk_mi355x_module_executor(None, 10, b"detect", None) == -1     # TK_STATUS_ERROR_NULL_POINTER
+    assert L.tk_mi355x_module_executor(None, 10, b"detect", buf) == -1      # zeroed command: no detector handle
+    assert L.tk_mi355x_module_executor(None, 0, None, buf) == -1

@@ -148,3 +148,70 @@ def test_cortex_with_depth_model_reports_distances(gpu, tmp_path):
     dist = [float(m) for m in re.findall(r"\((\d+\.\d)m, ", pr)]
     assert dist and any(0.1 <= d <= 10.0 for d in dist), pr[:400]
     cx.close()
+
+
+def test_module_executors_run_the_three_streams(gpu):
+    """tk_mi355x_module_executor (include/tk/tk_module_exec.h): "detect" / "transcribe" / "generate" through the reference's plugin
+    signature give what the wrapped tk_* entry points give when called directly"""
+    import ctypes as C
+    from trackiellm_amd import vision as V, audio as A
+    L = gpu.lib()
+    L.tk_mi355x_module_executor.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p]
+
+    class CmdDetect(C.Structure):
+        _fields_ = [("detector", C.c_void_p), ("frame", C.c_void_p), ("results", C.POINTER(V.DetectionResult)), ("count", C.c_size_t), ("error", C.c_int)]
+
+    class CmdTranscribe(C.Structure):
+        _fields_ = [("asr", C.c_void_p), ("pcm", C.c_void_p), ("frame_count", C.c_size_t), ("is_final", C.c_bool), ("result", C.POINTER(A.AsrResult)), ("error", C.c_int)]
+
+    class CmdGenerate(C.Structure):
+        _fields_ = [("runner", C.c_void_p), ("prompt", C.c_char_p), ("use_tool_grammar", C.c_bool), ("max_tokens", C.c_int32), ("out_text", C.c_void_p),
+                    ("out_cap", C.c_size_t), ("out_len", C.c_size_t), ("n_tokens", C.c_int32), ("tool_call", C.c_bool), ("error", C.c_int)]
+
+    rng = np.random.default_rng(3)
+    # vision
+    det = gpu.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", width=640, height=640, conf=0.5, iou=0.5)
+    frame = rng.integers(0, 256, (640, 640, 3), dtype=np.uint8)
+    want = det.detect(frame)
+    f, keep = V.make_frame(frame)
+    cd = CmdDetect(det.h, C.cast(C.pointer(f), C.c_void_p), None, 0, 0)
+    assert L.tk_mi355x_module_executor(None, 10, b"detect", C.byref(cd)) == 0 and cd.error == 0
+    got = [(cd.results[i].class_id, cd.results[i].label, cd.results[i].confidence, (cd.results[i].bbox.x, cd.results[i].bbox.y, cd.results[i].bbox.w, cd.results[i].bbox.h))
+           for i in range(cd.count)]
+    L.tk_object_detector_free_results(C.byref(cd.results))
+    assert got == want and len(got) > 0
+    det.close()
+    # audio
+    asr = gpu.Asr()
+    asr.set_decode_steps(6)
+    pcm = np.clip(rng.normal(0, 3000, 16000), -32768, 32767).astype(np.int16)
+    want_a = asr.process_audio(pcm, True)
+    ct = CmdTranscribe(asr.h, pcm.ctypes.data_as(C.c_void_p), pcm.size, True, None, 0)
+    assert L.tk_mi355x_module_executor(None, 20, b"transcribe", C.byref(ct)) == 0 and ct.error == 0 and bool(ct.result)
+    got_a = (ct.result.contents.text.decode() if ct.result.contents.text else None, ct.result.contents.text_length, ct.result.contents.confidence, ct.result.contents.is_partial)
+    L.tk_asr_whisper_free_result(C.byref(ct.result))
+    assert got_a == want_a
+    asr.close()
+    # cortex / LLM
+    loader = gpu.ModelLoader()
+    h = loader.load("synthetic://tiny?seed=4")
+    runner = gpu.LlmRunner(h, context_size=64)
+    runner.prepare("hi there")
+    pieces = []
+    for _ in range(5):
+        p = runner.next_token()
+        if p is None or p == "<tool_call>":
+            break
+        pieces.append(p)
+    runner.reset()
+    out = C.create_string_buffer(256)
+    cg = CmdGenerate(runner.h, b"hi there", False, 5, C.cast(out, C.c_void_p), 256, 0, 0, False, 0)
+    assert L.tk_mi355x_module_executor(None, 0, b"generate", C.byref(cg)) == 0 and cg.error == 0
+    assert out.raw[:cg.out_len] == b"".join(pieces) and cg.n_tokens == len(pieces) and not cg.tool_call
+    small = C.create_string_buffer(1)
+    cg2 = CmdGenerate(runner.h, b"hi there", False, 5, C.cast(small, C.c_void_p), 1, 0, 0, False, 0)
+    if len(b"".join(pieces)) > 0:
+        assert L.tk_mi355x_module_executor(None, 0, b"generate", C.byref(cg2)) == -2 and cg2.error == 1004   # TK_ERROR_BUFFER_TOO_SMALL
+    runner.close()
+    loader.unload(h)
+    loader.close()
