@@ -118,3 +118,20 @@ def test_module_executors_register_through_the_hosts_function():
     assert L.tk_mi355x_module_executor(None, 10, b"detect", None) == -1     # TK_STATUS_ERROR_NULL_POINTER
     assert L.tk_mi355x_module_executor(None, 10, b"detect", buf) == -1      # zeroed command: no detector handle
     assert L.tk_mi355x_module_executor(None, 0, None, buf) == -1
+
+
+def test_diagnostics_patch_still_applies_and_the_product_exports_no_debug_symbol():
+    """the product kernel file carries no diagnostic code: tools/diag/g32_diagnostics.patch re-creates the ablation / stamp variants on a
+    scratch copy (tools/build_variant.sh).  It must keep applying to the shipped source, and the shipped library must not export tk_debug_*"""
+    import shutil
+    import tempfile
+    patch = os.path.join(ROOT, "tools", "diag", "g32_diagnostics.patch")
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "llm"))
+        shutil.copy(os.path.join(ROOT, "trackiellm_amd", "csrc", "llm", "tk_llm_kernels.hip"), os.path.join(td, "llm", "tk_llm_kernels.hip"))
+        r = subprocess.run(["patch", "-s", "-p0", "--dry-run", "llm/tk_llm_kernels.hip"], stdin=open(patch), cwd=td, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    src = open(os.path.join(ROOT, "trackiellm_amd", "csrc", "llm", "tk_llm_kernels.hip")).read()
+    assert "TK_G32_ABL" not in src and "tk_debug_g32" not in src
+    out = subprocess.run(["nm", "-D", os.path.join(ROOT, "trackiellm_amd", "libtrackie_mi355x.so")], capture_output=True, text=True).stdout
+    assert "tk_debug_" not in out
