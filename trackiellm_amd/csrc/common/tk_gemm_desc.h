@@ -26,6 +26,10 @@ struct TkGemm {
     int b_f16;
     /* hint, no arithmetic: C is only read as the A operand of the next linear layer (fc1 -> fc2); a backend may emit it pre-packed */
     int c_feeds_linear;
+    /* implicit im2col (im_C > 0): A is a convolution's NHWC input [B][im_H][im_W] pixels of pitch im_ldx; GEMM row m = (b, oy, ox) over
+     * im_Ho x im_Wo outputs and column k = (ky im_kw + kx) im_C + c address it directly (zero outside the image), K = kh kw im_C.
+     * Same values in the same order as the explicit column matrix; lda, batch and b_kn are unused */
+    int im_C, im_H, im_W, im_ldx, im_kw, im_stride, im_pad, im_Ho, im_Wo;
 };
 
 

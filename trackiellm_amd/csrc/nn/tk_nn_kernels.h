@@ -20,6 +20,8 @@
 #include "../common/tk_gemm_desc.h"
 
 void tk_launch_gemm(const TkGemm& g, hipStream_t s);
+/* whether a convolution input can be addressed by the GEMM itself (TkGemm::im_*): channels and pitch multiples of 4, 16-byte aligned */
+bool tk_gemm_im2col_ok(const float* x, int C, int ldx);
 /* opts the large-tile GEMM into its dynamic LDS on the calling thread's current device; idempotent, thread-safe.  tk_launch_gemm does
  * it on first use; callers that capture launches into a hipGraph call it beforehand. */
 bool tk_nn_prepare_device();

@@ -36,6 +36,41 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+/* Implicit im2col (TkGemm::im_C > 0): A is a convolution's NHWC input and GEMM row m = (b, oy, ox), column k = (ky kw + kx) C + c are
+ * decoded on the fly, so the column matrix (kh kw times the input) is never written or read.  A thread's rows are fixed for the whole
+ * launch (decoded once) and its k advances by one slab per load: (c, kx, ky) are carried, no division in the loop.  Same values, same
+ * chain: bit-identical to the explicit matrix. */
+struct ImRow { int64_t pix0; int iy0, ix0; bool ok; };
+struct ImCol { int c, kx, ky; };
+__device__ __forceinline__ ImRow im_row(const TkGemm& g, int m) {
+    ImRow r;
+    r.ok = m < g.M;
+    const int mm = r.ok ? m : 0;
+    const int ox = mm % g.im_Wo, t = mm / g.im_Wo, oy = t % g.im_Ho, b = t / g.im_Ho;
+    r.iy0 = oy * g.im_stride - g.im_pad;
+    r.ix0 = ox * g.im_stride - g.im_pad;
+    r.pix0 = (int64_t)b * g.im_H * g.im_W;
+    return r;
+}
+__device__ __forceinline__ ImCol im_col(const TkGemm& g, int k) {
+    ImCol q;
+    const int tap = k / g.im_C;
+    q.c = k - tap * g.im_C; q.ky = tap / g.im_kw; q.kx = tap - q.ky * g.im_kw;
+    return q;
+}
+__device__ __forceinline__ void im_advance(const TkGemm& g, ImCol& q, int dk) {
+    q.c += dk;
+    while (q.c >= g.im_C) { q.c -= g.im_C; if (++q.kx == g.im_kw) { q.kx = 0; ++q.ky; } }
+}
+__device__ __forceinline__ void im_load4(const TkGemm& g, const float* X, const ImRow& r, const ImCol& q, int k, float out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    const int iy = r.iy0 + q.ky, ix = r.ix0 + q.kx;
+    if (r.ok && k < g.K && iy >= 0 && iy < g.im_H && ix >= 0 && ix < g.im_W) {
+        const float4 t = *(const float4*)(X + (r.pix0 + (int64_t)iy * g.im_W + ix) * g.im_ldx + q.c);
+        out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+    }
+}
+
 /*
  * 64x64 output tile per workgroup, 4 waves in 2x2, one 32x32 fp32 MFMA accumulator per wave.
  * A/B k-slabs of 32 are staged through LDS with 16 B coalesced loads (row pitch 33 floats:
@@ -43,6 +78,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
  * issued before the current slab's MFMAs, so small launches (a few workgroups, the Whisper decoder
  * steps) are not a chain of exposed load latencies.
  */
+template <bool IM>
 __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     __shared__ float As[BM * LDS_LD];
     __shared__ float Bs[BN * LDS_LD];
@@ -65,6 +101,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
     const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & (g.b_f16 ? 7 : 15)) == 0;
     float ra[2][4], rb[2][4]; /* the next k slab on its way from global memory while the current one feeds the MFMAs */
+    ImRow ir[2]; ImCol ic;
+    if (IM) {
+        ir[0] = im_row(g, m0 + (tid >> 3)); ir[1] = im_row(g, m0 + ((tid + 256) >> 3));
+        ic = im_col(g, (tid & 7) * 4);
+    }
 
     /* A: 64 rows x 32 k, thread -> (row = e / 8, 4 consecutive k) for e = tid, tid + 256; B likewise ([N][K]) or, for [K][N],
      * 4 consecutive n of one k (scattered transposed into LDS) */
@@ -76,7 +117,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
                 const int row = e >> 3, kc = (e & 7) * 4;
                 const int m = m0 + row, k = k0 + kc;
                 ra[h][0] = ra[h][1] = ra[h][2] = ra[h][3] = 0.0f;
-                if (m < g.M) {
+                if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
+                else if (m < g.M) {
                     const float* p = A + (int64_t)m * g.lda + k;
                     if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; ra[h][0] = t.x; ra[h][1] = t.y; ra[h][2] = t.z; ra[h][3] = t.w; }
                     else {
@@ -110,6 +152,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
                 }
             }
         }
+        if (IM) im_advance(g, ic, BK);
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -165,6 +208,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
  * with k contiguous only.
  */
 #define NBM 128
+template <bool IM>
 __global__ __launch_bounds__(256) void k_gemm_f32_n32(TkGemm g) {
     __shared__ float As[NBM * LDS_LD];
     __shared__ float Bs[32 * LDS_LD];
@@ -179,13 +223,20 @@ __global__ __launch_bounds__(256) void k_gemm_f32_n32(TkGemm g) {
     const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
     const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & 15) == 0;
     float ra[4][4], rb[4];
+    ImRow ir[4]; ImCol ic;
+    if (IM) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ir[h] = im_row(g, m0 + ((tid + 256 * h) >> 3));
+        ic = im_col(g, (tid & 7) * 4);
+    }
     auto gload = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) { /* A: 128 rows x 32 k = 1024 groups of 4 k */
             const int e = tid + 256 * h, row = e >> 3, kc = (e & 7) * 4;
             const int m = m0 + row, k = k0 + kc;
             ra[h][0] = ra[h][1] = ra[h][2] = ra[h][3] = 0.0f;
-            if (m < g.M) {
+            if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
+            else if (m < g.M) {
                 const float* p = A + (int64_t)m * g.lda + k;
                 if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; ra[h][0] = t.x; ra[h][1] = t.y; ra[h][2] = t.z; ra[h][3] = t.w; }
                 else {
@@ -206,6 +257,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_n32(TkGemm g) {
                 }
             }
         }
+        if (IM) im_advance(g, ic, BK);
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -254,6 +306,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_n32(TkGemm g) {
  */
 #define LBM 128
 #define LBN 128
+template <bool IM>
 __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
     extern __shared__ float lsm[]; /* [2][LBM*LDS_LD] A, then [2][LBN*LDS_LD] B */
     float* As = lsm;
@@ -281,6 +334,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
     const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
     const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & (g.b_f16 ? 7 : 15)) == 0;
     float ra[4][4], rb[4][4]; /* register staging of the next slab: 4 float4 per thread per operand */
+    ImRow ir[4]; ImCol ic;
+    if (IM) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ir[h] = im_row(g, m0 + ((tid + 256 * h) >> 3));
+        ic = im_col(g, (tid & 7) * 4);
+    }
 
     auto gload = [&](int k0) {
 #pragma unroll
@@ -290,7 +349,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
                 const int row = e >> 3, kc = (e & 7) * 4;
                 const int m = m0 + row, k = k0 + kc;
                 ra[h][0] = ra[h][1] = ra[h][2] = ra[h][3] = 0.0f;
-                if (m < g.M) {
+                if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
+                else if (m < g.M) {
                     const float* p = A + (int64_t)m * g.lda + k;
                     if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; ra[h][0] = t.x; ra[h][1] = t.y; ra[h][2] = t.z; ra[h][3] = t.w; }
                     else {
@@ -324,6 +384,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
                 }
             }
         }
+        if (IM) im_advance(g, ic, BK);
     };
     auto lstore = [&](int buf) {
         float* as = As + buf * LBM * LDS_LD;
@@ -400,26 +461,36 @@ bool tk_nn_prepare_device() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     if (g_big_opted[dev].load(std::memory_order_acquire)) return true;
     std::lock_guard<std::mutex> lk(g_big_mu);
-    if (hipFuncSetAttribute((const void*)k_gemm_f32_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)k_gemm_f32_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_gemm_f32_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     g_big_opted[dev].store(true, std::memory_order_release);
     return true;
 }
 
 void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
     const int nz = g.batch > 0 ? g.batch : 1;
+    const bool im = g.im_C > 0; /* validated by tk_gemm_im2col_ok(): C % 4 == 0, aligned input, [N][K] weights, no batch */
     if (g.M >= 256 && g.N >= 96) {
         const size_t lds = (size_t)2 * (LBM + LBN) * LDS_LD * sizeof(float);
         (void)tk_nn_prepare_device();
         dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
-        hipLaunchKernelGGL(k_gemm_f32_big, grid, dim3(256), lds, s, g);
+        if (im) hipLaunchKernelGGL(k_gemm_f32_big<true>, grid, dim3(256), lds, s, g);
+        else hipLaunchKernelGGL(k_gemm_f32_big<false>, grid, dim3(256), lds, s, g);
         return;
     }
     if (g.N <= 32 && g.M >= 4 * NBM && !g.b_kn && !g.b_f16 && nz == 1 && g.batch_inner == 0) { /* narrow and tall: no MFMAs on absent columns */
-        hipLaunchKernelGGL(k_gemm_f32_n32, dim3(1, (g.M + NBM - 1) / NBM, 1), dim3(256), 0, s, g);
+        const dim3 grid(1, (g.M + NBM - 1) / NBM, 1);
+        if (im) hipLaunchKernelGGL(k_gemm_f32_n32<true>, grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(k_gemm_f32_n32<false>, grid, dim3(256), 0, s, g);
         return;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nz);
-    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, s, g);
+    if (im) hipLaunchKernelGGL(k_gemm_f32<true>, grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(k_gemm_f32<false>, grid, dim3(256), 0, s, g);
+}
+
+bool tk_gemm_im2col_ok(const float* x, int C, int ldx) {
+    return C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0;
 }
 
 __global__ void k_im2col(const float* x, int B, int H, int W, int C, int ldx, int kh, int kw, int stride, int pad, int Ho, int Wo, float* col) {

@@ -187,7 +187,11 @@ struct TkGpuOps {
         TkGemm g{};
         g.M = y.B * y.H * y.W; g.N = sp.cout; g.K = sp.k * sp.k * sp.cin;
         if (sp.k == 1 && sp.s == 1) { g.A = x.p; g.lda = x.ld; }
-        else {
+        else if (tk_gemm_im2col_ok(x.p, x.C, x.ld)) { /* the GEMM addresses the input directly: no column matrix */
+            g.A = x.p; g.lda = 0;
+            g.im_C = x.C; g.im_H = x.H; g.im_W = x.W; g.im_ldx = x.ld; g.im_kw = sp.k; g.im_stride = sp.s; g.im_pad = sp.k / 2;
+            g.im_Ho = y.H; g.im_Wo = y.W;
+        } else { /* the 3-channel stem */
             tk_launch_im2col(x.p, x.B, x.H, x.W, x.C, x.ld, sp.k, sp.k, sp.s, sp.k / 2, d->col, s);
             g.A = d->col; g.lda = g.K;
         }
