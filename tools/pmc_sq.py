@@ -14,10 +14,13 @@ import sys
 from collections import defaultdict
 
 
+FILTER = sys.argv[2:] or ["w4a8", "k_attention", "k_gemm_tiled"]  # kernel-name substrings (further arguments replace the default)
+
+
 def main():
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(sys.argv[1])):
-        if "w4a8" not in r["Kernel_Name"] and "k_attention" not in r["Kernel_Name"] and "k_gemm_tiled" not in r["Kernel_Name"]:
+        if not any(f in r["Kernel_Name"] for f in FILTER):
             continue
         key = (r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]), int(r["Workgroup_Size"]))
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

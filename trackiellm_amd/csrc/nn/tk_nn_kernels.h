@@ -20,8 +20,13 @@
 #include "../common/tk_gemm_desc.h"
 
 void tk_launch_gemm(const TkGemm& g, hipStream_t s);
-/* whether a convolution input can be addressed by the GEMM itself (TkGemm::im_*): channels and pitch multiples of 4, 16-byte aligned */
-bool tk_gemm_im2col_ok(const float* x, int C, int ldx);
+/* whether a convolution can be addressed by the GEMM itself (TkGemm::im_*): channels and pitch multiples of 4, input x and the [N][K]
+ * f32 weights w 16-byte aligned */
+bool tk_gemm_im2col_ok(const float* x, int C, int ldx, const float* w);
+/* direct 3x3 convolution of a 3-channel image into 16 channels (the detector's stem), the GEMM's chain and epilogue (bias, act) per
+ * output; false (nothing launched): another shape — use im2col + tk_launch_gemm */
+bool tk_launch_conv_stem(const float* x, int B, int H, int W, int C, int ldx, const float* w, const float* bias, int act, int N, int k, int stride, int pad, float* y,
+                         int ldy, hipStream_t s);
 /* opts the large-tile GEMM into its dynamic LDS on the calling thread's current device; idempotent, thread-safe.  tk_launch_gemm does
  * it on first use; callers that capture launches into a hipGraph call it beforehand. */
 bool tk_nn_prepare_device();

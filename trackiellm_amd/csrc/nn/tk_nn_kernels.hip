@@ -72,13 +72,120 @@ __device__ __forceinline__ void im_load4(const TkGemm& g, const float* X, const 
 }
 
 /*
+ * Operand loads of the three GEMM kernels below, 4 consecutive elements (one k-group, or one n-group of a [K][N] matrix) per call.
+ * PATH 0 is the general case: any pitch, alignment and extent, f32 or f16 B — element-wise fallbacks under run-time tests, which also
+ * keep the compiler from batching a slab's loads (each waits for the previous one: measured 2x on the Whisper Q.K^T launch).
+ * PATH 1 ([N][K] weights) and PATH 2 ([K][N]) are the same loads when tk_gemm_fast() holds — every pitch, batch offset and extent along
+ * the vector a multiple of 4, bases 16-byte aligned, f32 — as ONE predicated 16-byte load each, so all of a slab's loads are in flight
+ * together.  Values and order of the arithmetic are identical on every path.
+ */
+__device__ __forceinline__ void ld4_if(bool ok, const float* p, float out[4]) {
+    float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (ok) t = *(const float4*)p;
+    out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+}
+/* A[m][k .. k+3] */
+template <int PATH>
+__device__ __forceinline__ void load_a4(const TkGemm& g, const float* A, bool a_vec, int m, int k, float out[4]) {
+    if (PATH != 0) { ld4_if(m < g.M && k < g.K, A + (int64_t)m * g.lda + k, out); return; }
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (m < g.M) {
+        const float* p = A + (int64_t)m * g.lda + k;
+        if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w; }
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (k + i < g.K) out[i] = p[i];
+        }
+    }
+}
+/* B as [N][ldb]: B[n][k .. k+3] */
+template <int PATH>
+__device__ __forceinline__ void load_b4_nk(const TkGemm& g, const float* B, bool b_vec, int n, int k, float out[4]) {
+    if (PATH != 0) { ld4_if(n < g.N && k < g.K, B + (int64_t)n * g.ldb + k, out); return; }
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (n < g.N) {
+        const int64_t p = (int64_t)n * g.ldb + k;
+        if (b_vec && k + 3 < g.K) ldb4(B, g.b_f16, p, out);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (k + i < g.K) out[i] = ldb1(B, g.b_f16, p + i);
+        }
+    }
+}
+/* B as [K][ldb]: B[k][n .. n+3] */
+template <int PATH>
+__device__ __forceinline__ void load_b4_kn(const TkGemm& g, const float* B, bool b_vec, int k, int n, float out[4]) {
+    if (PATH != 0) { ld4_if(k < g.K && n < g.N, B + (int64_t)k * g.ldb + n, out); return; }
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (k < g.K) {
+        const int64_t p = (int64_t)k * g.ldb + n;
+        if (b_vec && n + 3 < g.N) ldb4(B, g.b_f16, p, out);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (n + i < g.N) out[i] = ldb1(B, g.b_f16, p + i);
+        }
+    }
+}
+
+/* epilogue of one 32x32 accumulator tile: v = act(alpha acc + bias[n]) + residual, rows m_base + (r % 4) + 8 (r / 4) + 4 (lane / 32),
+ * column n.  The activation is chosen once per tile, not per element. */
+__device__ __forceinline__ void store_tile(const TkGemm& g, const v16f& acc, float* C, const float* R, int m_base, int n, int lane) {
+    if (n >= g.N) return;
+    const float bias = g.bias ? g.bias[n] : 0.0f;
+    const float alpha = g.alpha;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    if (alpha != 1.0f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v[r] * alpha;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = v[r] + bias;
+    if (g.act == TK_ACT_SILU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = tk_siluf(v[r]);
+    } else if (g.act == TK_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = tk_geluf(v[r]);
+    } else if (g.act == TK_ACT_SIGMOID) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = tk_sigmoidf(v[r]);
+    }
+    const int mb = m_base + 4 * (lane >> 5);
+    if (R) {
+        const float* rp = R + (int64_t)mb * g.ldr + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dm = (r & 3) + 8 * (r >> 2);
+            if (mb + dm < g.M) v[r] = v[r] + rp[(int64_t)dm * g.ldr];
+        }
+    }
+    float* cp = C + (int64_t)mb * g.ldc + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2);
+        if (mb + dm < g.M) cp[(int64_t)dm * g.ldc] = v[r];
+    }
+}
+
+__device__ __forceinline__ void batch_offsets(const TkGemm& g, int z, int64_t& oA, int64_t& oB, int64_t& oC, int64_t& oR) {
+    if (g.batch_inner > 0) {
+        const int zo = z / g.batch_inner, zi = z % g.batch_inner;
+        oA = zo * g.sA2 + zi * g.sA; oB = zo * g.sB2 + zi * g.sB; oC = zo * g.sC2 + zi * g.sC; oR = zo * g.sR2 + zi * g.sR;
+    } else {
+        oA = (int64_t)z * g.sA; oB = (int64_t)z * g.sB; oC = (int64_t)z * g.sC; oR = (int64_t)z * g.sR;
+    }
+}
+
+/*
  * 64x64 output tile per workgroup, 4 waves in 2x2, one 32x32 fp32 MFMA accumulator per wave.
  * A/B k-slabs of 32 are staged through LDS with 16 B coalesced loads (row pitch 33 floats:
  * the 32 lanes of an MFMA operand read hit 32 different banks); the next slab's global loads are
  * issued before the current slab's MFMAs, so small launches (a few workgroups, the Whisper decoder
  * steps) are not a chain of exposed load latencies.
  */
-template <bool IM>
+template <bool IM, int PATH>
 __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     __shared__ float As[BM * LDS_LD];
     __shared__ float Bs[BN * LDS_LD];
@@ -86,12 +193,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     int64_t oA, oB, oC, oR;
-    if (g.batch_inner > 0) {
-        const int zo = blockIdx.z / g.batch_inner, zi = blockIdx.z % g.batch_inner;
-        oA = zo * g.sA2 + zi * g.sA; oB = zo * g.sB2 + zi * g.sB; oC = zo * g.sC2 + zi * g.sC; oR = zo * g.sR2 + zi * g.sR;
-    } else {
-        oA = (int64_t)blockIdx.z * g.sA; oB = (int64_t)blockIdx.z * g.sB; oC = (int64_t)blockIdx.z * g.sC; oR = (int64_t)blockIdx.z * g.sR;
-    }
+    batch_offsets(g, blockIdx.z, oA, oB, oC, oR);
     const float* A = g.A + oA;
     const float* B = g.b_f16 ? (const float*)((const _Float16*)g.B + oB) : g.B + oB;
     float* C = g.C + oC;
@@ -112,45 +214,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
     auto gload = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int e = tid + 256 * h;
-            {
-                const int row = e >> 3, kc = (e & 7) * 4;
-                const int m = m0 + row, k = k0 + kc;
-                ra[h][0] = ra[h][1] = ra[h][2] = ra[h][3] = 0.0f;
-                if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
-                else if (m < g.M) {
-                    const float* p = A + (int64_t)m * g.lda + k;
-                    if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; ra[h][0] = t.x; ra[h][1] = t.y; ra[h][2] = t.z; ra[h][3] = t.w; }
-                    else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) if (k + i < g.K) ra[h][i] = p[i];
-                    }
-                }
-            }
-            rb[h][0] = rb[h][1] = rb[h][2] = rb[h][3] = 0.0f;
-            if (!g.b_kn) {
-                const int row = e >> 3, kc = (e & 7) * 4;
-                const int n = n0 + row, k = k0 + kc;
-                if (n < g.N) {
-                    const int64_t p = (int64_t)n * g.ldb + k;
-                    if (b_vec && k + 3 < g.K) ldb4(B, g.b_f16, p, rb[h]);
-                    else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[h][i] = ldb1(B, g.b_f16, p + i);
-                    }
-                }
-            } else {
-                const int kk = e >> 4, nc = (e & 15) * 4;
-                const int k = k0 + kk, n = n0 + nc;
-                if (k < g.K) {
-                    const int64_t p = (int64_t)k * g.ldb + n;
-                    if (b_vec && n + 3 < g.N) ldb4(B, g.b_f16, p, rb[h]);
-                    else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) if (n + i < g.N) rb[h][i] = ldb1(B, g.b_f16, p + i);
-                    }
-                }
-            }
+            const int e = tid + 256 * h, row = e >> 3, k = k0 + (e & 7) * 4;
+            if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
+            else load_a4<PATH>(g, A, a_vec, m0 + row, k, ra[h]);
+            if (PATH == 2 || (PATH == 0 && g.b_kn)) load_b4_kn<PATH>(g, B, b_vec, k0 + (e >> 4), n0 + (e & 15) * 4, rb[h]);
+            else load_b4_nk<PATH>(g, B, b_vec, n0 + row, k, rb[h]);
         }
         if (IM) im_advance(g, ic, BK);
     };
@@ -161,13 +229,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
             const int row = e >> 3, kc = (e & 7) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) As[row * LDS_LD + kc + i] = ra[h][i];
-            if (!g.b_kn) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) Bs[row * LDS_LD + kc + i] = rb[h][i];
-            } else {
+            if (PATH == 2 || (PATH == 0 && g.b_kn)) {
                 const int kk = e >> 4, nc = (e & 15) * 4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) Bs[(nc + i) * LDS_LD + kk] = rb[h][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Bs[row * LDS_LD + kc + i] = rb[h][i];
             }
         }
     };
@@ -183,46 +251,33 @@ __global__ __launch_bounds__(256) void k_gemm_f32(TkGemm g) {
         for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
         __syncthreads();
     }
-    const int n = n0 + wn * 32 + (lane & 31);
-    if (n >= g.N) return;
-    const float bias = g.bias ? g.bias[n] : 0.0f;
-    const float* R = g.residual ? g.residual + oR : nullptr;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < g.M) {
-            float v = acc[r];
-            if (g.alpha != 1.0f) v = v * g.alpha;
-            v = v + bias;
-            v = apply_act(v, g.act);
-            if (R) v = v + R[(int64_t)m * g.ldr + n];
-            C[(int64_t)m * g.ldc + n] = v;
-        }
-    }
+    store_tile(g, acc, C, g.residual ? g.residual + oR : nullptr, m0 + wm * 32, n0 + wn * 32 + (lane & 31), lane);
 }
 
 /*
- * Narrow outputs (N <= 32: the detector's high-resolution layers have 16 or 32 output channels and hundreds of thousands of rows): the
- * 64x64 tile above spends half or three quarters of its MFMAs on columns that do not exist.  Here a workgroup covers 128 rows x 32
- * columns, its four waves stacked in M; same slabs, same k-ordered chain per output element (bit-identical), A [M][lda] and B [N][ldb]
- * with k contiguous only.
+ * Narrow outputs (N < 96: the detector's high-resolution layers have 16 .. 80 output channels and up to hundreds of thousands of rows):
+ * the 64x64 tile above spends MFMAs on columns that do not exist (N = 16, 32, 80) and reads A once per 64 columns.  Here a workgroup
+ * covers 128 rows x ALL columns, its four waves stacked in M with NT = ceil(N / 32) accumulators each: A — the expensive operand, above
+ * all when it is a convolution input addressed on the fly — is read exactly once, and one operand read feeds NT MFMAs.  Same slabs, same
+ * k-ordered chain per output element (bit-identical); A [M][lda] and B [N][ldb] with k contiguous only, f32, no batch.
  */
 #define NBM 128
-template <bool IM>
-__global__ __launch_bounds__(256) void k_gemm_f32_n32(TkGemm g) {
+template <bool IM, int PATH, int NT>
+__global__ __launch_bounds__(256) void k_gemm_f32_tall(TkGemm g) {
     __shared__ float As[NBM * LDS_LD];
-    __shared__ float Bs[32 * LDS_LD];
+    __shared__ float Bs[NT * 32 * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * NBM;
     const float* A = g.A;
     const float* B = g.B;
-    float* C = g.C;
-    v16f acc;
+    v16f acc[NT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     const bool a_vec = (g.lda & 3) == 0 && (((uintptr_t)A) & 15) == 0;
     const bool b_vec = (g.ldb & 3) == 0 && (((uintptr_t)B) & 15) == 0;
-    float ra[4][4], rb[4];
+    float ra[4][4], rb[NT][4];
     ImRow ir[4]; ImCol ic;
     if (IM) {
 #pragma unroll
@@ -230,45 +285,30 @@ __global__ __launch_bounds__(256) void k_gemm_f32_n32(TkGemm g) {
         ic = im_col(g, (tid & 7) * 4);
     }
     auto gload = [&](int k0) {
+        const int k = k0 + (tid & 7) * 4;
 #pragma unroll
         for (int h = 0; h < 4; ++h) { /* A: 128 rows x 32 k = 1024 groups of 4 k */
-            const int e = tid + 256 * h, row = e >> 3, kc = (e & 7) * 4;
-            const int m = m0 + row, k = k0 + kc;
-            ra[h][0] = ra[h][1] = ra[h][2] = ra[h][3] = 0.0f;
             if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
-            else if (m < g.M) {
-                const float* p = A + (int64_t)m * g.lda + k;
-                if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; ra[h][0] = t.x; ra[h][1] = t.y; ra[h][2] = t.z; ra[h][3] = t.w; }
-                else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (k + i < g.K) ra[h][i] = p[i];
-                }
-            }
+            else load_a4<PATH>(g, A, a_vec, m0 + ((tid + 256 * h) >> 3), k, ra[h]);
         }
-        { /* B: 32 rows x 32 k = 256 groups */
-            const int row = tid >> 3, kc = (tid & 7) * 4, k = k0 + kc;
-            rb[0] = rb[1] = rb[2] = rb[3] = 0.0f;
-            if (row < g.N) {
-                const float* p = B + (int64_t)row * g.ldb + k;
-                if (b_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; rb[0] = t.x; rb[1] = t.y; rb[2] = t.z; rb[3] = t.w; }
-                else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[i] = p[i];
-                }
-            }
-        }
+        for (int t = 0; t < NT; ++t) load_b4_nk<PATH>(g, B, b_vec, (tid >> 3) + 32 * t, k, rb[t]); /* B: NT x 32 rows x 32 k */
         if (IM) im_advance(g, ic, BK);
     };
     auto lstore = [&]() {
+        const int kc = (tid & 7) * 4;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int e = tid + 256 * h, row = e >> 3, kc = (e & 7) * 4;
+            const int row = (tid + 256 * h) >> 3;
 #pragma unroll
             for (int i = 0; i < 4; ++i) As[row * LDS_LD + kc + i] = ra[h][i];
         }
-        const int row = tid >> 3, kc = (tid & 7) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Bs[row * LDS_LD + kc + i] = rb[i];
+        for (int t = 0; t < NT; ++t) {
+            const int row = (tid >> 3) + 32 * t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Bs[row * LDS_LD + kc + i] = rb[t][i];
+        }
     };
     gload(0);
     for (int k0 = 0; k0 < g.K; k0 += BK) {
@@ -278,25 +318,15 @@ __global__ __launch_bounds__(256) void k_gemm_f32_n32(TkGemm g) {
         const float* ap = As + (wave * 32 + (lane & 31)) * LDS_LD + (lane >> 5);
         const float* bp = Bs + (lane & 31) * LDS_LD + (lane >> 5);
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float av = ap[kk];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[t * 32 * LDS_LD + kk], acc[t], 0, 0, 0);
+        }
         __syncthreads();
     }
-    const int n = lane & 31;
-    if (n >= g.N) return;
-    const float bias = g.bias ? g.bias[n] : 0.0f;
-    const float* R = g.residual;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < g.M) {
-            float v = acc[r];
-            if (g.alpha != 1.0f) v = v * g.alpha;
-            v = v + bias;
-            v = apply_act(v, g.act);
-            if (R) v = v + R[(int64_t)m * g.ldr + n];
-            C[(int64_t)m * g.ldc + n] = v;
-        }
-    }
+    for (int t = 0; t < NT; ++t) store_tile(g, acc[t], g.C, g.residual, m0 + wave * 32, 32 * t + (lane & 31), lane);
 }
 
 /*
@@ -306,7 +336,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_n32(TkGemm g) {
  */
 #define LBM 128
 #define LBN 128
-template <bool IM>
+template <bool IM, int PATH>
 __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
     extern __shared__ float lsm[]; /* [2][LBM*LDS_LD] A, then [2][LBN*LDS_LD] B */
     float* As = lsm;
@@ -315,12 +345,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
     int64_t oA, oB, oC, oR;
-    if (g.batch_inner > 0) {
-        const int zo = blockIdx.z / g.batch_inner, zi = blockIdx.z % g.batch_inner;
-        oA = zo * g.sA2 + zi * g.sA; oB = zo * g.sB2 + zi * g.sB; oC = zo * g.sC2 + zi * g.sC; oR = zo * g.sR2 + zi * g.sR;
-    } else {
-        oA = (int64_t)blockIdx.z * g.sA; oB = (int64_t)blockIdx.z * g.sB; oC = (int64_t)blockIdx.z * g.sC; oR = (int64_t)blockIdx.z * g.sR;
-    }
+    batch_offsets(g, blockIdx.z, oA, oB, oC, oR);
     const float* A = g.A + oA;
     const float* B = g.b_f16 ? (const float*)((const _Float16*)g.B + oB) : g.B + oB;
     float* C = g.C + oC;
@@ -344,45 +369,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
     auto gload = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int e = tid + 256 * h;
-            { /* A: row = e / 8, 4 consecutive k */
-                const int row = e >> 3, kc = (e & 7) * 4;
-                const int m = m0 + row, k = k0 + kc;
-                ra[h][0] = ra[h][1] = ra[h][2] = ra[h][3] = 0.0f;
-                if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
-                else if (m < g.M) {
-                    const float* p = A + (int64_t)m * g.lda + k;
-                    if (a_vec && k + 3 < g.K) { const float4 t = *(const float4*)p; ra[h][0] = t.x; ra[h][1] = t.y; ra[h][2] = t.z; ra[h][3] = t.w; }
-                    else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) if (k + i < g.K) ra[h][i] = p[i];
-                    }
-                }
-            }
-            rb[h][0] = rb[h][1] = rb[h][2] = rb[h][3] = 0.0f;
-            if (!g.b_kn) {
-                const int row = e >> 3, kc = (e & 7) * 4;
-                const int n = n0 + row, k = k0 + kc;
-                if (n < g.N) {
-                    const int64_t p = (int64_t)n * g.ldb + k;
-                    if (b_vec && k + 3 < g.K) ldb4(B, g.b_f16, p, rb[h]);
-                    else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) if (k + i < g.K) rb[h][i] = ldb1(B, g.b_f16, p + i);
-                    }
-                }
-            } else { /* B is [K][N]: 4 consecutive n of one k */
-                const int kk = e >> 5, nc = (e & 31) * 4;
-                const int k = k0 + kk, n = n0 + nc;
-                if (k < g.K) {
-                    const int64_t p = (int64_t)k * g.ldb + n;
-                    if (b_vec && n + 3 < g.N) ldb4(B, g.b_f16, p, rb[h]);
-                    else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) if (n + i < g.N) rb[h][i] = ldb1(B, g.b_f16, p + i);
-                    }
-                }
-            }
+            const int e = tid + 256 * h, row = e >> 3, k = k0 + (e & 7) * 4;
+            if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
+            else load_a4<PATH>(g, A, a_vec, m0 + row, k, ra[h]);
+            if (PATH == 2 || (PATH == 0 && g.b_kn)) load_b4_kn<PATH>(g, B, b_vec, k0 + (e >> 5), n0 + (e & 31) * 4, rb[h]); /* [K][N]: 4 consecutive n of one k */
+            else load_b4_nk<PATH>(g, B, b_vec, n0 + row, k, rb[h]);
         }
         if (IM) im_advance(g, ic, BK);
     };
@@ -395,13 +386,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
             const int row = e >> 3, kc = (e & 7) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) as[row * LDS_LD + kc + i] = ra[h][i];
-            if (!g.b_kn) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bs[row * LDS_LD + kc + i] = rb[h][i];
-            } else {
+            if (PATH == 2 || (PATH == 0 && g.b_kn)) {
                 const int kk = e >> 5, nc = (e & 31) * 4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bs[(nc + i) * LDS_LD + kk] = rb[h][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bs[row * LDS_LD + kc + i] = rb[h][i];
             }
         }
     };
@@ -429,25 +420,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
     }
     const float* R = g.residual ? g.residual + oR : nullptr;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (n >= g.N) continue;
-        const float bias = g.bias ? g.bias[n] : 0.0f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < g.M) {
-                    float v = acc[i][j][r];
-                    if (g.alpha != 1.0f) v = v * g.alpha;
-                    v = v + bias;
-                    v = apply_act(v, g.act);
-                    if (R) v = v + R[(int64_t)m * g.ldr + n];
-                    C[(int64_t)m * g.ldc + n] = v;
-                }
-            }
-    }
+        for (int i = 0; i < 2; ++i) store_tile(g, acc[i][j], C, R, m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32 + (lane & 31), lane);
 }
 
 /* > 64 KiB of dynamic LDS is an opt-in HIP keeps per (function, device): one flag per device, set once under a lock (several host
@@ -461,36 +436,121 @@ bool tk_nn_prepare_device() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     if (g_big_opted[dev].load(std::memory_order_acquire)) return true;
     std::lock_guard<std::mutex> lk(g_big_mu);
-    if (hipFuncSetAttribute((const void*)k_gemm_f32_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_gemm_f32_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    const void* fns[4] = {(const void*)k_gemm_f32_big<false, 0>, (const void*)k_gemm_f32_big<false, 1>, (const void*)k_gemm_f32_big<false, 2>,
+                          (const void*)k_gemm_f32_big<true, 1>};
+    for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     g_big_opted[dev].store(true, std::memory_order_release);
+    return true;
+}
+
+/* the conditions of the one-load-per-group paths (PATH 1 / 2): f32, every base 16-byte aligned, every pitch and batch offset a multiple
+ * of 4 floats, and the extent along the loaded vector (K; N too for [K][N] weights) a multiple of 4 */
+static bool tk_gemm_fast(const TkGemm& g) {
+    auto m4 = [](int64_t v) { return (v & 3) == 0; };
+    if (g.b_f16 || !m4(g.K) || !m4(g.ldb) || (((uintptr_t)g.B) & 15)) return false;
+    if (g.im_C == 0 && (!m4(g.lda) || (((uintptr_t)g.A) & 15))) return false;
+    if (g.b_kn && !m4(g.N)) return false;
+    if (g.batch > 1 && (!m4(g.sA) || !m4(g.sB))) return false;
+    if (g.batch_inner > 0 && (!m4(g.sA2) || !m4(g.sB2))) return false;
     return true;
 }
 
 void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
     const int nz = g.batch > 0 ? g.batch : 1;
-    const bool im = g.im_C > 0; /* validated by tk_gemm_im2col_ok(): C % 4 == 0, aligned input, [N][K] weights, no batch */
+    const bool im = g.im_C > 0; /* validated by tk_gemm_im2col_ok(): aligned [N][K] f32 weights, C % 4 == 0, no batch */
+    const int path = tk_gemm_fast(g) ? (g.b_kn ? 2 : 1) : 0;
+#define TK_GEMM_PATHS(KERNEL, GRID, LDS)                                                                      \
+    do {                                                                                                      \
+        if (im) hipLaunchKernelGGL((KERNEL<true, 1>), GRID, dim3(256), LDS, s, g);                            \
+        else if (path == 1) hipLaunchKernelGGL((KERNEL<false, 1>), GRID, dim3(256), LDS, s, g);               \
+        else if (path == 2) hipLaunchKernelGGL((KERNEL<false, 2>), GRID, dim3(256), LDS, s, g);               \
+        else hipLaunchKernelGGL((KERNEL<false, 0>), GRID, dim3(256), LDS, s, g);                              \
+    } while (0)
     if (g.M >= 256 && g.N >= 96) {
         const size_t lds = (size_t)2 * (LBM + LBN) * LDS_LD * sizeof(float);
         (void)tk_nn_prepare_device();
-        dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
-        if (im) hipLaunchKernelGGL(k_gemm_f32_big<true>, grid, dim3(256), lds, s, g);
-        else hipLaunchKernelGGL(k_gemm_f32_big<false>, grid, dim3(256), lds, s, g);
+        const dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
+        TK_GEMM_PATHS(k_gemm_f32_big, grid, lds);
         return;
     }
-    if (g.N <= 32 && g.M >= 4 * NBM && !g.b_kn && !g.b_f16 && nz == 1 && g.batch_inner == 0) { /* narrow and tall: no MFMAs on absent columns */
+    if (g.N < 96 && g.M >= 4 * NBM && !g.b_kn && !g.b_f16 && nz == 1 && g.batch_inner == 0) { /* narrow and tall: every column in one workgroup */
         const dim3 grid(1, (g.M + NBM - 1) / NBM, 1);
-        if (im) hipLaunchKernelGGL(k_gemm_f32_n32<true>, grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL(k_gemm_f32_n32<false>, grid, dim3(256), 0, s, g);
+        const int nt = (g.N + 31) / 32;
+#define TK_TALL(NTV)                                                                                          \
+    do {                                                                                                      \
+        if (im) hipLaunchKernelGGL((k_gemm_f32_tall<true, 1, NTV>), grid, dim3(256), 0, s, g);                \
+        else if (path == 1) hipLaunchKernelGGL((k_gemm_f32_tall<false, 1, NTV>), grid, dim3(256), 0, s, g);   \
+        else hipLaunchKernelGGL((k_gemm_f32_tall<false, 0, NTV>), grid, dim3(256), 0, s, g);                  \
+    } while (0)
+        if (nt == 1) TK_TALL(1); else if (nt == 2) TK_TALL(2); else TK_TALL(3);
+#undef TK_TALL
         return;
     }
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nz);
-    if (im) hipLaunchKernelGGL(k_gemm_f32<true>, grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(k_gemm_f32<false>, grid, dim3(256), 0, s, g);
+    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nz);
+    TK_GEMM_PATHS(k_gemm_f32, grid, 0);
+#undef TK_GEMM_PATHS
 }
 
-bool tk_gemm_im2col_ok(const float* x, int C, int ldx) {
-    return C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+bool tk_gemm_im2col_ok(const float* x, int C, int ldx, const float* w) {
+    return C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0;
+}
+
+/*
+ * The detector's stem (3 input channels: no 16-byte groups for the implicit path, and its column matrix would be 9x the image): one thread
+ * per output pixel evaluates all N output channels as the SAME chain the GEMM evaluates — acc = fma(a[k], w[n][k], acc) over
+ * k = (ky kw + kx) C + c ascending from +0, padding taps taking part as a = 0 — then the GEMM's epilogue.  Weights sit in LDS.
+ */
+template <int N, int C, int KW>
+__global__ __launch_bounds__(256) void k_conv_stem(const float* x, int H, int W, int ldx, const float* w, const float* bias, int act, int stride, int pad, int Ho,
+                                                   int Wo, uint32_t total, float* y, int ldy) {
+    constexpr int K = KW * KW * C;
+    __shared__ __attribute__((aligned(16))) float ws[K * N]; /* [k][n]: a wave reads one k of all n as 16-byte broadcasts */
+    for (int i = threadIdx.x; i < K * N; i += 256) ws[i] = w[(i % N) * K + i / N];
+    __syncthreads();
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t ox = t % (uint32_t)Wo, r = t / (uint32_t)Wo, oy = r % (uint32_t)Ho, b = r / (uint32_t)Ho;
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < KW; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int iy = (int)(oy * stride) + ky - pad, ix = (int)(ox * stride) + kx - pad;
+            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float* p = x + (((int64_t)b * H + (in ? iy : 0)) * W + (in ? ix : 0)) * ldx;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float a = in ? p[c] : 0.0f;
+                const float4* wk = (const float4*)(ws + ((ky * KW + kx) * C + c) * N);
+#pragma unroll
+                for (int n = 0; n < N; n += 4) {
+                    const float4 q = wk[n >> 2];
+                    acc[n] = __builtin_fmaf(a, q.x, acc[n]); acc[n + 1] = __builtin_fmaf(a, q.y, acc[n + 1]);
+                    acc[n + 2] = __builtin_fmaf(a, q.z, acc[n + 2]); acc[n + 3] = __builtin_fmaf(a, q.w, acc[n + 3]);
+                }
+            }
+        }
+    float4* o = (float4*)(y + (int64_t)t * ldy); /* ldy % 4 == 0 and y 16-byte aligned: checked by the launcher */
+#pragma unroll
+    for (int n = 0; n < N; n += 4) {
+        float4 v;
+        v.x = apply_act(acc[n] + (bias ? bias[n] : 0.0f), act); v.y = apply_act(acc[n + 1] + (bias ? bias[n + 1] : 0.0f), act);
+        v.z = apply_act(acc[n + 2] + (bias ? bias[n + 2] : 0.0f), act); v.w = apply_act(acc[n + 3] + (bias ? bias[n + 3] : 0.0f), act);
+        o[n >> 2] = v;
+    }
+}
+
+bool tk_launch_conv_stem(const float* x, int B, int H, int W, int C, int ldx, const float* w, const float* bias, int act, int N, int k, int stride, int pad, float* y,
+                         int ldy, hipStream_t s) {
+    if (!(N == 16 && C == 3 && k == 3) || (ldy & 3) || (((uintptr_t)y) & 15)) return false;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const int64_t total = (int64_t)B * Ho * Wo;
+    if (total <= 0 || total >= ((int64_t)1 << 31)) return false;
+    hipLaunchKernelGGL((k_conv_stem<16, 3, 3>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, H, W, ldx, w, bias, act, stride, pad, Ho, Wo, (uint32_t)total, y, ldy);
+    return true;
 }
 
 __global__ void k_im2col(const float* x, int B, int H, int W, int C, int ldx, int kh, int kw, int stride, int pad, int Ho, int Wo, float* col) {

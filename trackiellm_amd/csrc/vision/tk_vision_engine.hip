@@ -187,11 +187,14 @@ struct TkGpuOps {
         TkGemm g{};
         g.M = y.B * y.H * y.W; g.N = sp.cout; g.K = sp.k * sp.k * sp.cin;
         if (sp.k == 1 && sp.s == 1) { g.A = x.p; g.lda = x.ld; }
-        else if (tk_gemm_im2col_ok(x.p, x.C, x.ld)) { /* the GEMM addresses the input directly: no column matrix */
+        else if (tk_gemm_im2col_ok(x.p, x.C, x.ld, d->model->w[idx])) { /* the GEMM addresses the input directly: no column matrix */
             g.A = x.p; g.lda = 0;
             g.im_C = x.C; g.im_H = x.H; g.im_W = x.W; g.im_ldx = x.ld; g.im_kw = sp.k; g.im_stride = sp.s; g.im_pad = sp.k / 2;
             g.im_Ho = y.H; g.im_Wo = y.W;
-        } else { /* the 3-channel stem */
+        } else if (!res && tk_launch_conv_stem(x.p, x.B, x.H, x.W, x.C, x.ld, d->model->w[idx], d->model->b[idx], sp.act ? TK_ACT_SILU : TK_ACT_NONE, sp.cout, sp.k,
+                                               sp.s, sp.k / 2, y.p, y.ld, s)) {
+            return; /* the 3-channel stem: a direct kernel, the GEMM's chain */
+        } else {
             tk_launch_im2col(x.p, x.B, x.H, x.W, x.C, x.ld, sp.k, sp.k, sp.s, sp.k / 2, d->col, s);
             g.A = d->col; g.lda = g.K;
         }
@@ -247,28 +250,38 @@ __global__ void k_yolo_decode(TkT h0, TkT h1, TkT h2, int nc, int n_anchors, flo
     cand[(size_t)b * n_anchors + a] = c;
 }
 
-/* rank of every candidate among the candidates: (score desc, anchor asc); the best MAX_CAND are kept */
-__global__ void k_yolo_rank(const tk_yolo_cand_t* cand, int n_anchors, int32_t* order, int32_t* n_cand) {
+/* rank of every candidate among the candidates: (score desc, anchor asc); the best MAX_CAND are kept.  Most anchors fall below the
+ * confidence threshold, so each 256-anchor tile is compacted in LDS first (ballot + prefix) and only its survivors are compared. */
+__global__ __launch_bounds__(256) void k_yolo_rank(const tk_yolo_cand_t* cand, int n_anchors, int32_t* order, int32_t* n_cand) {
     const int b = blockIdx.y;
     const tk_yolo_cand_t* cb = cand + (size_t)b * n_anchors;
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ float ss[256];
-    __shared__ int sc[256];
+    __shared__ int sj[256];
+    __shared__ int wcnt[4];
     const bool valid = a < n_anchors && cb[a].cls >= 0;
     const float mys = valid ? cb[a].score : 0.0f;
     int rank = 0, total = 0;
     for (int base = 0; base < n_anchors; base += 256) {
         const int j = base + threadIdx.x;
-        ss[threadIdx.x] = j < n_anchors ? cb[j].score : 0.0f;
-        sc[threadIdx.x] = j < n_anchors ? cb[j].cls : -1;
+        const bool v = j < n_anchors && cb[j].cls >= 0;
+        const float sco = v ? cb[j].score : 0.0f;
+        const uint64_t bal = __ballot(v);
+        if (lane == 0) wcnt[wave] = __popcll(bal);
         __syncthreads();
-        const int lim = n_anchors - base < 256 ? n_anchors - base : 256;
-        for (int k = 0; k < lim; ++k) {
-            if (sc[k] < 0) continue;
-            ++total;
-            const int j2 = base + k;
-            if (ss[k] > mys || (ss[k] == mys && j2 < a)) ++rank;
+        int off = 0, nt = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = wcnt[w]; if (w < wave) off += c; nt += c; }
+        if (v) {
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            ss[pos] = sco; sj[pos] = j;
         }
+        __syncthreads();
+        if (valid)
+            for (int k = 0; k < nt; ++k)
+                if (ss[k] > mys || (ss[k] == mys && sj[k] < a)) ++rank;
+        total += nt;
         __syncthreads();
     }
     if (valid && rank < TK_YOLO_MAX_CAND) order[(size_t)b * TK_YOLO_MAX_CAND + rank] = a;
