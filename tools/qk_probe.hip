@@ -46,6 +46,30 @@ int main() {
         printf("%-58s %8.3f ms  %6.1f TFLOP/s  stores %5.2f TB/s\n", c.name, ms, 2.0 * c.Tq * c.Tk * 64 * B * nh / ms * 1e-9, (double)c.Tq * c.Tk * 4 * B * nh / ms * 1e-9);
     }
     (void)fl;
+    { /* the whole attention (Q.K^T, softmax, P.V) over all 32 clips at once vs in chunks of few clips whose scores stay in the 256 MB
+         Infinity Cache between the three launches */
+        for (int chunk : {32, 8, 4, 2}) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            float ms = 0;
+            for (int rep = 0; rep < 4; ++rep) {
+                if (rep == 1) hipEventRecord(a, 0);
+                for (int c0 = 0; c0 < B; c0 += chunk) {
+                    TkGemm s1 = qk(1500, 1500, 1500, 0.125f);
+                    s1.A = q + (size_t)c0 * T * d; s1.B = k + (size_t)c0 * T * d; s1.batch = chunk * nh;
+                    tk_launch_gemm(s1, 0);
+                    tk_launch_softmax_rows(sc, (int64_t)chunk * nh * T, T, T, 0);
+                    TkGemm p{};
+                    p.A = sc; p.B = v + (size_t)c0 * T * d; p.C = out + (size_t)c0 * T * d; p.M = T; p.N = hd; p.K = T; p.lda = T; p.ldb = d; p.ldc = d; p.b_kn = 1; p.alpha = 1.0f;
+                    p.batch = chunk * nh; p.batch_inner = nh; p.sA = (int64_t)T * T; p.sB = hd; p.sC = hd;
+                    p.sA2 = (int64_t)nh * T * T; p.sB2 = (int64_t)T * d; p.sC2 = (int64_t)T * d;
+                    tk_launch_gemm(p, 0);
+                }
+            }
+            hipEventRecord(b, 0); hipEventSynchronize(b);
+            hipEventElapsedTime(&ms, a, b);
+            printf("attention of 32 clips in chunks of %2d clips (scores %4.0f MB)  %8.3f ms\n", chunk, (double)chunk * nh * T * T * 4 * 1e-6, ms / 3);
+        }
+    }
     run_variants(qk(1500, 1500, 1500, 0.125f));
     { /* every (clip, head) writes the SAME 9 MB: the stores stay on chip — is HBM's write path the bound? */
         TkGemm g = qk(1500, 1500, 1500, 0.125f);

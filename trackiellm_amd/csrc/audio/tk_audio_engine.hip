@@ -202,7 +202,7 @@ struct TkAudioGpuOps {
      * once.  It sits on top of the arena and is dropped — its space handed back — by every other op, by any allocation of the graph and
      * by a GEMM that writes into the matrix it was made from. */
     struct { const float* A = nullptr; int M = 0, K = 0, lda = 0; float* img = nullptr; size_t mark = 0; bool live = false; } pk;
-    /* linear layers of a short pass (<= 256 rows: the decoder steps) on the SAME packed input are collected — up to three — and go out as ONE
+    /* linear layers on the SAME packed input (q / k / v of a layer, the cross keys and values) are collected — up to three — and go out as ONE
      * launch with a destination per segment (q | k | v: the query buffer and row p of the two caches); anything else flushes the batch first */
     struct { TkTiledGemm t{}; int n = 0; } pend;
     void flush() {
@@ -252,7 +252,7 @@ struct TkAudioGpuOps {
             tk_launch_pack_a(g.A, g.M, g.K, g.lda, 0, pk.img, s);
             pk.A = g.A; pk.M = g.M; pk.K = g.K; pk.lda = g.lda; pk.live = true;
         }
-        const bool plain = short_pass(g.M) && !g.residual && !g.c_feeds_linear && g.N % 16 == 0;
+        const bool plain = !g.residual && !g.c_feeds_linear && g.N % 16 == 0;
         if (plain) { /* joins (or opens) the batch of layers on this input */
             if (pend.n > 0 && (pend.t.a_img != pk.img || pend.t.K != g.K || pend.t.nrows != g.M || pend.t.act != g.act)) flush();
             TkTiledGemm& t = pend.t;
@@ -274,7 +274,7 @@ struct TkAudioGpuOps {
         t.a_img = pk.img; t.a_ts = (size_t)g.K * 16; t.out = g.C;
         t.bias = g.bias; t.residual = g.residual; t.ldr = g.ldr; t.act = g.act; t.add_zero_bias = 1;
         /* fc1 of a short pass: its output is only ever the input of fc2 — written as fc2's operand image as well (on top of fc1's own) */
-        const bool emit_img = g.c_feeds_linear && short_pass(g.M) && g.N % 128 == 0 && g.ldc == g.N && !g.residual;
+        const bool emit_img = g.c_feeds_linear && g.N % 128 == 0 && g.ldc == g.N && !g.residual;
         float* cimg = nullptr;
         if (emit_img) {
             TkGemm nx{};
@@ -297,7 +297,7 @@ struct TkAudioGpuOps {
     void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) { drop_image(); tk_launch_im2col1d(x, B, T, C, ldx, kw, stride, pad, col, s); }
     void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) {
         drop_image();
-        float* img = (short_pass(rows) && D % 128 == 0) ? image_for(y, rows, D, D) : nullptr; /* a short pass's norm feeds linear layers: packed on the way out */
+        float* img = D % 128 == 0 ? image_for(y, rows, D, D) : nullptr; /* a norm feeds linear layers: packed on the way out */
         tk_launch_layernorm(x, rows, D, w, b, TK_WH_LN_EPS, y, s, img);
     }
     void softmax_rows(float* x, int rows, int cols, int ld) { drop_image(); tk_launch_softmax_rows(x, rows, cols, ld, s); }
@@ -337,11 +337,10 @@ struct TkAudioSizeOps {
     void gemm(const TkGemm& g) { /* the tiled path's activation image is scratch on top of the live allocations; fc1 of a short pass adds fc2's image */
         if (!tk_tiled_gemm_applies(g)) return;
         size_t top = used + ((tk_tiled_gemm_scratch(g) + 63) & ~(size_t)63);
-        if (g.c_feeds_linear && g.M <= TK_TW_MAX_BLOCK_ROWS) { TkGemm nx{}; nx.M = g.M; nx.K = g.N; top += (tk_tiled_gemm_scratch(nx) + 63) & ~(size_t)63; }
+        if (g.c_feeds_linear) { TkGemm nx{}; nx.M = g.M; nx.K = g.N; top += (tk_tiled_gemm_scratch(nx) + 63) & ~(size_t)63; }
         if (top > peak) peak = top;
     }
-    void image(int M, int K) { /* a producer's packed output (layer norm, decoder attention of a short pass) */
-        if (M > TK_TW_MAX_BLOCK_ROWS) return;
+    void image(int M, int K) { /* a producer's packed output (layer norm, decoder attention) */
         TkGemm g{};
         g.M = M; g.K = K;
         const size_t top = used + ((tk_tiled_gemm_scratch(g) + 63) & ~(size_t)63);

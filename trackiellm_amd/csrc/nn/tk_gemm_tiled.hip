@@ -40,10 +40,8 @@ __device__ __forceinline__ float tw_act(float v, int act) {
 /* WB = bytes per weight value (2: f16, 4: f32); MT = M-tiles per workgroup.  (Twelve weight pieces in flight for the Whisper decoder's
  * K = 384 launches — one round trip to the weights instead of three — measured 20 % SLOWER per launch: the whole activation image must
  * then land before the first MFMA, profiles/r04_perception.txt.) */
-template <int MT, int WB>
-__global__ __launch_bounds__(512) void k_gemm_tiled(TkTiledGemm a, int groups, int total_row_tiles, int rk /* k per ring slot */) {
-    /* weight pieces in flight per wave; a ring slot holds a multiple of PF chunks (the launcher's rk), so piece c sits in register set c % PF */
-    constexpr int PF = MT == 16 ? 2 : 4;
+template <int MT, int WB, int PF /* weight pieces in flight per wave; a ring slot holds a multiple of PF chunks (the launcher's rk), so piece c sits in register set c % PF */>
+__global__ __launch_bounds__(512) void k_gemm_tiled(TkTiledGemm a, int groups, int total_row_tiles, int rk /* k per ring slot */, int slot_bytes /* ring slot pitch */) {
     constexpr int LPC = WB == 4 ? 2 : 1; /* 16-byte requests per piece and lane */
     constexpr int PIECE = 512 * WB;      /* bytes of one (row tile, 32 k) piece */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -74,7 +72,7 @@ __global__ __launch_bounds__(512) void k_gemm_tiled(TkTiledGemm a, int groups, i
             const int j = p / MT, m = p % MT;
             const uint8_t* src = (const uint8_t*)(a_img + (size_t)m * a.a_ts + ((size_t)(k0 + s * rk) / 16 + j) * 256);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + voff),
-                                             (__attribute__((address_space(3))) void*)(lds + (size_t)slot * TK_TW_SLOT_BYTES + (size_t)p * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds + (size_t)slot * slot_bytes + (size_t)p * 1024), 16, 0, 0);
         }
     };
 
@@ -102,7 +100,7 @@ __global__ __launch_bounds__(512) void k_gemm_tiled(TkTiledGemm a, int groups, i
         tw_wait_vmcnt(PF * LPC);
         __syncthreads();
         if (s + 1 < nslots) stage(s + 1, (s + 1) & 1);
-        const uint8_t* slot = lds + (size_t)(s & 1) * TK_TW_SLOT_BYTES + lane * 16;
+        const uint8_t* slot = lds + (size_t)(s & 1) * slot_bytes + lane * 16;
 #pragma unroll 1
         for (int cc = 0; cc < cps; cc += PF) {
 #pragma unroll
@@ -276,8 +274,8 @@ bool tk_gemm_tiled_prepare_device() {
     if (g_tw_opted[dev].load(std::memory_order_acquire)) return true;
     std::lock_guard<std::mutex> lk(g_tw_mu);
     hipError_t e = hipSuccess;
-#define TK_TW_OPT(MTV) do { if (e == hipSuccess) e = tw_opt_in(k_gemm_tiled<MTV, 2>); if (e == hipSuccess) e = tw_opt_in(k_gemm_tiled<MTV, 4>); } while (0)
-    TK_TW_OPT(1); TK_TW_OPT(2); TK_TW_OPT(4); TK_TW_OPT(8); TK_TW_OPT(16);
+#define TK_TW_OPT(MTV, PFV) do { if (e == hipSuccess) e = tw_opt_in(k_gemm_tiled<MTV, 2, PFV>); if (e == hipSuccess) e = tw_opt_in(k_gemm_tiled<MTV, 4, PFV>); } while (0)
+    TK_TW_OPT(1, 4); TK_TW_OPT(2, 4); TK_TW_OPT(4, 4); TK_TW_OPT(8, 4); TK_TW_OPT(16, 2); TK_TW_OPT(8, 2);
 #undef TK_TW_OPT
     if (e != hipSuccess) return false;
     g_tw_opted[dev].store(true, std::memory_order_release);
@@ -286,22 +284,14 @@ bool tk_gemm_tiled_prepare_device() {
 
 bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
     if (a.nseg < 1 || a.nseg > 3 || a.ks < 1 || a.K <= 0 || a.K % (32 * a.ks) || a.nrows <= 0 || (a.wbytes != 2 && a.wbytes != 4) || (a.ks > 1 && a.nrows > TK_TW_MAX_BLOCK_ROWS)) return false;
-    if ((a.per_seg || a.c_img) && (a.ks != 1 || a.nrows > TK_TW_MAX_BLOCK_ROWS)) return false;
+    if ((a.per_seg || a.c_img) && a.ks != 1) return false;
     if (a.per_seg && (a.residual || a.c_img)) return false;
     if (a.c_img && (a.n_valid % 16 || a.nseg != 1)) return false;
     int row_tiles = 0;
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.row_tiles[i];
     const int rows_blk = a.nrows < TK_TW_MAX_BLOCK_ROWS ? a.nrows : TK_TW_MAX_BLOCK_ROWS;
     int mt = rows_blk > 128 ? 16 : rows_blk > 64 ? 8 : rows_blk > 32 ? 4 : rows_blk > 16 ? 2 : 1;
-    if (mt == 16 && a.nrows > TK_TW_MAX_BLOCK_ROWS) {
-        /* many row blocks: one workgroup per CU at a time (128 KiB of ring), so the launch takes ceil(workgroups / 256) rounds of ~mt
-         * units each; 128-row blocks win when they waste less of the last round (N = 384: 564 workgroups = 3 rounds of 16 against
-         * 1125 = 5 rounds of 8; measured -2 % on the Whisper encoder) */
-        const int wg_per_blk = (row_tiles + 7) / 8;
-        const long r16 = ((long)((a.nrows + 255) / 256) * wg_per_blk + 255) / 256 * 16;
-        const long r8 = ((long)((a.nrows + 127) / 128) * wg_per_blk + 255) / 256 * 8;
-        if (r8 < r16) mt = 8;
-    }
+    if (mt == 16 && a.nrows > TK_TW_MAX_BLOCK_ROWS && (a.K / a.ks) % 64 == 0) mt = 8; /* many row blocks: 128-row blocks, two workgroups per CU (below) */
     const int ny = (a.nrows + mt * TK_TW_ROWS_PER_TILE - 1) / (mt * TK_TW_ROWS_PER_TILE);
     /* one pass of <= 256 rows (the LLM): spread the row tiles over the CUs, K-split ranges side by side; many row blocks: eight tiles
      * per workgroup share one activation ring */
@@ -322,22 +312,27 @@ bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
     }
     const int Kr = a.K / a.ks;
     /* k per ring slot: the largest multiple of 32 PF that divides the K range and fits a 64 KiB slot (rk / 16 * mt KiB) — a whole short
-     * range in one slot spares a small launch its ring hand-overs (Whisper decoder: K = 384 at two M-tiles is one 48 KiB slot) */
-    const int pf = mt == 16 ? 2 : 4;
+     * range in one slot spares a small launch its ring hand-overs (Whisper decoder: K = 384 at two M-tiles is one 48 KiB slot).
+     * Many row blocks of 128 rows (the Whisper encoder's linears, 48000 rows): 32 KiB slots and two weight pieces in flight instead, so
+     * that TWO workgroups share a CU and one's ring fill and epilogue run under the other's MFMAs. */
+    const bool twin = ny > 1 && mt == 8 && Kr % 64 == 0;
+    const int pf = (mt == 16 || twin) ? 2 : 4;
+    const int slot_kib = twin ? 32 : 64;
     int rk = 0;
-    for (int c = (1024 / mt) / (32 * pf) * (32 * pf); c >= 32 * pf; c -= 32 * pf)
+    for (int c = (slot_kib * 16 / mt) / (32 * pf) * (32 * pf); c >= 32 * pf; c -= 32 * pf)
         if (Kr % c == 0) { rk = c; break; }
     if (rk == 0) return false;
     if (Kr % rk) return false;
-    const size_t ldsb = (size_t)2 * TK_TW_SLOT_BYTES;
-#define TK_TW_LAUNCH(MTV, WBV) hipLaunchKernelGGL((k_gemm_tiled<MTV, WBV>), dim3(groups * a.ks, ny), dim3(64 * waves), ldsb, s, a, groups, row_tiles, rk)
-#define TK_TW_WB(MTV) do { if (a.wbytes == 2) TK_TW_LAUNCH(MTV, 2); else TK_TW_LAUNCH(MTV, 4); } while (0)
+    const int slot_bytes = twin ? slot_kib * 1024 : TK_TW_SLOT_BYTES;
+    const size_t ldsb = (size_t)2 * slot_bytes;
+#define TK_TW_LAUNCH(MTV, WBV, PFV) hipLaunchKernelGGL((k_gemm_tiled<MTV, WBV, PFV>), dim3(groups * a.ks, ny), dim3(64 * waves), ldsb, s, a, groups, row_tiles, rk, slot_bytes)
+#define TK_TW_WB(MTV, PFV) do { if (a.wbytes == 2) TK_TW_LAUNCH(MTV, 2, PFV); else TK_TW_LAUNCH(MTV, 4, PFV); } while (0)
     switch (mt) {
-        case 1: TK_TW_WB(1); break;
-        case 2: TK_TW_WB(2); break;
-        case 4: TK_TW_WB(4); break;
-        case 8: TK_TW_WB(8); break;
-        default: TK_TW_WB(16); break;
+        case 1: TK_TW_WB(1, 4); break;
+        case 2: TK_TW_WB(2, 4); break;
+        case 4: TK_TW_WB(4, 4); break;
+        case 8: if (twin) TK_TW_WB(8, 2); else TK_TW_WB(8, 4); break;
+        default: TK_TW_WB(16, 2); break;
     }
 #undef TK_TW_WB
 #undef TK_TW_LAUNCH
