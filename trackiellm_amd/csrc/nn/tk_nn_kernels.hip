@@ -724,8 +724,55 @@ __global__ __launch_bounds__(256) void k_softmax_rows_reg(float* x, int cols, in
         if (threadIdx.x + 256 * u < cols) xr[threadIdx.x + 256 * u] = tk_divf(v[u], tot);
 }
 
+/* rows of up to 2048 columns with 16-byte aligned rows (cols and ld multiples of 4): ONE WAVE per row, no barrier and no LDS.  Lane l reads
+ * the 16-byte groups l, l + 64, ...: element e = 4 l + c + 256 u is exactly an element of the canonical partial t = e % 256 = 4 l + c, so
+ * the lane holds partials 4 l .. 4 l + 3 and adds to each in ascending u — the order of k_softmax_rows.  The canonical tree (a 64-wide
+ * xor butterfly inside each quarter t / 64, then ((q0 + q1) + q2) + q3) becomes: xor 8, 4, 2, 1 across the 16 lanes of a quarter (t ^ 32,
+ * 16, 8, 4), then components c ^ 2 and c ^ 1 inside the lane (t ^ 2, 1).  Same pairs at every level: bit-identical. */
+__global__ __launch_bounds__(256) void k_softmax_rows_wave(float* x, int64_t rows, int cols, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float4* xr = (float4*)(x + r * ld);
+    const int n4 = cols >> 2;
+    float4 v[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = lane + 64 * u;
+        if (i < n4) {
+            v[u] = xr[i];
+            m = tk_fmaxf(tk_fmaxf(tk_fmaxf(tk_fmaxf(m, v[u].x), v[u].y), v[u].z), v[u].w);
+        }
+    }
+    for (int s = 32; s >= 1; s >>= 1) m = tk_fmaxf(m, __shfl_xor(m, s, 64));
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (lane + 64 * u < n4) {
+            v[u].x = tk_expf(v[u].x - m); v[u].y = tk_expf(v[u].y - m); v[u].z = tk_expf(v[u].z - m); v[u].w = tk_expf(v[u].w - m);
+            p0 = p0 + v[u].x; p1 = p1 + v[u].y; p2 = p2 + v[u].z; p3 = p3 + v[u].w;
+        }
+    for (int s = 8; s >= 1; s >>= 1) { /* t ^ 32, 16, 8, 4 */
+        p0 = p0 + __shfl_xor(p0, s, 64); p1 = p1 + __shfl_xor(p1, s, 64); p2 = p2 + __shfl_xor(p2, s, 64); p3 = p3 + __shfl_xor(p3, s, 64);
+    }
+    const float q = (p0 + p2) + (p1 + p3); /* t ^ 2: (c0 + c2), (c1 + c3); t ^ 1: their sum */
+    const float tot = ((__shfl(q, 0, 64) + __shfl(q, 16, 64)) + __shfl(q, 32, 64)) + __shfl(q, 48, 64);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = lane + 64 * u;
+        if (i < n4) {
+            float4 o;
+            o.x = tk_divf(v[u].x, tot); o.y = tk_divf(v[u].y, tot); o.z = tk_divf(v[u].z, tot); o.w = tk_divf(v[u].w, tot);
+            xr[i] = o;
+        }
+    }
+}
+
 void tk_launch_softmax_rows(float* x, int rows, int cols, int ld, hipStream_t s) {
-    if (cols <= 2048) hipLaunchKernelGGL(k_softmax_rows_reg, dim3(rows), dim3(256), 0, s, x, cols, ld);
+    if (cols <= 2048 && (cols & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)x) & 15) == 0 && rows >= 1024)
+        hipLaunchKernelGGL(k_softmax_rows_wave, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, (int64_t)rows, cols, ld);
+    else if (cols <= 2048) hipLaunchKernelGGL(k_softmax_rows_reg, dim3(rows), dim3(256), 0, s, x, cols, ld);
     else hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, s, x, cols, ld);
 }
 
