@@ -472,7 +472,7 @@ TkAsr::~TkAsr() {
 bool TkAsr::init(TkWhisperModel* m, int mb) {
     model = m;
     max_batch = mb;
-    if (!m || mb < 1 || mb > 64) { error = "max_batch must be in [1,64]"; return false; }
+    if (!m || mb < 1 || mb > 256) { error = "max_batch must be in [1,256]"; return false; }
     HIPQ(hipSetDevice(m->device));
     HIPQ(tk_create_perception_stream(&stream));
     TkAudioSizeOps so;

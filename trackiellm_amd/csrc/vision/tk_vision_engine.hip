@@ -350,7 +350,7 @@ TkDetector::~TkDetector() {
 bool TkDetector::init(TkYoloModel* m, int w, int h, int mb) {
     model = m; in_w = w; in_h = h; max_batch = mb;
     if (!m || w <= 0 || h <= 0 || (w % 32) || (h % 32)) { error = "detector input must be a positive multiple of 32"; return false; }
-    if (mb < 1 || mb > 64) { error = "max_batch must be in [1,64]"; return false; }
+    if (mb < 1 || mb > 256) { error = "max_batch must be in [1,256]"; return false; }
     HIPQ(hipSetDevice(m->device));
     HIPQ(tk_create_perception_stream(&stream));
     TkSizeOps so{&m->specs};
