@@ -153,6 +153,17 @@ __device__ __forceinline__ void store_tile(const TkGemm& g, const v16f& acc, flo
         for (int r = 0; r < 16; ++r) v[r] = tk_sigmoidf(v[r]);
     }
     const int mb = m_base + 4 * (lane >> 5);
+    float* cp = C + (int64_t)mb * g.ldc + n;
+    if (m_base + 32 <= g.M) { /* the whole tile lies inside the matrix (wave-uniform): straight-line stores, no test per row */
+        if (R) {
+            const float* rp = R + (int64_t)mb * g.ldr + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = v[r] + rp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldr];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+        return;
+    }
     if (R) {
         const float* rp = R + (int64_t)mb * g.ldr + n;
 #pragma unroll
@@ -161,7 +172,6 @@ __device__ __forceinline__ void store_tile(const TkGemm& g, const v16f& acc, flo
             if (mb + dm < g.M) v[r] = v[r] + rp[(int64_t)dm * g.ldr];
         }
     }
-    float* cp = C + (int64_t)mb * g.ldc + n;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int dm = (r & 3) + 8 * (r >> 2);
