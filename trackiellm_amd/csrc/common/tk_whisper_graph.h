@@ -199,24 +199,28 @@ struct TkWhisperGraph {
         return ml;
     }
 
-    /* attention over `Tk` keys for `Tq` queries per batch element; q/k/v/out row pitch = d; scores scratch [B*nh][Tq][Tk] */
+    /* row pitch of the scores scratch: whole 128-byte lines per row (1500 keys -> 1504 floats would do for 16-byte groups; 1536 keeps every
+     * row, and every 128-column tile of it, on cache-line boundaries: Q.K^T's stores and the row kernels' 16-byte groups never straddle) */
+    static int score_pitch(int Tk) { return (Tk + 31) & ~31; }
+    /* attention over `Tk` keys for `Tq` queries per batch element; q/k/v/out row pitch = d; scores scratch [B*nh][Tq][score_pitch(Tk)] */
     void attention(Ops& o, const float* q, const float* k, const float* v, float* out, int B, int Tq, int Tk, int64_t q_bstride, int64_t kv_bstride,
                    int d, int nh, float* scores) const {
         const int hd = d / nh;
         if (Tq == 1 && o.attend1(q, k, v, out, B, Tk, q_bstride, kv_bstride, d, nh)) return; /* decoder steps: one kernel, same arithmetic */
+        const int Tp = score_pitch(Tk);
         TkGemm s{};
-        s.A = q; s.B = k; s.C = scores; s.M = Tq; s.N = Tk; s.K = hd; s.lda = d; s.ldb = d; s.ldc = Tk; s.b_kn = 0; s.act = 0;
+        s.A = q; s.B = k; s.C = scores; s.M = Tq; s.N = Tk; s.K = hd; s.lda = d; s.ldb = d; s.ldc = Tp; s.b_kn = 0; s.act = 0;
         s.alpha = tk_divf(1.0f, tk_sqrtf((float)hd));
         s.batch = B * nh; s.batch_inner = nh;
-        s.sA = hd; s.sB = hd; s.sC = (int64_t)Tq * Tk;
-        s.sA2 = q_bstride; s.sB2 = kv_bstride; s.sC2 = (int64_t)nh * Tq * Tk;
+        s.sA = hd; s.sB = hd; s.sC = (int64_t)Tq * Tp;
+        s.sA2 = q_bstride; s.sB2 = kv_bstride; s.sC2 = (int64_t)nh * Tq * Tp;
         o.gemm(s);
-        o.softmax_rows(scores, B * nh * Tq, Tk, Tk);
+        o.softmax_rows(scores, B * nh * Tq, Tk, Tp);
         TkGemm p{};
-        p.A = scores; p.B = v; p.C = out; p.M = Tq; p.N = hd; p.K = Tk; p.lda = Tk; p.ldb = d; p.ldc = d; p.b_kn = 1; p.act = 0; p.alpha = 1.0f;
+        p.A = scores; p.B = v; p.C = out; p.M = Tq; p.N = hd; p.K = Tk; p.lda = Tp; p.ldb = d; p.ldc = d; p.b_kn = 1; p.act = 0; p.alpha = 1.0f;
         p.batch = B * nh; p.batch_inner = nh;
-        p.sA = (int64_t)Tq * Tk; p.sB = hd; p.sC = hd;
-        p.sA2 = (int64_t)nh * Tq * Tk; p.sB2 = kv_bstride; p.sC2 = q_bstride;
+        p.sA = (int64_t)Tq * Tp; p.sB = hd; p.sC = hd;
+        p.sA2 = (int64_t)nh * Tq * Tp; p.sB2 = kv_bstride; p.sC2 = q_bstride;
         o.gemm(p);
     }
 
@@ -238,7 +242,7 @@ struct TkWhisperGraph {
         float* v = o.alloc((size_t)B * Tc * d);
         float* at = o.alloc((size_t)B * Tc * d);
         float* ff = o.alloc((size_t)B * Tc * 4 * d);
-        float* sc = o.alloc((size_t)B * nh * Tc * Tc);
+        float* sc = o.alloc((size_t)B * nh * Tc * score_pitch(Tc));
         const int R = B * Tc;
         for (int l = 0; l < h.n_audio_layer; ++l) {
             const TkWhLayerIdx& L = m.enc[l];
@@ -283,7 +287,7 @@ struct TkWhisperGraph {
         s.k = o.alloc((size_t)B * dt); s.v = o.alloc((size_t)B * dt); s.at = o.alloc((size_t)B * dt);
         s.ff = o.alloc((size_t)B * 4 * dt);
         const int tmax = Tc > h.n_text_ctx ? Tc : h.n_text_ctx;
-        s.sc = o.alloc((size_t)B * h.n_text_head * tmax);
+        s.sc = o.alloc((size_t)B * h.n_text_head * score_pitch(tmax));
         s.logits = o.alloc((size_t)B * h.n_vocab);
         s.tok = o.alloc_i32(B); s.pos = o.alloc_i32(B); s.next = o.alloc_i32(B);
         return s;
