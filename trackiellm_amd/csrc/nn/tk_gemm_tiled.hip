@@ -263,6 +263,16 @@ void tk_launch_pack_a(const float* A, int64_t rows, int K, int lda, int round_f1
 
 /* ---- launch ---- */
 
+static int tk_tiled_num_cu() {
+    static std::atomic<int> n{0};
+    int v = n.load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    n.store(v, std::memory_order_relaxed);
+    return v;
+}
+
 template <typename F>
 static hipError_t tw_opt_in(F* fn) { return hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TK_TW_SLOT_BYTES); }
 
@@ -275,7 +285,7 @@ bool tk_gemm_tiled_prepare_device() {
     std::lock_guard<std::mutex> lk(g_tw_mu);
     hipError_t e = hipSuccess;
 #define TK_TW_OPT(MTV, PFV) do { if (e == hipSuccess) e = tw_opt_in(k_gemm_tiled<MTV, 2, PFV>); if (e == hipSuccess) e = tw_opt_in(k_gemm_tiled<MTV, 4, PFV>); } while (0)
-    TK_TW_OPT(1, 4); TK_TW_OPT(2, 4); TK_TW_OPT(4, 4); TK_TW_OPT(8, 4); TK_TW_OPT(16, 2); TK_TW_OPT(8, 2);
+    TK_TW_OPT(1, 4); TK_TW_OPT(2, 4); TK_TW_OPT(4, 4); TK_TW_OPT(8, 4); TK_TW_OPT(16, 2); TK_TW_OPT(8, 2); TK_TW_OPT(6, 2);
 #undef TK_TW_OPT
     if (e != hipSuccess) return false;
     g_tw_opted[dev].store(true, std::memory_order_release);
@@ -291,7 +301,15 @@ bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.row_tiles[i];
     const int rows_blk = a.nrows < TK_TW_MAX_BLOCK_ROWS ? a.nrows : TK_TW_MAX_BLOCK_ROWS;
     int mt = rows_blk > 128 ? 16 : rows_blk > 64 ? 8 : rows_blk > 32 ? 4 : rows_blk > 16 ? 2 : 1;
-    if (mt == 16 && a.nrows > TK_TW_MAX_BLOCK_ROWS && (a.K / a.ks) % 64 == 0) mt = 8; /* many row blocks: 128-row blocks, two workgroups per CU (below) */
+    if (mt == 16 && a.nrows > TK_TW_MAX_BLOCK_ROWS && (a.K / a.ks) % 64 == 0) {
+        /* many row blocks: two workgroups per CU (below), 512 at a time on the chip; of 128- and 96-row blocks the one whose last round
+         * wastes less (N = 384 at 48 000 rows: 1 125 workgroups = 3 rounds of 8 M-tiles against 1 500 = 3 rounds of 6) */
+        const long wg_per_blk = (row_tiles + 7) / 8;
+        const long slots = 2L * tk_tiled_num_cu();
+        const long c8 = (((a.nrows + 127) / 128) * wg_per_blk + slots - 1) / slots * 8;
+        const long c6 = (((a.nrows + 95) / 96) * wg_per_blk + slots - 1) / slots * 6;
+        mt = c6 < c8 ? 6 : 8;
+    }
     const int ny = (a.nrows + mt * TK_TW_ROWS_PER_TILE - 1) / (mt * TK_TW_ROWS_PER_TILE);
     /* one pass of <= 256 rows (the LLM): spread the row tiles over the CUs, K-split ranges side by side; many row blocks: eight tiles
      * per workgroup share one activation ring */
@@ -315,7 +333,7 @@ bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
      * range in one slot spares a small launch its ring hand-overs (Whisper decoder: K = 384 at two M-tiles is one 48 KiB slot).
      * Many row blocks of 128 rows (the Whisper encoder's linears, 48000 rows): 32 KiB slots and two weight pieces in flight instead, so
      * that TWO workgroups share a CU and one's ring fill and epilogue run under the other's MFMAs. */
-    const bool twin = ny > 1 && mt == 8 && Kr % 64 == 0;
+    const bool twin = ny > 1 && (mt == 8 || mt == 6) && Kr % 64 == 0;
     const int pf = (mt == 16 || twin) ? 2 : 4;
     const int slot_kib = twin ? 32 : 64;
     int rk = 0;
@@ -331,6 +349,7 @@ bool tk_launch_gemm_tiled(const TkTiledGemm& a, hipStream_t s) {
         case 1: TK_TW_WB(1, 4); break;
         case 2: TK_TW_WB(2, 4); break;
         case 4: TK_TW_WB(4, 4); break;
+        case 6: TK_TW_WB(6, 2); break;
         case 8: if (twin) TK_TW_WB(8, 2); else TK_TW_WB(8, 4); break;
         default: TK_TW_WB(16, 2); break;
     }
