@@ -182,6 +182,33 @@ def test_mistral_shaped_layer_batched_bit_exact(gpu):
         sess.close()
 
 
+@pytest.mark.parametrize("nrows", [1, 2])
+def test_mistral_shaped_one_and_two_row_passes_form_their_inputs_in_the_matvec_launch(gpu, nrows, monkeypatch):
+    """passes of one or two rows (the reference's own use: one runner, one token per step) run the norm / SwiGLU producers INSIDE the
+    q|k|v, gate|up, down and logits launches (TkGemvArgs::fuse, csrc/llm/tk_llm_engine.hip enqueue_range): two Mistral-7B-shaped layers
+    (so the second layer folds the first one's seven down-projection slabs), three positions through the KV cache, logits bit-exact
+    against the oracle — and against the same passes with the producers as launches of their own (TK_MI355X_NO_FUSE=1)."""
+    hp = gpu.MISTRAL_7B()
+    hp.n_layer = 2
+    model = gpu.LlmModel(hp).fill_synthetic(4)
+    hp = model.hparams
+    orc = O.OracleLlm(oracle_cfg_from(hp, 8, nrows), seed=4)
+    rng = np.random.default_rng(3)
+    seq = np.arange(nrows, dtype=np.int32)
+    toks = [rng.integers(3, hp.vocab, nrows).astype(np.int32) for _ in range(3)]
+    runs = []
+    for no_fuse in ("0", "1"):
+        monkeypatch.setenv("TK_MI355X_NO_FUSE", no_fuse)
+        sess = gpu.LlmSession(model, nrows, 8)
+        runs.append([sess.forward(seq, np.full(nrows, p, np.int32), toks[p]) for p in range(3)])
+        sess.close()
+    for p in range(3):
+        want, wam = orc.forward(seq, np.full(nrows, p, np.int32), toks[p])
+        for got, gam in (runs[0][p], runs[1][p]):
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+            assert np.array_equal(gam, wam)
+
+
 def test_full_7b_pass_width_invariance(gpu):
     """size-independent property at BASELINE size (full 32-layer Mistral-7B Q4_K_M, synthetic weights): a row's logits do not depend on
     how many other rows share its pass — 256 rows in one pass (16 M-tiles, batched kernel), the same rows as 2 x 128 and 16 x 16 passes

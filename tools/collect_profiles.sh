@@ -58,6 +58,15 @@ for B in 256 16; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_b -o b -- python3 bench.py --llm-only --batch $B --sessions 1 --steps 1 --warmup 1 --no-extras > $O/${R}_llm_b${B}_solo_run.json 2> $O/${R}_llm_b${B}_solo.err || { echo "solo trace $B failed"; exit 1; }
   cp "$(find /tmp/kt_b -name '*kernel_stats.csv' | head -1)" $O/${R}_llm_b${B}_solo_kernel_stats.csv
 done
+# one runner through the reference entry points (tools/time_b1.py), the norm / SwiGLU producers inside the mat-vec launches (shipped) and as launches of their own
+: > $O/${R}_b1_runner.txt
+for NF in 0 1; do
+  name=fused; [ $NF = 1 ] && name=unfused
+  rm -rf /tmp/kt_b1
+  TK_MI355X_NO_FUSE=$NF timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_b1 -o b -- python3 tools/time_b1.py > $O/${R}_b1_${name}.log 2>&1 || { echo "b1 trace $name failed"; exit 1; }
+  cp "$(find /tmp/kt_b1 -name '*kernel_stats.csv' | head -1)" $O/${R}_b1_runner_${name}_kernel_stats.csv
+done
 echo "traces done"
 unset ROC_AQL_QUEUE_SIZE
+for NF in 0 1 0 1; do TK_MI355X_NO_FUSE=$NF python3 tools/time_b1.py >> $O/${R}_b1_runner.txt 2>&1; done; cat $O/${R}_b1_runner.txt
 timeout -k 10 900 python3 bench.py > $O/${R}_bench_default.json 2> $O/${R}_bench_default.err; echo "bench rc=$?"; tail -c 1500 $O/${R}_bench_default.json

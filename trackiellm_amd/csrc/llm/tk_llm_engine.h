@@ -115,7 +115,7 @@ private:
     void enqueue_range(int nrows, int l0, int l1, bool embed, bool fold_out, bool lm_head, bool fused_attn);
     int enqueue_matmul(const TkDevTensor* const* t, int nseg, int K, int ks, int n_total, const TkActQ8& act, float* out, int nrows);
     uint16_t *kcache = nullptr, *vcache = nullptr;
-    float *x = nullptr, *qbuf = nullptr, *partial = nullptr, *logits = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    float *x = nullptr, *x2 = nullptr, *qbuf = nullptr, *partial = nullptr, *partial2 = nullptr, *logits = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
     TkActQ8 act_d{}, act_qd{}, act_ff{};
     int32_t *d_seq = nullptr, *d_pos = nullptr, *d_tok = nullptr, *d_nsteps = nullptr, *d_hist = nullptr;
     uint32_t* d_mask = nullptr;     /* [TK_MAX_ROWS][(vocab + 31) / 32] allowed-token bits of the masked rows of the current pass */

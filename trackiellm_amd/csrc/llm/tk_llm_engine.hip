@@ -243,6 +243,10 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     pmax = std::max(pmax, (size_t)h.ks_gateup * 2 * h.d_ff);
     pmax = std::max(pmax, (size_t)h.ks_down * h.d_model);
     HIPQ(hipMalloc((void**)&partial, pmax * TK_MAX_ROWS * 4));
+    /* twins for passes whose mat-vec launches run their producer themselves (enqueue_range): such a launch reads one (x, slab) pair while
+     * its workgroups write the other */
+    HIPQ(hipMalloc((void**)&x2, (size_t)TK_MAX_ROWS * h.d_model * 4));
+    HIPQ(hipMalloc((void**)&partial2, pmax * TK_MAX_ROWS * 4));
     HIPQ(hipMalloc((void**)&logits, (size_t)TK_MAX_ROWS * h.vocab * 4));
     if (!alloc_act(&act_d, h.d_model, m->has_f16, error) || !alloc_act(&act_qd, QD, m->has_f16, error) || !alloc_act(&act_ff, h.d_ff, m->has_f16, error)) return false;
     HIPQ(hipMalloc((void**)&d_seq, TK_MAX_ROWS * 4));
@@ -282,7 +286,7 @@ TkLlmSession::~TkLlmSession() {
     for (auto& g : graph_exec) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : graph_prefill) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : graph_head_nf) if (g) (void)hipGraphExecDestroy(g);
-    void* ptrs[] = {kcache, vcache, x, qbuf, partial, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_mask_row, d_tab};
+    void* ptrs[] = {kcache, vcache, x, x2, qbuf, partial, partial2, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_mask_row, d_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     free_act(&act_d); free_act(&act_qd); free_act(&act_ff);
     if (stream) (void)hipStreamDestroy(stream);
@@ -357,26 +361,70 @@ int TkLlmSession::enqueue_matmul(const TkDevTensor* const* t, int nseg, int K, i
     return ks;
 }
 
+static bool producer_fusion_enabled() {
+    /* TK_MI355X_NO_FUSE=1: the norm / SwiGLU kernels stay launches of their own at every row count (A/B timing, bisecting) */
+    const char* nf = getenv("TK_MI355X_NO_FUSE");
+    return !(nf && nf[0] == '1');
+}
+
 void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fold_out, bool lm_head, bool fused_attn) {
     const TkLlmHParams& h = model->hp;
     const int D = h.d_model, QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim, FF = h.d_ff;
     hipStream_t s = stream;
     if (embed) tk_launch_embed(model->token_embd.data, model->token_embd.type, D, d_tok, nrows, x, s);
+    /* One or two rows (the reference's own use: one runner, one token per step): a launch boundary (~1.5 us) plus a norm or SwiGLU kernel
+     * that is one load latency long (5 - 6 us) costs more than that kernel's work repeated by every workgroup of the mat-vec launch that
+     * consumes it — so q|k|v, gate|up and the logits matrix form their normalised int8 input themselves (TkGemvArgs::fuse = 1), the down
+     * projection its SwiGLU input (fuse = 2): 8 launches per layer become 5.  Same arithmetic, value for value.  Such a launch reads
+     * (x, slabs) of one buffer pair while workgroup 0 writes the updated stream into the other and all write their slabs there:
+     *   q|k|v: x, partial -> x2, partial2;  attention reads partial2;  o -> partial;  gate|up: x2, partial -> x, partial2;
+     *   down: partial2 -> partial — at every layer boundary x and `partial` hold what the unfused path leaves there. */
+    bool kq = model->output.type != TK_TYPE_F16;
+    for (int l = l0; l < l1 && kq; ++l) {
+        const TkLlmLayer& L = model->layers[l];
+        kq = L.q.type != TK_TYPE_F16 && L.k.type != TK_TYPE_F16 && L.v.type != TK_TYPE_F16 && L.o.type != TK_TYPE_F16 && L.gate.type != TK_TYPE_F16 &&
+             L.up.type != TK_TYPE_F16 && L.down.type != TK_TYPE_F16;
+    }
+    const bool fuse = kq && producer_fusion_enabled() && tk_gemv_fuses_producer(nrows, D, h.ks_qkv, h.ks_down) &&
+                      tk_gemv_fuses_producer(nrows, D, h.ks_gateup, h.ks_o) && tk_gemv_fuses_producer(nrows, FF, h.ks_down, h.ks_gateup) &&
+                      tk_gemv_fuses_producer(nrows, D, 1, h.ks_down);
+    auto fused_gemv = [&](const TkDevTensor* const* t, int nseg, int K, int ks, int n_total, float* out, int mode, const float* xin, float* xout,
+                          const float* slab, int slab_ks, int slab_pitch, const float* w) {
+        TkGemvArgs a{};
+        for (int i = 0; i < nseg; ++i) a.seg[i] = seg_of(*t[i]);
+        a.nseg = nseg; a.K = K; a.ks = ks; a.n_total = n_total; a.nrows = nrows; a.out = out;
+        a.fuse = mode; a.fx_in = xin; a.fx_out = xout; a.fslab = slab; a.fks = slab_ks; a.fn_total = slab_pitch; a.fw = w; a.feps = h.rms_eps;
+        tk_launch_gemv(a, s);
+        return ks;
+    };
     int ks_res = 1; /* slabs of the pending residual update (the previous layer's down projection) */
     for (int l = l0; l < l1; ++l) {
         const TkLlmLayer& L = model->layers[l];
-        tk_launch_rmsnorm_q8(x, l == l0 ? nullptr : partial, ks_res, D, (const float*)L.attn_norm.data, h.rms_eps, D, nrows, act_d, s);
         const TkDevTensor* qkv[3] = {&L.q, &L.k, &L.v};
+        const TkDevTensor* ot[1] = {&L.o};
+        const TkDevTensor* gu[2] = {&L.gate, &L.up};
+        const TkDevTensor* dn[1] = {&L.down};
+        if (fuse) {
+            const int ks_qkv = fused_gemv(qkv, 3, D, h.ks_qkv, QD + 2 * KVD, partial2, 1, x, x2, l == l0 ? nullptr : partial, ks_res, D, (const float*)L.attn_norm.data);
+            if (!fused_attn)
+                tk_launch_qkv_rope_append(partial2, ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
+                                          qbuf, kcache, vcache, l, max_seq, max_ctx, s);
+            tk_launch_attention(qbuf, partial2, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
+                                h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
+            const int ks_o = enqueue_matmul(ot, 1, QD, h.ks_o, D, act_qd, partial, nrows);
+            const int ks_gu = fused_gemv(gu, 2, D, h.ks_gateup, 2 * FF, partial2, 1, x2, x, partial, ks_o, D, (const float*)L.ffn_norm.data);
+            ks_res = fused_gemv(dn, 1, FF, h.ks_down, D, partial, 2, nullptr, nullptr, partial2, ks_gu, 2 * FF, nullptr);
+            continue;
+        }
+        tk_launch_rmsnorm_q8(x, l == l0 ? nullptr : partial, ks_res, D, (const float*)L.attn_norm.data, h.rms_eps, D, nrows, act_d, s);
         const int ks_qkv = enqueue_matmul(qkv, 3, D, h.ks_qkv, QD + 2 * KVD, act_d, partial, nrows);
         if (!fused_attn)
             tk_launch_qkv_rope_append(partial, ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
                                       qbuf, kcache, vcache, l, max_seq, max_ctx, s);
         tk_launch_attention(qbuf, partial, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
                             h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
-        const TkDevTensor* ot[1] = {&L.o};
         const int ks_o = enqueue_matmul(ot, 1, QD, h.ks_o, D, act_qd, partial, nrows);
         tk_launch_rmsnorm_q8(x, partial, ks_o, D, (const float*)L.ffn_norm.data, h.rms_eps, D, nrows, act_d, s);
-        const TkDevTensor* gu[2] = {&L.gate, &L.up};
         if (tk_gemv_fuses_swiglu(nrows, h.ks_gateup, L.gate.type, L.up.type)) { /* wide pass: SwiGLU in the launch's epilogue, `partial` holds h [rows][FF] */
             TkGemvArgs a{};
             a.seg[0] = seg_of(L.gate); a.seg[1] = seg_of(L.up);
@@ -388,7 +436,6 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
             const int ks_gu = enqueue_matmul(gu, 2, D, h.ks_gateup, 2 * FF, act_d, partial, nrows);
             tk_launch_swiglu_q8(partial, ks_gu, FF, nrows, act_ff, s);
         }
-        const TkDevTensor* dn[1] = {&L.down};
         ks_res = enqueue_matmul(dn, 1, FF, h.ks_down, D, act_ff, partial, nrows);
     }
     last_ks_res = ks_res;
@@ -396,9 +443,12 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         if (fold_out && l1 > l0) tk_launch_residual_fold(x, partial, ks_res, D, D, nrows, s);
         return;
     }
-    tk_launch_rmsnorm_q8(x, l1 > l0 ? partial : nullptr, ks_res, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
     const TkDevTensor* lm[1] = {&model->output};
-    (void)enqueue_matmul(lm, 1, D, 1, h.vocab, act_d, logits, nrows);
+    if (fuse) (void)fused_gemv(lm, 1, D, 1, h.vocab, logits, 1, x, x2, l1 > l0 ? partial : nullptr, ks_res, D, (const float*)model->out_norm.data);
+    else {
+        tk_launch_rmsnorm_q8(x, l1 > l0 ? partial : nullptr, ks_res, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
+        (void)enqueue_matmul(lm, 1, D, 1, h.vocab, act_d, logits, nrows);
+    }
     tk_launch_argmax(logits, h.vocab, nrows, d_mask, d_mask_row, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
 }
 

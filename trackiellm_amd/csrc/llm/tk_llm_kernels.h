@@ -32,6 +32,19 @@ struct TkGemvArgs {
     const int8_t* abs; /* sub-block sums as (l, h) int8 images: [K/256][2][16][8] */
     const uint16_t* abs16; /* the same sums as two f16 images (sum = 2 hh + ll): [K/256][2][16][8] halves, M-tile stride abs_ts halves */
     float* out;
+    /* fuse != 0 (only where tk_gemv_fuses_producer() says so: passes of one or two rows, where a launch boundary costs more than the
+     * producer's work repeated in every workgroup): the launch builds its int8 activation image in LDS itself and aq / ad / abs are unused.
+     *   1: residual update + RMS norm + Q8 — k_rmsnorm_q8's arithmetic: row = fx_in + (the fks slabs of fslab, ascending; pitch
+     *      fn_total; fslab null: none), written once to fx_out (a buffer OTHER than fx_in: other workgroups still read it), norm
+     *      weights fw, epsilon feps; K = d_model
+     *   2: SwiGLU + Q8 — k_swiglu_q8's arithmetic on the fks slabs of the gate | up projection in fslab ([.][2 K] per row); K = d_ff */
+    int fuse;
+    const float* fx_in;
+    float* fx_out;
+    const float* fslab;
+    int fks, fn_total;
+    const float* fw;
+    float feps;
 };
 
 struct TkActQ8 { /* quantised-activation buffers for one K */
@@ -67,6 +80,9 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
                          int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, bool fused, hipStream_t s);
 void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ8 out, hipStream_t s);
 /* wide passes: the gate | up launch forms h = silu(gate) * up in its epilogue (half the slab bytes written and read back); then only the quantisation is left */
+/* rows up to which the norm / SwiGLU producer of a mat-vec launch runs inside it (TkGemvArgs::fuse) */
+#define TK_GEMV_FUSE_MAX_ROWS 2
+bool tk_gemv_fuses_producer(int nrows, int K, int ks, int fks);
 bool tk_gemv_fuses_swiglu(int nrows, int ks, int type_gate, int type_up);
 void tk_launch_quant_q8(const float* hbuf, int FF, int nrows, TkActQ8 out, hipStream_t s);
 /* allow_base / allow_row (both optional): per-row allowed-token bit masks, allow_row[r] = mask index or -1 */

@@ -214,9 +214,11 @@ __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot,
         mb[128] = (int8_t)(sum >> 6);
         /* and as two f16 numbers, sum = 2 hh + ll (|hh| <= 2032 and ll in {0, 1} are exact in f16): the batched kernel contracts them with
          * (2 m, m) in ONE f16 MFMA */
-        uint16_t* hb = out.abs16 + mt * out.abs_ts + (size_t)(c >> 5) * 256 + (size_t)sl * 8 + ((c >> 2) & 7);
-        hb[0] = tk_f32_to_f16((float)(sum >> 1));
-        hb[128] = tk_f32_to_f16((float)(sum & 1));
+        if (out.abs16) { /* null: an image built in LDS by a mat-vec launch for itself (TkGemvArgs::fuse), which reads only (l, h) */
+            uint16_t* hb = out.abs16 + mt * out.abs_ts + (size_t)(c >> 5) * 256 + (size_t)sl * 8 + ((c >> 2) & 7);
+            hb[0] = tk_f32_to_f16((float)(sum >> 1));
+            hb[128] = tk_f32_to_f16((float)(sum & 1));
+        }
     }
     if ((c & 31) == 0) out.ad[mt * out.ad_ts + (size_t)(c >> 5) * TK_ROW_SLOTS + sl] = amax > 0.0f ? tk_divf(amax, 127.0f) : 0.0f;
 }
@@ -527,7 +529,9 @@ size_t tk_gemv_lds_bytes(int K, int ks, int mtiles) {
  * staged once per CU, (c) all waves of a CU walk disjoint contiguous tile runs.
  */
 /* TYPES: bit 0 = the launch contains Q4_K tiles, bit 1 = Q6_K tiles; single-type launches keep only one fragment ring in registers */
-template <int PF, int MT, int TYPES>
+/* FUSE (TkGemvArgs::fuse, MT = 1 only): 0 = the activation image comes from global memory; 1 / 2 = every workgroup forms it itself —
+ * the norm's or SwiGLU's arithmetic, value for value what k_rmsnorm_q8 / k_swiglu_q8 write — under the latency of its first weight tiles */
+template <int PF, int MT, int TYPES, int FUSE>
 __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int total_row_tiles) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
@@ -583,7 +587,93 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
 #pragma unroll
         for (int u = 0; u < PF; ++u) f6[HAS6 ? u : 0] = load_q6(tile + (size_t)u * tile_bytes, lane);
     }
-    {
+    if (FUSE != 0) {
+        const int nw = nthr >> 6, hw = tid >> 5, nhw = nthr >> 5;
+        TkActQ8 lo{}; /* the LDS image as quantize_chunk8's destination: same layout as the global one, block 0 = this K-range's first */
+        lo.aq = (int8_t*)lds_act; lo.ad = lds_ad; lo.abs = (int8_t*)lds_abs; lo.aq_ts = act_ts; lo.ad_ts = (size_t)ad_ts; lo.abs_ts = (size_t)abs_ts;
+        if (FUSE == 1) {
+            const int D = a.K, ngrp4 = D / 4;
+            float* hbuf = (float*)(lds_abs + MT * abs_ts); /* the finished row, then 4 floats of the canonical sum */
+            float* red = hbuf + D;
+            /* norm weights of this half-wave's first block: requested before the reductions so their latency hides under them */
+            v4f wa0 = {0.0f, 0.0f, 0.0f, 0.0f}, wa1 = wa0;
+            if (hw < nb) { const int c = 32 * (blk0 + hw) + (lane & 31); wa0 = *(const v4f*)(a.fw + 8 * c); wa1 = *(const v4f*)(a.fw + 8 * c + 4); }
+            for (int r = 0; r < a.nrows; ++r) {
+                if (r > 0) __syncthreads(); /* hbuf and red are reused */
+                for (int gi = tid; gi < ngrp4; gi += nthr) { /* the row and ALL its slabs requested before the first add (k_rmsnorm_q8) */
+                    v4f v = *(const v4f*)(a.fx_in + (int64_t)r * D + 4 * gi);
+                    if (a.fslab) {
+                        v4f p[TK_RMS_MAX_KS];
+#pragma unroll
+                        for (int sl = 0; sl < TK_RMS_MAX_KS; ++sl)
+                            if (sl < a.fks) p[sl] = *(const v4f*)(a.fslab + ((int64_t)sl * TK_MAX_ROWS + r) * a.fn_total + 4 * gi);
+                        v4f o = p[0];
+#pragma unroll
+                        for (int sl = 1; sl < TK_RMS_MAX_KS; ++sl)
+                            if (sl < a.fks) o = o + p[sl];
+                        v = v + o;
+                    }
+                    if (blockIdx.x == 0) *(v4f*)(a.fx_out + (int64_t)r * D + 4 * gi) = v; /* the residual stream moves on once */
+                    *(v4f*)(hbuf + 4 * gi) = v;
+                }
+                __syncthreads();
+                /* sum of squares as the canonical 256 chains; chain t = 64 vw + lane belongs to "wave" vw of k_rmsnorm_q8's first four */
+                for (int vw = wave; vw < 4; vw += nw) {
+                    float ss = 0.0f;
+                    for (int gi = 64 * vw + lane; gi < ngrp4; gi += 256) {
+                        const v4f v = *(const v4f*)(hbuf + 4 * gi);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ss = tk_fmaf(v[i], v[i], ss);
+                    }
+                    for (int sh = 32; sh >= 1; sh >>= 1) ss = ss + wave_xor_f(ss, sh);
+                    if (lane == 0) red[vw] = ss;
+                }
+                __syncthreads();
+                const float tot = ((red[0] + red[1]) + red[2]) + red[3];
+                const float scale = tk_divf(1.0f, tk_sqrtf(tk_divf(tot, (float)D) + a.feps));
+                for (int b = hw; b < nb; b += nhw) { /* a half-wave quantises one 256-block of this K-range */
+                    const int cl = 32 * b + (lane & 31), c = 32 * blk0 + cl;
+                    v4f w0, w1;
+                    if (b == hw) { w0 = wa0; w1 = wa1; }
+                    else { w0 = *(const v4f*)(a.fw + 8 * c); w1 = *(const v4f*)(a.fw + 8 * c + 4); }
+                    const v4f h0 = *(const v4f*)(hbuf + 8 * c), h1 = *(const v4f*)(hbuf + 8 * c + 4);
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = (h0[i] * scale) * w0[i];
+                        v[4 + i] = (h1[i] * scale) * w1[i];
+                    }
+                    quantize_chunk8(v, cl, r, lo);
+                }
+            }
+        } else {
+            const int FF = a.K;
+            for (int r = 0; r < a.nrows; ++r)
+                for (int b = hw; b < nb; b += nhw) {
+                    const int cl = 32 * b + (lane & 31), c = 32 * blk0 + cl;
+                    v4f g[2], u[2];
+                    {
+                        v4f pg[TK_RMS_MAX_KS][2], pu[TK_RMS_MAX_KS][2];
+#pragma unroll
+                        for (int sl = 0; sl < TK_RMS_MAX_KS; ++sl)
+                            if (sl < a.fks) {
+                                const float* row = a.fslab + ((int64_t)sl * TK_MAX_ROWS + r) * (2 * (int64_t)FF);
+                                pg[sl][0] = *(const v4f*)(row + 8 * c); pg[sl][1] = *(const v4f*)(row + 8 * c + 4);
+                                pu[sl][0] = *(const v4f*)(row + FF + 8 * c); pu[sl][1] = *(const v4f*)(row + FF + 8 * c + 4);
+                            }
+                        g[0] = pg[0][0]; g[1] = pg[0][1]; u[0] = pu[0][0]; u[1] = pu[0][1];
+#pragma unroll
+                        for (int sl = 1; sl < TK_RMS_MAX_KS; ++sl)
+                            if (sl < a.fks) { g[0] = g[0] + pg[sl][0]; g[1] = g[1] + pg[sl][1]; u[0] = u[0] + pu[sl][0]; u[1] = u[1] + pu[sl][1]; }
+                    }
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = tk_siluf(g[i >> 2][i & 3]) * u[i >> 2][i & 3];
+                    quantize_chunk8(v, cl, r, lo);
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0); /* the image's stores and the first weight tiles */
+    } else {
         /* activations: LDS-DMA (global_load_lds_dwordx4), one contiguous 1 KiB piece per wave-instruction, no VGPR
          * round trip and no per-piece wait: the whole K-range image is in flight at once. */
         const int nw = nthr >> 6, npiece = Kr * TK_ROW_SLOTS / 1024;
@@ -1417,12 +1507,19 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
      * depth; the two-type kernel does not. */
     if (mt == 2 && types == 2) types = 3;
     const int pf = nb % 2 == 0 ? 2 : 1;
-#define TK_GEMV_LAUNCH(PFV, MTV, TYV) hipLaunchKernelGGL((k_gemv_w4a8<PFV, MTV, TYV>), dim3(groups * a.ks), dim3(64 * waves), lds, s, a, groups, row_tiles)
-#define TK_GEMV_TY(PFV, MTV) do { if (types == 1) TK_GEMV_LAUNCH(PFV, MTV, 1); else if (types == 2) TK_GEMV_LAUNCH(PFV, MTV, 2); else TK_GEMV_LAUNCH(PFV, MTV, 3); } while (0)
-    if (mt == 1) { if (pf == 2) TK_GEMV_TY(2, 1); else TK_GEMV_TY(1, 1); }
-    else { if (pf == 2) TK_GEMV_TY(2, 2); else TK_GEMV_TY(1, 2); }
+#define TK_GEMV_LAUNCH(PFV, MTV, TYV, FUV) hipLaunchKernelGGL((k_gemv_w4a8<PFV, MTV, TYV, FUV>), dim3(groups * a.ks), dim3(64 * waves), lds + fuse_lds, s, a, groups, row_tiles)
+#define TK_GEMV_TY(PFV, MTV, FUV) do { if (types == 1) TK_GEMV_LAUNCH(PFV, MTV, 1, FUV); else if (types == 2) TK_GEMV_LAUNCH(PFV, MTV, 2, FUV); else TK_GEMV_LAUNCH(PFV, MTV, 3, FUV); } while (0)
+    const size_t fuse_lds = a.fuse == 1 ? ((size_t)a.K + 4) * sizeof(float) : 0; /* the finished row and the canonical sum's four partials */
+    if (a.fuse && mt == 1 && pf == 2) { /* tk_gemv_fuses_producer() admits only such launches */
+        if (a.fuse == 1) TK_GEMV_TY(2, 1, 1); else TK_GEMV_TY(2, 1, 2);
+    } else if (mt == 1) { if (pf == 2) TK_GEMV_TY(2, 1, 0); else TK_GEMV_TY(1, 1, 0); }
+    else { if (pf == 2) TK_GEMV_TY(2, 2, 0); else TK_GEMV_TY(1, 2, 0); }
 #undef TK_GEMV_TY
 #undef TK_GEMV_LAUNCH
+}
+
+bool tk_gemv_fuses_producer(int nrows, int K, int ks, int fks) {
+    return nrows >= 1 && nrows <= TK_GEMV_FUSE_MAX_ROWS && ks >= 1 && K % (512 * ks) == 0 && fks >= 0 && fks <= TK_RMS_MAX_KS;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1898,8 +1995,9 @@ const char* tk_llm_prepare_device(int device) {
 #define TK_OPT_GEMM(MTV) do { TK_OPT((k_gemm_w4a8<MTV, 1, 1>)); TK_OPT((k_gemm_w4a8<MTV, 2, 1>)); TK_OPT((k_gemm_w4a8<MTV, 3, 1>)); } while (0)
     TK_OPT_GEMM(4); TK_OPT_GEMM(8);
     TK_OPT((k_gemm32_w4a8<1>)); TK_OPT((k_gemm32_w4a8<2>)); TK_OPT((k_gemm32_w4a8<3>));
-#define TK_OPT_GEMV(PFV, MTV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3>)); } while (0)
-    TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2);
+#define TK_OPT_GEMV_F(PFV, MTV, FUV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1, FUV>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2, FUV>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3, FUV>)); } while (0)
+#define TK_OPT_GEMV(PFV, MTV) TK_OPT_GEMV_F(PFV, MTV, 0)
+    TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2); TK_OPT_GEMV_F(2, 1, 1); TK_OPT_GEMV_F(2, 1, 2);
 #define TK_OPT_ATT_C(H, C, S) do { TK_OPT((k_attention<1, true, H, C, S>)); TK_OPT((k_attention<2, true, H, C, S>)); TK_OPT((k_attention<4, true, H, C, S>)); \
                                  TK_OPT((k_attention<1, false, H, C, S>)); TK_OPT((k_attention<2, false, H, C, S>)); TK_OPT((k_attention<4, false, H, C, S>)); } while (0)
 #define TK_OPT_ATT(H) do { TK_OPT_ATT_C(H, 32, TK_ATT_WIDE_SLOTS); TK_OPT_ATT_C(H, 64, 2); } while (0)
