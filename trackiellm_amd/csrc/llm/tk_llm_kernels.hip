@@ -1606,9 +1606,13 @@ __device__ __forceinline__ float sum_partials_wide(const float* partial, int ks,
 /* stage rows [row0, row0 + 32) of one (sequence, kv head) cache run into an LDS slot; rows past `last_row` are clamped (their
  * content is never used).  swz: XOR-swizzle the 16-byte pieces of a row by the row number (K); plain copy otherwise (V).
  * Every wave issues exactly chunk_bytes / 4096 one-KiB pieces: the counted waits rely on it. */
-__device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int last_row, int rb /* row bytes */, uint8_t* slot, bool swz, int wave, int lane, int chunk) {
+/* row_end (< 0: off): pieces whose rows all lie at or past it are not requested at all — only where every wait is a vmcnt(0) (two ring
+ * slots), which a 128-position chunk of a short context needs (its unused three quarters would cost a 64-position context 1.5 us) */
+__device__ __forceinline__ void att_stage(const uint16_t* run, int row0, int last_row, int rb /* row bytes */, uint8_t* slot, bool swz, int wave, int lane, int chunk,
+                                          int row_end = -1) {
     const int pieces = chunk * rb / 1024, ppr = rb / 16; /* 1 KiB pieces per chunk; 16-byte pieces per row */
     for (int pc = wave; pc < pieces; pc += 4) {
+        if (row_end >= 0 && row0 + pc * 64 / ppr >= row_end) continue; /* wave-uniform: a piece's first row (no early exit: the loop stays unrolled) */
         const int idx = pc * 64 + lane;           /* 16-byte piece index inside the chunk */
         const int r = idx / ppr, cs = idx % ppr;  /* row inside the chunk, piece slot inside the row */
         int gr = row0 + r;
@@ -1663,7 +1667,7 @@ __global__ __launch_bounds__(256, TK_ATT_WAVES) void k_attention(const float* __
     auto issue = [&](int j) { /* chunk j of the stream into slot j % SLOTS; always issued (a chunk with nothing cached yet re-reads clamped rows) */
         const bool is_k = j < nchunk;
         const int c = is_k ? j : j - nchunk;
-        att_stage(is_k ? krun : vrun, c * CH, last_row, rb, ring + (j % SLOTS) * slot_bytes, is_k, wave, lane, CH);
+        att_stage(is_k ? krun : vrun, c * CH, last_row, rb, ring + (j % SLOTS) * slot_bytes, is_k, wave, lane, CH, (SLOTS == 2 && CH > 64) ? T : -1);
     };
     /* before touching chunk j: all but the chunks issued after it have landed; everybody is done with chunk j - 1, whose slot takes
      * chunk j + SLOTS - 1 */
@@ -1744,12 +1748,22 @@ __global__ __launch_bounds__(256, TK_ATT_WAVES) void k_attention(const float* __
         }
     }
     /* row maximum per head: thread idx = h * CHUNK + rr served head h in every chunk (GQ * CHUNK <= 256 threads: one idx per thread) */
-    {
+    if (CH <= 64) {
         float m = mx;
         for (int s = CH / 2; s >= 1; s >>= 1) m = tk_fmaxf(m, wave_xor_f(m, s)); /* over the CHUNK lanes of one head */
         if ((lane & (CH - 1)) == 0 && t < GQ * CH) red[t / CH] = m;
+    } else { /* a head's CHUNK threads span CH / 64 whole waves: per-wave maxima, joined below (a maximum does not depend on the order) */
+        float m = mx;
+        for (int s = 32; s >= 1; s >>= 1) m = tk_fmaxf(m, wave_xor_f(m, s));
+        if (lane == 0) red[TK_ATT_MAX_GRP + wave] = m; /* the second row of red[4][GQ <= 4]: free until the epilogue's lpart, which lives in the ring */
     }
     __syncthreads(); /* every score is written */
+    if (CH > 64 && t < GQ) {
+        float m = red[TK_ATT_MAX_GRP + t * (CH / 64)];
+        for (int w = 1; w < CH / 64; ++w) m = tk_fmaxf(m, red[TK_ATT_MAX_GRP + t * (CH / 64) + w]);
+        red[t] = m;
+    }
+    if (CH > 64) __syncthreads();
     for (int h = 0; h < GQ; ++h) {
         const float m = red[h];
         for (int tt = t; tt < T; tt += 256) sc[(size_t)h * max_ctx + tt] = tk_expf(sc[(size_t)h * max_ctx + tt] - m);
@@ -1853,7 +1867,15 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
     /* positions per ring slot: 64 while the launch is a latency chain of few workgroups (fewer, longer phases), 32 once several
      * workgroups per CU are resident (16 KiB less LDS each: more of them fit; 256 rows: 47.9 -> 43.3 us, 16 rows would lose 24 %;
      * profiles/r02_attention_variants.txt) */
-    const int chunk = (n_head / gq) * nrows > 4 * TK_NUM_CU ? 32 : 64;
+#ifndef TK_ATT_NARROW_CHUNK
+#define TK_ATT_NARROW_CHUNK 128 /* 64: the round-3 form */
+#endif
+    /* at most one workgroup per CU and <= 2 query heads per workgroup: 128 positions per slot — the score phase (one fma chain per (head,
+     * position): 2 x 64 threads of a 64-position chunk leave two of the four waves idle) runs on all four waves and a context has half as
+     * many barrier-separated phases */
+    const bool narrow = TK_ATT_NARROW_CHUNK == 128 && gq * 128 <= 256 && (n_head / gq) * nrows <= TK_NUM_CU && (head_dim == 128 || head_dim == 64) &&
+                        tk_attention_lds_bytes(gq, head_dim, max_ctx, 128, 2) <= (size_t)TK_MAX_DYN_LDS;
+    const int chunk = narrow ? 128 : (n_head / gq) * nrows > 4 * TK_NUM_CU ? 32 : 64;
     /* ring depth 2 at every pass width: with few workgroups a five-slot ring (every K and V chunk of a 128-position context in flight at
      * once) measured no faster — 16 rows x 128 positions 10.7 us against 11.1, decode step unchanged (profiles/r03_attention_slots.txt): a
      * one-row launch already takes 9.8 us, the launch is a chain of ~10 barrier-separated phases, not of DMA latencies */
@@ -1865,7 +1887,7 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
 #define TK_ATT_LAUNCH_CH(G, F, H, C, S)                                                                                                       \
     hipLaunchKernelGGL((k_attention<G, F, H, C, S>), dim3(n_head / gq, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin, kcache, \
                        vcache, seq, pos, n_head, n_kv_head, head_dim, layer, max_seq, max_ctx, out)
-#define TK_ATT_LAUNCH_HD(G, F, H) do { if (chunk == 32) TK_ATT_LAUNCH_CH(G, F, H, 32, TK_ATT_WIDE_SLOTS); else TK_ATT_LAUNCH_CH(G, F, H, 64, 2); } while (0)
+#define TK_ATT_LAUNCH_HD(G, F, H) do { if (chunk == 32) TK_ATT_LAUNCH_CH(G, F, H, 32, TK_ATT_WIDE_SLOTS); else if (chunk == 128 && G <= 2 && H != 0) TK_ATT_LAUNCH_CH((G <= 2 ? G : 2), F, (H ? H : 128), 128, 2); else TK_ATT_LAUNCH_CH(G, F, H, 64, 2); } while (0)
 #define TK_ATT_LAUNCH(G, F) do { if (head_dim == 128) TK_ATT_LAUNCH_HD(G, F, 128); else if (head_dim == 64) TK_ATT_LAUNCH_HD(G, F, 64); else TK_ATT_LAUNCH_HD(G, F, 0); } while (0)
     if (fused) {
         if (gq == 4) TK_ATT_LAUNCH(4, true); else if (gq == 2) TK_ATT_LAUNCH(2, true); else TK_ATT_LAUNCH(1, true);
@@ -2032,6 +2054,9 @@ const char* tk_llm_prepare_device(int device) {
                                  TK_OPT((k_attention<1, false, H, C, S>)); TK_OPT((k_attention<2, false, H, C, S>)); TK_OPT((k_attention<4, false, H, C, S>)); } while (0)
 #define TK_OPT_ATT(H) do { TK_OPT_ATT_C(H, 32, TK_ATT_WIDE_SLOTS); TK_OPT_ATT_C(H, 64, 2); } while (0)
     TK_OPT_ATT(0); TK_OPT_ATT(64); TK_OPT_ATT(128);
+#define TK_OPT_ATT_N(H) do { TK_OPT((k_attention<1, true, H, 128, 2>)); TK_OPT((k_attention<2, true, H, 128, 2>)); TK_OPT((k_attention<1, false, H, 128, 2>)); TK_OPT((k_attention<2, false, H, 128, 2>)); } while (0)
+    TK_OPT_ATT_N(64); TK_OPT_ATT_N(128);
+#undef TK_OPT_ATT_N
 #undef TK_OPT_ATT
 #undef TK_OPT_GEMV
 #undef TK_OPT_GEMM
