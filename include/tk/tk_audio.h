@@ -85,7 +85,7 @@ typedef struct {
     int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
     int32_t n_text_ctx, n_text_state, n_text_head, n_text_layer, n_vocab;
 } tk_mi355x_whisper_hparams_t;
-/* explicit geometry + batch (parity tests use a small geometry; bench uses tiny.en with max_batch = B) */
+/* explicit geometry + batch (parity tests use a small geometry; bench uses tiny.en with max_batch = B); max_batch in [1, 256] */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_create(tk_asr_whisper_context_t** out, const tk_mi355x_whisper_hparams_t* hp, uint64_t seed,
                                                          int device, int max_batch);
 /* B utterances of n_samples int16 each -> exactly n_steps greedy tokens per utterance (forced, EOT ignored);

@@ -124,7 +124,7 @@ TK_API TK_NODISCARD tk_error_code_t tk_vision_pipeline_process_frame(tk_vision_p
 TK_API void tk_vision_result_destroy(tk_vision_result_t** result);
 
 /* ---- extensions (no reference counterpart) ---- */
-/* B frames of identical geometry in one pass (one per concurrent cortex cycle); results[i] / counts[i] per frame */
+/* B frames of identical geometry in one pass (one per concurrent cortex cycle); results[i] / counts[i] per frame; max_batch in [1, 256] */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_set_max_batch(tk_object_detector_t* detector, int max_batch);
 /* ONNX detector file (tk_object_detector_config_t.model_path, src/vision/tk_object_detector.c:93-152): parse the Conv initialisers
  * (no ONNX Runtime, no GPU) and check them against the YOLOv8n graph this path runs; n_convs / n_params optional */
