@@ -202,11 +202,23 @@ def test_mistral_shaped_one_and_two_row_passes_form_their_inputs_in_the_matvec_l
         sess = gpu.LlmSession(model, nrows, 8)
         runs.append([sess.forward(seq, np.full(nrows, p, np.int32), toks[p]) for p in range(3)])
         sess.close()
+    wams = []
     for p in range(3):
         want, wam = orc.forward(seq, np.full(nrows, p, np.int32), toks[p])
+        wams.append(wam)
         for got, gam in (runs[0][p], runs[1][p]):
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
             assert np.array_equal(gam, wam)
+    # layer-sharded with the producers inside the launches: stage 0 = layer 0 (its stream leaves folded), stage 1 = layer 1 + head
+    monkeypatch.setenv("TK_MI355X_NO_FUSE", "0")
+    a, b = gpu.LlmSession(model, nrows, 8), gpu.LlmSession(model, nrows, 8)
+    for p in range(3):
+        x01 = np.empty((nrows, hp.d_model), np.float32)
+        a.forward_stage(seq, np.full(nrows, p, np.int32), 0, 1, tok=toks[p], x_out=x01)
+        am = b.forward_stage(seq, np.full(nrows, p, np.int32), 1, 2, x_in=x01, head=True)
+        assert np.array_equal(am, wams[p])
+    a.close()
+    b.close()
 
 
 def test_full_7b_pass_width_invariance(gpu):
