@@ -56,6 +56,9 @@ TK_API void tk_mi355x_llm_model_destroy(tk_mi355x_llm_model_t** m);
  * are coalesced into passes by one scheduler thread per session.  Set before the first tk_llm_runner_create on the model (default:
  * $TK_MI355X_RUNNER_SLOTS, else 16; at most tk_mi355x_llm_max_rows()).  KV memory = slots x context_size x 128 KiB for Mistral-7B. */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_set_runner_slots(void* model_handle, int slots);
+/* Passes of one or two rows (one runner stepping alone) run their RMS-norm and SwiGLU producers inside the mat-vec launches that consume
+ * them (five launches per layer instead of eight; same values); $TK_MI355X_NO_FUSE=1, read when a pass is recorded, keeps them as launches of
+ * their own.  $TK_MI355X_NO_GRAPH=1 launches every pass eagerly instead of replaying hipGraphs (profilers). */
 /* what the schedulers of a model have done so far: passes run, rows processed, the widest pass */
 TK_API void tk_mi355x_llm_model_batch_stats(void* model_handle, uint64_t* passes, uint64_t* rows, int32_t* max_rows_in_a_pass);
 /* run-ahead rows (csrc/llm/tk_llm_batcher.h) that no owner came back for: the scheduler feeds a sequence's sampled id one position ahead
