@@ -83,6 +83,25 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_forward(tk_mi355x_llm_session_
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_forward_stage(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos,
                                                                 const int32_t* tok, const float* x_in, float* x_out, int x_on_host, int layer0,
                                                                 int layer1, int head, int32_t* argmax);
+/* ---- sampling.  The reference installs llama.cpp's default sampler (llama_sampling_default_params(), src/ai_models/tk_runner_lifecycle.c:76-77;
+ * llama_sampling_sample, tk_runner_streaming.c:60-61; seed = tk_llm_config_t.random_seed, tk_runner_lifecycle.c:49): top-k 40, top-p 0.95,
+ * min-p 0.05, temperature 0.8, one draw.  Here the default of a runner is GREEDY (the parity definition, and what the bench
+ * runs); tk_mi355x_llm_runner_set_sampling switches a runner to that chain, on the device, with a counter-based generator keyed by
+ * (random_seed, tokens sampled so far by this runner): the same seed gives the same ids whatever else shares the runner's passes, and the
+ * oracle restates the arithmetic (orc_sample_row) so tests compare ids for fixed seeds.  temperature 0 = back to greedy.  top_k 0 = 64 (the
+ * most candidates kept); top_p 1 and min_p 0 switch those filters off.  llama.cpp itself is absent (parity unpinned vs its generator). ---- */
+typedef struct {
+    float temperature, top_p, min_p;
+    int32_t top_k;
+    uint64_t seed;
+    uint32_t counter; /* draws made so far with this seed */
+    uint32_t reserved;
+} tk_mi355x_sampling_t;
+struct tk_llm_runner_s;
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_runner_set_sampling(struct tk_llm_runner_s* runner, float temperature, int32_t top_k, float top_p, float min_p);
+/* tk_mi355x_llm_forward with a sampling state per row (temperature <= 0: that row takes the arg max); ids [nrows] */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_forward_sampled(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos,
+                                                                  const int32_t* tok, const tk_mi355x_sampling_t* sampling, float* logits, int32_t* ids);
 /* KV cache import / export: positions [pos0, pos0 + n_pos) of one (layer, sequence) as IEEE f16 bits, host arrays laid out
  * [position][kv head][head_dim] (what llama.cpp's llama_state_seq_* moves for one sequence; the reference clears the cache per prompt,
  * src/ai_models/tk_runner_streaming.c:31, so it has no counterpart there).  Restores a saved prompt prefix; the parity tests use it to put

@@ -35,6 +35,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../trackiellm_amd/csrc/common/tk_exact_math.h"
@@ -519,6 +520,72 @@ void orc_llm_kv_read(orc_llm* m, int layer, int seq, int pos0, int n_pos, uint16
     const size_t base = (((size_t)layer * c.max_seq + seq) * c.max_ctx + pos0) * row;
     memcpy(k, &m->kcache[base], (size_t)n_pos * row * 2);
     memcpy(v, &m->vcache[base], (size_t)n_pos * row * 2);
+}
+
+/* The stochastic sampler (test infrastructure, like the rest of this file).  What it restates: the chain the reference installs with
+ * llama_sampling_default_params() and runs in llama_sampling_sample (/root/reference/src/ai_models/tk_runner_lifecycle.c:76-77,
+ * tk_runner_streaming.c:60-61, seed tk_runner_lifecycle.c:49): top-k, top-p, min-p, temperature, one draw.  llama.cpp is an empty,
+ * un-pinned submodule of the reference: its generator (std::mt19937 + std::discrete_distribution) cannot be reproduced bit for bit —
+ * parity unpinned vs llama.cpp.  The arithmetic below is the canonical order the HIP kernel (k_argmax / sample_row) follows:
+ *   candidates: allowed tokens ordered by (logit descending under the order-preserving integer key, id ascending), the first
+ *               K = min(top_k or 64, 64, allowed);
+ *   p_i = exp(l_i - l_0) / S, S summed in candidate order;  top-p: shortest prefix whose running sum of p reaches top_p;
+ *   min-p: drop the tail with p_i < min_p * p_0;  w_i = exp((l_i - l_0) / temp);  u = (splitmix64(seed, counter) >> 40) * 2^-24;
+ *   the first i whose running sum of w exceeds u * W (W summed in candidate order), else the last candidate.
+ * allow: (vocab + 31) / 32 words or NULL.  temp <= 0: the arg max over the allowed tokens (first index). */
+static uint32_t orc_sample_key(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+int32_t orc_sample_row(const float* logits, int vocab, const uint32_t* allow, float temp, int32_t top_k, float top_p, float min_p, uint64_t seed,
+                       uint32_t counter) {
+    std::vector<int32_t> ids;
+    for (int i = 0; i < vocab; ++i)
+        if (!allow || ((allow[i >> 5] >> (i & 31)) & 1u)) ids.push_back(i);
+    if (ids.empty()) return 0;
+    if (!(temp > 0.0f)) {
+        int32_t best = ids[0];
+        for (int32_t i : ids) if (logits[i] > logits[best]) best = i;
+        return best;
+    }
+    int K = top_k > 0 ? top_k : 64;
+    if (K > 64) K = 64;
+    if (K > (int)ids.size()) K = (int)ids.size();
+    std::partial_sort(ids.begin(), ids.begin() + K, ids.end(), [&](int32_t a, int32_t b) {
+        const uint32_t ka = orc_sample_key(logits[a]), kb = orc_sample_key(logits[b]);
+        return ka != kb ? ka > kb : a < b;
+    });
+    const float l0 = logits[ids[0]];
+    float S = 0.0f;
+    for (int i = 0; i < K; ++i) S = S + tk_expf(logits[ids[i]] - l0);
+    int n = K;
+    if (top_p < 1.0f) {
+        float c = 0.0f;
+        for (int i = 0; i < K; ++i) {
+            c = c + tk_divf(tk_expf(logits[ids[i]] - l0), S);
+            if (c >= top_p) { n = i + 1; break; }
+        }
+    }
+    if (min_p > 0.0f) {
+        const float thr = min_p * tk_divf(1.0f, S);
+        while (n > 1 && tk_divf(tk_expf(logits[ids[n - 1]] - l0), S) < thr) --n;
+    }
+    float W = 0.0f;
+    for (int i = 0; i < n; ++i) W = W + tk_expf(tk_divf(logits[ids[i]] - l0, temp));
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)counter + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;
+    const float target = u * W;
+    float c = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        c = c + tk_expf(tk_divf(logits[ids[i]] - l0, temp));
+        if (c > target) return ids[i];
+    }
+    return ids[n - 1];
 }
 
 void orc_llm_reset(orc_llm* m) {

@@ -55,6 +55,8 @@ def lib():
         L.orc_llm_get_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int64]
         L.orc_llm_tensor_type.argtypes = [C.POINTER(LlmConfig), C.c_int, C.c_int]
         L.orc_llm_forward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.orc_sample_row.restype = C.c_int32
+        L.orc_sample_row.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_uint32]
         L.orc_llm_kv_write.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 2
         L.orc_llm_kv_read.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 2
         L.orc_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
@@ -138,6 +140,14 @@ class OracleLlm:
         am = np.empty(n, dtype=np.int32)
         lib().orc_llm_forward(self.h, n, ptr(seq), ptr(pos), ptr(tok), ptr(logits) if want_logits else None, ptr(am))
         return logits, am
+
+
+def sample_row(logits, temp, top_k, top_p, min_p, seed, counter, allow=None):
+    """the canonical stochastic sampler (oracle/tk_oracle_llm.cpp: orc_sample_row); allow = uint32 bit words or None"""
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    if allow is not None:
+        allow = np.ascontiguousarray(allow, dtype=np.uint32)
+    return int(lib().orc_sample_row(ptr(logits), logits.size, ptr(allow) if allow is not None else None, temp, top_k, top_p, min_p, seed, counter))
 
 
 def q8k_quantize(x):

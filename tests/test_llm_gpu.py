@@ -768,3 +768,108 @@ def test_f16_weights_wide_passes_bit_exact(gpu, nseq, npos):
         g1, _ = narrow.forward(seq[sel], pos[sel], tok[sel])
         assert np.array_equal(g1.view(np.uint32), got[sel].view(np.uint32))
     sess.close(); narrow.close(); model.close()
+
+
+SAMPLING_CASES = [  # (temperature, top_k, top_p, min_p): llama.cpp's defaults first, then each filter alone / switched off
+    (0.8, 40, 0.95, 0.05), (1.0, 0, 1.0, 0.0), (0.3, 8, 1.0, 0.0), (1.7, 64, 0.5, 0.0), (1.0, 40, 1.0, 0.3), (0.0, 40, 0.95, 0.05),
+]
+
+
+@pytest.mark.parametrize("seed", [0, 7, 0xDEADBEEF, (1 << 63) + 12345])
+def test_stochastic_sampler_ids_equal_the_oracle(gpu, seed):
+    """the reference samples through llama.cpp's default chain (/root/reference/src/ai_models/tk_runner_lifecycle.c:76-77,
+    tk_runner_streaming.c:60-61); here it runs on the device (k_argmax / sample_row: radix select + one canonical arithmetic order) and the
+    oracle restates it (orc_sample_row): for a fixed (seed, counter) every id is equal — 12 rows per pass with different parameter sets and
+    counters, greedy rows mixed in, over three steps of a Mistral-sized vocabulary (32000 logits per row) and on the tiny model."""
+    for hp0, nl in ((gpu.MISTRAL_7B(), 1), (gpu.TINY(), 2)):
+        hp0.n_layer = nl
+        model = gpu.LlmModel(hp0).fill_synthetic(4)
+        hp = model.hparams
+        n = 12
+        sess = gpu.LlmSession(model, n, 16)
+        orc = O.OracleLlm(oracle_cfg_from(hp, 16, n), seed=4)
+        rng = np.random.default_rng(seed & 0xFFFF)
+        seq = np.arange(n, dtype=np.int32)
+        tok = rng.integers(3, hp.vocab, n).astype(np.int32)
+        for step in range(3):
+            pos = np.full(n, step, np.int32)
+            samp = [SAMPLING_CASES[(r + step) % len(SAMPLING_CASES)] + (seed, 100 * r + step) for r in range(n)]
+            want_logits, wam = orc.forward(seq, pos, tok)
+            got_logits, ids = sess.forward_sampled(seq, pos, tok, samp)
+            assert np.array_equal(got_logits.view(np.uint32), want_logits.view(np.uint32))
+            want = [O.sample_row(want_logits[r], *samp[r]) for r in range(n)]
+            assert ids.tolist() == want, (step, ids.tolist(), want)
+            greedy = [r for r in range(n) if samp[r][0] <= 0]
+            assert greedy and all(ids[r] == wam[r] for r in greedy)
+            tok = ids.astype(np.int32)
+        assert len(set(ids.tolist())) > 3
+        # a pass without sampling states afterwards is greedy again (the table of the previous pass is cleared)
+        _, am = sess.forward(seq, np.full(n, 3, np.int32), tok, want_logits=False)
+        _, wam = orc.forward(seq, np.full(n, 3, np.int32), tok, want_logits=False)
+        assert np.array_equal(am, wam)
+        sess.close()
+        model.close()
+        orc.close()
+
+
+def test_runner_with_the_reference_sampler_is_seeded_and_batch_invariant(gpu):
+    """tk_llm_config_t.random_seed (src/ai_models/tk_model_runner.h:45-49) + tk_mi355x_llm_runner_set_sampling: a runner's stochastic ids
+    equal the oracle's for its seed, do not change when other runners share its passes, and differ for another seed"""
+    loader = gpu.ModelLoader()
+    h = loader.load("synthetic://tiny?seed=4")
+    hp = gpu.LlmHParams()
+    gpu.lib().tk_mi355x_llm_model_get_hparams(h, __import__("ctypes").byref(hp))
+
+    def oracle_ids(seed, n):
+        orc = O.OracleLlm(oracle_cfg_from(hp, 64, 1), seed=4)
+        ids = [1, 3 + ord("h"), 3 + ord("i")]
+        lg, _ = orc.forward([0, 0, 0], [0, 1, 2], ids)
+        out, counter = [], 0
+        cur = O.sample_row(lg[-1], 0.8, 40, 0.95, 0.05, seed, counter)
+        for i in range(n):
+            out.append(cur)
+            counter += 1
+            lg, _ = orc.forward([0], [3 + i], [cur])
+            cur = O.sample_row(lg[0], 0.8, 40, 0.95, 0.05, seed, counter)
+        orc.close()
+        return out
+
+    def run(runner, n):
+        runner.prepare("hi")
+        out = []
+        for _ in range(n):
+            p = runner.next_token()
+            if p is None:
+                break
+            out.append(3 + p[0] if len(p) == 1 else int(p.decode().strip()[1:]))
+        return out
+
+    want = oracle_ids(21, 10)
+    eos = 2
+    if eos in want:
+        want = want[: want.index(eos)]
+    r1 = gpu.LlmRunner(h, context_size=64, random_seed=21)
+    r1.set_sampling(0.8)
+    assert run(r1, 10) == want
+    # a second generation continues the generator (the counter is the runner's, not the prompt's): different ids, same as the oracle's continuation
+    # and two more runners with other seeds decoding at the same time do not change runner 1's stream
+    import threading
+    r2 = gpu.LlmRunner(h, context_size=64, random_seed=21)
+    r2.set_sampling(0.8)
+    r3 = gpu.LlmRunner(h, context_size=64, random_seed=22)
+    r3.set_sampling(0.8)
+    res = {}
+    ths = [threading.Thread(target=lambda k, r: res.__setitem__(k, run(r, 10)), args=(k, r)) for k, r in (("a", r2), ("b", r3))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert res["a"] == want and res["b"] != want
+    r1.set_sampling(0.0)  # back to greedy
+    g = run(r1, 6)
+    r4 = gpu.LlmRunner(h, context_size=64)
+    assert g == run(r4, 6)
+    with pytest.raises(gpu.TkError):
+        r1.set_sampling(-1.0)
+    for r in (r1, r2, r3, r4):
+        r.close()
+    loader.unload(h)
+    loader.close()

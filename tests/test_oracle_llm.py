@@ -223,3 +223,40 @@ def test_f16_conversion_matches_numpy():
         assert got == int(want.view(np.uint16)), (v, got, int(want.view(np.uint16)))
     for h in range(0, 0x7c00, 7):
         assert L.orc_f16_to_f32(h) == float(np.uint16(h).view(np.float16))
+
+
+def test_sampler_canonical_chain_properties():
+    """orc_sample_row (the canonical order of the on-device sampler; the reference installs llama.cpp's default chain,
+    /root/reference/src/ai_models/tk_runner_lifecycle.c:76-77): temperature 0 and top_k 1 are the arg max (first index on ties), a
+    (seed, counter) pair is a pure function, masks are honoured, top-p / min-p only ever cut the tail, and over many draws the token
+    frequencies follow softmax(l / T) over the kept candidates."""
+    rng = np.random.default_rng(5)
+    lg = rng.standard_normal(512).astype(np.float32) * 2.0
+    lg[17] = lg[400] = lg.max() + 1.0  # a tie at the top: the lower id wins
+    assert O.sample_row(lg, 0.0, 40, 0.95, 0.05, 1, 0) == 17
+    assert O.sample_row(lg, 0.8, 1, 1.0, 0.0, 99, 3) == 17
+    allow = np.zeros(16, np.uint32)
+    for t in (5, 300, 400):
+        allow[t >> 5] |= np.uint32(1 << (t & 31))
+    assert O.sample_row(lg, 0.0, 40, 0.95, 0.05, 1, 0, allow) == 400
+    lg[5], lg[300] = lg[400] - 0.5, lg[400] - 1.0
+    draws = [O.sample_row(lg, 1.5, 0, 1.0, 0.0, 7, c, allow) for c in range(64)]
+    assert set(draws) <= {5, 300, 400} and len(set(draws)) >= 2
+    assert draws == [O.sample_row(lg, 1.5, 0, 1.0, 0.0, 7, c, allow) for c in range(64)]  # pure in (seed, counter)
+    assert draws != [O.sample_row(lg, 1.5, 0, 1.0, 0.0, 8, c, allow) for c in range(64)]  # and the seed matters
+    # frequencies against softmax(l / T) over the top-8 (top_p 1, min_p 0)
+    T, K, N = 0.9, 8, 20000
+    order = sorted(range(512), key=lambda i: (-lg[i], i))[:K]
+    w = np.exp((lg[order].astype(np.float64) - float(lg[order[0]])) / T)
+    p = w / w.sum()
+    got = np.bincount([O.sample_row(lg, T, K, 1.0, 0.0, 12345, c) for c in range(N)], minlength=512)
+    assert got.sum() == N and set(np.nonzero(got)[0]) <= set(order)
+    assert np.abs(got[order] / N - p).max() < 0.012
+    # top-p 0.5 keeps the shortest prefix whose probability reaches 0.5; min-p cuts candidates below min_p * p_0
+    p1 = np.exp(lg[order].astype(np.float64) - float(lg[order[0]]))
+    p1 /= np.exp(np.sort(lg.astype(np.float64))[::-1][:K] - float(lg[order[0]])).sum()
+    keep = int(np.searchsorted(np.cumsum(p1), 0.5) + 1)
+    got = set(O.sample_row(lg, T, K, 0.5, 0.0, 3, c) for c in range(2000))
+    assert got <= set(order[:keep])
+    got = set(O.sample_row(lg, T, K, 1.0, 0.6, 3, c) for c in range(2000))
+    assert got <= set(i for i, q in zip(order, p1) if q >= 0.6 * p1[0] - 1e-9)

@@ -255,6 +255,18 @@ tk_error_code_t tk_mi355x_llm_forward(tk_mi355x_llm_session_t* s, int nrows, con
     return TK_SUCCESS;
 }
 
+tk_error_code_t tk_mi355x_llm_forward_sampled(tk_mi355x_llm_session_t* s, int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok,
+                                              const tk_mi355x_sampling_t* sampling, float* logits, int32_t* ids) {
+    if (!s || !seq || !pos || !tok || !sampling || nrows < 1 || nrows > TK_MAX_ROWS) return TK_ERROR_INVALID_ARGUMENT;
+    TkSampleRow rows[TK_MAX_ROWS] = {};
+    for (int r = 0; r < nrows; ++r) {
+        const tk_mi355x_sampling_t& p = sampling[r];
+        rows[r].temp = p.temperature; rows[r].top_p = p.top_p; rows[r].min_p = p.min_p; rows[r].top_k = p.top_k; rows[r].seed = p.seed; rows[r].counter = p.counter;
+    }
+    if (!s->session.forward(nrows, seq, pos, tok, logits, ids, true, nullptr, rows)) return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);
+    return TK_SUCCESS;
+}
+
 tk_error_code_t tk_mi355x_llm_session_kv_write(tk_mi355x_llm_session_t* s, int layer, int seq, int pos0, int n_pos, const uint16_t* k, const uint16_t* v) {
     if (!s || !k || !v) return TK_ERROR_INVALID_ARGUMENT;
     if (!s->session.kv_write(layer, seq, pos0, n_pos, k, v)) return fail(TK_ERROR_INVALID_ARGUMENT, s->session.error);
@@ -540,6 +552,10 @@ struct tk_llm_runner_s {
     int n_ctx = 0;
     int n_past = 0;
     int32_t pending = -1; /* token sampled from the last logits, not yet decoded */
+    /* sampling: greedy unless tk_mi355x_llm_runner_set_sampling gave a temperature; the generator is keyed by (config.random_seed, number of
+     * tokens this runner has sampled since its creation), so a runner's ids do not depend on which other runners share its passes */
+    TkSampleRow samp{};
+    const TkSampleRow* next_samp() { return samp.temp > 0.0f ? &samp : nullptr; }
     bool is_processing = false;
     std::string piece;
     std::string system_prompt;
@@ -586,12 +602,20 @@ static std::string load_tool_grammar_text() {
 
 const char* tk_mi355x_llm_runner_tool_call_text(tk_llm_runner_t* runner) { return runner ? runner->tool_call_text.c_str() : NULL; }
 
+tk_error_code_t tk_mi355x_llm_runner_set_sampling(tk_llm_runner_t* runner, float temperature, int32_t top_k, float top_p, float min_p) {
+    if (!runner || !(temperature >= 0.0f) || top_k < 0 || !(top_p > 0.0f) || top_p > 1.0f || !(min_p >= 0.0f) || min_p > 1.0f) return TK_ERROR_INVALID_ARGUMENT;
+    if (temperature > 0.0f && runner->model->model.hp.vocab > 65536) return fail(TK_ERROR_NOT_IMPLEMENTED, "stochastic sampling supports vocabularies of at most 65536 tokens");
+    runner->samp.temp = temperature; runner->samp.top_k = top_k; runner->samp.top_p = top_p; runner->samp.min_p = min_p;
+    return TK_SUCCESS;
+}
+
 tk_error_code_t tk_llm_runner_create(tk_llm_runner_t** out_runner, void* model_handle, const tk_llm_config_t* config) {
     if (!out_runner || !model_handle || !config) return TK_ERROR_INVALID_ARGUMENT;
     std::unique_ptr<tk_llm_runner_s> r(new tk_llm_runner_s());
     r->model = (tk_mi355x_llm_model_t*)model_handle;
     r->n_ctx = config->context_size ? (int)config->context_size : 4096;
     if (config->system_prompt) r->system_prompt = config->system_prompt;
+    r->samp.seed = config->random_seed;
     {   /* a sequence slot in a shared session of this context size; a new session when every slot is taken */
         std::lock_guard<std::mutex> lk(r->model->batch_mu);
         for (auto& b : r->model->batchers)
@@ -636,7 +660,8 @@ static tk_error_code_t feed(tk_llm_runner_s* r, const std::vector<int32_t>& toks
     if (r->n_past + (int)toks.size() >= r->n_ctx) return fail(TK_ERROR_INFERENCE_FAILED, "prompt exceeds the context window");
     int32_t am = -1;
     std::string err;
-    if (!r->batcher->submit(r->slot, r->n_past, toks.data(), (int)toks.size(), r->next_mask(), &am, &err)) return fail(TK_ERROR_INFERENCE_FAILED, err);
+    if (!r->batcher->submit(r->slot, r->n_past, toks.data(), (int)toks.size(), r->next_mask(), &am, &err, r->next_samp())) return fail(TK_ERROR_INFERENCE_FAILED, err);
+    if (r->samp.temp > 0.0f) r->samp.counter++;
     r->n_past += (int)toks.size();
     r->pending = am;
     return TK_SUCCESS;
@@ -681,11 +706,12 @@ const char* tk_llm_runner_generate_next_token(tk_llm_runner_t* runner) {
     if (runner->n_past + 1 >= runner->n_ctx) { runner->is_processing = false; return NULL; }
     int32_t t = id, am = -1;
     std::string err;
-    if (!runner->batcher->submit(runner->slot, runner->n_past, &t, 1, runner->next_mask(), &am, &err)) {
+    if (!runner->batcher->submit(runner->slot, runner->n_past, &t, 1, runner->next_mask(), &am, &err, runner->next_samp())) {
         tk_error_set_detail("%s", err.c_str());
         runner->is_processing = false;
         return NULL;
     }
+    if (runner->samp.temp > 0.0f) runner->samp.counter++;
     runner->n_past++;
     runner->pending = am;
     runner->piece = runner->model->tok.piece(id);

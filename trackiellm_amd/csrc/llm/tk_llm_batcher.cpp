@@ -62,16 +62,18 @@ void TkLlmBatcher::drop_ahead(int slot) {
     a = Ahead();
 }
 
-bool TkLlmBatcher::submit(int slot, int pos0, const int32_t* toks, int n, const uint32_t* mask, int32_t* sampled, std::string* err) {
+bool TkLlmBatcher::submit(int slot, int pos0, const int32_t* toks, int n, const uint32_t* mask, int32_t* sampled, std::string* err, const TkSampleRow* samp) {
     if (n <= 0) { *err = "nothing to feed"; return false; }
     if (slot < 0 || slot >= (int)slot_used_.size() || pos0 < 0 || pos0 + n > n_ctx_) { *err = "rows do not fit the context window"; return false; }
     Request r;
     r.slot = slot; r.pos0 = pos0; r.n = n; r.toks = toks; r.mask = mask;
+    if (samp) r.samp = *samp;
+    const bool stochastic = r.samp.temp > 0.0f;
     std::unique_lock<std::mutex> lk(mu_);
     if (stop_) { *err = "scheduler stopped"; return false; }
     Ahead& a = ahead_[(size_t)slot];
     if (a.st != Ahead::NONE && !a.discard) {
-        if (n == 1 && !mask && pos0 == a.pos && toks[0] == a.tok) { /* the row this call asks for is the one that ran (or runs) ahead */
+        if (n == 1 && !mask && !stochastic && pos0 == a.pos && toks[0] == a.tok) { /* the row this call asks for is the one that ran (or runs) ahead */
             if (a.st == Ahead::DONE) {
                 const bool ok = a.ok;
                 const int32_t got = a.sampled;
@@ -103,6 +105,7 @@ bool TkLlmBatcher::submit(int slot, int pos0, const int32_t* toks, int n, const 
 void TkLlmBatcher::loop() {
     std::vector<int32_t> sq, ps, tk, am;
     std::vector<const uint32_t*> masks;
+    std::vector<TkSampleRow> samps;
     std::vector<Request*> in_pass, completing;
     std::vector<int> ahead_rows; /* slots whose run-ahead row rides this pass, in row order after the queued requests' rows */
     auto any_planned = [&] {
@@ -111,8 +114,8 @@ void TkLlmBatcher::loop() {
     };
     for (;;) {
         in_pass.clear(); completing.clear(); ahead_rows.clear();
-        sq.clear(); ps.clear(); tk.clear(); masks.clear();
-        bool any_mask = false;
+        sq.clear(); ps.clear(); tk.clear(); masks.clear(); samps.clear();
+        bool any_mask = false, any_samp = false;
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait(lk, [&] { return stop_ || !queue_.empty() || any_planned(); });
@@ -141,12 +144,15 @@ void TkLlmBatcher::loop() {
                     ps.push_back(r->pos0 + r->done_rows + i);
                     tk.push_back(r->toks[r->done_rows + i]);
                     masks.push_back(nullptr);
+                    samps.push_back(TkSampleRow{});
                 }
                 in_pass.push_back(r);
                 if (r->done_rows + take == r->n) {
                     completing.push_back(r);
                     masks.back() = r->mask; /* the row that is sampled */
+                    samps.back() = r->samp;
                     any_mask = any_mask || r->mask != nullptr;
+                    any_samp = any_samp || r->samp.temp > 0.0f;
                 }
             }
             /* then the run-ahead rows, one per sequence whose owner holds the id they feed */
@@ -158,6 +164,7 @@ void TkLlmBatcher::loop() {
                 ps.push_back(a.pos);
                 tk.push_back(a.tok);
                 masks.push_back(nullptr);
+                samps.push_back(TkSampleRow{});
                 ahead_rows.push_back((int)s);
             }
         }
@@ -165,7 +172,8 @@ void TkLlmBatcher::loop() {
         if (nrows == 0) continue;
         am.assign((size_t)nrows, -1);
         const bool head = !completing.empty() || !ahead_rows.empty();
-        const bool ok = session_.forward(nrows, sq.data(), ps.data(), tk.data(), nullptr, head ? am.data() : nullptr, head, head && any_mask ? masks.data() : nullptr);
+        const bool ok = session_.forward(nrows, sq.data(), ps.data(), tk.data(), nullptr, head ? am.data() : nullptr, head, head && any_mask ? masks.data() : nullptr,
+                                        head && any_samp ? samps.data() : nullptr);
         {
             std::lock_guard<std::mutex> lk(mu_);
             passes_++;
@@ -183,7 +191,7 @@ void TkLlmBatcher::loop() {
                     r->sampled = ok ? am[(size_t)row - 1] : -1;
                     for (auto it = queue_.begin(); it != queue_.end(); ++it)
                         if (*it == r) { queue_.erase(it); break; }
-                    if (ok) plan_ahead(r->slot, r->pos0 + r->n - 1, r->sampled, r->mask != nullptr);
+                    if (ok) plan_ahead(r->slot, r->pos0 + r->n - 1, r->sampled, r->mask != nullptr || r->samp.temp > 0.0f);
                     if (!ok || ahead_[(size_t)r->slot].st != Ahead::PLANNED) held++;
                     r->finished = true;
                     r->cv.notify_all();

@@ -41,7 +41,9 @@ public:
     int slots() const { return (int)slot_used_.size(); }
     /* Blocking: feed `n` tokens of sequence `slot` at positions pos0, pos0 + 1, ...; *sampled = arg max after the last one (over the
      * tokens `mask` allows, when given: (vocab + 31) / 32 words, bit t = token t).  Thread-safe; one outstanding call per slot. */
-    bool submit(int slot, int pos0, const int32_t* toks, int n, const uint32_t* mask, int32_t* sampled, std::string* err);
+    /* samp (optional): sampling state of the sampled row — temp > 0 draws from the reference's default stochastic chain with the given
+     * (seed, counter) instead of the arg max; such rows never run ahead (the next counter is the owner's) */
+    bool submit(int slot, int pos0, const int32_t* toks, int n, const uint32_t* mask, int32_t* sampled, std::string* err, const TkSampleRow* samp = nullptr);
     /* counters for tests and bench: passes run, rows processed FOR AN OWNER (a run-ahead row counts when its owner takes it; wasted ones
      * are in *wasted), the widest pass so far */
     void stats(uint64_t* passes, uint64_t* rows, int* max_rows, uint64_t* wasted = nullptr);
@@ -51,6 +53,7 @@ private:
         int slot, pos0, n, done_rows = 0;
         const int32_t* toks;
         const uint32_t* mask;
+        TkSampleRow samp{};
         int32_t sampled = -1;
         bool finished = false, ok = true;
         std::string error;

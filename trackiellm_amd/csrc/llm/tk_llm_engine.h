@@ -80,9 +80,10 @@ public:
     bool init(TkLlmModel* m, int max_seq, int max_ctx);
     /* one pass over nrows <= TK_MAX_ROWS rows (16-row M-tiles); host arrays.  row_masks (optional): row_masks[r] = nullptr or the
      * (vocab + 31) / 32 words whose bit t says token t may be sampled for row r: grammar-constrained greedy sampling, per row, so
-     * constrained and unconstrained rows share passes (and the captured graphs) */
+     * constrained and unconstrained rows share passes (and the captured graphs).  row_samp (optional): [nrows] sampling state, temp > 0
+     * = the reference's default stochastic chain for that row (tk_llm_kernels.h), else greedy */
     bool forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
-                 bool lm_head = true, const uint32_t* const* row_masks = nullptr);
+                 bool lm_head = true, const uint32_t* const* row_masks = nullptr, const TkSampleRow* row_samp = nullptr);
     /* one pipeline stage of a pass: layers [l0, l1) on this GPU.  The first stage starts from `tok` (x_in == nullptr), later stages
      * from the residual stream x_in [nrows][d_model] fp32; every stage but the last writes the stream to x_out; the last one
      * (head == true, l1 == n_layer) samples.  x_on_host: x_in / x_out are host pointers (gloo transport), otherwise device
@@ -121,6 +122,8 @@ private:
     uint32_t* d_mask = nullptr;     /* [TK_MAX_ROWS][(vocab + 31) / 32] allowed-token bits of the masked rows of the current pass */
     int32_t* d_mask_row = nullptr;  /* [TK_MAX_ROWS] index into d_mask, -1 = the row samples unconstrained */
     bool mask_rows_dirty = true;    /* d_mask_row holds something other than all -1 */
+    TkSampleRow* d_samp = nullptr;  /* [TK_MAX_ROWS] sampling state of the rows of the current pass (temp 0 = greedy); decode() continues from it */
+    bool samp_dirty = false;        /* d_samp holds a stochastic row */
     std::string launch_error; /* set by enqueue_* when a launcher refuses its arguments (no HIP error is raised for that) */
     int hist_cap = 0;
     hipGraphExec_t graph_exec[TK_MAX_ROWS + 1] = {};    /* decode pass (head + sampling, fused attention), by row count */

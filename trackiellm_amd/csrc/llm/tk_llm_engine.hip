@@ -260,6 +260,9 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     HIPQ(hipMalloc((void**)&d_mask_row, TK_MAX_ROWS * 4));
     HIPQ(hipMemset(d_mask_row, 0xFF, TK_MAX_ROWS * 4));
     mask_rows_dirty = false;
+    HIPQ(hipMalloc((void**)&d_samp, TK_MAX_ROWS * sizeof(TkSampleRow)));
+    HIPQ(hipMemset(d_samp, 0, TK_MAX_ROWS * sizeof(TkSampleRow))); /* temp 0: every row samples greedily */
+    samp_dirty = false;
     /* RoPE table, double precision on the host (same formula as the oracle) */
     std::vector<float> cs((size_t)mctx * half), sn((size_t)mctx * half);
     for (int p = 0; p < mctx; ++p)
@@ -286,7 +289,7 @@ TkLlmSession::~TkLlmSession() {
     for (auto& g : graph_exec) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : graph_prefill) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : graph_head_nf) if (g) (void)hipGraphExecDestroy(g);
-    void* ptrs[] = {kcache, vcache, x, x2, qbuf, partial, partial2, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_mask_row, d_tab};
+    void* ptrs[] = {kcache, vcache, x, x2, qbuf, partial, partial2, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_mask_row, d_samp, d_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     free_act(&act_d); free_act(&act_qd); free_act(&act_ff);
     if (stream) (void)hipStreamDestroy(stream);
@@ -449,7 +452,7 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         tk_launch_rmsnorm_q8(x, l1 > l0 ? partial : nullptr, ks_res, D, (const float*)model->out_norm.data, h.rms_eps, D, nrows, act_d, s);
         (void)enqueue_matmul(lm, 1, D, 1, h.vocab, act_d, logits, nrows);
     }
-    tk_launch_argmax(logits, h.vocab, nrows, d_mask, d_mask_row, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
+    tk_launch_argmax(logits, h.vocab, nrows, d_mask, d_mask_row, d_samp, d_tok, d_pos, d_nsteps, d_hist, TK_MAX_ROWS, s);
 }
 
 static bool graphs_enabled() {
@@ -486,7 +489,7 @@ bool TkLlmSession::capture_pass(hipGraphExec_t* slot, int nrows, bool lm_head, b
 }
 
 bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, float* logits_host, int32_t* argmax_host,
-                           bool lm_head, const uint32_t* const* row_masks) {
+                           bool lm_head, const uint32_t* const* row_masks, const TkSampleRow* row_samp) {
     if (nrows <= 0 || nrows > TK_MAX_ROWS) { error = "nrows must be in [1,256]"; return false; }
     for (int r = 0; r < nrows; ++r) {
         if (seq[r] < 0 || seq[r] >= max_seq || pos[r] < 0 || pos[r] >= max_ctx || tok[r] < 0 || tok[r] >= model->hp.vocab) {
@@ -517,6 +520,19 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
         if (nmask > 0 || mask_rows_dirty) {
             HIPQ(hipMemcpyAsync(d_mask_row, rowtab, TK_MAX_ROWS * 4, hipMemcpyHostToDevice, stream)); /* whole table (a wider pass may have left entries); pageable source: staged before the call returns */
             mask_rows_dirty = nmask > 0;
+        }
+        /* per-row sampling state (temp <= 0: greedy): data of the pass like the masks, so sampled and greedy rows share passes and graphs */
+        bool any_samp = false;
+        for (int r = 0; r < nrows && row_samp; ++r) any_samp = any_samp || row_samp[r].temp > 0.0f;
+        if (any_samp) {
+            if (model->hp.vocab > 65536) { error = "stochastic sampling supports vocabularies of at most 65536 tokens"; return false; }
+            TkSampleRow tab[TK_MAX_ROWS] = {};
+            for (int r = 0; r < nrows; ++r) tab[r] = row_samp[r];
+            HIPQ(hipMemcpyAsync(d_samp, tab, sizeof tab, hipMemcpyHostToDevice, stream));
+            samp_dirty = true;
+        } else if (samp_dirty) {
+            HIPQ(hipMemsetAsync(d_samp, 0, TK_MAX_ROWS * sizeof(TkSampleRow), stream));
+            samp_dirty = false;
         }
     }
     /* a pass replays a captured graph (one per (row count, form)): a host that asks for one token at a time — the reference's runner

@@ -1248,10 +1248,27 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
 
 template <bool Q4> struct G32Frag { typedef FragQ4 type; };
 template <> struct G32Frag<false> { typedef FragQ6 type; };
+/* `tile` is wave-uniform (an SGPR pair); the per-lane offsets are 32-bit and opaque per call, so the loads take the scalar-base form and no
+ * 64-bit per-lane address is hoisted out of the K loop and held across it (load_q4 / load_q6 with a lane pointer cost 12 registers there) */
 template <bool Q4>
 __device__ __forceinline__ typename G32Frag<Q4>::type g32_load(const uint8_t* tile, int lane) {
-    if constexpr (Q4) return load_q4(tile, lane);
-    else return load_q6(tile, lane);
+    unsigned lo = (unsigned)lane * 16u, ho = (unsigned)(lane & 15) * 16u;
+    asm volatile("" : "+v"(lo), "+v"(ho));
+    if constexpr (Q4) {
+        FragQ4 f;
+        f.q0 = ldg_nt(tile + lo);
+        f.q1 = ldg_nt(tile + 1024 + lo);
+        f.h = ldg_nt(tile + 2048 + ho);
+        return f;
+    } else {
+        FragQ6 f;
+        f.q0 = ldg_nt(tile + lo);
+        f.q1 = ldg_nt(tile + 1024 + lo);
+        f.qh = ldg_nt(tile + 2048 + lo);
+        f.sc = ldg_nt(tile + 3072 + ho);
+        f.d = *(const uint16_t*)(tile + 3328 + (ho >> 3));
+        return f;
+    }
 }
 template <bool Q4>
 __device__ __forceinline__ void g32_unpack(const typename G32Frag<Q4>::type& f0, const typename G32Frag<Q4>::type& f1, int lane, Ops32& o) {
@@ -1362,24 +1379,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
      * tile, every lane takes part: no exec masking, so the issue can sit between the MFMA phases of the tile loop) in four parts of two
      * pieces; the f16 sub-block sums (32 lanes) and the block scales (4 lanes) separately at the top of a block */
     const int m0 = half * MT; /* the half's first M-tile in the pass's activation images */
+    /* addresses = wave-uniform base (SGPR pair) + this lane's 32-bit offset, formed where they are used: the compiler otherwise hoists five
+     * 64-bit per-lane addresses out of the K loop and holds ten registers for them across it (the asm keeps the offset opaque per use) */
     auto stage_part = [&](int c, int slot, int part) {
+        unsigned lane16 = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(lane16));
         const int m = pair + 4 * (part >> 1);
-        const uint8_t* src = (const uint8_t*)a.aq + (size_t)(m0 + m) * a.aq_ts + (size_t)(blk0 + c) * 4096 + (part & 1) * 2048 + lane * 16;
-        const auto gs = (const __attribute__((address_space(1))) void*)src;
+        const uint8_t* src = (const uint8_t*)a.aq + (size_t)(m0 + m) * a.aq_ts + (size_t)(blk0 + c) * 4096 + (part & 1) * 2048;
+        const auto gs = (const __attribute__((address_space(1))) void*)(src + lane16);
         const auto ls = (__attribute__((address_space(3))) void*)(lds + slot * CH + m * 4096 + (part & 1) * 2048);
         __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
     };
     auto stage_small = [&](int c, int slot) {
         uint8_t* dst = lds + slot * CH;
+        unsigned lane16 = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(lane16));
         for (int m = pair; m < MT; m += 4) {
-            const uint8_t* sm = (const uint8_t*)(a.abs16 + (size_t)(m0 + m) * a.abs_ts + (size_t)(blk0 + c) * 256) + lane * 16;
+            const uint8_t* sm = (const uint8_t*)(a.abs16 + (size_t)(m0 + m) * a.abs_ts + (size_t)(blk0 + c) * 256);
             if (lane < 32)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sm,
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sm + lane16),
                                                  (__attribute__((address_space(3))) void*)(dst + OFF_AMN + m * 512), 16, 0, 0);
-            const uint8_t* sd = (const uint8_t*)(a.ad + (size_t)(m0 + m) * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS) + lane * 16;
+            const uint8_t* sd = (const uint8_t*)(a.ad + (size_t)(m0 + m) * a.ad_ts + (size_t)(blk0 + c) * TK_ROW_SLOTS);
             if (lane < 4)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sd + lane16),
                                                  (__attribute__((address_space(3))) void*)(dst + OFF_AD + m * 64), 16, 0, 0);
         }
     };
@@ -1956,13 +1979,134 @@ void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ
 }
 
 /* ------------------------------------------------------------------------------------------
- * greedy sampling: first index of the maximum; feeds the next step entirely on-device
- * (tok <- argmax, pos <- pos + 1, history append) so a decode loop is a pure graph replay.
+ * sampling.  Greedy (the default, the parity definition of SURVEY §0 F8 and the bench's mode): first index of the maximum.  Stochastic
+ * (a row whose TkSampleRow::temp > 0): the chain the reference installs with llama_sampling_default_params()
+ * (src/ai_models/tk_runner_lifecycle.c:76-77, sampled in tk_runner_streaming.c:60-61) — top-k, top-p, min-p, temperature, one draw —
+ * restated with ONE canonical arithmetic order (oracle: orc_sample_row) so a seed gives the same ids on both sides:
+ *   candidates = the K = min(top_k or 64, 64, allowed) tokens of largest logit, ties to the lower id, in that order (l_0 >= l_1 >= ...)
+ *   p_i = exp(l_i - l_0) / sum (sum over i ascending);  top-p: the shortest prefix whose running sum reaches top_p;  min-p: drop the tail
+ *   with p_i < min_p * p_0;  w_i = exp((l_i - l_0) / temp), W = sum ascending;  u = 24 random bits * 2^-24 from splitmix64(seed, counter);
+ *   the first i whose running sum of w exceeds u * W.
+ * Either way the result feeds the next step on-device (tok <- id, pos <- pos + 1, history append, counter + 1) so a decode loop is a pure
+ * graph replay.  The selection is a radix select over (order-preserving logit key, ~id): six 8-bit rounds of an LDS histogram.
  * ------------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab, const uint32_t* allow_base, const int32_t* allow_row, int32_t* tok,
-                                                  int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride) {
+__device__ __forceinline__ uint32_t sample_key(float f) { /* unsigned order == float order (-0 < +0) */
+    const uint32_t u = tk_f32_bits(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ void sample_row(const float* lg, int vocab, const uint32_t* allow, const TkSampleRow& sp, int32_t* out_id, uint32_t* lds_u32) {
+    /* lds_u32: 256 histogram bins + 8 control words + 64 x (key, id) + 64 x (logit, id) sorted */
+    uint32_t* hist = lds_u32;
+    uint32_t* ctl = lds_u32 + 256; /* [0] digit found, [1] k left, [2] list count, [3] allowed count */
+    uint32_t* lkey = ctl + 8;      /* [64] keys as collected */
+    uint32_t* lid = lkey + 64;     /* [64] ids as collected */
+    float* slog = (float*)(lid + 64); /* [64] logits, sorted */
+    uint32_t* sid = (uint32_t*)(slog + 64); /* [64] ids, sorted */
+    const int t = threadIdx.x, nthr = blockDim.x;
+    auto allowed = [&](int i) { return !allow || ((allow[i >> 5] >> (i & 31)) & 1u); };
+    if (t < 8) ctl[t] = 0;
+    __syncthreads();
+    { /* how many tokens may be drawn at all */
+        uint32_t n = 0;
+        for (int i = t; i < vocab; i += nthr) n += allowed(i) ? 1u : 0u;
+        for (int s = 32; s >= 1; s >>= 1) n += __shfl_xor(n, s, TK_WAVE);
+        if ((t & 63) == 0) atomicAdd(&ctl[3], n);
+    }
+    __syncthreads();
+    int K = sp.top_k > 0 ? sp.top_k : TK_SAMPLE_MAX_K;
+    K = K > TK_SAMPLE_MAX_K ? TK_SAMPLE_MAX_K : K;
+    K = K > (int)ctl[3] ? (int)ctl[3] : K;
+    if (K <= 0) { if (t == 0) *out_id = 0; return; } /* nothing allowed: cannot happen behind a grammar mask, which always allows something */
+    /* composite key = (key << 32) | ~id: the K-th largest composite is unique.  Rounds: key bits 31..0, then id bits 15..0 (vocab <= 65536) */
+    uint32_t pre_key = 0, pre_id = 0; /* decided prefixes */
+    int kleft = K;
+    for (int round = 0; round < 6; ++round) {
+        for (int i = t; i < 256; i += nthr) hist[i] = 0;
+        __syncthreads();
+        const int shift = round < 4 ? 24 - 8 * round : 8 - 8 * (round - 4);
+        for (int i = t; i < vocab; i += nthr) {
+            if (!allowed(i)) continue;
+            const uint32_t k = sample_key(lg[i]), ni = (~(uint32_t)i) & 0xFFFFu;
+            bool in;
+            uint32_t digit;
+            if (round < 4) { in = round == 0 || (k >> (shift + 8)) == (pre_key >> (shift + 8)); digit = (k >> shift) & 255u; }
+            else { in = k == pre_key && (round == 4 || (ni >> 8) == (pre_id >> 8)); digit = (ni >> shift) & 255u; }
+            if (in) atomicAdd(&hist[digit], 1u);
+        }
+        __syncthreads();
+        if (t == 0) { /* the digit whose bucket holds the kleft-th largest of what is still in */
+            uint32_t above = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (above + hist[d] >= (uint32_t)kleft) break;
+                above += hist[d];
+            }
+            ctl[0] = (uint32_t)d;
+            ctl[1] = (uint32_t)kleft - above;
+        }
+        __syncthreads();
+        if (round < 4) pre_key |= ctl[0] << shift; else pre_id |= ctl[0] << shift;
+        kleft = (int)ctl[1];
+        __syncthreads();
+    }
+    /* everything at or above the threshold composite: exactly K entries */
+    for (int i = t; i < vocab; i += nthr) {
+        if (!allowed(i)) continue;
+        const uint32_t k = sample_key(lg[i]), ni = (~(uint32_t)i) & 0xFFFFu;
+        if (k > pre_key || (k == pre_key && ni >= pre_id)) {
+            const uint32_t slot = atomicAdd(&ctl[2], 1u);
+            if (slot < TK_SAMPLE_MAX_K) { lkey[slot] = k; lid[slot] = (uint32_t)i; }
+        }
+    }
+    __syncthreads();
+    if (t < K) { /* rank by comparison: descending key, ascending id */
+        const uint32_t k = lkey[t], id = lid[t];
+        int rank = 0;
+        for (int j = 0; j < K; ++j) rank += (lkey[j] > k || (lkey[j] == k && lid[j] < id)) ? 1 : 0;
+        slog[rank] = lg[id];
+        sid[rank] = id;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const float l0 = slog[0];
+        float sum = 0.0f;
+        for (int i = 0; i < K; ++i) sum = sum + tk_expf(slog[i] - l0);
+        int n = K;
+        if (sp.top_p < 1.0f) {
+            float c = 0.0f;
+            for (int i = 0; i < K; ++i) {
+                c = c + tk_divf(tk_expf(slog[i] - l0), sum);
+                if (c >= sp.top_p) { n = i + 1; break; }
+            }
+        }
+        if (sp.min_p > 0.0f) {
+            const float thr = sp.min_p * tk_divf(1.0f, sum); /* p_0 = exp(0) / sum */
+            while (n > 1 && tk_divf(tk_expf(slog[n - 1] - l0), sum) < thr) --n;
+        }
+        float W = 0.0f;
+        for (int i = 0; i < n; ++i) W = W + tk_expf(tk_divf(slog[i] - l0, sp.temp));
+        uint64_t z = sp.seed + 0x9E3779B97F4A7C15ull * ((uint64_t)sp.counter + 1ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const float u = (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f; /* 24 bits * 2^-24: exact */
+        const float target = u * W;
+        int pick = n - 1;
+        float c = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            c = c + tk_expf(tk_divf(slog[i] - l0, sp.temp));
+            if (c > target) { pick = i; break; }
+        }
+        *out_id = (int32_t)sid[pick];
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab, const uint32_t* allow_base, const int32_t* allow_row, TkSampleRow* samp,
+                                                  int32_t* tok, int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride) {
     __shared__ float bv[16];
     __shared__ int bi[16];
+    __shared__ uint32_t sm[256 + 8 + 4 * TK_SAMPLE_MAX_K];
     const int r = blockIdx.x, t = threadIdx.x;
     const float* lg = logits + (int64_t)r * vocab;
     /* per-row token masks: allow_row[r] = index of this row's mask ((vocab + 31) / 32 words each) or -1 = unconstrained, so rows sampling
@@ -1971,6 +2115,13 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab,
     const uint32_t* allow = mi >= 0 ? allow_base + (size_t)mi * ((vocab + 31) / 32) : nullptr;
     float best = -INFINITY;
     int idx = 0x7fffffff;
+    if (samp && samp[r].temp > 0.0f) { /* wave-uniform per workgroup: a row is sampled by its whole workgroup */
+        __shared__ int32_t picked;
+        const TkSampleRow sp = samp[r];
+        sample_row(lg, vocab, allow, sp, &picked, sm);
+        __syncthreads();
+        if (t == 0) { idx = picked; samp[r].counter = sp.counter + 1; }
+    } else {
     /* a thread's candidates i = t, t + 1024, ... in ascending order, eight loads in flight at a time: a load under a test (the mask's
      * `continue`) waits for the one before it — 32 latencies in a row were 14 us of a one-row decode step.  Indices past the vocabulary
      * load a clamped element and are skipped by the test. */
@@ -2016,6 +2167,9 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab,
     if (t == 0) {
         for (int w = 1; w < 16; ++w)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    }
+    }
+    if (t == 0) {
         if (tok) tok[r] = idx;
         if (pos) pos[r] = pos[r] + 1;
         if (hist) {
@@ -2026,9 +2180,9 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int vocab,
     }
 }
 
-void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow_base, const int32_t* allow_row, int32_t* tok, int32_t* pos,
-                      int32_t* nsteps, int32_t* hist, int hist_stride, hipStream_t s) {
-    hipLaunchKernelGGL(k_argmax, dim3(nrows), dim3(1024), 0, s, logits, vocab, allow_base, allow_row, tok, pos, nsteps, hist, hist_stride);
+void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow_base, const int32_t* allow_row, TkSampleRow* samp, int32_t* tok,
+                      int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride, hipStream_t s) {
+    hipLaunchKernelGGL(k_argmax, dim3(nrows), dim3(1024), 0, s, logits, vocab, allow_base, allow_row, samp, tok, pos, nsteps, hist, hist_stride);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -15,6 +15,11 @@ class LlmHParams(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class Sampling(C.Structure):  # tk_mi355x_sampling_t
+    _fields_ = [("temperature", C.c_float), ("top_p", C.c_float), ("min_p", C.c_float), ("top_k", C.c_int32), ("seed", C.c_uint64),
+                ("counter", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 def MISTRAL_7B():
     return LlmHParams(32, 4096, 32, 8, 128, 14336, 32000, 1e-5, 10000.0, 0, 0, 0, 0, 1)
 
@@ -83,6 +88,21 @@ class LlmSession:
         am = np.empty(n, dtype=np.int32)
         check(lib().tk_mi355x_llm_forward(self.h, n, _p(seq), _p(pos), _p(tok), _p(logits), _p(am)))
         return logits, am
+
+    def forward_sampled(self, seq, pos, tok, sampling, want_logits=True):
+        """forward() with a sampling state per row: sampling = [(temperature, top_k, top_p, min_p, seed, counter), ...]; temperature <= 0
+        takes the arg max for that row"""
+        seq = np.ascontiguousarray(seq, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        tok = np.ascontiguousarray(tok, dtype=np.int32)
+        n = len(seq)
+        tab = (Sampling * n)()
+        for r, (temp, top_k, top_p, min_p, seed, counter) in enumerate(sampling):
+            tab[r] = Sampling(temp, top_p, min_p, top_k, seed, counter, 0)
+        logits = np.empty((n, self.vocab), dtype=np.float32) if want_logits else None
+        ids = np.empty(n, dtype=np.int32)
+        check(lib().tk_mi355x_llm_forward_sampled(self.h, n, _p(seq), _p(pos), _p(tok), tab, _p(logits), _p(ids)))
+        return logits, ids
 
     def forward_stage(self, seq, pos, layer0, layer1, tok=None, x_in=None, x_out=None, head=False, on_host=True):
         """layers [layer0, layer1) of one pass (pipeline stage).  x_in / x_out: float32 [n][d_model] numpy arrays (on_host) or raw
@@ -271,14 +291,18 @@ class ModelLoader:
 class LlmRunner:
     """tk_llm_runner_* exactly as the reference's Rust GgufRunner drives it."""
 
-    def __init__(self, model_handle, context_size=4096):
+    def __init__(self, model_handle, context_size=4096, random_seed=0):
         self.h = C.c_void_p()
-        cfg = _LlmConfig(context_size, None, 0)
+        cfg = _LlmConfig(context_size, None, random_seed)
         check(lib().tk_llm_runner_create(C.byref(self.h), model_handle, C.byref(cfg)))
         lib().tk_llm_runner_generate_next_token.restype = C.c_void_p
 
     def prepare(self, prompt, use_tool_grammar=False):
         check(lib().tk_llm_runner_prepare_generation(self.h, prompt.encode(), use_tool_grammar))
+
+    def set_sampling(self, temperature, top_k=40, top_p=0.95, min_p=0.05):
+        """the reference's default stochastic chain (llama_sampling_default_params) instead of greedy; temperature 0 = greedy again"""
+        check(lib().tk_mi355x_llm_runner_set_sampling(self.h, C.c_float(temperature), top_k, C.c_float(top_p), C.c_float(min_p)))
 
     def next_token(self):
         p = lib().tk_llm_runner_generate_next_token(self.h)
