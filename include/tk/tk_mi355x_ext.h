@@ -156,6 +156,13 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_sessio
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_time_attention(tk_mi355x_llm_session_t* s, int nrows, int ctx, int iters, float* avg_ms,
                                                                  double* kv_bytes);
 
+/* which attention launch a pass of `nrows` rows takes on `device` (the choice depends on its CU count): out = {kernel, query heads per
+ * workgroup, positions per ring slot / resident chunk, ring slots}; kernel 0 = k_attention (ring of chunks), 1 = k_attention_narrow (<= one
+ * workgroup per CU, the context resident in LDS).  fused != 0: a decode pass (every sequence once), else a prefill-shaped pass.  The parity
+ * tests assert the instantiation they exercise from this answer (csrc/llm/tk_llm_kernels.hip: tk_attention_plan). */
+TK_API int tk_mi355x_device_cu_count(int device); /* compute units of a HIP device (256 on an MI355X), -1 when there is no such device */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_attention_plan(int device, int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, int fused, int32_t out[4]);
+
 /* ---- tool-call grammar (GBNF) — the sampling constraint of tk_llm_runner_prepare_generation(..., use_tool_grammar = true)
  * (reference: src/ai_models/grammars/tool_call.gbnf via llama.cpp's grammar sampler, tk_runner_lifecycle.c:59,
  * tk_runner_streaming.c:44-48,69-75).  gbnf == NULL selects the built-in tool-call grammar.  No GPU involved. ---- */

@@ -358,6 +358,19 @@ tk_error_code_t tk_mi355x_llm_time_gemv(tk_mi355x_llm_session_t* s, int layer, i
     return TK_SUCCESS;
 }
 
+int tk_mi355x_device_cu_count(int device) {
+    int n = 0;
+    return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess ? n : -1;
+}
+
+tk_error_code_t tk_mi355x_attention_plan(int device, int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, int fused, int32_t out[4]) {
+    if (!out || nrows < 1 || nrows > TK_MAX_ROWS || n_head < 1 || n_kv_head < 1 || n_head % n_kv_head || head_dim < 1 || max_ctx < 1) return TK_ERROR_INVALID_ARGUMENT;
+    if (hipSetDevice(device) != hipSuccess) return fail(TK_ERROR_GPU_DEVICE_NOT_FOUND, "no such HIP device");
+    const TkAttentionPlan pl = tk_attention_plan(nrows, n_head, n_kv_head, head_dim, max_ctx, fused != 0);
+    out[0] = pl.kernel; out[1] = pl.gq; out[2] = pl.chunk; out[3] = pl.slots;
+    return TK_SUCCESS;
+}
+
 tk_error_code_t tk_mi355x_llm_time_attention(tk_mi355x_llm_session_t* s, int nrows, int ctx, int iters, float* avg_ms, double* kv_bytes) {
     if (!s || !avg_ms || !kv_bytes) return TK_ERROR_INVALID_ARGUMENT;
     if (!s->session.time_attention(nrows, ctx, iters, avg_ms, kv_bytes)) return fail(TK_ERROR_GPU_ROCM_ERROR, s->session.error);

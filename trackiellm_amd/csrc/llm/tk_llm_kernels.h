@@ -98,6 +98,11 @@ struct TkSampleRow {
 void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow_base, const int32_t* allow_row, TkSampleRow* samp, int32_t* tok,
                       int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride, hipStream_t s);
 
+/* the attention launch a pass takes: kernel 0 = k_attention<gq, fused, head_dim, chunk, slots> (chunk = positions per ring slot), kernel 1 =
+ * k_attention_narrow (gq 2, chunk = positions resident per chunk, the whole context when it fits) */
+struct TkAttentionPlan { int kernel, gq, chunk, slots; size_t lds_bytes; };
+TkAttentionPlan tk_attention_plan(int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, bool fused);
+
 size_t tk_gemv_lds_bytes(int K, int ks, int mtiles);
 /* dynamic LDS of one k_attention workgroup; must stay below 160 KiB (the session checks it against its max_ctx) */
 size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk /* positions per ring slot: 32 or 64 */, int slots = 2 /* ring depth: 2 or 5 */);

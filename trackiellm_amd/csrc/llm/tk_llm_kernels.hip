@@ -1870,6 +1870,205 @@ __global__ __launch_bounds__(256, TK_ATT_WAVES) void k_attention(const float* __
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Narrow decode passes (at most one workgroup per CU: 1 .. 16 rows of Mistral-7B): the same attention, arithmetic for arithmetic, as
+ * k_attention<2, true, 128, ...>, laid out for LATENCY.  There the launch is a chain of ~11 barrier-separated phases of four waves (two
+ * K chunks, two V chunks, their own-row patches, max, exp, three epilogue steps: 15 us per layer of a one-runner decode step, a quarter of
+ * the token for under 1 % of its bytes).  Here a workgroup has 16 waves and the CU's whole LDS: every cached key and value row of the
+ * context (up to `cap` positions, ~290 at a 512-position window; longer contexts go through the same code chunk by chunk) is requested by
+ * LDS-DMA in the first instructions, under the q / k / v prologue; then ONE score phase (wave = 64 positions of one head), max, exp, ONE
+ * value phase (wave = one head x one of the four canonical interleaved partial sums), combine, quantise: six barriers.
+ * Workgroup = (row, two query heads of one KV group); grid (n_head / 2, rows).
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(1024) void k_attention_narrow(const float* __restrict__ partial, int ks, int n_total, const float* __restrict__ rope_cos,
+                                                            const float* __restrict__ rope_sin, uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache,
+                                                            const int32_t* __restrict__ seq, const int32_t* __restrict__ pos, int n_head, int n_kv_head, int layer,
+                                                            int max_seq, int max_ctx, int cap, TkActQ8 out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t att_lds[];
+    constexpr int HD = 128, GQ = 2, W = GQ * HD, RB = HD * 2, PPR = RB / 16; /* outputs per workgroup, bytes per cache row, 16-byte pieces per row */
+    const int hb = blockIdx.x, r = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kvh = hb * GQ / (n_head / n_kv_head);
+    const int p = pos[r], T = p + 1, sq = seq[r];
+    const int half = HD / 2, QD = n_head * HD, KVD = n_kv_head * HD;
+    uint8_t* kbuf = att_lds;                                  /* [cap][256 B], 16-byte pieces XOR-swizzled by the row number */
+    uint8_t* vbuf = att_lds + (size_t)cap * RB;               /* [cap][256 B] */
+    float* qs = (float*)(att_lds + (size_t)2 * cap * RB);     /* [GQ][HD] */
+    float* sc = qs + W;                                       /* [GQ][max_ctx] */
+    float* red = sc + (size_t)GQ * ((max_ctx + 3) & ~3);      /* [16] wave maxima, [GQ] head maxima; 16-byte aligned */
+    uint16_t* own = (uint16_t*)(red + 32);                    /* [2][HD]: this row's own K and V */
+    float* part = (float*)kbuf;                               /* epilogue, aliases the key rows: [4][W] partial outputs, [4][GQ] denominators, [W] outputs */
+    float* lpart = part + TK_ATT_TSPLIT * W;
+    float* obuf = lpart + TK_ATT_TSPLIT * TK_ATT_MAX_GRP;
+    const int64_t run0 = (((int64_t)layer * max_seq + sq) * n_kv_head + kvh) * (int64_t)max_ctx * HD;
+    const int nchunk = (T + cap - 1) / cap;
+    /* rows [row0, row0 + cap) of a cache run into a buffer: 1 KiB pieces (four rows) dealt to the 16 waves; pieces wholly past the context are
+     * not requested, rows past it inside a piece are clamped (never used) */
+    auto stage = [&](const uint16_t* run, int row0, uint8_t* buf, bool swz) {
+        const int pieces = cap * RB / 1024;
+        for (int pc = wave; pc < pieces; pc += 16) {
+            if (row0 + pc * 4 >= T) break; /* wave-uniform */
+            const int rr = pc * 4 + (lane >> 4), cs = lane & 15;
+            int gr = row0 + rr;
+            gr = gr < max_ctx - 1 ? gr : max_ctx - 1;
+            const int src = swz ? (cs ^ (rr & (PPR - 1))) : cs;
+            const auto gs = (const __attribute__((address_space(1))) void*)((const uint8_t*)run + (int64_t)gr * RB + src * 16);
+            const auto ls = (__attribute__((address_space(3))) void*)(buf + pc * 1024);
+            __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
+        }
+    };
+    stage(kcache + run0, 0, kbuf, true);
+    stage(vcache + run0, 0, vbuf, false);
+    /* prologue: this row's q (two heads), k and v — K-split sums, RoPE, f16 rounding, cache append (k_attention's FUSED prologue) */
+    if (t < (GQ + 2) * half) {
+        const float* cs = rope_cos + (int64_t)p * half;
+        const float* sn = rope_sin + (int64_t)p * half;
+        const int hsel = t / half, i = t % half;
+        if (hsel < GQ) {
+            const int col = (hb * GQ + hsel) * HD + 2 * i;
+            const float a = sum_partials_wide(partial, ks, n_total, r, col), b = sum_partials_wide(partial, ks, n_total, r, col + 1);
+            qs[hsel * HD + 2 * i] = tk_fmaf(-b, sn[i], a * cs[i]);
+            qs[hsel * HD + 2 * i + 1] = tk_fmaf(a, sn[i], b * cs[i]);
+        } else if (hsel == GQ) {
+            const int col = QD + kvh * HD + 2 * i;
+            const float a = sum_partials_wide(partial, ks, n_total, r, col), b = sum_partials_wide(partial, ks, n_total, r, col + 1);
+            const uint16_t k0 = tk_f32_to_f16(tk_fmaf(-b, sn[i], a * cs[i])), k1 = tk_f32_to_f16(tk_fmaf(a, sn[i], b * cs[i]));
+            const uint32_t kk = (uint32_t)k0 | ((uint32_t)k1 << 16);
+            if ((hb * GQ) % (n_head / n_kv_head) == 0) *(uint32_t*)(kcache + run0 + (int64_t)p * HD + 2 * i) = kk; /* one workgroup of the KV group appends */
+            *(uint32_t*)(own + 2 * i) = kk;
+        } else {
+            const int col = QD + KVD + kvh * HD + 2 * i;
+            const uint16_t v0 = tk_f32_to_f16(sum_partials_wide(partial, ks, n_total, r, col)), v1 = tk_f32_to_f16(sum_partials_wide(partial, ks, n_total, r, col + 1));
+            const uint32_t vv = (uint32_t)v0 | ((uint32_t)v1 << 16);
+            if ((hb * GQ) % (n_head / n_kv_head) == 0) *(uint32_t*)(vcache + run0 + (int64_t)p * HD + 2 * i) = vv;
+            *(uint32_t*)(own + HD + 2 * i) = vv;
+        }
+    }
+    const float att_scale = tk_divf(1.0f, tk_sqrtf((float)HD));
+    /* ---- scores: wave w = head w & 1, positions (w >> 1) * 64 + lane of the chunk; one fma chain over head_dim per (head, position) ---- */
+    const int sh = wave & 1;
+    float mx = -INFINITY;
+    for (int c = 0; c < nchunk; ++c) {
+        if (c > 0) { __syncthreads(); stage(kcache + run0, c * cap, kbuf, true); } /* everybody is done with the previous chunk's key rows */
+        __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): this wave's pieces (and its prologue loads) */
+        __syncthreads();                     /* everybody's; qs and own are written */
+        if (c == nchunk - 1) { /* the row's own key (position p, in the last chunk) comes from LDS, swizzled like the rest */
+            const int rr = p - c * cap;
+            if (t < PPR) *(uint4*)(kbuf + rr * RB + ((t ^ (rr & (PPR - 1))) * 16)) = *(const uint4*)((const uint8_t*)own + t * 16);
+            if (t >= 64 && t < 64 + PPR && nchunk == 1) *(uint4*)(vbuf + rr * RB + (t - 64) * 16) = *(const uint4*)((const uint8_t*)(own + HD) + (t - 64) * 16);
+            __syncthreads();
+        }
+        const int tc = T - c * cap < cap ? T - c * cap : cap;
+        for (int rr = (wave >> 1) * 64 + lane; rr < tc; rr += 512) {
+            const uint8_t* kr = kbuf + rr * RB;
+            const float* qh = qs + sh * HD;
+            uint4 kv[PPR];
+#pragma unroll
+            for (int u = 0; u < PPR; ++u) kv[u] = *(const uint4*)(kr + ((u ^ (rr & (PPR - 1))) * 16));
+            float a = 0.0f;
+#pragma unroll
+            for (int u = 0; u < PPR; ++u) {
+                const v4f q0 = *(const v4f*)(qh + 8 * u), q1 = *(const v4f*)(qh + 8 * u + 4);
+                const uint32_t kw[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float kf = f16bits_to_f32((kw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                    a = tk_fmaf(e < 4 ? q0[e] : q1[e - 4], kf, a);
+                }
+            }
+            const float sv = a * att_scale;
+            sc[(size_t)sh * max_ctx + c * cap + rr] = sv;
+            mx = tk_fmaxf(mx, sv);
+        }
+    }
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) mx = tk_fmaxf(mx, wave_xor_f(mx, s2));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads(); /* every score and every wave maximum is written */
+    if (t < GQ) {
+        float m = red[t];
+        for (int w = 1; w < 8; ++w) m = tk_fmaxf(m, red[t + 2 * w]); /* a maximum does not depend on the order */
+        red[16 + t] = m;
+    }
+    __syncthreads();
+    for (int i = t; i < GQ * T; i += 1024) {
+        const int h = i / T, tt = i - h * T;
+        sc[(size_t)h * max_ctx + tt] = tk_expf(sc[(size_t)h * max_ctx + tt] - red[16 + h]);
+    }
+    /* ---- PV: wave w < 8 = head w >> 2, partial sum w & 3 (positions = w & 3 mod 4, ascending); lane owns dims 2 lane, 2 lane + 1 ---- */
+    const int ph = wave >> 2, pj = wave & 3;
+    float acc0 = 0.0f, acc1 = 0.0f, lsum = 0.0f;
+    for (int c = 0; c < nchunk; ++c) {
+        if (c > 0 || nchunk > 1) { /* long contexts: the value rows arrive chunk by chunk too (chunk 0 was requested at the start) */
+            if (c > 0) { __syncthreads(); stage(vcache + run0, c * cap, vbuf, false); }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            if (c == nchunk - 1) {
+                const int rr = p - c * cap;
+                if (t < PPR) *(uint4*)(vbuf + rr * RB + t * 16) = *(const uint4*)((const uint8_t*)(own + HD) + t * 16);
+            }
+        }
+        __syncthreads(); /* the probabilities (and a patched value row) are written */
+        if (wave < 8) {
+            const int tc = T - c * cap < cap ? T - c * cap : cap;
+            const float* prow = sc + (size_t)ph * max_ctx + c * cap;
+            constexpr int PB = 8;
+            for (int rr0 = pj; rr0 < tc; rr0 += PB * TK_ATT_TSPLIT) {
+                float pr[PB];
+                uint32_t vv[PB];
+#pragma unroll
+                for (int u = 0; u < PB; ++u) { /* slots past the context read the last live row and enter with probability 0: exact no-ops */
+                    const int rr = rr0 + u * TK_ATT_TSPLIT;
+                    const bool live = rr < tc;
+                    const int rc = live ? rr : tc - 1;
+                    pr[u] = live ? prow[rc] : 0.0f;
+                    vv[u] = *(const uint32_t*)(vbuf + rc * RB + lane * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    acc0 = tk_fmaf(pr[u], f16bits_to_f32(vv[u] & 0xffffu), acc0);
+                    acc1 = tk_fmaf(pr[u], f16bits_to_f32(vv[u] >> 16), acc1);
+                    lsum = lsum + pr[u];
+                }
+            }
+        }
+    }
+    __syncthreads(); /* every wave is done with the key and value rows: the key buffer now holds the epilogue's arrays */
+    if (wave < 8) {
+        part[pj * W + ph * HD + 2 * lane] = acc0;
+        part[pj * W + ph * HD + 2 * lane + 1] = acc1;
+        if (lane == 0) lpart[pj * TK_ATT_MAX_GRP + ph] = lsum;
+    }
+    __syncthreads();
+    if (t < W) {
+        const int h = t / HD;
+        const float a = ((part[t] + part[W + t]) + part[2 * W + t]) + part[3 * W + t];
+        const float ll = ((lpart[h] + lpart[TK_ATT_MAX_GRP + h]) + lpart[2 * TK_ATT_MAX_GRP + h]) + lpart[3 * TK_ATT_MAX_GRP + h];
+        obuf[t] = tk_divf(a, ll);
+    }
+    __syncthreads();
+    if (t < W / 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = obuf[8 * t + i];
+        quantize_chunk8(v, hb * (W / 8) + t, r, out);
+    }
+}
+
+static size_t tk_attention_narrow_fixed_lds(int max_ctx) { /* everything but the key / value rows: q, scores, maxima, own row */
+    return (size_t)(2 * 128 + 2 * (size_t)((max_ctx + 3) & ~3) + 32) * sizeof(float) + 2 * 128 * 2;
+}
+/* positions the narrow kernel keeps resident per chunk (a multiple of 32), 0 when it does not apply */
+static int tk_attention_narrow_cap(int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, bool fused) {
+    const int grp = n_kv_head > 0 ? n_head / n_kv_head : 0;
+    if (!fused || head_dim != 128 || (grp != 2 && grp != 4) || (n_head / 2) * nrows > TK_NUM_CU) return 0;
+    const size_t fixed = tk_attention_narrow_fixed_lds(max_ctx);
+    if (fixed + 64 * 512 > (size_t)TK_MAX_DYN_LDS) return 0;
+    int cap = (int)(((size_t)TK_MAX_DYN_LDS - fixed) / 512);
+    const int want = (max_ctx + 31) / 32 * 32;
+    cap = cap > want ? want : cap;
+    return cap / 32 * 32;
+}
+
 size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk, int slots) {
     const size_t W = (size_t)gq * head_dim;
     const size_t ring = (size_t)slots * chunk * head_dim * 2;
@@ -1877,9 +2076,23 @@ size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk, int 
     return (ring > epilogue ? ring : epilogue) + (W + (size_t)gq * max_ctx + 4 * TK_ATT_MAX_GRP) * sizeof(float) + (size_t)2 * head_dim * 2;
 }
 
-void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_total, const float* rope_cos, const float* rope_sin,
-                         uint16_t* kcache, uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows, int n_head, int n_kv_head,
-                         int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, bool fused, hipStream_t s) {
+#ifndef TK_ATT_NARROW_CHUNK
+#define TK_ATT_NARROW_CHUNK 128 /* 64: the round-3 form */
+#endif
+#ifndef TK_ATT_WIDE_SLOTS
+#define TK_ATT_WIDE_SLOTS 2 /* ring depth of the many-workgroup (32-position chunk) form */
+#endif
+/* Which attention launch a pass takes on the calling thread's device (the choice depends on its CU count): the one place that decides,
+ * used by the launcher and exported (tk_mi355x_attention_plan) so tests assert what they run from the launcher's own answer. */
+TkAttentionPlan tk_attention_plan(int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, bool fused) {
+    TkAttentionPlan pl{};
+#ifndef TK_ATT_NO_NARROW
+    if (const int cap = tk_attention_narrow_cap(nrows, n_head, n_kv_head, head_dim, max_ctx, fused)) {
+        pl.kernel = 1; pl.gq = 2; pl.chunk = cap; pl.slots = 1;
+        pl.lds_bytes = tk_attention_narrow_fixed_lds(max_ctx) + (size_t)cap * 512;
+        return pl;
+    }
+#endif
     int gq = n_head / n_kv_head; /* 1, 2 or 4 (TkLlmModel::init) */
     /* few rows: two workgroups per KV head (two query heads each) — twice the workgroups, half the dependent work in each; K / V are then
      * read twice, which costs nothing while the launch is latency-bound (16 rows: 15.9 -> see profiles/r02_attention_variants.txt) */
@@ -1890,9 +2103,6 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
     /* positions per ring slot: 64 while the launch is a latency chain of few workgroups (fewer, longer phases), 32 once several
      * workgroups per CU are resident (16 KiB less LDS each: more of them fit; 256 rows: 47.9 -> 43.3 us, 16 rows would lose 24 %;
      * profiles/r02_attention_variants.txt) */
-#ifndef TK_ATT_NARROW_CHUNK
-#define TK_ATT_NARROW_CHUNK 128 /* 64: the round-3 form */
-#endif
     /* at most one workgroup per CU and <= 2 query heads per workgroup: 128 positions per slot — the score phase (one fma chain per (head,
      * position): 2 x 64 threads of a 64-position chunk leave two of the four waves idle) runs on all four waves and a context has half as
      * many barrier-separated phases */
@@ -1902,11 +2112,22 @@ void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_
     /* ring depth 2 at every pass width: with few workgroups a five-slot ring (every K and V chunk of a 128-position context in flight at
      * once) measured no faster — 16 rows x 128 positions 10.7 us against 11.1, decode step unchanged (profiles/r03_attention_slots.txt): a
      * one-row launch already takes 9.8 us, the launch is a chain of ~10 barrier-separated phases, not of DMA latencies */
-#ifndef TK_ATT_WIDE_SLOTS
-#define TK_ATT_WIDE_SLOTS 2 /* ring depth of the many-workgroup (32-position chunk) form */
-#endif
-    const int slots = chunk == 32 ? TK_ATT_WIDE_SLOTS : 2;
-    const size_t lds = tk_attention_lds_bytes(gq, head_dim, max_ctx, chunk, slots);
+    pl.kernel = 0; pl.gq = gq; pl.chunk = chunk; pl.slots = chunk == 32 ? TK_ATT_WIDE_SLOTS : 2;
+    pl.lds_bytes = tk_attention_lds_bytes(gq, head_dim, max_ctx, chunk, pl.slots);
+    return pl;
+}
+
+void tk_launch_attention(const float* qbuf, const float* partial, int ks, int n_total, const float* rope_cos, const float* rope_sin,
+                         uint16_t* kcache, uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows, int n_head, int n_kv_head,
+                         int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out, bool fused, hipStream_t s) {
+    const TkAttentionPlan pl = tk_attention_plan(nrows, n_head, n_kv_head, head_dim, max_ctx, fused);
+    if (pl.kernel == 1) {
+        hipLaunchKernelGGL(k_attention_narrow, dim3(n_head / 2, nrows), dim3(1024), pl.lds_bytes, s, partial, ks, n_total, rope_cos, rope_sin, kcache,
+                           vcache, seq, pos, n_head, n_kv_head, layer, max_seq, max_ctx, pl.chunk, out);
+        return;
+    }
+    const int gq = pl.gq, chunk = pl.chunk;
+    const size_t lds = pl.lds_bytes;
 #define TK_ATT_LAUNCH_CH(G, F, H, C, S)                                                                                                       \
     hipLaunchKernelGGL((k_attention<G, F, H, C, S>), dim3(n_head / gq, nrows), dim3(256), lds, s, qbuf, partial, ks, n_total, rope_cos, rope_sin, kcache, \
                        vcache, seq, pos, n_head, n_kv_head, head_dim, layer, max_seq, max_ctx, out)
@@ -2210,6 +2431,7 @@ const char* tk_llm_prepare_device(int device) {
     TK_OPT_ATT(0); TK_OPT_ATT(64); TK_OPT_ATT(128);
 #define TK_OPT_ATT_N(H) do { TK_OPT((k_attention<1, true, H, 128, 2>)); TK_OPT((k_attention<2, true, H, 128, 2>)); TK_OPT((k_attention<1, false, H, 128, 2>)); TK_OPT((k_attention<2, false, H, 128, 2>)); } while (0)
     TK_OPT_ATT_N(64); TK_OPT_ATT_N(128);
+    TK_OPT(k_attention_narrow);
 #undef TK_OPT_ATT_N
 #undef TK_OPT_ATT
 #undef TK_OPT_GEMV

@@ -15,6 +15,14 @@ class LlmHParams(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+def attention_plan(nrows, n_head, n_kv_head, head_dim, max_ctx, fused=True, device=0):
+    """the attention launch a pass takes on `device`: (kernel, query heads per workgroup, positions per slot / resident chunk, slots);
+    kernel 0 = k_attention, 1 = k_attention_narrow (tk_mi355x_attention_plan)"""
+    out = (C.c_int32 * 4)()
+    check(lib().tk_mi355x_attention_plan(device, nrows, n_head, n_kv_head, head_dim, max_ctx, 1 if fused else 0, out))
+    return tuple(out)
+
+
 class Sampling(C.Structure):  # tk_mi355x_sampling_t
     _fields_ = [("temperature", C.c_float), ("top_p", C.c_float), ("min_p", C.c_float), ("top_k", C.c_int32), ("seed", C.c_uint64),
                 ("counter", C.c_uint32), ("reserved", C.c_uint32)]
