@@ -26,21 +26,15 @@ def pcm_fixture(n=16000, B=2):
     return np.stack([a, b])[:B].astype(np.int16)
 
 
-def make_whisper():
+def hf_whisper_reference(hp, orc, pcm, mel, chunk_length):
+    """HF transformers' feature extractor and WhisperForConditionalGeneration (eager attention, gelu_new = the tanh GELU ggml evaluates) carrying
+    the oracle's synthetic weights: (log-mel [B][frames][mels], encoder states, first-step logits) of the INDEPENDENT implementation"""
     import torch
     from transformers import WhisperConfig, WhisperFeatureExtractor, WhisperForConditionalGeneration
 
-    hp = O.whisper_tiny_test()
-    orc = O.OracleWhisper(hp, seed=6)
-    pcm = pcm_fixture()
-    toks, mel, enc, lg = orc.transcribe(pcm, 6)
-
-    fe = WhisperFeatureExtractor(feature_size=hp.n_mels, sampling_rate=16000, hop_length=160, chunk_length=1, n_fft=400)
-    feats = fe([p.astype(np.float32) / 32768.0 for p in pcm], sampling_rate=16000, return_tensors="np")["input_features"]  # [B,80,100]
+    fe = WhisperFeatureExtractor(feature_size=hp.n_mels, sampling_rate=16000, hop_length=160, chunk_length=chunk_length, n_fft=400)
+    feats = fe([p.astype(np.float32) / 32768.0 for p in pcm], sampling_rate=16000, return_tensors="np")["input_features"]  # [B][mels][frames]
     hf_mel = np.transpose(feats, (0, 2, 1))
-    e_mel = np.abs(hf_mel - mel).max()
-    print(f"log-mel: oracle vs HF feature extractor max abs diff {e_mel:.3e}")
-    assert e_mel < 2e-4
 
     cfg = WhisperConfig(vocab_size=hp.n_vocab, num_mel_bins=hp.n_mels, encoder_layers=hp.n_audio_layer, encoder_attention_heads=hp.n_audio_head,
                         decoder_layers=hp.n_text_layer, decoder_attention_heads=hp.n_text_head, d_model=hp.n_audio_state,
@@ -96,6 +90,18 @@ def make_whisper():
                     decoder_input_ids=torch.from_numpy(np.tile(prompt.astype(np.int64), (len(pcm), 1))), output_hidden_states=False)
         hf_enc = out.encoder_last_hidden_state.numpy()
         hf_lg = out.logits[:, -1].numpy()
+    return hf_mel, hf_enc, hf_lg
+
+
+def make_whisper():
+    hp = O.whisper_tiny_test()
+    orc = O.OracleWhisper(hp, seed=6)
+    pcm = pcm_fixture()
+    toks, mel, enc, lg = orc.transcribe(pcm, 6)
+    hf_mel, hf_enc, hf_lg = hf_whisper_reference(hp, orc, pcm, mel, 1)
+    e_mel = np.abs(hf_mel - mel).max()
+    print(f"log-mel: oracle vs HF feature extractor max abs diff {e_mel:.3e}")
+    assert e_mel < 2e-4
     e_enc = np.abs(hf_enc - enc).max()
     e_lg = np.abs(hf_lg - lg).max()
     print(f"encoder states: max abs diff {e_enc:.3e} (max |v| {np.abs(hf_enc).max():.2f}); first-step logits: {e_lg:.3e} (max |v| {np.abs(hf_lg).max():.2f})")
@@ -104,6 +110,40 @@ def make_whisper():
     np.savez_compressed(os.path.join(HERE, "whisper_tiny.npz"), pcm=pcm, hf_mel=hf_mel.astype(np.float32), hf_enc=hf_enc.astype(np.float32),
                         hf_logits=hf_lg.astype(np.float32), oracle_tokens=toks, oracle_mel=mel, oracle_logits=lg)
     print("wrote whisper_tiny.npz; oracle tokens", toks.tolist())
+
+
+def whisper_full_pcm():
+    """the 1 s utterance of whisper_full_tiny_en.npz (seeded: the fixture stores no input)"""
+    return pcm_fixture(16000, 1)
+
+
+def make_whisper_full():
+    """whisper_full_tiny_en.npz — the tiny.en GEOMETRY of the bench (80 mels, 30 s window -> 1500 positions, d 384, 6 heads, 4 + 4 layers,
+    vocabulary 51864): HF's log-mel, encoder states and first-step logits for one 1 s utterance, kept as sampled values + statistics (KB-sized).
+    Pins the oracle's graph walker (shared with the product: csrc/common/tk_whisper_graph.h) by an independent implementation at the real size."""
+    hp = O.whisper_tiny_en()
+    orc = O.OracleWhisper(hp, seed=6)
+    pcm = whisper_full_pcm()
+    toks, mel, enc, lg = orc.transcribe(pcm, 1)
+    hf_mel, hf_enc, hf_lg = hf_whisper_reference(hp, orc, pcm, mel, 30)
+    assert hf_mel.shape == mel.shape == (1, 3000, 80) and hf_enc.shape == enc.shape == (1, 1500, 384) and hf_lg.shape == lg.shape == (1, 51864)
+    e_mel, e_enc, e_lg = np.abs(hf_mel - mel).max(), np.abs(hf_enc - enc).max(), np.abs(hf_lg - lg).max()
+    s_enc, s_lg = float(np.abs(hf_enc).max()), float(np.abs(hf_lg).max())
+    print(f"tiny.en geometry: log-mel {e_mel:.3e}; encoder states {e_enc:.3e} (max |v| {s_enc:.2f}); first-step logits {e_lg:.3e} (max |v| {s_lg:.2f})")
+    assert e_mel < 2e-4 and e_enc < 2e-4 * max(1.0, s_enc) and e_lg < 2e-4 * max(1.0, s_lg)
+    assert int(hf_lg.argmax(1)[0]) == int(toks[0, 0])
+    rng = np.random.default_rng(13)
+    i_mel = np.stack([rng.integers(0, 3000, 1024), rng.integers(0, 80, 1024)], 1).astype(np.int32)
+    i_mel[:256, 0] = rng.integers(0, 110, 256)  # the frames that hold the utterance
+    i_enc = np.stack([rng.integers(0, 1500, 2048), rng.integers(0, 384, 2048)], 1).astype(np.int32)
+    i_enc[:512, 0] = rng.integers(0, 60, 512)
+    i_lg = rng.integers(0, 51864, 2048).astype(np.int32)
+    top = np.argsort(-hf_lg[0])[:16].astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "whisper_full_tiny_en.npz"), i_mel=i_mel, hf_mel=hf_mel[0][i_mel[:, 0], i_mel[:, 1]].astype(np.float32),
+                        i_enc=i_enc, hf_enc=hf_enc[0][i_enc[:, 0], i_enc[:, 1]].astype(np.float32), enc_scale=np.float32(s_enc),
+                        enc_stats=np.array([hf_enc.mean(), hf_enc.std()], np.float64), i_lg=i_lg, hf_lg=hf_lg[0][i_lg].astype(np.float32),
+                        lg_scale=np.float32(s_lg), top_ids=top, top_logits=hf_lg[0][top].astype(np.float32))
+    print("wrote whisper_full_tiny_en.npz; first token", int(toks[0, 0]))
 
 
 def make_vad():
@@ -127,3 +167,4 @@ def make_vad():
 if __name__ == "__main__":
     make_vad()
     make_whisper()
+    make_whisper_full()

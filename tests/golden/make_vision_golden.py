@@ -110,6 +110,35 @@ def make_yolo():
     print("wrote yolo_tiny.npz")
 
 
+def yolo_full_input():
+    """the 640 x 640 frame of yolo_full_640.npz: seeded, so the fixture stores no input"""
+    return np.random.default_rng(11).standard_normal((1, 640, 640, 3)).astype(np.float32)
+
+
+def make_yolo_full():
+    """yolo_full_640.npz — YOLOv8n at the BASELINE geometry (640 x 640 input, 8400 anchors x 144 channels): the INDEPENDENT torch graph's raw
+    head maps, kept as 2048 sampled values + per-scale statistics (a few KB).  Pins the oracle's graph walker (which the oracle shares with the
+    product, csrc/common/tk_yolov8n_graph.h) against a second implementation at the size the bench runs, not only at 64 x 64."""
+    import torch
+    orc = O.OracleYolo(nc=80, seed=5, cls_bias=-4.0)
+    x = yolo_full_input()
+    with torch.no_grad():
+        ref = torch_yolov8n(orc.layers(), torch.from_numpy(x).permute(0, 3, 1, 2).contiguous(), 80)[0]  # [8400][144]
+    assert ref.shape == (8400, 144)
+    raw = orc.forward(x)[0]
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(raw - ref).max())
+    print(f"oracle vs independent torch YOLOv8n at 640 x 640: max abs diff {err:.3e} (max |v| {scale:.3f})")
+    assert err < 2e-4 * max(1.0, scale)
+    rng = np.random.default_rng(12)
+    idx = np.stack([rng.integers(0, 8400, 2048), rng.integers(0, 144, 2048)], 1).astype(np.int32)
+    idx[:96, 0] = np.repeat([0, 79, 80, 6399, 6400, 6401, 7999, 8000, 8001, 8399, 4242, 8123], 8)  # scale seams and corners
+    stats = np.array([[ref[a:b].mean(), np.abs(ref[a:b]).max(), ref[a:b].std()] for a, b in ((0, 6400), (6400, 8000), (8000, 8400))], np.float64)
+    np.savez_compressed(os.path.join(HERE, "yolo_full_640.npz"), idx=idx, torch_vals=ref[idx[:, 0], idx[:, 1]].astype(np.float32), stats=stats,
+                        scale=np.float32(scale))
+    print("wrote yolo_full_640.npz")
+
+
 def torch_yolo_post(raw, H, W, nc, conf, iou, max_det=500, max_cand=2048):
     """INDEPENDENT decode + NMS of a YOLOv8 head in the published Ultralytics / torchvision formulation (vectorised torch): DFL =
     softmax over 16 bins . arange(16); dist2bbox(xyxy) on anchor centres (x + 0.5, y + 0.5) per stride; scores = sigmoid; class =
@@ -198,4 +227,5 @@ if __name__ == "__main__":
     make_attribute_vectors()
     make_preprocess()
     make_yolo()
+    make_yolo_full()
     make_yolo_dets()

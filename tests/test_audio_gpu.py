@@ -49,6 +49,15 @@ def test_whisper_tiny_en_full_size_encoder(gpu):
     assert np.array_equal(toks, wt) and np.array_equal(lg, wlg)
 
 
+def test_whisper_tiny_en_full_size_against_hf(gpu):
+    """the HIP ASR engine itself against HF transformers at the tiny.en geometry (whisper_full_tiny_en.npz: sampled log-mel, encoder states,
+    first-step logits; 2e-4 of the tensors' scale), without the oracle in between"""
+    from test_oracle_audio import check_against_hf_full_geometry, full_geometry_pcm
+    asr = gpu.Asr()
+    toks, mel, enc, lg = asr.transcribe_tokens(full_geometry_pcm(), 1)
+    check_against_hf_full_geometry(mel, enc, lg, toks[0, 0])
+
+
 def test_asr_batch_composition_invariance_full_size(gpu):
     """size-independent property at the BASELINE geometry: an utterance's mel, encoder states, logits and tokens do not depend on which
     other utterances share its batch (5 utterances: 7500 encoder rows, 30 row blocks of the tiled GEMM; alone: 6 row blocks; the decoder

@@ -51,6 +51,21 @@ def test_yolo_oracle_matches_torch_fixture():
     assert len(orc.layers()) == 63 and sum(l["w"].size + l["b"].size for l in orc.layers()) > 3_000_000
 
 
+def test_yolo_oracle_matches_independent_torch_graph_at_640x640():
+    """the BASELINE geometry (640 x 640 -> 8400 anchors x 144 channels), not only the 64 x 64 toy: 2048 sampled head-map values and per-scale
+    statistics of an INDEPENDENT torch implementation of the published YOLOv8n graph (tests/golden/make_vision_golden.py: make_yolo_full) —
+    the graph walker the oracle shares with the product is pinned by a second implementation at the size the bench runs"""
+    g = np.load(os.path.join(GOLD, "yolo_full_640.npz"))
+    x = np.random.default_rng(11).standard_normal((1, 640, 640, 3)).astype(np.float32)  # make_vision_golden.yolo_full_input()
+    raw = O.OracleYolo(nc=80, seed=5, cls_bias=-4.0).forward(x)[0]
+    assert raw.shape == (8400, 144)
+    scale = float(g["scale"])
+    got = raw[g["idx"][:, 0], g["idx"][:, 1]]
+    assert np.abs(got - g["torch_vals"]).max() < 2e-4 * max(1.0, scale)
+    for (a, b), st in zip(((0, 6400), (6400, 8000), (8000, 8400)), g["stats"]):
+        assert abs(raw[a:b].mean() - st[0]) < 1e-4 and abs(np.abs(raw[a:b]).max() - st[1]) < 2e-4 * scale and abs(raw[a:b].std() - st[2]) < 1e-4
+
+
 def test_yolo_post_matches_independent_torch_detections():
     """DFL decode + class-aware NMS against an independent torch implementation (Ultralytics decode, torchvision-style batched NMS):
     anchor indices and classes identical, boxes / scores within 1e-3 (SURVEY 8c's yolo_tiny_dets)."""

@@ -68,6 +68,18 @@ def test_detector_full_size_frame_bit_exact(gpu):
     assert np.array_equal(anc, wa) and np.array_equal(cls, wc) and np.array_equal(boxes, wb)
 
 
+def test_detector_full_size_frame_against_the_independent_torch_graph(gpu):
+    """the HIP detector itself against the independent torch YOLOv8n at 640 x 640 (yolo_full_640.npz: sampled head-map values), 2e-4 of the
+    head maps' scale — north_star's fp tolerance on boxes, checked without the oracle in between"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolo_full_640.npz"))
+    det = gpu.ObjectDetector(width=640, height=640, conf=0.05)
+    x = np.random.default_rng(11).standard_normal((1, 640, 640, 3)).astype(np.float32)
+    raw = det.forward_raw(x)[0]
+    got = raw[g["idx"][:, 0], g["idx"][:, 1]]
+    assert np.abs(got - g["torch_vals"]).max() < 2e-4 * max(1.0, float(g["scale"]))
+
+
 def test_detector_weights_from_onnx_file(gpu, tmp_path):
     """an .onnx detector file (Conv initialisers in execution order + DFL conv, raw and packed float storage) goes in through
     tk_object_detector_create's model_path: head maps equal the oracle that owns the same weights"""
