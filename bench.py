@@ -18,6 +18,7 @@ What the line carries besides the contract keys (all measured live in this run, 
   north_star_point    a second, short timed run at 3 x 16 rows per pass: the configuration that meets north_star's
                       ">= 30 cycles/s at >= 40 % of the HBM roofline" together, reported beside the throughput-optimal headline
   reference_abi_b1    batch 1 through the reference's own entry points only (tk_llm_runner_*, tk_cortex_*)
+  reference_abi_batched_cortex   K cortex handles on one model file, one DATA-DEPENDENT cycle each through tk_cortex_* only
   cpu_baseline        one whole fused cycle on the CPU oracle ("port"), at the box's core share and at 1 core
 """
 import argparse
@@ -394,6 +395,63 @@ def reference_abi_b1(tk, hp, N, roof1):
     return out
 
 
+def reference_abi_batched_cortex(tk, K, N):
+    """K cortex handles (tk_cortex_create ... tk_cortex_destroy only) that share one LLM model file, each driven by its own host thread through
+    ONE data-dependent cycle of the reference's loop (/root/reference/src/cortex/tk_cortex_main.c:1149-1237, 1323-1379): 1 s of PCM + the
+    silence that ends the segment -> VAD -> Whisper -> the transcript becomes a conversation turn -> reasoner context string -> LLM response;
+    then a 640 x 640 frame -> detector -> the detections enter the context string -> LLM response.  The prompts are built from THAT
+    cycle's transcript and detections (different frames / audio per cortex); the LLM rows of all cortices are decoded together behind the
+    runner API (csrc/llm/tk_llm_batcher.h).  Two responses of N / 2 tokens each = N tokens per cycle.  Perception runs per handle at batch 1,
+    as the reference's API shapes it.  The synthetic vocabulary is byte-level, so a context string costs one prompt token per byte."""
+    t_create = time.time()
+    cxs = [tk.Cortex(llm="synthetic://mistral-7b?seed=4", detector="synthetic://yolov8n?seed=5&cls_bias=-0.45", asr="synthetic://whisper-tiny.en?seed=6",
+                     vad="synthetic://vad?seed=7") for _ in range(K)]
+    t_create = time.time() - t_create
+    for cx in cxs:
+        cx.set_max_tokens(max(N // 2, 1))
+        cx.start()
+    done = [0.0] * K
+    plen = [0] * K
+
+    def drive(i):
+        rng = np.random.default_rng(1000 + i)
+        frame = rng.integers(0, 256, (640, 640, 3), dtype=np.uint8)
+        pcm = np.concatenate([np.clip(rng.normal(0, 9000, 16000), -32768, 32767), np.zeros(9600)]).astype(np.int16)
+        cx = cxs[i]
+        base = cx.stats().llm_responses
+        for chunk in np.split(pcm, 16):  # 100 ms chunks, like the reference's microphone worker
+            cx.inject_audio(chunk)
+        want = base + (1 if cx.stats().speech_segments > 0 else 0)
+        t_end = time.time() + 600
+        while cx.stats().llm_responses < want and time.time() < t_end:
+            time.sleep(0.002)
+        cx.inject_frame(frame)
+        while cx.stats().frames_processed < 1 and time.time() < t_end:
+            time.sleep(0.002)
+        want += 1 if cx.stats().frames_with_objects > 0 else 0
+        while cx.stats().llm_responses < want and time.time() < t_end:
+            time.sleep(0.002)
+        done[i] = time.time()
+        plen[i] = len(cx.last_prompt())
+
+    th = [threading.Thread(target=drive, args=(i,)) for i in range(K)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = max(done) - t0
+    st = [cx.stats() for cx in cxs]
+    for cx in cxs:
+        cx.stop()
+    for cx in cxs:
+        cx.close()
+    return {"cortices": K, "host_threads": K, "wall_s": round(dt, 3), "cycles_per_s": round(K / dt, 3), "create_s": round(t_create, 2),
+            "llm_responses": int(sum(s.llm_responses for s in st)), "llm_tokens": int(sum(s.llm_tokens for s in st)),
+            "speech_segments": int(sum(s.speech_segments for s in st)), "frames_with_objects": int(sum(s.frames_with_objects for s in st)),
+            "last_prompt_bytes_mean": int(np.mean(plen)), "data_dependent": True}
+
+
 def reference_abi_runners(tk, K, N):
     """K tk_llm_runner_t handles on ONE model handle, each driven by its own host thread through tk_llm_runner_prepare_generation /
     tk_llm_runner_generate_next_token only: what a host gets when it opens K runners instead of one (continuous batching behind the
@@ -486,6 +544,8 @@ def main():
     ap.add_argument("--perception-batch", type=int, default=64, help="frames / utterances per detector / ASR call")
     ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     ap.add_argument("--ns-steps", type=int, default=4, help="timed steps of the north_star_point run")
+    ap.add_argument("--cortices", type=lambda v: [int(x) for x in v.split(",") if x], default=[16, 64, 256],
+                    help="cortex-handle counts of the reference_abi_batched_cortex extras (256 handles: ~45 s, most of it creating them)")
     ap.add_argument("--weights", choices=["q4_k_m", "f16"], default="q4_k_m",
                     help="f16: BASELINE configs[4]'s fp16 checkpoint (14.2 GB of weights per decode step) on the exact fp32 MFMA GEMM; LLM stream only, "
                          "no W4A8 roofline object (other kernels)")
@@ -634,6 +694,13 @@ def main():
         out["reference_abi_batched"] = [reference_abi_runners(tk, K, N) for K in (16, 64, 256)]
         # the same runners from a C host: the difference is the Python driver (GIL hand-offs between K threads that each make one ctypes call per token)
         out["reference_abi_batched_c_host"] = [reference_abi_runners_c_host(K, N) for K in (16, 256)]
+        # data-dependent cycles through tk_cortex_* only, K cortices on one model file (prompts built from each cycle's own detections / transcript)
+        out["reference_abi_batched_cortex"] = []
+        for K in args.cortices:
+            try:
+                out["reference_abi_batched_cortex"].append(reference_abi_batched_cortex(tk, K, N))
+            except Exception as e:  # reported, never fatal for the headline
+                out["reference_abi_batched_cortex"].append({"cortices": K, "error": str(e)[:200]})
     if extras and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(tk, model, hp, P, N, args.asr_steps)
     print(json.dumps(out))

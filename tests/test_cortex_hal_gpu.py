@@ -215,3 +215,66 @@ def test_module_executors_run_the_three_streams(gpu):
     runner.close()
     loader.unload(h)
     loader.close()
+
+
+def test_cortices_on_one_model_give_the_tokens_each_gives_alone(gpu):
+    """the data-dependent cycle at more than one cortex (reference loop: /root/reference/src/cortex/tk_cortex_main.c:1149-1237, 1323-1379):
+    three tk_cortex_t handles share one LLM model file; each builds its prompts from ITS frame's detections and ITS audio's transcript.  Driven
+    at the same time from three threads (their LLM rows share decode passes behind the runner API) each returns exactly the response — and has
+    built exactly the prompt — it produces when it runs alone."""
+    import threading
+
+    def cycle(cx, seed, out):
+        rng = np.random.default_rng(seed)
+        frame = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+        pcm = np.concatenate([np.clip(rng.normal(0, 9000, 16000), -32768, 32767), np.zeros(9600)]).astype(np.int16)
+        base = cx.stats().llm_responses
+        for chunk in np.split(pcm, 16):
+            assert cx.inject_audio(chunk) == 0
+        out["segments"] = int(cx.stats().speech_segments)  # 0 or 1: the synthetic VAD may or may not call this noise speech
+        want = base + out["segments"]
+        deadline = time.time() + 120
+        while cx.stats().llm_responses < want and time.time() < deadline:
+            time.sleep(0.01)
+        first = (cx.last_prompt(), cx.last_response())
+        frames0 = cx.stats().frames_processed
+        assert cx.inject_frame(frame) == 0
+        while cx.stats().frames_processed == frames0 and time.time() < deadline:
+            time.sleep(0.01)
+        want += 1  # cls_bias 0.5: every frame has detections
+        while cx.stats().llm_responses < want and time.time() < deadline:
+            time.sleep(0.01)
+        assert cx.stats().llm_responses == want
+        out["result"] = (out["segments"], first, (cx.last_prompt(), cx.last_response()))
+
+    def make():
+        cx = gpu.Cortex(llm="synthetic://tiny?seed=4", detector="synthetic://yolov8n?seed=5&cls_bias=0.5")
+        cx.set_max_tokens(12)
+        cx.start()
+        return cx
+
+    alone = {}
+    for seed in (31, 32, 33):  # one cortex at a time
+        cx = make()
+        o = {}
+        cycle(cx, seed, o)
+        alone[seed] = o["result"]
+        cx.stop()
+        cx.close()
+    assert alone[31] != alone[32]                      # the cycles differ: prompts are built from each cortex's own perception
+    assert any(alone[sd][0] for sd in (31, 32, 33)), "no seed produced a speech segment: pick others"
+    for sd in (31, 32, 33):
+        nseg, (p1, r1), (p2, r2) = alone[sd]
+        if nseg:                                        # the transcript became a conversation turn of the first prompt
+            assert b'User: "' in p1 and len(r1) > 0
+        assert b"% confidence)" in p2 and p2 != p1      # the frame's detections entered the second prompt
+    cxs = [make(), make(), make()]                      # all at once, one thread each
+    outs = [{}, {}, {}]
+    th = [threading.Thread(target=cycle, args=(cxs[i], 31 + i, outs[i])) for i in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(3):
+        assert outs[i]["result"] == alone[31 + i]
+    for cx in cxs:
+        cx.stop()
+        cx.close()
