@@ -533,6 +533,8 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="opt-in: the ranks form ONE layer-sharded LLM pipeline (RCCL send / recv of the residual stream between consecutive "
                          "GPUs, SURVEY.md 8e) instead of independent replicas; LLM stream only; --sessions row groups keep the stages busy")
+    ap.add_argument("--pipe-rccl", action="store_true", help="pipeline hand-off as ncclSend / ncclRecv of the fp32 stream (RCCL over xGMI) instead of the peer-mapped "
+                    "mailboxes: needs one GPU per stage and fails otherwise")
     ap.add_argument("--pipe-f16", action="store_true", help="pipeline hand-off payload in IEEE f16 (SURVEY.md 8e's 8 KiB per row) instead of exact fp32")
     ap.add_argument("--placement", choices=["replicas", "model-per-gpu", "combined"], default="replicas",
                     help="model-per-gpu (SURVEY.md 8e): rank 0 runs the LLM for ALL cycles of the job, the other ranks run the detector / ASR / VAD "
@@ -726,9 +728,9 @@ def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, com
         model = tk.LlmModel(hp, device=local_rank).fill_synthetic(4, f16=f16)  # every stage builds the same weights and runs only its layers
         hp = model.hparams
         make = D.gpu_pipe_factory(tk, model, B, P + N + 8, payload_f16=args.pipe_f16)
-        pipe = D.LibPipeline(dist, roles["llm"], hp.n_layer, G, make)
+        pipe = D.LibPipeline(dist, roles["llm"], hp.n_layer, G, make, rccl=args.pipe_rccl)
     else:
-        D.LibPipeline(dist, roles["llm"], hp.n_layer, G, None)  # takes part in the handle exchange, owns no stage
+        D.LibPipeline(dist, roles["llm"], hp.n_layer, G, None, rccl=args.pipe_rccl)  # takes part in the handle exchange, owns no stage
         share_v = -(-cycles // len(roles["vision"])) if rank in roles["vision"] else 0
         share_a = -(-cycles // len(roles["audio"])) if rank in roles["audio"] else 0
         cb = PerceptionBench(tk, share_v, share_a, rank, local_rank, args.perception_batch, args.asr_steps)
@@ -765,6 +767,8 @@ def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, com
         n_st = len(roles["llm"])
         bounds = D.stage_bounds(hp.n_layer, n_st)
         par = "pipeline x%d (in-library hand-off of [rows, 4096] %s through peer-mapped device mailboxes, hipGraph replays)" % (n_st, "f16" if args.pipe_f16 else "fp32")
+        if args.pipe_rccl:
+            par = "pipeline x%d (in-library hand-off of [rows, 4096] fp32 by ncclSend / ncclRecv over RCCL, eager launches)" % n_st
         if combined:
             par += "; detector on ranks %s; VAD+ASR on ranks %s" % (roles["vision"], roles["audio"])
         wl = ("configs[4]: Mistral-7B fp16" if f16 else "configs[1] weights (Q4_K_M)") + " layer-sharded, 64-token prefill + 128-token greedy decode per cycle, %d row groups of %d" % (G, B)

@@ -138,6 +138,14 @@ TK_API void tk_mi355x_pipe_destroy(tk_mi355x_pipe_t** p);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_connect(tk_mi355x_pipe_t* p, const tk_mi355x_pipe_handle_t* next, const tk_mi355x_pipe_handle_t* prev);
 /* the same for stages created in this process (several GPUs driven by one process, or the tests' two stages on one GPU) */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_connect_local(tk_mi355x_pipe_t* p, tk_mi355x_pipe_t* next, tk_mi355x_pipe_t* prev);
+/* The collective form of the same hand-off (ncclSend / ncclRecv; north_star: "RCCL over xGMI only for the LLM shard"): the stages
+ * form one RCCL communicator — tk_mi355x_pipe_rccl_unique_id in ONE process (128 plain bytes, moved to the others any way), then
+ * tk_mi355x_pipe_connect_rccl in every stage's process INSTEAD of tk_mi355x_pipe_connect — and every boundary is an ncclSend of the exact fp32
+ * stream on the producer's stream matched by an ncclRecv on the consumer's; ids return to stage 0 the same way.  One GPU per stage: with fewer
+ * than two visible devices, or two stages on one device, the call FAILS (TK_ERROR_GPU_DEVICE_NOT_FOUND) — it never falls back to the
+ * mailboxes.  Decode steps are launched eagerly.  pass / decode / sync are used as with the mailbox transport and give the same tokens. */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_rccl_unique_id(uint8_t out[128]);
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_connect_rccl(tk_mi355x_pipe_t* p, const uint8_t unique_id[128]);
 /* enqueue one pass (returns at once).  tok: stage 0 only; NULL = feed the ids the last stage sampled for these rows.  head != 0: the last stage
  * samples and returns the ids to stage 0; every stage's device-side positions then stand one past the rows' (a decode loop may follow). */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_pipe_pass(tk_mi355x_pipe_t* p, int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, int head);

@@ -73,6 +73,7 @@ class _RecorderPipe:
     """what LibPipeline drives, without a GPU: records the calls"""
 
     def __init__(self, rank, g, stage, n_stages, l0, l1):
+        self.rank, self.g = rank, g
         self.handle_bytes = ("mailbox r%d g%d" % (rank, g)).encode().ljust(80, b".")
         self.meta = (stage, n_stages, l0, l1)
         self.calls = []
@@ -80,6 +81,12 @@ class _RecorderPipe:
 
     def connect(self, nxt, prv):
         self.links = (nxt, prv)
+
+    def new_unique_id(self):  # the collective transport: stage 0 names a communicator per row group
+        return ("rccl id of r%d g%d" % (self.rank, self.g)).encode().ljust(128, b".")
+
+    def connect_rccl(self, unique_id):
+        self.links = ("rccl", unique_id)
 
     def enqueue(self, seq, pos, tok, head):
         self.calls.append(("pass", list(map(int, seq)), list(map(int, pos)), None if tok is None else list(map(int, tok)), bool(head)))
@@ -93,7 +100,7 @@ class _RecorderPipe:
         return np.zeros((n_steps, nrows), np.int32) if n_steps else None
 
 
-def _combined_worker(rank, world, port, q):
+def _combined_worker(rank, world, port, q, rccl=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import numpy as np
@@ -106,7 +113,7 @@ def _combined_worker(rank, world, port, q):
         made.append(_RecorderPipe(rank, g, stage, n_stages, l0, l1))
         return made[-1]
 
-    pipe = D.LibPipeline(dist, roles["llm"], 32, 2, make if rank in roles["llm"] else None)
+    pipe = D.LibPipeline(dist, roles["llm"], 32, 2, make if rank in roles["llm"] else None, rccl=rccl)
     rng = np.random.default_rng(1)
     prompts = [rng.integers(3, 100, (3, 6)).astype(np.int32) for _ in range(2)]
     out = pipe.generate(prompts, 4, rows_per_pass=8)
@@ -145,6 +152,28 @@ def test_world_size_3_combined_job_two_stages_plus_perception_rank():
         assert [c[4] for c in passes0] == [False, False, True]                  # 15 prompt rows in chunks of 8, then the sampling pass
         assert ("decode", 3, 4) in s0[g][2] and s0[g][2][-1] == ("sync", 3, 4)
     assert res[0][3] == [(4, 3), (4, 3)] and res[1][3] == [(4, 3), (4, 3)]
+
+
+def test_world_size_3_combined_job_over_the_rccl_transport():
+    """bench.py --pipe-rccl: stage 0 names one RCCL communicator per row group, the 128-byte ids reach every stage through the same exchange
+    and each stage joins the communicator of ITS group; the pass lists are the mailbox transport's"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_combined_worker, args=(r, 3, port, q, True)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=120) for _ in range(3))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = res[0][2], res[1][2]
+    for g in range(2):
+        want = ("rccl", ("rccl id of r0 g%d" % g).encode().ljust(128, b"."))
+        assert s0[g][1] == want and s1[g][1] == want
+        assert [c[0] for c in s0[g][2]] == [c[0] for c in s1[g][2]]
+    assert res[2][2] == []
 
 
 def _handover_worker(rank, world, port, q):

@@ -223,3 +223,75 @@ def test_pipe_wait_is_bounded_fails_fast_and_stays_failed(gpu, monkeypatch):
         p.close()
     for s in sess:
         s.close()
+
+
+def _rccl_stage_worker(stage, conn, device):
+    sys.path.insert(0, ROOT)
+    import trackiellm_amd as tk
+    tk.lib().tk_mi355x_set_default_device(device)
+    hp = tk.TINY()
+    hp.n_layer = 4
+    model = tk.LlmModel(hp, device=device).fill_synthetic(31)
+    hp = model.hparams
+    prompts = np.random.default_rng(7).integers(3, hp.vocab, (5, 12)).astype(np.int32)
+    sess = tk.LlmSession(model, 5, 48)
+    bounds = [0, 2, 4]
+    pipe = tk.LlmPipe(sess, stage, 2, bounds[stage], bounds[stage + 1])
+    if stage == 0:
+        conn.send(tk.LlmPipe.rccl_unique_id())
+    uid = conn.recv()
+    pipe.connect_rccl(uid)                                            # both ranks enter ncclCommInitRank together
+    for gen in range(2):                                              # two generations on one communicator: the id messages stay paired
+        _drive_stage(pipe, prompts, 9, rows_per_pass=4)
+        toks = pipe.sync(5, 9)
+    conn.send(toks.tolist())
+    conn.recv()
+    pipe.close()
+    sess.close()
+
+
+def test_rccl_transport_needs_one_gpu_per_stage_and_says_so(gpu):
+    """the collective form of the stage hand-off (SURVEY.md §8e: ncclSend / ncclRecv; north_star: "RCCL over xGMI only for the LLM shard";
+    tk_mi355x_pipe_connect_rccl).  With >= 2 visible devices: two processes, one stage per device, two generations — the last stage's ids
+    equal a single session's (the mailbox transport's cross-check on a real link).  With fewer — the GPU boxes of this build — selecting the
+    transport must FAIL loudly, never fall back to the mailboxes: that refusal is what is asserted there."""
+    import ctypes as C
+    ndev = gpu.lib().tk_mi355x_device_count()
+    hp = gpu.TINY()
+    hp.n_layer = 4
+    model = gpu.LlmModel(hp).fill_synthetic(31)
+    if ndev < 2:
+        sess = gpu.LlmSession(model, 5, 48)
+        pipe = gpu.LlmPipe(sess, 0, 2, 0, 2)
+        uid = gpu.LlmPipe.rccl_unique_id()                            # librccl itself loads and answers
+        assert len(uid) == 128 and any(uid)
+        with pytest.raises(gpu.TkError) as e:
+            pipe.connect_rccl(uid)
+        assert "one GPU per stage" in e.value.detail and "1 device(s) visible" in e.value.detail, e.value.detail
+        with pytest.raises(gpu.TkError):                              # and the pipe stays unconnected: nothing silently took another path
+            pipe.enqueue(np.zeros(1, np.int32), np.zeros(1, np.int32), np.ones(1, np.int32))
+        pipe.close()
+        sess.close()
+        model.close()
+        return
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ends = [ctx.Pipe() for _ in range(2)]
+    procs = [ctx.Process(target=_rccl_stage_worker, args=(s, ends[s][1], s)) for s in range(2)]
+    for p in procs:
+        p.start()
+    uid = ends[0][0].recv()
+    for s in range(2):
+        ends[s][0].send(uid)
+    toks = []
+    for s in range(2):
+        assert ends[s][0].poll(300), "stage %d did not finish" % s
+        toks.append(np.array(ends[s][0].recv()))
+    for s in range(2):
+        ends[s][0].send("bye")
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    prompts = np.random.default_rng(7).integers(3, model.hparams.vocab, (5, 12)).astype(np.int32)
+    want = _single_session_reference(gpu, model, [prompts], 9)[0]
+    assert np.array_equal(toks[1], want[1:]) and np.array_equal(toks[0], want[:9])

@@ -326,6 +326,19 @@ tk_error_code_t tk_mi355x_pipe_connect_local(tk_mi355x_pipe_t* p, tk_mi355x_pipe
     return TK_SUCCESS;
 }
 
+tk_error_code_t tk_mi355x_pipe_rccl_unique_id(uint8_t out[128]) {
+    if (!out) return TK_ERROR_INVALID_ARGUMENT;
+    std::string err;
+    if (!tk_pipe_rccl_unique_id(out, &err)) return fail(TK_ERROR_GPU_ROCM_ERROR, err);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_pipe_connect_rccl(tk_mi355x_pipe_t* p, const uint8_t unique_id[128]) {
+    if (!p || !unique_id) return TK_ERROR_INVALID_ARGUMENT;
+    if (!p->pipe.connect_rccl(unique_id)) return fail(TK_ERROR_GPU_DEVICE_NOT_FOUND, p->pipe.error);
+    return TK_SUCCESS;
+}
+
 tk_error_code_t tk_mi355x_pipe_pass(tk_mi355x_pipe_t* p, int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, int head) {
     if (!p || !seq || !pos) return TK_ERROR_INVALID_ARGUMENT;
     if (!p->pipe.pass(nrows, seq, pos, tok, head != 0)) return fail(TK_ERROR_INFERENCE_FAILED, p->pipe.error);

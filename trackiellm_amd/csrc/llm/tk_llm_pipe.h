@@ -53,6 +53,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <deque>
 #include <string>
 
 #include "tk_llm_engine.h"
@@ -91,6 +92,10 @@ struct TkPipeHandle { /* what the host exchanges between stages: 64 handle bytes
     int32_t pid;
 };
 
+/* 128 bytes that identify a new RCCL communicator (ncclGetUniqueId); made by ONE process, handed to every stage.  false + *err when librccl
+ * cannot be loaded. */
+bool tk_pipe_rccl_unique_id(unsigned char out[128], std::string* err);
+
 class TkLlmPipe {
 public:
     std::string error;
@@ -101,6 +106,13 @@ public:
     bool connect(const TkPipeHandle* next, const TkPipeHandle* prev);
     /* the same for stages that live in this process (pointers; enables peer access when the devices differ) */
     bool connect_local(TkLlmPipe* next, TkLlmPipe* prev);
+    /* the collective form of the hand-off (ncclSend / ncclRecv is the path's primary collective, north_star: "RCCL over xGMI only
+     * for the LLM shard"): instead of mapping mailboxes, the n_stages ranks form one RCCL communicator (unique id from
+     * tk_pipe_rccl_unique_id of stage 0's process, any channel) and every boundary is an ncclSend of the folded fp32 stream on the producer's
+     * stream matched by an ncclRecv into the consumer's residual buffer; the sampled ids return to stage 0 the same way.  One GPU per stage:
+     * refused when fewer than two devices are visible or when two stages sit on one device (RCCL rejects duplicate devices).  fp32 payload
+     * only; decode steps are launched eagerly (no graph replay: the insurance path, and the cross-check of the mailbox path on real xGMI). */
+    bool connect_rccl(const unsigned char unique_id[128]);
     /* enqueue one pass of this stage on the session's stream (returns without waiting for the GPU).  tok: stage 0 only — the rows' tokens,
      * or NULL to take them from the id mailbox (the ids the last stage sampled for these rows' previous positions).  head: the last stage
      * runs the lm head, samples and sends the ids to stage 0. */
@@ -129,6 +141,9 @@ private:
     int32_t* h_rows_ = nullptr;        /* pinned staging ring for (seq, pos, tok) of host-described passes */
     int h_next_ = 0;
     hipGraphExec_t graph_[TK_MAX_ROWS + 1] = {};
+    void* rccl_comm_ = nullptr;        /* ncclComm_t when the RCCL transport is selected */
+    int32_t* rccl_scratch_ = nullptr;  /* [TK_MAX_ROWS] ids of a drained message */
+    std::deque<int> id_msg_rows_;      /* RCCL transport, stage 0: row counts of the id messages not yet received (sends and receives must pair) */
     void enqueue_stage(int nrows, bool take_ids, bool head, bool advance_pos, bool fused_attn);
     uint8_t* x_payload(TkPipeBlock* b) const { return (uint8_t*)b + sizeof(TkPipeBlock); }
 };

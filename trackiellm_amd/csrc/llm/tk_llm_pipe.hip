@@ -194,6 +194,81 @@ __global__ void k_pipe_advance(int32_t* pos, int nrows) {
     if (r < nrows) pos[r] = pos[r] + 1;
 }
 
+/* stage 0, RCCL transport: the ids an ncclRecv has just put into `tok` are what the rows feed; note them in the history like k_pipe_take_ids */
+__global__ void k_pipe_note_ids(const int32_t* __restrict__ tok, int nrows, int32_t* nsteps, int32_t* hist, int hist_stride, int hist_cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    const int n = nsteps[i];
+    if (n < hist_cap) { hist[(int64_t)n * hist_stride + i] = tok[i]; nsteps[i] = n + 1; }
+}
+
+/* ---- RCCL (loaded on first use: a host that never selects the collective transport does not need librccl) ------------------------ */
+#include <dlfcn.h>
+namespace {
+typedef struct { char internal[128]; } tk_nccl_id;
+struct RcclApi {
+    int (*GetUniqueId)(tk_nccl_id*) = nullptr;
+    int (*CommInitRank)(void**, int, tk_nccl_id, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+enum { TK_NCCL_INT32 = 2, TK_NCCL_FLOAT32 = 7 }; /* ncclDataType_t (rccl.h: ncclInt32 = 2, ncclFloat32 = 7) */
+RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { api.why = std::string("librccl could not be loaded: ") + dlerror(); return; }
+        api.GetUniqueId = (int (*)(tk_nccl_id*))dlsym(h, "ncclGetUniqueId");
+        api.CommInitRank = (int (*)(void**, int, tk_nccl_id, int))dlsym(h, "ncclCommInitRank");
+        api.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+        api.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+        api.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+        api.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.Send && api.Recv && api.GetErrorString;
+        if (!api.ok) api.why = "librccl lacks ncclSend / ncclRecv";
+    });
+    return api;
+}
+}  // namespace
+
+bool tk_pipe_rccl_unique_id(unsigned char out[128], std::string* err) {
+    RcclApi& r = rccl();
+    if (!r.ok) { if (err) *err = r.why; return false; }
+    tk_nccl_id id;
+    const int rc = r.GetUniqueId(&id);
+    if (rc != 0) { if (err) *err = std::string("ncclGetUniqueId: ") + r.GetErrorString(rc); return false; }
+    memcpy(out, id.internal, 128);
+    return true;
+}
+
+bool TkLlmPipe::connect_rccl(const unsigned char unique_id[128]) {
+    if (n_stages == 1) return true;
+    if (!unique_id) { error = "no RCCL unique id"; return false; }
+    if (f16_) { error = "the RCCL transport carries the exact fp32 stream only"; return false; }
+    int ndev = 0;
+    PQ(hipGetDeviceCount(&ndev));
+    if (ndev < 2) {
+        error = "the RCCL transport needs one GPU per stage: " + std::to_string(ndev) + " device(s) visible to this process, " + std::to_string(n_stages) +
+                " stages asked for (stages that share a GPU use the mailbox transport: tk_mi355x_pipe_connect / _connect_local)";
+        return false;
+    }
+    RcclApi& r = rccl();
+    if (!r.ok) { error = r.why; return false; }
+    PQ(hipSetDevice(s_->model->device));
+    tk_nccl_id id;
+    memcpy(id.internal, unique_id, 128);
+    const int rc = r.CommInitRank(&rccl_comm_, n_stages, id, stage);
+    if (rc != 0) { rccl_comm_ = nullptr; error = std::string("ncclCommInitRank: ") + r.GetErrorString(rc) + " (two stages on one GPU?)"; return false; }
+    PQ(hipMalloc((void**)&rccl_scratch_, TK_MAX_ROWS * sizeof(int32_t)));
+    return true;
+}
+
 /* ---- host side ------------------------------------------------------------------------------------------------------------------ */
 
 static std::mutex g_pipe_capture_mu;
@@ -207,6 +282,8 @@ TkLlmPipe::~TkLlmPipe() {
     for (auto& g : graph_) if (g) (void)hipGraphExecDestroy(g);
     if (next_ && next_ipc_) (void)hipIpcCloseMemHandle(next_);
     if (prev_ && prev_ipc_ && prev_ != next_) (void)hipIpcCloseMemHandle(prev_);
+    if (rccl_comm_) (void)rccl().CommDestroy(rccl_comm_);
+    if (rccl_scratch_) (void)hipFree(rccl_scratch_);
     if (mine_) (void)hipFree(mine_);
     if (st_) (void)hipFree(st_);
     if (h_rows_) (void)hipHostFree(h_rows_);
@@ -301,6 +378,24 @@ void TkLlmPipe::enqueue_stage(int nrows, bool take_ids, bool head, bool advance_
     hipStream_t st = s_->stream;
     const int D = h.d_model, slot_floats = TK_MAX_ROWS * D;
     const bool first = stage == 0, last = stage == n_stages - 1;
+    if (rccl_comm_) { /* the collective transport: one ncclRecv / ncclSend per boundary on this stage's stream, matched by the neighbour's */
+        RcclApi& r = rccl();
+        auto chk = [&](int rc, const char* what) { if (rc != 0 && s_->launch_error.empty()) s_->launch_error = std::string(what) + ": " + r.GetErrorString(rc); };
+        if (first) {
+            if (take_ids) {
+                chk(r.Recv(s_->d_tok, (size_t)nrows, TK_NCCL_INT32, n_stages - 1, rccl_comm_, st), "ncclRecv (ids)");
+                hipLaunchKernelGGL(k_pipe_note_ids, dim3((nrows + 63) / 64), dim3(64), 0, st, s_->d_tok, nrows, s_->d_nsteps, s_->d_hist, TK_MAX_ROWS, s_->hist_cap);
+            }
+        } else {
+            chk(r.Recv(s_->x, (size_t)nrows * D, TK_NCCL_FLOAT32, stage - 1, rccl_comm_, st), "ncclRecv (stream)");
+        }
+        const bool sample = head && last;
+        s_->enqueue_range(nrows, l0, l1, first, !last, sample, fused_attn); /* fold_out: the stream that leaves is complete */
+        if (!last) chk(r.Send(s_->x, (size_t)nrows * D, TK_NCCL_FLOAT32, stage + 1, rccl_comm_, st), "ncclSend (stream)");
+        else if (sample) chk(r.Send(s_->d_tok, (size_t)nrows, TK_NCCL_INT32, 0, rccl_comm_, st), "ncclSend (ids)");
+        if (advance_pos && !sample) hipLaunchKernelGGL(k_pipe_advance, dim3((nrows + 63) / 64), dim3(64), 0, st, s_->d_pos, nrows);
+        return;
+    }
     if (first) {
         if (take_ids && n_stages > 1)
             hipLaunchKernelGGL(k_pipe_take_ids, dim3(1), dim3(256), 0, st, mine_, prev_, st_, s_->d_tok, nrows, s_->d_nsteps, s_->d_hist, TK_MAX_ROWS, s_->hist_cap);
@@ -324,7 +419,7 @@ void TkLlmPipe::enqueue_stage(int nrows, bool take_ids, bool head, bool advance_
 bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const int32_t* tok, bool head) {
     const TkLlmHParams& h = s_->model->hp;
     if (nrows <= 0 || nrows > TK_MAX_ROWS || !seq || !pos) { error = "nrows must be in [1, 256] and (seq, pos) given"; return false; }
-    if (n_stages > 1 && (!next_ || !prev_)) { error = "the pipe is not connected"; return false; }
+    if (n_stages > 1 && !rccl_comm_ && (!next_ || !prev_)) { error = "the pipe is not connected"; return false; }
     if (failed_) { error = kFailedMsg; return false; }
     bool distinct = true;
     for (int r = 0; r < nrows; ++r) {
@@ -350,11 +445,19 @@ bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const in
      * whatever the FIFO still holds stale — the previous generation's last sample — so it is drained before this pass */
     const bool take = stage == 0 && !from_tok && n_stages > 1;
     if (stage == 0 && from_tok && n_stages > 1 && ids_outstanding_ > 0) {
-        hipLaunchKernelGGL(k_pipe_drain_ids, dim3(1), dim3(1), 0, s_->stream, mine_, prev_, st_, ids_outstanding_);
+        if (rccl_comm_) { /* every ncclSend of the last stage needs its ncclRecv: the stale messages are received into a scratch buffer */
+            for (int rows : id_msg_rows_) {
+                const int rc = rccl().Recv(rccl_scratch_, (size_t)rows, TK_NCCL_INT32, n_stages - 1, rccl_comm_, s_->stream);
+                if (rc != 0) { error = std::string("ncclRecv (drain): ") + rccl().GetErrorString(rc); return false; }
+            }
+            id_msg_rows_.clear();
+        } else {
+            hipLaunchKernelGGL(k_pipe_drain_ids, dim3(1), dim3(1), 0, s_->stream, mine_, prev_, st_, ids_outstanding_);
+        }
         ids_outstanding_ = 0;
     }
-    if (take) --ids_outstanding_;
-    if (head && n_stages > 1) ++ids_outstanding_;
+    if (take) { --ids_outstanding_; if (rccl_comm_ && !id_msg_rows_.empty()) id_msg_rows_.pop_front(); }
+    if (head && n_stages > 1) { ++ids_outstanding_; if (rccl_comm_ && stage == 0) id_msg_rows_.push_back(nrows); }
     /* host-described passes go eagerly (their row tables differ); distinct rows take the fused-attention form, as forward() does */
     enqueue_stage(nrows, take, head, head, distinct);
     if (!s_->launch_error.empty()) { error = s_->launch_error; return false; }
@@ -364,14 +467,14 @@ bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const in
 
 bool TkLlmPipe::decode(int nrows, int n_steps) {
     if (nrows <= 0 || nrows > TK_MAX_ROWS || n_steps <= 0 || n_steps > s_->hist_cap) { error = "nrows must be in [1, 256] and n_steps within the session's context"; return false; }
-    if (n_stages > 1 && (!next_ || !prev_)) { error = "the pipe is not connected"; return false; }
+    if (n_stages > 1 && !rccl_comm_ && (!next_ || !prev_)) { error = "the pipe is not connected"; return false; }
     if (failed_) { error = kFailedMsg; return false; }
     if (stage == 0 && n_stages > 1 && ids_outstanding_ < 1) { error = "decode() without a sampling pass before it: the id mailbox would be empty"; return false; }
     PQ(hipSetDevice(s_->model->device));
     if (s_->mask_rows_dirty) { PQ(hipMemsetAsync(s_->d_mask_row, 0xFF, TK_MAX_ROWS * 4, s_->stream)); s_->mask_rows_dirty = false; }
     PQ(hipMemsetAsync(s_->d_nsteps, 0, TK_MAX_ROWS * 4, s_->stream));
     const char* ng = getenv("TK_MI355X_NO_GRAPH");
-    const bool use_graph = !(ng && ng[0] == '1');
+    const bool use_graph = !(ng && ng[0] == '1') && !rccl_comm_; /* collective calls are launched eagerly */
     if (use_graph && !graph_[nrows]) {
         std::lock_guard<std::mutex> lk(g_pipe_capture_mu);
         hipGraph_t g = nullptr;
@@ -389,6 +492,8 @@ bool TkLlmPipe::decode(int nrows, int n_steps) {
             return false;
         }
     }
+    /* a step takes one id message and (the last stage) sends one: the FIFO's length is unchanged, its row counts all become nrows */
+    if (rccl_comm_ && stage == 0 && n_stages > 1) { id_msg_rows_.assign(id_msg_rows_.size(), nrows); }
     for (int i = 0; i < n_steps; ++i) {
         if (use_graph) PQ(hipGraphLaunch(graph_[nrows], s_->stream));
         else { s_->launch_error.clear(); enqueue_stage(nrows, true, true, true, true); if (!s_->launch_error.empty()) { error = s_->launch_error; return false; } }

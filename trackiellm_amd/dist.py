@@ -172,9 +172,11 @@ class LibPipeline:
     synchronises with the host between a prompt and its last decoded token.
 
     make_pipe(group_index, stage, n_stages, l0, l1) -> an object with .handle_bytes, .connect(next_bytes, prev_bytes), .enqueue(seq, pos,
-    tok, head), .decode(nrows, n_steps), .sync(nrows, n_steps); the GPU one wraps tk.LlmPipe (below), tests inject a recorder."""
+    tok, head), .decode(nrows, n_steps), .sync(nrows, n_steps); the GPU one wraps tk.LlmPipe (below), tests inject a recorder.
+    rccl=True: the collective transport instead (SURVEY.md 8e's ncclSend / ncclRecv; bench.py --pipe-rccl): stage 0 makes one RCCL unique id
+    per row group (.new_unique_id()), the 128-byte ids go round in the same exchange, every stage joins (.connect_rccl(id)); one GPU per stage."""
 
-    def __init__(self, dist, llm_ranks, n_layer, n_groups, make_pipe):
+    def __init__(self, dist, llm_ranks, n_layer, n_groups, make_pipe, rccl=False):
         self.dist = dist
         self.rank = dist.get_rank() if dist is not None else 0
         self.llm_ranks = list(llm_ranks)
@@ -187,13 +189,19 @@ class LibPipeline:
             for g in range(n_groups):
                 self.pipes.append(make_pipe(g, self.stage, self.n_stages, self.bounds[self.stage], self.bounds[self.stage + 1]))
             mine = [p.handle_bytes for p in self.pipes]
+            if rccl:  # the collective transport: stage 0 names one communicator per row group, everybody joins it
+                mine = [p.new_unique_id() for p in self.pipes] if self.stage == 0 else []
         # every rank of the job takes part in the exchange (perception ranks contribute nothing), so any process group works
         if dist is not None and dist.get_world_size() > 1:
             table = [None] * dist.get_world_size()
             dist.all_gather_object(table, mine)
         else:
             table = [mine]
-        if self.stage is not None and self.n_stages > 1:
+        if self.stage is not None and self.n_stages > 1 and rccl:
+            ids = table[self.llm_ranks[0]]
+            for g, p in enumerate(self.pipes):
+                p.connect_rccl(ids[g])
+        elif self.stage is not None and self.n_stages > 1:
             nxt = table[self.llm_ranks[(self.stage + 1) % self.n_stages]]
             prv = table[self.llm_ranks[(self.stage - 1) % self.n_stages]]
             for g, p in enumerate(self.pipes):
@@ -237,6 +245,12 @@ class _GpuPipe:
 
     def connect(self, nxt, prv):
         self.pipe.connect(self.tk.PipeHandle.from_bytes(nxt), self.tk.PipeHandle.from_bytes(prv))
+
+    def new_unique_id(self):
+        return self.tk.LlmPipe.rccl_unique_id()
+
+    def connect_rccl(self, unique_id):
+        self.pipe.connect_rccl(unique_id)
 
     def enqueue(self, seq, pos, tok, head):
         self.pipe.enqueue(seq, pos, tok, head)

@@ -203,6 +203,18 @@ class LlmPipe:
     def connect_local(self, nxt, prv):
         check(lib().tk_mi355x_pipe_connect_local(self.h, nxt.h, prv.h))
 
+    @staticmethod
+    def rccl_unique_id():
+        """128 bytes naming a new RCCL communicator: made in ONE process, handed to every stage (tk_mi355x_pipe_rccl_unique_id)"""
+        buf = (C.c_uint8 * 128)()
+        check(lib().tk_mi355x_pipe_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def connect_rccl(self, unique_id):
+        """the collective transport (ncclSend / ncclRecv per boundary) instead of the mailboxes; needs one GPU per stage and FAILS otherwise"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(lib().tk_mi355x_pipe_connect_rccl(self.h, buf))
+
     def enqueue(self, seq, pos, tok=None, head=False):
         seq = np.ascontiguousarray(seq, dtype=np.int32)
         pos = np.ascontiguousarray(pos, dtype=np.int32)
