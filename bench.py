@@ -334,12 +334,12 @@ def cpu_baseline(tk, model, hp, P, N, asr_steps):
     orc.close()
     r = lambda d: {k: round(v, 5) for k, v in d.items()}
     return {"value": round(1.0 / full["cycle_s"], 5), "unit": "cycles/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (CPU restatement, not llama.cpp/ORT/whisper.cpp): 1 cycle = detector 640x640 + Whisper tiny.en mel/encoder/{asr_steps} steps "
-                      f"+ Mistral-7B Q4_K_M {P}-token batched prefill (timed whole) + {N}-token decode (8 tokens timed, extrapolated); "
-                      f"weights synthesised in {t_synth:.0f} s (untimed)",
+            "sample": f"EXTRAPOLATED: 8 of the {N} decode tokens timed and scaled to {N}; the rest timed whole.  ONE cycle on the oracle (CPU restatement, "
+                      f"not llama.cpp/ORT/whisper.cpp): detector 640x640 + Whisper tiny.en mel/encoder/{asr_steps} steps + Mistral-7B Q4_K_M {P}-token batched "
+                      f"prefill + {N}-token decode; weights synthesised in {t_synth:.0f} s (untimed)",
             "breakdown": r(full), "llm_tok_per_s": round(1.0 / full["decode_s_per_token"], 3),
             "one_core": {"value": round(1.0 / single["cycle_s"], 6), "unit": "cycles/s", "cores": 1,
-                         "sample": "same cycle at 1 thread: detector + ASR timed whole, 4 prompt + 2 decode tokens timed and extrapolated",
+                         "sample": "EXTRAPOLATED: 4 prompt + 2 decode tokens timed and scaled; the same cycle at 1 thread, detector + ASR timed whole",
                          "breakdown": r(single)},
             "token_ids_match_gpu": gtoks == toks, "detections": n_det, "asr_ids_head": asr_ids[:4]}
 

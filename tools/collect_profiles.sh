@@ -9,7 +9,7 @@
 # Everything lands under gpurun_out/; copy what should be judged into profiles/.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 O=gpurun_out
 one_csv() { # exactly one counter file per pass, or stop: a stale directory must never feed a freshly stamped summary
   local n; n=$(find "$1" -name '*counter_collection.csv' | wc -l)
@@ -26,7 +26,8 @@ export ROC_AQL_QUEUE_SIZE=524288
 check_budget() { # kernel-trace rows of a finished run against the ring
   local n; n=$(($(cat "$1" | wc -l) - 1))
   echo "packet budget: $n dispatches in $1 (all queues together; a HIP stream has a queue of its own) against a ring of $ROC_AQL_QUEUE_SIZE packets per queue"
-  [ "$n" -lt $((ROC_AQL_QUEUE_SIZE * 9 / 10)) ] || echo "WARNING: within 10 % of the ring: enlarge ROC_AQL_QUEUE_SIZE before profiling a longer run" >&2
+  # the count is over ALL queues, so it over-estimates every single queue's share: a run that passes this test cannot have wrapped any ring
+  [ "$n" -lt $((ROC_AQL_QUEUE_SIZE * 9 / 10)) ] || { echo "ERROR: $n dispatches are within 10 % of the ring of $ROC_AQL_QUEUE_SIZE packets: enlarge ROC_AQL_QUEUE_SIZE before profiling this run" >&2; exit 1; }
 }
 for B in 256 16; do
   for C in FETCH_SIZE WRITE_SIZE; do

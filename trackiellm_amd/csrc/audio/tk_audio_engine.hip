@@ -252,7 +252,13 @@ struct TkAudioGpuOps {
             tk_launch_pack_a(g.A, g.M, g.K, g.lda, 0, pk.img, s);
             pk.A = g.A; pk.M = g.M; pk.K = g.K; pk.lda = g.lda; pk.live = true;
         }
-        const bool plain = !g.residual && !g.c_feeds_linear && g.N % 16 == 0;
+        /* does the output overlap the packed matrix (an in-place layer)?  Then the image is stale once the launch has run */
+        const float* c0 = g.C;
+        const float* c1 = g.C + (size_t)(g.M - 1) * g.ldc + g.N;
+        const float* a0 = g.A;
+        const float* a1 = g.A + (size_t)(g.M - 1) * g.lda + g.K;
+        const bool in_place = c0 < a1 && a0 < c1;
+        const bool plain = !g.residual && !g.c_feeds_linear && g.N % 16 == 0 && !in_place; /* an in-place layer never joins a batch: it runs alone below */
         if (plain) { /* joins (or opens) the batch of layers on this input */
             if (pend.n > 0 && (pend.t.a_img != pk.img || pend.t.K != g.K || pend.t.nrows != g.M || pend.t.act != g.act)) flush();
             TkTiledGemm& t = pend.t;
@@ -265,7 +271,7 @@ struct TkAudioGpuOps {
             t.tiles[i] = a->model->wt[(size_t)idx]; t.row_tiles[i] = g.N / 16;
             t.seg_out[i] = g.C; t.seg_ldc[i] = g.ldc; t.seg_bias[i] = g.bias; t.seg_n[i] = g.N;
             if (pend.n == 3) flush();
-            return; /* none of these layers writes into its own input (q, k, v and the caches are buffers of their own) */
+            return; /* none of these layers writes into its own input: `plain` excludes in-place layers */
         }
         flush();
         TkTiledGemm t{};
@@ -273,8 +279,9 @@ struct TkAudioGpuOps {
         t.K = g.K; t.ks = 1; t.ldc = g.ldc; t.n_valid = g.N; t.nrows = g.M; t.slab_rows = 0;
         t.a_img = pk.img; t.a_ts = (size_t)g.K * 16; t.out = g.C;
         t.bias = g.bias; t.residual = g.residual; t.ldr = g.ldr; t.act = g.act; t.add_zero_bias = 1;
-        /* fc1 of a short pass: its output is only ever the input of fc2 — written as fc2's operand image as well (on top of fc1's own) */
-        const bool emit_img = g.c_feeds_linear && g.N % 128 == 0 && g.ldc == g.N && !g.residual;
+        /* fc1: its output is only ever the input of fc2 — written as fc2's operand image as well (on top of fc1's own), on long (encoder) passes
+         * too: there the second image replaces a k_pack_a launch over B x 1500 x 4 d values (9.8 -> 9.4 ms per call, profiles/r04_perception.txt) */
+        const bool emit_img = g.c_feeds_linear && g.N % 128 == 0 && g.ldc == g.N && !g.residual && !in_place;
         float* cimg = nullptr;
         if (emit_img) {
             TkGemm nx{};
@@ -287,12 +294,7 @@ struct TkAudioGpuOps {
             pk.img = cimg; pk.A = g.C; pk.M = g.M; pk.K = g.N; pk.lda = g.ldc; pk.live = true;
             return;
         }
-        /* the output may overwrite the packed matrix (an in-place layer): the image is then stale */
-        const float* c0 = g.C;
-        const float* c1 = g.C + (size_t)(g.M - 1) * g.ldc + g.N;
-        const float* a0 = g.A;
-        const float* a1 = g.A + (size_t)(g.M - 1) * g.lda + g.K;
-        if (c0 < a1 && a0 < c1) drop_image();
+        if (in_place) drop_image(); /* the output overwrote the packed matrix: the image is stale */
     }
     void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) { drop_image(); tk_launch_im2col1d(x, B, T, C, ldx, kw, stride, pad, col, s); }
     void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) {

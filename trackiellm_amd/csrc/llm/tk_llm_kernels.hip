@@ -17,6 +17,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../common/tk_ggml_blocks.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -1463,14 +1465,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
 
 /* compute units of the calling thread's current device (every launcher runs with the session's device current): read once per device */
 static int tk_num_cu() {
-    static int cached[64] = {};
+    static std::atomic<int> cached[64]; /* launchers run from several host threads (sessions, schedulers) */
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cached[dev] == 0) {
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
         int n = 0;
-        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        v = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        cached[dev].store(v, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return v;
 }
 #define TK_NUM_CU tk_num_cu()
 

@@ -456,6 +456,13 @@ bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const in
         }
         ids_outstanding_ = 0;
     }
+    /* the id FIFO has TK_PIPE_SLOTS slots and stage 0 only returns credits when it takes a message: more sampling passes than that without a
+     * take in between would park the last stage on credits until the next generation's drain.  One row group per pipe (LibPipeline, bench.py)
+     * keeps at most two outstanding; a host that interleaves many sampled prompts on one pipe is told so instead of being slowed silently. */
+    if (head && n_stages > 1 && !take && ids_outstanding_ >= TK_PIPE_SLOTS - 1) {
+        error = "more than " + std::to_string(TK_PIPE_SLOTS - 1) + " sampled ids are waiting in the id mailbox: decode (or feed host tokens) before sampling further prompts on this pipe";
+        return false;
+    }
     if (take) { --ids_outstanding_; if (rccl_comm_ && !id_msg_rows_.empty()) id_msg_rows_.pop_front(); }
     if (head && n_stages > 1) { ++ids_outstanding_; if (rccl_comm_ && stage == 0) id_msg_rows_.push_back(nrows); }
     /* host-described passes go eagerly (their row tables differ); distinct rows take the fused-attention form, as forward() does */

@@ -263,13 +263,16 @@ void tk_launch_pack_a(const float* A, int64_t rows, int K, int lda, int round_f1
 
 /* ---- launch ---- */
 
+/* compute units of the calling thread's current device, cached PER DEVICE (the ABI takes a device ordinal per handle; launchers run with
+ * the handle's device current and from several host threads) */
 static int tk_tiled_num_cu() {
-    static std::atomic<int> n{0};
-    int v = n.load(std::memory_order_relaxed);
-    if (v > 0) return v;
+    static std::atomic<int> n[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
-    n.store(v, std::memory_order_relaxed);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = n[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    n[dev].store(v, std::memory_order_relaxed);
     return v;
 }
 
