@@ -403,10 +403,18 @@ def reference_abi_batched_cortex(tk, K, N):
     cycle's transcript and detections (different frames / audio per cortex); the LLM rows of all cortices are decoded together behind the
     runner API (csrc/llm/tk_llm_batcher.h).  Two responses of N / 2 tokens each = N tokens per cycle.  Perception runs per handle at batch 1,
     as the reference's API shapes it.  The synthetic vocabulary is byte-level, so a context string costs one prompt token per byte."""
+    # the runners the cortices create share ONE decode session of K sequence slots (the library's default is 16 per session: 256 cortices would
+    # decode in sixteen separate 16-row streams); read when the first runner of the model is created
+    prev_slots = os.environ.get("TK_MI355X_RUNNER_SLOTS")
+    os.environ["TK_MI355X_RUNNER_SLOTS"] = str(min(K, 256))
     t_create = time.time()
     cxs = [tk.Cortex(llm="synthetic://mistral-7b?seed=4", detector="synthetic://yolov8n?seed=5&cls_bias=-0.45", asr="synthetic://whisper-tiny.en?seed=6",
                      vad="synthetic://vad?seed=7") for _ in range(K)]
     t_create = time.time() - t_create
+    if prev_slots is None:
+        os.environ.pop("TK_MI355X_RUNNER_SLOTS", None)
+    else:
+        os.environ["TK_MI355X_RUNNER_SLOTS"] = prev_slots
     for cx in cxs:
         cx.set_max_tokens(max(N // 2, 1))
         cx.start()

@@ -2,7 +2,7 @@
 """Decode-step time of one session at a given pass width (developer tool, needs an MI355X): a 64-token prompt per sequence, then
 N greedy steps through the captured pass — ms per step (HIP events around the loop) and the weight-stream rate it corresponds to.
     python tools/time_decode.py [rows] [steps]
-Environment switches read when a pass is recorded: TK_MI355X_NO_PREFETCH=1, TK_MI355X_NO_FUSE=1, TK_MI355X_NO_GRAPH=1."""
+Environment switches read when a pass is recorded: TK_MI355X_NO_TAIL=1, TK_MI355X_NO_FUSE=1, TK_MI355X_NO_GRAPH=1."""
 import os
 import sys
 
@@ -26,4 +26,4 @@ sess.decode(rows, 8)
 for rep in range(3):
     toks, ms = sess.decode(rows, steps)
     print(f"{rows} rows: {ms:.3f} ms per decode step, {rows / ms * 1e3:.0f} tok/s, weights at {nbytes / ms / 1e9:.2f} TB/s = {nbytes / ms / 1e9 / 8:.3f} of 8 TB/s "
-          f"(NO_PREFETCH={os.environ.get('TK_MI355X_NO_PREFETCH', '0')})", flush=True)
+          f"(NO_TAIL={os.environ.get('TK_MI355X_NO_TAIL', '0')} NO_FUSE={os.environ.get('TK_MI355X_NO_FUSE', '0')})", flush=True)
