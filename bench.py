@@ -554,8 +554,10 @@ def main():
     ap.add_argument("--perception-batch", type=int, default=64, help="frames / utterances per detector / ASR call")
     ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     ap.add_argument("--ns-steps", type=int, default=4, help="timed steps of the north_star_point run")
-    ap.add_argument("--cortices", type=lambda v: [int(x) for x in v.split(",") if x], default=[16, 64, 256],
-                    help="cortex-handle counts of the reference_abi_batched_cortex extras (256 handles: ~45 s, most of it creating them)")
+    ap.add_argument("--cortices", type=lambda v: [int(x) for x in v.split(",") if x], default=[16, 64],
+                    help="cortex-handle counts of the reference_abi_batched_cortex extras.  256 handles (a 4096-position KV cache for 256 sequences = 137 GB, "
+                         "+ 256 private detector / ASR engines) only fit beside nothing else: run tools/time_batched_cortex.py 256 on its own "
+                         "(profiles/r05_batched_cortex.txt: 25 cycles/s); inside this process the GPU's memory is oversubscribed and the driver evicts")
     ap.add_argument("--weights", choices=["q4_k_m", "f16"], default="q4_k_m",
                     help="f16: BASELINE configs[4]'s fp16 checkpoint (14.2 GB of weights per decode step) on the exact fp32 MFMA GEMM; LLM stream only, "
                          "no W4A8 roofline object (other kernels)")

@@ -765,9 +765,16 @@ bool TkLlmSession::time_attention(int nrows, int ctx, int iters, float* avg_ms, 
     HIPQ(hipMemcpyAsync(d_pos, ps.data(), nrows * 4, hipMemcpyHostToDevice, stream));
     HIPQ(hipStreamSynchronize(stream));
     const int QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim;
+    /* TK_MI355X_TIME_UNFUSED=1: time the two-launch form instead (k_qkv_rope_append + k_attention<.., not fused>): what a decode pass would
+     * cost without the fused prologue */
+    const char* uf = getenv("TK_MI355X_TIME_UNFUSED");
+    const bool unfused = uf && uf[0] == '1';
     auto launch = [&](int l) {
+        if (unfused)
+            tk_launch_qkv_rope_append(partial, h.ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows, qbuf, kcache,
+                                      vcache, l % h.n_layer, max_seq, max_ctx, stream);
         tk_launch_attention(qbuf, partial, h.ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
-                            h.head_dim, l % h.n_layer, max_seq, max_ctx, act_qd, true, stream);
+                            h.head_dim, l % h.n_layer, max_seq, max_ctx, act_qd, !unfused, stream);
     };
     *kv_bytes = (double)nrows * ctx * KVD * 2.0 * 2.0;
     const bool use_graph = graphs_enabled();
