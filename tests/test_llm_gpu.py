@@ -873,3 +873,68 @@ def test_runner_with_the_reference_sampler_is_seeded_and_batch_invariant(gpu):
         r.close()
     loader.unload(h)
     loader.close()
+
+
+@pytest.mark.parametrize("seed", [4, 8])
+def test_stochastic_sampling_under_the_tool_grammar_stays_inside_it(gpu, seed):
+    """the reference arms the grammar AND samples through llama.cpp's default chain (tk_runner_streaming.c:44-48, 60-61): with
+    tk_mi355x_llm_runner_set_sampling on, the draw is taken among the tokens the grammar allows (the mask enters the on-device top-k
+    selection), so every sampled piece keeps the text inside the grammar, the ids equal the oracle's sampler under the same masks, and two
+    runners with the same seed produce the same text"""
+    import ctypes as C
+    L = gpu.lib()
+    loader = gpu.ModelLoader()
+    h = loader.load("synthetic://tiny?seed=%d" % seed)
+    hp = gpu.LlmHParams()
+    L.tk_mi355x_llm_model_get_hparams(h, C.byref(hp))
+    n_ctx = 96
+
+    def accepted(bs):
+        n, c = C.c_int32(), C.c_int32()
+        assert L.tk_mi355x_grammar_check(None, bs, C.byref(n), C.byref(c)) == 0
+        return n.value == len(bs), bool(c.value)
+
+    def generate(rng_seed):
+        runner = gpu.LlmRunner(h, context_size=n_ctx, random_seed=rng_seed)
+        runner.set_sampling(0.9, 40, 0.95, 0.05)
+        runner.prepare("call", use_tool_grammar=True)
+        got, ended = [], None
+        for _ in range(n_ctx):
+            p = runner.next_token()
+            if p is None or p == "<tool_call>":
+                ended = p
+                break
+            got.append(p)
+        runner.close()
+        return got, ended
+
+    got, ended = generate(77)
+    assert generate(77) == (got, ended)                    # seeded
+    text = b"".join(got)
+    assert accepted(text)[0]                                # never left the grammar
+    # the oracle's sampler under the same masks: allowed = tokens whose piece keeps the text inside the grammar (EOS: only when complete)
+    orc = O.OracleLlm(oracle_cfg_from(hp, n_ctx, 1), seed=seed)
+    ids = [1] + [3 + b for b in b"call"]
+    logits, _ = orc.forward([0] * len(ids), list(range(len(ids))), ids)
+    lg, pos, sofar, want, counter = logits[-1], len(ids), b"", [], 0
+    while True:
+        allow = np.zeros((hp.vocab + 31) // 32, np.uint32)
+        for t in range(hp.vocab):
+            pc = _piece_of(t)
+            ok = accepted(sofar)[1] if t == 2 else (bool(pc) and accepted(sofar + pc)[0])
+            if ok:
+                allow[t >> 5] |= np.uint32(1 << (t & 31))
+        tok = O.sample_row(lg, 0.9, 40, 0.95, 0.05, 77, counter, allow)
+        counter += 1
+        if tok == 2:
+            break
+        sofar += _piece_of(tok)
+        if accepted(sofar)[1] or pos + 1 >= n_ctx:
+            break
+        want.append(_piece_of(tok))
+        lg = orc.forward([0], [pos], [tok])[0][0]
+        pos += 1
+    assert got == want
+    orc.close()
+    loader.unload(h)
+    loader.close()
