@@ -24,3 +24,6 @@ run "pipeline x2, Q4_K_M, two generations on the same pipes" 2 --pipeline --step
 run "pipeline x3, f16 payload" 3 --pipeline --pipe-f16 --steps 1 --warmup 1 --batch 32 --sessions 3
 run "combined x4 (2 stages + detector + ASR), perception hand-over every step" 4 --placement combined --steps 2 --warmup 1 --batch 32 --sessions 2
 run "model-per-gpu x3, perception hand-over every step" 3 --placement model-per-gpu --steps 2 --warmup 1 --batch 32 --sessions 1 --no-extras
+# the RCCL transport refuses below two devices (it never falls back to the mailboxes): rc must be non-zero here, with the reason on stderr
+run "pipeline x2 over RCCL on ONE device: must refuse" 2 --pipeline --pipe-rccl --steps 1 --warmup 0 --batch 32 --sessions 1
+grep -h "one GPU per stage" /tmp/rh.err | head -1
