@@ -94,6 +94,21 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_transcribe_tokens(tk_asr_whisp
                                                                     int n_steps, int32_t* tokens_out, float* mel_out, float* enc_out,
                                                                     float* logits_out);
 TK_API void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_steps);
+/* whisper.cpp's decoding policy, which the reference's wrapper arms with temperature_inc 0.2 / entropy_thold 2.4 / logprob_thold -1.0
+ * (src/audio/tk_asr_whisper.c:126-138; partial results: no fallback, :137).  OFF by default: the plain greedy decode is what the parity suite pins.
+ *   transcribe_policy: the forced decode of transcribe_tokens with the token of every step picked by temperature (0 = arg max; > 0 = one draw from
+ *     softmax(l / temperature) restricted to the 64 largest logits, by the library's counter-based sampler keyed (seed, position x batch + b)) and,
+ *     optionally, logprobs_out [batch][n_steps] = log-probability of each produced token under softmax(l / temperature) over the whole vocabulary;
+ *   set_decode_policy: tk_asr_whisper_process_audio then decodes a FINAL result at temperatures 0, inc, 2 inc, ... <= 1 until the decode passes
+ *     whisper.cpp's test (mean log-probability of the tokens up to and including end-of-text >= logprob_thold, and — past 32 tokens — entropy of
+ *     the histogram of the last 32 tokens >= entropy_thold); attempt a uses seed + a; a partial result decodes once at temperature 0;
+ *   last_decode: temperature, mean log-probability and attempt count of the decode the last process_audio returned. */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_transcribe_policy(tk_asr_whisper_context_t* ctx, int batch, const int16_t* pcm, int n_samples,
+                                                                    int n_steps, float temperature, uint64_t seed, int32_t* tokens_out,
+                                                                    float* logprobs_out);
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_set_decode_policy(tk_asr_whisper_context_t* ctx, int enable, float temperature_inc,
+                                                                    float entropy_thold, float logprob_thold, uint64_t seed);
+TK_API void tk_mi355x_asr_last_decode(const tk_asr_whisper_context_t* ctx, float* temperature, float* avg_logprob, int32_t* attempts);
 /* the decoder prompt the next transcription starts from (English-only: <|sot|><|notimestamps|>; multilingual: + language and task
  * tokens, whisper.cpp's whisper_full order); returns the count, -1 when the configured language has no token */
 TK_API int tk_mi355x_asr_prompt_tokens(tk_asr_whisper_context_t* ctx, int32_t* out, int cap);

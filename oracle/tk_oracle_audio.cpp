@@ -16,6 +16,8 @@
 
 #include "../trackiellm_amd/csrc/common/tk_whisper_graph.h"
 
+extern "C" int32_t orc_sample_row(const float* logits, int vocab, const uint32_t* allow, float temp, int32_t top_k, float top_p, float min_p, uint64_t seed,
+                                  uint32_t counter); /* tk_oracle_llm.cpp */
 extern "C" void orc_gemm(const float* A, const float* B, float* C, const float* bias, const float* residual, int M, int N, int K, int lda, int ldb,
                          int ldc, int ldr, int b_kn, int act, float alpha);
 
@@ -93,12 +95,46 @@ struct CpuAudioOps {
         for (int r = 0; r < rows; ++r)
             for (int i = 0; i < D; ++i) out[(int64_t)r * D + i] = table[(int64_t)idx[r] * D + i] + pos[(int64_t)pos_idx[r] * D + i];
     }
+    /* whisper.cpp's decoding policy (the reference arms it: src/audio/tk_asr_whisper.c:126-138), restating k_pick_rows of
+     * csrc/nn/tk_nn_kernels.hip: token by temperature (0 = first index of the maximum; > 0 = one draw of the canonical sampler over the 64
+     * largest logits, counter = position x rows + row) and its log-probability under softmax(l / temperature) over the whole vocabulary */
+    bool pick_on = false;
+    float pick_temp = 0.0f;
+    uint64_t pick_seed = 0;
+    float* pick_lp = nullptr; /* [positions][rows] */
+    int pick_step = 0;
     void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out) {
         for (int r = 0; r < rows; ++r) {
+            const float* xr = x + (int64_t)r * ld;
             int best = 0;
-            for (int i = 1; i < cols; ++i) if (x[(int64_t)r * ld + i] > x[(int64_t)r * ld + best]) best = i;
+            for (int i = 1; i < cols; ++i) if (xr[i] > xr[best]) best = i;
             out[r] = best;
+            if (!pick_on) continue;
+            const float mx = xr[best];
+            if (pick_temp > 0.0f)
+                out[r] = orc_sample_row(xr, cols, nullptr, pick_temp, 0, 1.0f, 0.0f, pick_seed, (uint32_t)(pick_step * rows + r));
+            if (!pick_lp) continue;
+            /* sum of exponentials: 1024 strided chains, each wave of 64 chains joined by the xor butterfly (32 .. 1), then waves 0 .. 15 in order */
+            float chain[1024];
+            for (int t = 0; t < 1024; ++t) {
+                float s = 0.0f;
+                for (int i = t; i < cols; i += 1024) s = s + tk_expf(pick_temp > 0.0f ? tk_divf(xr[i] - mx, pick_temp) : xr[i] - mx);
+                chain[t] = s;
+            }
+            float S = 0.0f;
+            for (int w = 0; w < 16; ++w) {
+                float a[64], nx[64];
+                for (int j = 0; j < 64; ++j) a[j] = chain[w * 64 + j];
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    for (int j = 0; j < 64; ++j) nx[j] = a[j] + a[j ^ sft];
+                    for (int j = 0; j < 64; ++j) a[j] = nx[j];
+                }
+                S = w == 0 ? a[0] : S + a[0];
+            }
+            const float z = pick_temp > 0.0f ? tk_divf(xr[out[r]] - mx, pick_temp) : xr[out[r]] - mx;
+            pick_lp[(int64_t)pick_step * rows + r] = z - tk_logf(S);
         }
+        if (pick_on) pick_step++;
     }
     void frames(const int16_t* pcm, int B, int n_samples, int pcm_stride, int n_total, int T, const float* window, float* out) {
         for (int b = 0; b < B; ++b)
@@ -181,6 +217,60 @@ void orc_whisper_transcribe(orc_whisper* m, int B, const int16_t* pcm, int n_sam
             for (int b = 0; b < B; ++b) tokens_out[(size_t)b * n_steps + step] = st.next[b];
         }
     }
+}
+
+/* same contract as TkAsr::transcribe_policy: the forced decode with the token picked by temperature; logprobs_out [B][n_steps] */
+void orc_whisper_transcribe_policy(orc_whisper* m, int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps,
+                                   float temperature, uint64_t seed, int32_t* tokens_out, float* logprobs_out) {
+    const TkWhisperHP& h = m->hp;
+    CpuAudioOps ops;
+    ops.bufs.reserve(4096);
+    TkWhisperGraph<CpuAudioOps> g{h, m->man, m->wp.data()};
+    float* ml = g.mel(ops, pcm, B, n_samples, n_samples);
+    float* enc = g.encode(ops, ml, B);
+    auto st = g.begin_decode(ops, enc, B);
+    const int total = n_prompt + n_steps - 1;
+    std::vector<float> lp((size_t)total * B);
+    ops.pick_on = true; ops.pick_temp = temperature; ops.pick_seed = seed; ops.pick_lp = lp.data(); ops.pick_step = 0;
+    for (int p = 0; p < total; ++p) {
+        for (int b = 0; b < B; ++b) { st.tok[b] = p < n_prompt ? prompt[p] : st.next[b]; st.pos[b] = p; }
+        g.decode_step(ops, st, p);
+        if (p >= n_prompt - 1) {
+            const int step = p - (n_prompt - 1);
+            for (int b = 0; b < B; ++b) {
+                tokens_out[(size_t)b * n_steps + step] = st.next[b];
+                if (logprobs_out) logprobs_out[(size_t)b * n_steps + step] = lp[(size_t)p * B + b];
+            }
+        }
+    }
+}
+
+/* whisper.cpp's acceptance test of one decode (the temperature-fallback loop of whisper_full_with_state; whisper.cpp is a dependency the reference does
+ * not vendor): length = up to and including the first end-of-text token (else n_steps); failed = mean log-probability below logprob_thold, or — with
+ * more than 32 tokens — the entropy of the histogram of the last 32 tokens below entropy_thold.  Returns 1 when failed; *avg = the mean. */
+int orc_whisper_decode_failed(const int32_t* toks, const float* lp, int n_steps, int32_t eot, float entropy_thold, float logprob_thold, float* avg) {
+    int len = n_steps;
+    for (int i = 0; i < n_steps; ++i)
+        if (toks[i] == eot) { len = i + 1; break; }
+    double sum = 0.0;
+    for (int i = 0; i < len; ++i) sum += (double)lp[i];
+    const float a = (float)(sum / (double)len);
+    if (avg) *avg = a;
+    int failed = a < logprob_thold;
+    if (len > 32) {
+        double ent = 0.0;
+        for (int i = len - 32; i < len; ++i) {
+            bool first = true;
+            for (int j = len - 32; j < i; ++j) if (toks[j] == toks[i]) { first = false; break; }
+            if (!first) continue;
+            int cnt = 0;
+            for (int j = i; j < len; ++j) cnt += toks[j] == toks[i];
+            const double pr = cnt / 32.0;
+            ent -= pr * log(pr);
+        }
+        if (ent < (double)entropy_thold) failed = 1;
+    }
+    return failed;
 }
 
 /* ---- VAD ---- */

@@ -404,6 +404,31 @@ class OracleWhisper:
         return toks[:, :n_steps], mel, enc, lg
 
 
+    def transcribe_policy(self, pcm, n_steps, temperature, seed, prompt=None):
+        """forced decode with the token picked by temperature -> (tokens [B][n_steps], logprobs [B][n_steps])"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        B, n = pcm.shape
+        prompt = whisper_prompt(self.hp) if prompt is None else np.ascontiguousarray(prompt, np.int32)
+        toks = np.zeros((B, n_steps), np.int32)
+        lp = np.zeros((B, n_steps), np.float32)
+        L = lib()
+        L.orc_whisper_transcribe_policy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64,
+                                                    C.c_void_p, C.c_void_p]
+        L.orc_whisper_transcribe_policy(self.h, B, ptr(pcm), n, ptr(prompt), len(prompt), n_steps, temperature, seed, ptr(toks), ptr(lp))
+        return toks, lp
+
+
+def whisper_decode_failed(toks, lp, eot, entropy_thold=2.4, logprob_thold=-1.0):
+    """whisper.cpp's acceptance test of one decode -> (failed, mean log-probability)"""
+    toks = np.ascontiguousarray(toks, np.int32)
+    lp = np.ascontiguousarray(lp, np.float32)
+    avg = C.c_float(0)
+    L = lib()
+    L.orc_whisper_decode_failed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    f = L.orc_whisper_decode_failed(ptr(toks), ptr(lp), toks.size, eot, entropy_thold, logprob_thold, C.byref(avg))
+    return bool(f), avg.value
+
+
 def vad_probabilities(seed, windows, hidden=64):
     windows = np.ascontiguousarray(windows, np.float32)
     n, w = windows.shape

@@ -1,4 +1,5 @@
 """GPU parity: log-mel, Whisper encoder/decoder tokens and the VAD against the oracle (bit-exact)."""
+import ctypes as C
 import json
 import os
 
@@ -343,3 +344,101 @@ def test_vad_onnx_graph_on_the_gpu_matches_torch(gpu, tmp_path):
     pa, pb = a8.probabilities(w8), b8.probabilities(w8)
     assert np.array_equal(pa, pb) and pa.std() > 1e-4
     a8.close(); b8.close()
+
+
+def _policy_geometry():
+    # the small test geometry with a 64-position text context: room for more than 32 decoded tokens (the entropy rule's window)
+    return O.WhisperHP(80, 50, 64, 2, 2, 64, 64, 2, 2, 512)
+
+
+def test_asr_decode_policy_tokens_and_logprobs_bit_exact(gpu):
+    """whisper.cpp's per-step bookkeeping (the reference arms its policy: tk_asr_whisper.c:126-138): tokens picked by temperature and their
+    log-probabilities, device against oracle, bit for bit; temperature 0 is the greedy decode"""
+    ohp = _policy_geometry()
+    asr = gpu.Asr(hp=hp_of(gpu, ohp), seed=6, max_batch=3)
+    orc = O.OracleWhisper(ohp, seed=6)
+    rng = np.random.default_rng(21)
+    pcm = np.clip(rng.normal(0, 3000, (3, 16000)), -32768, 32767).astype(np.int16)
+    greedy, _, _, lg = asr.transcribe_tokens(pcm, 40)
+    for temp, seed in ((0.0, 0), (0.4, 11), (1.0, 12), (1.0, 13)):
+        toks, lp = asr.transcribe_policy(pcm, 40, temp, seed)
+        wt, wlp = orc.transcribe_policy(pcm, 40, temp, seed)
+        assert np.array_equal(toks, wt), (temp, seed)
+        assert np.array_equal(lp.view(np.uint32), wlp.view(np.uint32)), (temp, np.abs(lp - wlp).max())
+        assert (lp <= 0).all() and np.isfinite(lp).all()
+        if temp == 0.0:
+            assert np.array_equal(toks, greedy)
+            z = lg.astype(np.float64)
+            ref = z.max(1) - np.log(np.exp(z - z.max(1, keepdims=True)).sum(1)) - z.max(1)      # log softmax at the arg max
+            assert np.abs(lp[:, 0] - ref).max() < 1e-5
+    a, _ = asr.transcribe_policy(pcm, 40, 1.0, 12)
+    b, _ = asr.transcribe_policy(pcm, 40, 1.0, 13)
+    assert not np.array_equal(a, b) and not np.array_equal(a, greedy)                          # the draws are real, and keyed by the seed
+    one, lp1 = asr.transcribe_policy(pcm[:1], 40, 1.0, 12)                                     # batch 1: counters are position x batch + row
+    w1, wlp1 = orc.transcribe_policy(pcm[:1], 40, 1.0, 12)
+    assert np.array_equal(one, w1) and np.array_equal(lp1.view(np.uint32), wlp1.view(np.uint32))
+    assert gpu.lib().tk_mi355x_asr_transcribe_policy(asr.h, 1, pcm.ctypes.data_as(C.c_void_p), 16000, 4, C.c_float(-0.5), C.c_uint64(0),
+                                                     one.ctypes.data_as(C.c_void_p), None) != 0   # negative temperature refused
+
+
+def _fallback(orc, pcm, n_steps, eot, inc, ent, lpt, seed, is_final=True):
+    """whisper.cpp's temperature ladder, restated on the oracle's decodes"""
+    t, attempts = np.float32(0.0), 0
+    while True:
+        toks, lp = orc.transcribe_policy(pcm[None], n_steps, float(t), seed + attempts)
+        attempts += 1
+        failed, avg = O.whisper_decode_failed(toks[0], lp[0], eot, ent, lpt)
+        nxt = np.float32(t + np.float32(inc))
+        if not failed or not is_final or not inc > 0 or not nxt < np.float32(np.float32(1.0) + np.float32(1e-6)):
+            return toks[0], float(t), avg, attempts
+        t = nxt
+
+
+def test_asr_decode_policy_fallback_on_the_reference_surface(gpu):
+    """tk_asr_whisper_process_audio with the policy on walks the temperature ladder exactly as the restated loop over oracle decodes does;
+    with the policy off (the default) it is the plain greedy decode"""
+    ohp = _policy_geometry()
+    asr = gpu.Asr(hp=hp_of(gpu, ohp), seed=6, max_batch=1)
+    orc = O.OracleWhisper(ohp, seed=6)
+    asr.set_decode_steps(40)
+    eot = ohp.n_vocab - 4
+    rng = np.random.default_rng(22)
+    pcm = np.clip(rng.normal(0, 3000, 16000), -32768, 32767).astype(np.int16)
+
+    def text_of(toks):
+        out = ""
+        for t in toks:
+            if t == eot:
+                break
+            out += " w%d" % t
+        return out
+
+    greedy, _, _, _ = asr.transcribe_tokens(pcm[None], 40, want_aux=False)
+    text, _, _, _ = asr.process_audio(pcm, True)
+    assert text == text_of(greedy[0]) and asr.last_decode() == (0.0, 0.0, 0)                  # default: off
+    # averages of the ladder's rungs, to place thresholds between them
+    avgs = []
+    for a in range(6):
+        toks, lp = orc.transcribe_policy(pcm[None], 40, float(np.float32(0.2) * a), 5 + a)
+        avgs.append(O.whisper_decode_failed(toks[0], lp[0], eot, 0.0, -1e9)[1])
+    cases = [(0.2, 2.4, -1.0), (0.2, 0.0, -1e9), (0.2, 1e9, -1e9), (0.2, 0.0, float(np.median(avgs))), (0.5, 0.0, 0.0), (-1.0, 1e9, 0.0)]
+    seen = set()
+    for inc, ent, lpt in cases:
+        asr.set_decode_policy(True, inc, ent, lpt, seed=5)
+        text, _, conf, partial = asr.process_audio(pcm, True)
+        wt, wtemp, wavg, watt = _fallback(orc, pcm, 40, eot, inc, ent, lpt, 5)
+        temp, avg, att = asr.last_decode()
+        assert text == text_of(wt), (inc, ent, lpt)
+        assert (np.float32(temp), att) == (np.float32(wtemp), watt) and np.float32(avg) == np.float32(wavg), (inc, ent, lpt, temp, avg, att, wtemp, wavg, watt)
+        assert not partial and abs(conf - 0.9) < 1e-7
+        seen.add(att)
+    assert 1 in seen and 6 in seen                                                            # accepted at once, and the whole ladder
+    # a partial result decodes once whatever the thresholds
+    asr.set_decode_policy(True, 0.2, 1e9, 0.0, seed=5)
+    text, _, _, partial = asr.process_audio(pcm, False)
+    wt, _, _, watt = _fallback(orc, pcm, 40, eot, 0.2, 1e9, 0.0, 5, is_final=False)
+    assert partial and text == text_of(wt) and asr.last_decode()[2] == 1 == watt
+    asr.reset()
+    asr.set_decode_policy(False)
+    text, _, _, _ = asr.process_audio(pcm, True)
+    assert text == text_of(greedy[0])

@@ -65,3 +65,36 @@ def test_vad_state_machine_fixture():
         assert [list(e) for e in ev] == case["events"], name
     ev, s = O.vad_run([0.9] * 30, threshold=0.8, min_silence_ms=500.0)                  # cortex settings (tk_cortex_main.c:881-882)
     assert ev == [(8, 0)] and s.active == 1
+
+
+def test_decode_policy_restatement_properties():
+    """whisper.cpp's decoding policy as the oracle restates it (the reference arms it with 0.2 / 2.4 / -1.0: tk_asr_whisper.c:126-138)"""
+    hp = O.WhisperHP(80, 50, 64, 2, 2, 64, 64, 2, 2, 512)
+    orc = O.OracleWhisper(hp, seed=6)
+    rng = np.random.default_rng(3)
+    pcm = np.clip(rng.normal(0, 3000, (2, 8000)), -32768, 32767).astype(np.int16)
+    greedy, _, _, lg = orc.transcribe(pcm, 36)
+    t0, lp0 = orc.transcribe_policy(pcm, 36, 0.0, 1)
+    assert np.array_equal(t0, greedy)                                          # temperature 0 is the greedy decode
+    z = lg.astype(np.float64)
+    want = -np.log(np.exp(z - z.max(1, keepdims=True)).sum(1))                 # log softmax at the arg max
+    assert np.abs(lp0[:, 0] - want).max() < 1e-5
+    ta, lpa = orc.transcribe_policy(pcm, 36, 1.0, 7)
+    tb, lpb = orc.transcribe_policy(pcm, 36, 1.0, 7)
+    tc, _ = orc.transcribe_policy(pcm, 36, 1.0, 8)
+    assert np.array_equal(ta, tb) and np.array_equal(lpa, lpb) and not np.array_equal(ta, tc)
+    assert (lpa <= 0).all() and lpa.mean() < lp0.mean()                        # drawn tokens are less probable than the arg max
+    # the acceptance test on known sequences
+    eot = 508
+    same = np.full(40, 7, np.int32)
+    lp = np.full(40, -0.5, np.float32)
+    assert O.whisper_decode_failed(same, lp, eot) == (True, -0.5)              # 32 identical tokens: entropy 0 < 2.4
+    distinct = np.arange(40, dtype=np.int32)
+    assert O.whisper_decode_failed(distinct, lp, eot) == (False, -0.5)         # entropy ln 32 = 3.47
+    assert O.whisper_decode_failed(distinct, lp * 4, eot) == (True, -2.0)      # improbable
+    assert O.whisper_decode_failed(same[:32], lp[:32], eot) == (False, -0.5)   # 32 tokens or fewer: no entropy rule
+    cut = distinct.copy(); cut[3] = eot
+    lp2 = lp.copy(); lp2[:4] = -0.25
+    assert O.whisper_decode_failed(cut, lp2 * 8, eot, logprob_thold=-2.5) == (False, -2.0)   # judged up to and including end-of-text only
+    half = np.array([i % 4 for i in range(40)], np.int32)                      # four tokens, eight times each: entropy ln 4 = 1.386
+    assert O.whisper_decode_failed(half, lp, eot, entropy_thold=1.38)[0] is False and O.whisper_decode_failed(half, lp, eot, entropy_thold=1.39)[0] is True

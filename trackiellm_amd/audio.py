@@ -63,6 +63,27 @@ class Asr:
         check(lib().tk_mi355x_asr_transcribe_tokens(self.h, B, p(pcm), n, n_steps, p(toks), p(mel), p(enc), p(lg)))
         return toks, mel, enc, lg
 
+    def transcribe_policy(self, pcm, n_steps, temperature=0.0, seed=0):
+        """the forced decode with whisper.cpp's per-step bookkeeping -> (tokens [B][n_steps], logprobs [B][n_steps])"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        B, n = pcm.shape
+        toks = np.zeros((B, n_steps), np.int32)
+        lp = np.zeros((B, n_steps), np.float32)
+        check(lib().tk_mi355x_asr_transcribe_policy(self.h, B, pcm.ctypes.data_as(C.c_void_p), n, n_steps, C.c_float(temperature), C.c_uint64(seed),
+                                                    toks.ctypes.data_as(C.c_void_p), lp.ctypes.data_as(C.c_void_p)))
+        return toks, lp
+
+    def set_decode_policy(self, enable=True, temperature_inc=0.2, entropy_thold=2.4, logprob_thold=-1.0, seed=0):
+        """whisper.cpp's temperature fallback on final results, with the thresholds the reference sets (tk_asr_whisper.c:126-138)"""
+        check(lib().tk_mi355x_asr_set_decode_policy(self.h, int(enable), C.c_float(temperature_inc), C.c_float(entropy_thold),
+                                                    C.c_float(logprob_thold), C.c_uint64(seed)))
+
+    def last_decode(self):
+        """(temperature, mean log-probability, attempts) of the decode the last process_audio returned"""
+        t, a, n = C.c_float(0), C.c_float(0), C.c_int32(0)
+        lib().tk_mi355x_asr_last_decode(self.h, C.byref(t), C.byref(a), C.byref(n))
+        return t.value, a.value, n.value
+
     def set_language(self, lang):
         return lib().tk_asr_whisper_set_language(self.h, lang.encode() if lang is not None else None)
 

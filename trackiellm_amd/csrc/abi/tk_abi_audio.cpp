@@ -2,6 +2,7 @@
  * tk_abi_audio.cpp — tk_asr_whisper_* and tk_vad_silero_* on the HIP audio engine; host-side buffering and state
  * machines restated from src/audio/tk_asr_whisper.c:282-344 and src/sensors/tk_vad_silero.c:283-390,488-600.
  */
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -40,6 +41,13 @@ struct tk_asr_whisper_context_s {
     int32_t sot = 0, nots = 0, eot = 0;
     bool multilingual = false, translate = false;
     std::vector<std::string> vocab; /* token id -> bytes, from a ggml checkpoint */
+    /* whisper.cpp's decoding policy as the reference's wrapper arms it (src/audio/tk_asr_whisper.c:126-138); off unless
+     * tk_mi355x_asr_set_decode_policy switched it on (the default path is the plain greedy decode the parity tests pin) */
+    bool policy_on = false;
+    float temperature_inc = 0.2f, entropy_thold = 2.4f, logprob_thold = -1.0f;
+    uint64_t policy_seed = 0;
+    float last_temperature = 0.0f, last_avg_logprob = 0.0f;
+    int last_attempts = 0;
 };
 
 /* Whisper's language table in token order (<|en|> = sot + 1, <|zh|> = sot + 2, ...): the published tokenizer order, which
@@ -189,6 +197,60 @@ tk_error_code_t tk_mi355x_asr_transcribe_tokens(tk_asr_whisper_context_t* c, int
     return TK_SUCCESS;
 }
 
+tk_error_code_t tk_mi355x_asr_transcribe_policy(tk_asr_whisper_context_t* c, int batch, const int16_t* pcm, int n_samples, int n_steps, float temperature,
+                                                uint64_t seed, int32_t* tokens_out, float* logprobs_out) {
+    if (!c || (!pcm && n_samples > 0) || !tokens_out || n_steps <= 0) return TK_ERROR_INVALID_ARGUMENT;
+    std::vector<int32_t> prompt;
+    std::string why;
+    if (!asr_prompt(c, &prompt, &why)) return afail(TK_ERROR_INFERENCE_FAILED, why);
+    if (!c->asr.transcribe_policy(batch, pcm, n_samples, prompt.data(), (int)prompt.size(), n_steps, temperature, seed, tokens_out, logprobs_out))
+        return afail(TK_ERROR_INFERENCE_FAILED, c->asr.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_asr_set_decode_policy(tk_asr_whisper_context_t* c, int enable, float temperature_inc, float entropy_thold, float logprob_thold, uint64_t seed) {
+    if (!c) return TK_ERROR_INVALID_ARGUMENT;
+    c->policy_on = enable != 0;
+    c->temperature_inc = temperature_inc; c->entropy_thold = entropy_thold; c->logprob_thold = logprob_thold; c->policy_seed = seed;
+    return TK_SUCCESS;
+}
+
+void tk_mi355x_asr_last_decode(const tk_asr_whisper_context_t* c, float* temperature, float* avg_logprob, int32_t* attempts) {
+    if (!c) return;
+    if (temperature) *temperature = c->last_temperature;
+    if (avg_logprob) *avg_logprob = c->last_avg_logprob;
+    if (attempts) *attempts = c->last_attempts;
+}
+
+/* whisper.cpp's acceptance test of one decode (whisper_full_with_state: the fallback loop over temperatures): the sequence up to and including
+ * the end-of-text token (or all n_steps), its mean log-probability, and — over its last 32 tokens, when it has more than 32 — the entropy of the
+ * token histogram; failed = repetitive (entropy below the threshold) or improbable (mean log-probability below the threshold) */
+static bool asr_decode_failed(const tk_asr_whisper_context_s* c, const int32_t* toks, const float* lp, int n_steps, float* avg_out) {
+    int len = n_steps;
+    for (int i = 0; i < n_steps; ++i)
+        if (toks[i] == c->eot) { len = i + 1; break; }
+    double sum = 0.0;
+    for (int i = 0; i < len; ++i) sum += (double)lp[i];
+    const float avg = (float)(sum / (double)len);
+    *avg_out = avg;
+    bool failed = avg < c->logprob_thold;
+    if (len > 32) {
+        int cnt[32];
+        int32_t ids[32];
+        int nd = 0;
+        for (int i = len - 32; i < len; ++i) {
+            int k = 0;
+            for (; k < nd; ++k) if (ids[k] == toks[i]) break;
+            if (k == nd) { ids[nd] = toks[i]; cnt[nd] = 0; ++nd; }
+            cnt[k]++;
+        }
+        double ent = 0.0;
+        for (int k = 0; k < nd; ++k) { const double pr = cnt[k] / 32.0; ent -= pr * log(pr); }
+        if (ent < (double)c->entropy_thold) failed = true;
+    }
+    return failed;
+}
+
 static std::string piece_of(const tk_asr_whisper_context_s* c, int32_t id) {
     if (!c->vocab.empty()) return id >= 0 && id < (int)c->vocab.size() ? c->vocab[(size_t)id] : std::string(); /* specials render as nothing */
     /* no GPT-2 BPE vocabulary ships with synthetic / TKWHSP1 weights: ids are rendered symbolically */
@@ -209,7 +271,24 @@ tk_error_code_t tk_asr_whisper_process_audio(tk_asr_whisper_context_t* c, const 
     if (!r) return TK_ERROR_OUT_OF_MEMORY;
     if (c->buffer_size < 16000 && !is_final) { *out_result = r; return TK_SUCCESS; } /* not enough audio yet: empty result */
     std::vector<int32_t> toks(c->decode_steps);
-    tk_error_code_t rc = tk_mi355x_asr_transcribe_tokens(c, 1, c->buffer.data(), (int)c->buffer_size, c->decode_steps, toks.data(), nullptr, nullptr, nullptr);
+    tk_error_code_t rc = TK_SUCCESS;
+    if (c->policy_on) {
+        /* the reference's parameters (tk_asr_whisper.c:126-138): final results fall back through temperatures 0, inc, 2 inc, ... <= 1 while the decode
+         * fails whisper.cpp's test; partial results decode once (temperature_inc = -1 there) */
+        std::vector<float> lp(c->decode_steps);
+        const float inc = is_final ? c->temperature_inc : -1.0f;
+        c->last_attempts = 0;
+        for (float t = 0.0f;; t += inc) {
+            rc = tk_mi355x_asr_transcribe_policy(c, 1, c->buffer.data(), (int)c->buffer_size, c->decode_steps, t, c->policy_seed + (uint64_t)c->last_attempts, toks.data(), lp.data());
+            if (rc != TK_SUCCESS) break;
+            c->last_attempts++;
+            c->last_temperature = t;
+            const bool failed = asr_decode_failed(c, toks.data(), lp.data(), c->decode_steps, &c->last_avg_logprob);
+            if (!failed || !(inc > 0.0f) || t + inc > 1.0f + 1e-6f) break;
+        }
+    } else {
+        rc = tk_mi355x_asr_transcribe_tokens(c, 1, c->buffer.data(), (int)c->buffer_size, c->decode_steps, toks.data(), nullptr, nullptr, nullptr);
+    }
     if (rc != TK_SUCCESS) { free(r); return rc; }
     std::string text;
     for (int32_t t : toks) {

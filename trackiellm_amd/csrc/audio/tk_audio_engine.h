@@ -47,6 +47,11 @@ public:
      * tokens_out[B][n_steps]; optional copies of the mel / encoder output for parity tests */
     bool transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps, int32_t* tokens_out,
                     std::vector<float>* mel_out, std::vector<float>* enc_out, std::vector<float>* first_logits);
+    /* the same with whisper.cpp's per-step bookkeeping: temperature 0 = arg max, > 0 = one draw per step from softmax(l / temperature) by the
+     * canonical sampler keyed by (seed, step x B + b); logprobs_out [B][n_steps] = log-probability of every produced token under that
+     * distribution (what the policy's logprob / entropy thresholds are taken on) */
+    bool transcribe_policy(int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps, float temperature, uint64_t seed,
+                           int32_t* tokens_out, float* logprobs_out);
 
 private:
     friend struct TkAudioGpuOps;
@@ -55,6 +60,8 @@ private:
     std::string launch_error; /* a launcher refused its arguments while the graph was being enqueued (no HIP error is raised for that) */
     int16_t* pcm_dev = nullptr;
     size_t pcm_cap = 0;
+    struct { bool on = false; float temp = 0.0f; uint64_t seed = 0; float* logprob = nullptr; int step = 0; } pick; /* token pick of the current transcribe */
+    std::vector<float> pick_logprobs; /* [total steps][B], read back by transcribe_policy */
 };
 
 /* tiny MLP speech-probability model over one 30 ms window: sigmoid(w2 . relu(W1 x + b1) + b2) */

@@ -317,7 +317,14 @@ struct TkAudioGpuOps {
         drop_image();
         tk_launch_embed_rows(table, pos, idx, pos_idx, rows, D, out, s);
     }
-    void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out) { drop_image(); tk_launch_argmax_rows(x, rows, cols, ld, out, s); }
+    void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out) {
+        drop_image();
+        if (!a->pick.on) { tk_launch_argmax_rows(x, rows, cols, ld, out, s); return; }
+        /* whisper.cpp's decoding policy: the step's token by temperature, its log-probability noted (step p of the decode loop, row b: slot p * B + b) */
+        TkPick pk{a->pick.temp, a->pick.seed, (uint32_t)(a->pick.step * rows), a->pick.logprob ? a->pick.logprob + (size_t)a->pick.step * rows : nullptr};
+        tk_launch_pick_rows(x, rows, cols, ld, out, pk, s);
+        a->pick.step++;
+    }
     void frames(const int16_t* pcm, int B, int n_samples, int pcm_stride, int n_total, int T, const float* window, float* out) {
         drop_image();
         const int64_t per = (int64_t)T * TK_WH_NFFT;
@@ -488,6 +495,30 @@ bool TkAsr::init(TkWhisperModel* m, int mb) {
     if (!tk_gemm_tiled_prepare_device()) { error = "LDS opt-in of the tiled GEMM failed"; return false; }
     HIPQ(hipMalloc((void**)&arena, arena_floats * 4));
     return true;
+}
+
+bool TkAsr::transcribe_policy(int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps, float temperature, uint64_t seed,
+                              int32_t* tokens_out, float* logprobs_out) {
+    if (!(temperature >= 0.0f) || model->hp.n_vocab > 65536) { error = "temperature must be >= 0 and the vocabulary at most 65536 tokens"; return false; }
+    const int total = n_prompt + n_steps - 1;
+    if (B < 1 || total < 1) { error = "nothing to decode"; return false; }
+    if (hipSetDevice(model->device) != hipSuccess) { error = "hipSetDevice failed"; return false; }
+    float* d_lp = nullptr;
+    if (hipMalloc((void**)&d_lp, (size_t)total * B * sizeof(float)) != hipSuccess) { error = "out of device memory (log-probabilities)"; return false; }
+    pick.on = true; pick.temp = temperature; pick.seed = seed; pick.logprob = d_lp; pick.step = 0;
+    const bool ok = transcribe(B, pcm, n_samples, prompt, n_prompt, n_steps, tokens_out, nullptr, nullptr, nullptr); /* synchronises the stream */
+    pick.on = false;
+    bool copied = true;
+    if (ok && logprobs_out) {
+        pick_logprobs.resize((size_t)total * B);
+        copied = hipMemcpy(pick_logprobs.data(), d_lp, pick_logprobs.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+        for (int step = 0; copied && step < n_steps; ++step)
+            for (int b = 0; b < B; ++b) logprobs_out[(size_t)b * n_steps + step] = pick_logprobs[(size_t)(n_prompt - 1 + step) * B + b];
+    }
+    (void)hipFree(d_lp);
+    pick.logprob = nullptr;
+    if (ok && !copied) error = "copy of the log-probabilities failed";
+    return ok && copied;
 }
 
 bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps, int32_t* tokens_out,

@@ -85,15 +85,7 @@ void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ
 bool tk_gemv_fuses_producer(int nrows, int K, int ks, int fks);
 bool tk_gemv_fuses_swiglu(int nrows, int ks, int type_gate, int type_up);
 void tk_launch_quant_q8(const float* hbuf, int FF, int nrows, TkActQ8 out, hipStream_t s);
-/* per-row sampling state: temp <= 0 = greedy (arg max); otherwise the reference's default chain (top-k, top-p, min-p, temperature, one draw
- * from a counter-based generator); the kernel adds one to `counter` per sampled token.  Vocabularies up to 65536 tokens. */
-#define TK_SAMPLE_MAX_K 64
-struct TkSampleRow {
-    float temp, top_p, min_p;
-    int32_t top_k;
-    uint64_t seed;
-    uint32_t counter, pad;
-};
+#include "../common/tk_sample.h"
 /* allow_base / allow_row (both optional): per-row allowed-token bit masks, allow_row[r] = mask index or -1; samp (optional): [nrows] */
 void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t* allow_base, const int32_t* allow_row, TkSampleRow* samp, int32_t* tok,
                       int32_t* pos, int32_t* nsteps, int32_t* hist, int hist_stride, hipStream_t s);

@@ -42,6 +42,10 @@ void tk_launch_im2col1d(const float* x, int B, int T, int C, int ldx, int kw, in
 /* out[r][:] = table[idx[r]][:] + pos[(pos0[r])][:] */
 void tk_launch_embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out, hipStream_t s);
 void tk_launch_argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out, hipStream_t s);
+/* token pick under whisper.cpp's decoding policy: arg max (temp 0) or one draw from softmax(l / temp), + the pick's log-probability under
+ * that distribution per row (logprob may be null); the generator is keyed by (seed, counter0 + row) */
+struct TkPick { float temp; uint64_t seed; uint32_t counter0; float* logprob; };
+void tk_launch_pick_rows(const float* x, int rows, int cols, int ld, int32_t* out, const TkPick& pk, hipStream_t s);
 void tk_launch_layernorm(const float* x, int rows, int D, const float* w, const float* b, float eps, float* y, hipStream_t s, float* img = nullptr /* optional: also the tiled GEMM's operand image of y */);
 void tk_launch_softmax_rows(float* x, int rows, int cols, int ld, hipStream_t s);
 void tk_launch_add_rows(float* x, const float* add, int rows, int D, int add_rows, hipStream_t s);

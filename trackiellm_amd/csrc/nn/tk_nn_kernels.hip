@@ -4,6 +4,7 @@
 #include <mutex>
 
 #include "../common/tk_exact_math.h"
+#include "../common/tk_sample_device.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -853,6 +854,69 @@ __global__ __launch_bounds__(1024) void k_argmax_rows(const float* x, int cols, 
         out[r] = idx;
     }
 }
+/* The ASR decoder's token pick when whisper.cpp's decoding policy is on (the reference's wrapper sets temperature_inc 0.2, entropy_thold 2.4,
+ * logprob_thold -1.0: src/audio/tk_asr_whisper.c:126-138): per row, the token — first index of the maximum at temperature 0, else one draw from
+ * softmax(l / temperature) by the canonical sampler (common/tk_sample_device.h; candidates = the 64 largest logits) — and its log-probability
+ * under softmax(l / temperature) over the WHOLE vocabulary, which the policy's thresholds are taken on:
+ *     z_i = (l_i - max) [/ temperature],  S = sum_i exp(z_i) as 1024 chains (chain t: i = t, t + 1024, ... ascending) joined per wave by the
+ *     xor butterfly (32 .. 1) and then wave 0 .. 15 in order,  logprob = z_tok - log S.
+ * Restated in oracle/tk_oracle_audio.cpp (pick_rows). */
+__global__ __launch_bounds__(1024) void k_pick_rows(const float* x, int cols, int ld, int32_t* out, TkPick pk) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ uint32_t sm[256 + 8 + 4 * TK_SAMPLE_MAX_K];
+    __shared__ int32_t picked;
+    const int r = blockIdx.x, t = threadIdx.x;
+    const float* xr = x + (int64_t)r * ld;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = t; i < cols; i += 1024) {
+        const float v = xr[i];
+        if (v > best) { best = v; idx = i; }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const float ov = __shfl_xor(best, s, 64);
+        const int oi = __shfl_xor(idx, s, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((t & 63) == 0) { bv[t >> 6] = best; bi[t >> 6] = idx; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        bv[0] = best; bi[0] = idx;
+    }
+    __syncthreads();
+    const float mx = bv[0];
+    int tok = bi[0];
+    __syncthreads();
+    if (pk.temp > 0.0f) {
+        TkSampleRow sp{};
+        sp.temp = pk.temp; sp.top_p = 1.0f; sp.min_p = 0.0f; sp.top_k = 0; sp.seed = pk.seed; sp.counter = pk.counter0 + (uint32_t)r;
+        sample_row(xr, cols, nullptr, sp, &picked, sm);
+        __syncthreads();
+        tok = picked;
+    }
+    if (t == 0) out[r] = tok;
+    if (pk.logprob) {
+        float ssum = 0.0f;
+        for (int i = t; i < cols; i += 1024) ssum = ssum + tk_expf(pk.temp > 0.0f ? tk_divf(xr[i] - mx, pk.temp) : xr[i] - mx);
+        for (int s = 32; s >= 1; s >>= 1) ssum = ssum + __shfl_xor(ssum, s, 64);
+        __syncthreads();
+        if ((t & 63) == 0) bv[t >> 6] = ssum;
+        __syncthreads();
+        if (t == 0) {
+            float S = bv[0];
+            for (int w = 1; w < 16; ++w) S = S + bv[w];
+            const float z = pk.temp > 0.0f ? tk_divf(xr[tok] - mx, pk.temp) : xr[tok] - mx;
+            pk.logprob[r] = z - tk_logf(S);
+        }
+    }
+}
+void tk_launch_pick_rows(const float* x, int rows, int cols, int ld, int32_t* out, const TkPick& pk, hipStream_t s) {
+    hipLaunchKernelGGL(k_pick_rows, dim3(rows), dim3(1024), 0, s, x, cols, ld, out, pk);
+}
+
 void tk_launch_argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_argmax_rows, dim3(rows), dim3(1024), 0, s, x, cols, ld, out);
 }
