@@ -43,6 +43,20 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_fill_synthetic_f16(tk_mi
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_set_tensor(tk_mi355x_llm_model_t* m, int layer, int which, int type, const void* data,
                                                                    size_t nbytes);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_load_gguf(tk_mi355x_llm_model_t** out, const char* path, int device);
+/* LoRA adapters.  The reference applies one right after the model is loaded, in place and once: llama_model_apply_lora_from_file
+ * (src/ai_models/tk_model_loader.c:259-270) — W' = W + (alpha / r) B A, a quantised W dequantised, added to and quantised back to its own type.
+ * Here the same merge runs on the GPU while a matrix is installed, so an adapted model decodes at the un-adapted model's speed.
+ * tk_model_load_params_t.lora_adapter is the reference's way in; these are the pieces:
+ *   load_gguf_lora: load_gguf with an adapter (NULL / "" = none);
+ *   set_lora: the adapter to merge into every matrix installed FROM NOW ON (set_tensor, fill_synthetic); NULL / "" = none.  Fails with
+ *     TK_ERROR_MODEL_LOAD_FAILED (the reference's code) on an unreadable file or factor shapes that do not fit the model;
+ *   lora_merged: matrices the adapter has changed so far;
+ *   lora_probe: rank, alpha and tensor-pair count of an adapter file ("ggla" v1 — what llama_model_apply_lora_from_file read — or a GGUF
+ *     adapter, general.type = "adapter"); no GPU involved. */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_load_gguf_lora(tk_mi355x_llm_model_t** out, const char* path, const char* lora_path, int device);
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_set_lora(tk_mi355x_llm_model_t* m, const char* adapter_path);
+TK_API int tk_mi355x_llm_model_lora_merged(const tk_mi355x_llm_model_t* m);
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_lora_probe(const char* path, int32_t* rank, float* alpha, int32_t* n_tensors);
 /* parses GGUF metadata only (runs without a GPU); n_vocab_tokens optional */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_gguf_probe(const char* path, tk_mi355x_llm_hparams_t* out, int32_t* n_vocab_tokens);
 /* token ids of `text` under the vocabulary of a GGUF file (CPU only); returns the count (may exceed cap) or -1 */

@@ -42,7 +42,7 @@ typedef struct {
     bool use_mlock;
     bool numa;
     uint32_t seed;
-    const char* lora_adapter; /* must be NULL: LoRA is out of scope */
+    const char* lora_adapter; /* NULL / "" = none; else a "ggla" or GGUF adapter merged into the weights at load (tk_model_loader.c:259-270) */
 } tk_model_load_params_t;
 
 TK_API TK_NODISCARD tk_error_code_t tk_model_loader_create(tk_model_loader_t** out_loader, const tk_model_loader_config_t* config);

@@ -352,6 +352,36 @@ int64_t orc_llm_get_tensor(orc_llm* m, int layer, int which, int* type, void* ou
     return (int64_t)t->data.size();
 }
 
+/* LoRA merge, the reference's llama_model_apply_lora_from_file (src/ai_models/tk_model_loader.c:259-270; llama.cpp un-vendored, ggml's add on a
+ * quantised destination restated): W' = W + scale (B A), A [r][k_in], B [n_out][r]; per weight delta = fma chain over j = 0 .. r-1 from 0.0f of
+ * B[n][j] A[j][k], w' = w + scale * delta (multiply, then add), every 256-weight block quantised back to the tensor's own type.  0 on success. */
+int orc_llm_apply_lora(orc_llm* m, int layer, int which, const float* A, const float* B, int r, float scale) {
+    orc_tensor* t = layer < 0 ? (which == ORC_T_TOKEN_EMBD ? &m->token_embd : which == ORC_T_OUT_NORM ? &m->out_norm : &m->output)
+                              : &m->layers[(size_t)layer * ORC_L_COUNT + which];
+    if (t->type != TK_TYPE_Q4_K && t->type != TK_TYPE_Q6_K && t->type != TK_TYPE_F16) return -1;
+    if (t->cols % 256 || r < 1) return -1;
+    const int64_t K = t->cols, nblk = K / 256;
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < t->rows; ++n)
+        for (int64_t bk = 0; bk < nblk; ++bk) {
+            float x[256];
+            const int64_t b = n * nblk + bk;
+            for (int e = 0; e < 256; ++e) {
+                float w;
+                if (t->type == TK_TYPE_Q4_K) w = tk_q4k_dequant((const tk_block_q4_K*)t->data.data() + b, e);
+                else if (t->type == TK_TYPE_Q6_K) w = tk_q6k_dequant((const tk_block_q6_K*)t->data.data() + b, e);
+                else w = tk_f16_to_f32(((const uint16_t*)t->data.data())[b * 256 + e]);
+                float delta = 0.0f;
+                for (int j = 0; j < r; ++j) delta = tk_fmaf(B[n * r + j], A[(int64_t)j * K + bk * 256 + e], delta);
+                x[e] = w + scale * delta;
+            }
+            if (t->type == TK_TYPE_Q4_K) tk_quantize_q4_K(x, (tk_block_q4_K*)t->data.data() + b);
+            else if (t->type == TK_TYPE_Q6_K) tk_quantize_q6_K(x, (tk_block_q6_K*)t->data.data() + b);
+            else for (int e = 0; e < 256; ++e) ((uint16_t*)t->data.data())[b * 256 + e] = tk_f32_to_f16(x[e]);
+        }
+    return 0;
+}
+
 /* structure-check mode: skip activation quantisation, plain fp32 dot on de-quantised weights
  * (used ONLY by tests/golden/make_llm_golden.py to compare with HF at ~1e-5) */
 static int g_fp32_activations = 0;

@@ -94,3 +94,41 @@ def write_llama_gguf(path, orc, cfg, with_vocab=True, drop=()):
         for w, (r, c) in enumerate(shapes):
             add(f"blk.{l}.{names[w]}.weight", l, w, r, c)
     write_gguf(path, kv, [t for t in tensors if t[0] not in drop])
+
+
+LORA_NAMES = {1: "attn_q", 2: "attn_k", 3: "attn_v", 4: "attn_output", 6: "ffn_gate", 7: "ffn_up", 8: "ffn_down"}
+
+
+def lora_base_name(layer, which):
+    return "output.weight" if layer < 0 else "blk.%d.%s.weight" % (layer, LORA_NAMES[which])
+
+
+def write_lora_ggla(path, r, alpha, factors, f16=False):
+    """the legacy adapter container llama_model_apply_lora_from_file read (convert-lora-to-ggml.py's output).
+    factors: {(layer, which): (A [r][k_in], B [n_out][r])}; loraA is stored transposed ([k_in][r], ne = {r, k_in}), loraB as is (ne = {r, n_out})"""
+    out = bytearray(struct.pack("<IIii", 0x67676C61, 1, r, int(alpha)))
+    dt = np.float16 if f16 else np.float32
+    for (layer, which), (A, B) in factors.items():
+        for kind, arr in (("loraA", np.ascontiguousarray(np.asarray(A, np.float32).T)), ("loraB", np.asarray(B, np.float32))):
+            name = (lora_base_name(layer, which) + "." + kind).encode()
+            out += struct.pack("<iii", 2, len(name), 1 if f16 else 0)
+            out += struct.pack("<ii", arr.shape[1], arr.shape[0])           # ne[0] is the contiguous dimension
+            out += name
+            out += b"\0" * ((-len(out)) % 32)
+            out += arr.astype(dt).tobytes()
+    open(path, "wb").write(bytes(out))
+
+
+def write_lora_gguf(path, alpha, factors, f16=False):
+    """a GGUF adapter (convert_lora_to_gguf.py's output): <base>.lora_a ne = {k_in, r}, <base>.lora_b ne = {r, n_out}"""
+    kv = [("general.architecture", GGUF_STRING, "llama"), ("general.type", GGUF_STRING, "adapter"), ("adapter.type", GGUF_STRING, "lora"),
+          ("adapter.lora.alpha", GGUF_F32, float(alpha))]
+    dt = np.float16 if f16 else np.float32
+    tensors = []
+    for (layer, which), (A, B) in factors.items():
+        A = np.asarray(A, np.float32)
+        B = np.asarray(B, np.float32)
+        base = lora_base_name(layer, which)
+        tensors.append((base + ".lora_a", [A.shape[1], A.shape[0]], 1 if f16 else 0, A.astype(dt).tobytes()))
+        tensors.append((base + ".lora_b", [B.shape[1], B.shape[0]], 1 if f16 else 0, B.astype(dt).tobytes()))
+    write_gguf(path, kv, tensors)

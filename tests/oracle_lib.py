@@ -109,6 +109,15 @@ class OracleLlm:
         rc = lib().orc_llm_set_tensor(self.h, layer, which, ttype, ptr(data), data.size)
         assert rc == 0, "tensor size mismatch"
 
+    def apply_lora(self, layer, which, A, B, scale):
+        """W += scale (B A): A [r][k_in], B [n_out][r]; the tensor is quantised back to its own type"""
+        A = np.ascontiguousarray(A, np.float32)
+        B = np.ascontiguousarray(B, np.float32)
+        L = lib()
+        L.orc_llm_apply_lora.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+        rc = L.orc_llm_apply_lora(self.h, layer, which, ptr(A), ptr(B), A.shape[0], scale)
+        assert rc == 0, "tensor cannot take an adapter"
+
     def dequant(self, layer, which, rows, cols):
         t, buf = self.get_tensor(layer, which)
         out = np.empty((rows, cols), dtype=np.float32)

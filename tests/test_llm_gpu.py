@@ -938,3 +938,117 @@ def test_stochastic_sampling_under_the_tool_grammar_stays_inside_it(gpu, seed):
     orc.close()
     loader.unload(h)
     loader.close()
+
+
+def _lora_factors(cfg, rng, r, which=((0, 1), (1, 3), (1, 8), (0, 6), (0, 4), (-1, O.T_OUTPUT))):
+    D, QD, KVD, FF, V = cfg.d_model, cfg.n_head * cfg.head_dim, cfg.n_kv_head * cfg.head_dim, cfg.d_ff, cfg.vocab
+    shape = {1: (QD, D), 2: (KVD, D), 3: (KVD, D), 4: (D, QD), 6: (FF, D), 7: (FF, D), 8: (D, FF)}
+    out = {}
+    for layer, w in which:
+        n, k = (V, D) if layer < 0 else shape[w]
+        out[(layer, w)] = (rng.normal(0, 0.05, (r, k)).astype(np.float32), rng.normal(0, 0.05, (n, r)).astype(np.float32))
+    return out
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_lora_adapter_merged_at_load_bit_exact(gpu, tmp_path, f16):
+    """the reference applies a LoRA adapter once, in place, right after the load (tk_model_loader.c:259-270): W' = W + (alpha / r) B A, quantised back
+    to W's own type.  The GPU merge (k_lora_merge, while a matrix is installed) gives the oracle's merged model bit for bit — Q4_K, Q6_K and f16
+    matrices, both adapter containers, f32 and f16 factors"""
+    import gguf_util
+    cfg = O.tiny_config(max_ctx=32, max_seq=2)
+    rng = np.random.default_rng(31)
+    fs = _lora_factors(cfg, rng, 8)
+    # f16 factors: both sides get the values the file holds
+    fs16 = {k: (a.astype(np.float16).astype(np.float32), b.astype(np.float16).astype(np.float32)) for k, (a, b) in fs.items()}
+    files = []
+    for name, writer, fac in (("a.ggla", lambda p: gguf_util.write_lora_ggla(p, 8, 16, fs), fs), ("b.gguf", lambda p: gguf_util.write_lora_gguf(p, 16.0, fs), fs),
+                              ("c.gguf", lambda p: gguf_util.write_lora_gguf(p, 16.0, fs, f16=True), fs16),
+                              ("d.ggla", lambda p: gguf_util.write_lora_ggla(p, 8, 16, fs, f16=True), fs16)):
+        path = str(tmp_path / name)
+        writer(path)
+        files.append((path, fac))
+    base = O.OracleLlm(cfg, seed=4, f16=f16)
+    seq, pos, tok = [0, 0, 0, 1], [0, 1, 2, 0], [5, 9, 300, 7]
+    base_logits, _ = base.forward(seq, pos, tok)
+    hp = gpu.LlmHParams(cfg.n_layer, cfg.d_model, cfg.n_head, cfg.n_kv_head, cfg.head_dim, cfg.d_ff, cfg.vocab, cfg.rms_eps, cfg.rope_theta,
+                        cfg.ks_qkv, cfg.ks_o, cfg.ks_gateup, cfg.ks_down, cfg.ks_out)
+    seen = []
+    for path, fac in files:
+        orc = O.OracleLlm(cfg, seed=4, f16=f16)
+        for (layer, w), (A, B) in fac.items():
+            orc.apply_lora(layer, w, A, B, 16.0 / 8)
+        want, _ = orc.forward(seq, pos, tok)
+        model = gpu.LlmModel(hp).set_lora(path)
+        copy_oracle_weights(base, model, cfg.n_layer)                   # the BASE weights go in: the library merges while it installs them
+        assert model.lora_merged == len(fac)
+        sess = gpu.LlmSession(model, 2, 32)
+        got, _ = sess.forward(seq, pos, tok)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (path, np.abs(got - want).max())
+        assert np.abs(got - base_logits).max() > 1e-3                   # and the adapter is what moved the logits
+        seen.append(got)
+        sess.close(); model.close()
+    assert np.array_equal(seen[0], seen[1]) and np.array_equal(seen[2], seen[3])   # the container does not matter, the factor values do
+    # an adapter that does not fit: refused with the reference's code, nothing half-applied
+    bad = str(tmp_path / "bad.gguf")
+    gguf_util.write_lora_gguf(bad, 16.0, {(0, 1): (fs[(0, 1)][0][:, :128], fs[(0, 1)][1])})
+    model = gpu.LlmModel(hp)
+    with pytest.raises(gpu.TkError) as ei:
+        model.set_lora(bad)
+    assert ei.value.code == 4000
+    far = str(tmp_path / "far.gguf")
+    gguf_util.write_lora_gguf(far, 16.0, {(7, 1): fs[(0, 1)]})          # layer 7 of a 2-layer model
+    with pytest.raises(gpu.TkError):
+        model.set_lora(far)
+    model.close()
+
+
+def test_lora_adapter_through_the_reference_loader(gpu, tmp_path):
+    """tk_model_load_params_t.lora_adapter, the reference's way in: a GGUF checkpoint + a ggla adapter through tk_model_loader_load_model and
+    tk_llm_runner_*; the registry keeps the adapted and the plain model apart"""
+    import gguf_util
+    cfg = O.tiny_config()
+    orc = O.OracleLlm(cfg, seed=4)
+    path = str(tmp_path / "tiny.gguf")
+    gguf_util.write_llama_gguf(path, orc, cfg)
+    rng = np.random.default_rng(32)
+    fs = _lora_factors(cfg, rng, 4)
+    adapter = str(tmp_path / "tiny.ggla")
+    gguf_util.write_lora_ggla(adapter, 4, 32, fs)
+    loader = gpu.ModelLoader()
+    h_plain = loader.load(path)
+    h_lora = loader.load(path, lora_adapter=adapter)
+    h_again = loader.load(path, lora_adapter=adapter)
+    assert h_plain.value != h_lora.value and h_again.value == h_lora.value
+    assert gpu.lib().tk_mi355x_llm_model_lora_merged(h_lora) == len(fs) and gpu.lib().tk_mi355x_llm_model_lora_merged(h_plain) == 0
+    hp = gpu.LlmHParams()
+    gpu.lib().tk_mi355x_llm_model_get_hparams(h_lora, __import__("ctypes").byref(hp))
+    ids = [1, 263, 273]                                                  # " hello world" (test_gguf_cpu.py)
+    out = {}
+    for name, h, adapted in (("plain", h_plain, False), ("lora", h_lora, True)):
+        o = O.OracleLlm(oracle_cfg_from(hp, 64, 1), seed=4)
+        if adapted:
+            for (layer, w), (A, B) in fs.items():
+                o.apply_lora(layer, w, A, B, 32.0 / 4)
+        runner = gpu.LlmRunner(h, context_size=64)
+        runner.prepare("hello world")
+        _, am = o.forward([0, 0, 0], [0, 1, 2], ids, want_logits=False)
+        cur, got = int(am[-1]), []
+        for i in range(8):
+            piece = runner.next_token()
+            got.append(cur)
+            if cur == 2:
+                assert piece is None
+                break
+            assert piece == gguf_util.expected_piece(cfg.vocab, cur), (name, i, cur, piece)
+            _, am = o.forward([0], [3 + i], [cur], want_logits=False)
+            cur = int(am[0])
+        out[name] = got
+        runner.close()
+    assert out["plain"] != out["lora"]                                   # alpha / r = 8: the adapter changes what is said
+    with pytest.raises(gpu.TkError) as ei:
+        loader.load(path, lora_adapter=str(tmp_path / "absent.ggla"))
+    assert ei.value.code == 4000                                         # TK_ERROR_MODEL_LOAD_FAILED, as the reference returns
+    for h in (h_again, h_lora, h_plain):
+        loader.unload(h)
+    loader.close()

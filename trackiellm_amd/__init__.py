@@ -8,7 +8,7 @@ calling a compute entry without a gfx950 device returns a TK_ERROR_GPU_* code, a
 .so raises immediately.
 """
 from ._lib import lib, TkError, check, LIB_PATH  # noqa: F401
-from .llm import LlmHParams, LlmModel, LlmSession, LlmPipe, PipeHandle, ModelLoader, LlmRunner, MISTRAL_7B, TINY, attention_plan  # noqa: F401
+from .llm import LlmHParams, LlmModel, LlmSession, LlmPipe, PipeHandle, ModelLoader, LlmRunner, MISTRAL_7B, TINY, attention_plan, lora_probe  # noqa: F401
 from .vision import ObjectDetector, VisionPipeline, classify_attributes, preprocess, COCO80  # noqa: F401,E402
 from .vision import DepthEstimator, depth_onnx_probe, fuse_data, fusion_reset, fusion_raw_distance  # noqa: F401,E402
 from .audio import Asr, Vad, WhisperHP, WHISPER_TINY_EN, AudioPipeline  # noqa: F401,E402

@@ -26,6 +26,7 @@
 #include "../llm/tk_grammar.h"
 #include "../llm/tk_llm_batcher.h"
 #include "../llm/tk_llm_engine.h"
+#include "../llm/tk_lora.h"
 #include "../llm/tk_llm_pipe.h"
 #include "../llm/tk_tokenizer.h"
 #include "../common/tk_ggml_blocks.h"
@@ -37,6 +38,7 @@ struct tk_mi355x_llm_model_s {
     TkTokenizer tok;
     int context_length = 4096;
     std::string path;
+    std::unique_ptr<TkLoraAdapter> lora; /* the adapter merged into this model's matrices at load (tk_lora.h); part of the registry key */
     int refcount = 1;
     /* continuous batching behind tk_llm_runner_*: the runners created on this model share decode sessions (declared after `model`:
      * destroyed before it) */
@@ -110,6 +112,35 @@ tk_error_code_t tk_mi355x_llm_model_fill_synthetic(tk_mi355x_llm_model_t* m, uin
 tk_error_code_t tk_mi355x_llm_model_fill_synthetic_f16(tk_mi355x_llm_model_t* m, uint64_t seed) {
     if (!m) return TK_ERROR_INVALID_ARGUMENT;
     if (!m->model.fill_synthetic(seed, true)) return fail(TK_ERROR_GPU_ROCM_ERROR, m->model.error);
+    return TK_SUCCESS;
+}
+
+tk_error_code_t tk_mi355x_llm_model_set_lora(tk_mi355x_llm_model_t* m, const char* adapter_path) {
+    if (!m) return TK_ERROR_INVALID_ARGUMENT;
+    if (!adapter_path || !*adapter_path) { m->model.lora = nullptr; m->lora.reset(); return TK_SUCCESS; }
+    std::unique_ptr<TkLoraAdapter> ad(new TkLoraAdapter());
+    if (!ad->load(adapter_path)) return fail(TK_ERROR_MODEL_LOAD_FAILED, "LoRA adapter: " + ad->error);
+    const TkLlmHParams& hp = m->model.hp;
+    for (const auto& t : ad->tensors) {
+        int64_t rows = 0, cols = 0;
+        if (t.layer >= hp.n_layer) return fail(TK_ERROR_MODEL_LOAD_FAILED, "LoRA adapter names a layer this model does not have");
+        m->model.shape(t.layer, t.which, &rows, &cols);
+        if (rows != t.n_out || cols != t.k_in) return fail(TK_ERROR_MODEL_LOAD_FAILED, "LoRA adapter does not fit this model (factor shapes against the base matrix)");
+    }
+    m->lora = std::move(ad);
+    m->model.lora = m->lora.get();
+    return TK_SUCCESS;
+}
+
+int tk_mi355x_llm_model_lora_merged(const tk_mi355x_llm_model_t* m) { return m ? m->model.lora_merged : 0; }
+
+tk_error_code_t tk_mi355x_lora_probe(const char* path, int32_t* rank, float* alpha, int32_t* n_tensors) {
+    if (!path) return TK_ERROR_INVALID_ARGUMENT;
+    TkLoraAdapter ad;
+    if (!ad.load(path)) return fail(TK_ERROR_FILE_CORRUPT, "LoRA adapter: " + ad.error);
+    if (rank) *rank = ad.r;
+    if (alpha) *alpha = ad.alpha;
+    if (n_tensors) *n_tensors = (int32_t)ad.tensors.size();
     return TK_SUCCESS;
 }
 
@@ -197,6 +228,10 @@ int tk_mi355x_gguf_tokenize(const char* path, const char* text, int add_bos, int
 }
 
 tk_error_code_t tk_mi355x_llm_model_load_gguf(tk_mi355x_llm_model_t** out, const char* path, int device) {
+    return tk_mi355x_llm_model_load_gguf_lora(out, path, nullptr, device);
+}
+
+tk_error_code_t tk_mi355x_llm_model_load_gguf_lora(tk_mi355x_llm_model_t** out, const char* path, const char* lora_path, int device) {
     if (!out || !path) return TK_ERROR_INVALID_ARGUMENT;
     tk_mi355x_llm_hparams_t h{};
     tk_error_code_t rc = tk_mi355x_gguf_probe(path, &h, nullptr);
@@ -206,6 +241,10 @@ tk_error_code_t tk_mi355x_llm_model_load_gguf(tk_mi355x_llm_model_t** out, const
     tk_mi355x_llm_model_t* m = nullptr;
     rc = tk_mi355x_llm_model_create(&m, &h, device);
     if (rc != TK_SUCCESS) return rc;
+    if (lora_path && *lora_path) {
+        rc = tk_mi355x_llm_model_set_lora(m, lora_path);
+        if (rc != TK_SUCCESS) { delete m; return rc; } /* private to this call, like the failure path below */
+    }
     auto put = [&](int layer, int which, const std::string& name, const char* alt) -> bool {
         const TkGgufTensor* t = f.find(name);
         if (!t && alt) t = f.find(alt);
@@ -514,11 +553,13 @@ static bool parse_synthetic(const std::string& p, std::string* name, uint64_t* s
 
 tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_model_load_params_t* params, void** out_model_handle) {
     if (!loader || !params || !out_model_handle || !params->model_path || !params->model_path->path_str) return TK_ERROR_INVALID_ARGUMENT;
-    if (params->lora_adapter) return fail(TK_ERROR_NOT_IMPLEMENTED, "LoRA adapters are out of scope of the MI355X path");
     if (params->model_type == TK_MODEL_FORMAT_ONNX) return fail(TK_ERROR_NOT_IMPLEMENTED, "ONNX graphs are not interpreted: the detector/ASR/VAD streams have dedicated entry points");
     std::lock_guard<std::mutex> lk(loader->mu);
     std::lock_guard<std::mutex> gl(g_models_mu); /* also serialises loads: two threads asking for the same file get one copy */
-    const std::string path = params->model_path->path_str;
+    const std::string lora = params->lora_adapter ? params->lora_adapter : "";
+    /* the registry's key: a model with an adapter merged in (tk_model_loader.c:259-270) is another model than the file alone */
+    const std::string path = std::string(params->model_path->path_str) + (lora.empty() ? "" : "\n+lora=" + lora);
+    const std::string file = params->model_path->path_str;
     const int device = tk_mi355x_get_default_device();
     if (!params->force_reload)
         for (auto* m : g_models)
@@ -536,7 +577,7 @@ tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_m
     std::string name;
     uint64_t seed;
     tk_error_code_t rc;
-    if (parse_synthetic(path, &name, &seed)) {
+    if (parse_synthetic(file, &name, &seed)) {
         tk_mi355x_llm_hparams_t h{};
         const bool f16 = name.size() > 4 && name.compare(name.size() - 4, 4, "-f16") == 0; /* the fp16 checkpoint recipe (BASELINE configs[4]) */
         if (f16) name.resize(name.size() - 4);
@@ -544,12 +585,14 @@ tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_m
         else if (name == "tiny") h = tk_mi355x_llm_hparams_t{2, 256, 8, 2, 64, 512, 512, 1e-5f, 10000.0f, 0, 0, 0, 0, 1};
         else return fail(TK_ERROR_FILE_NOT_FOUND, "unknown synthetic model: " + name);
         rc = tk_mi355x_llm_model_create(&m, &h, device);
+        if (rc == TK_SUCCESS && !lora.empty()) rc = tk_mi355x_llm_model_set_lora(m, lora.c_str());
         if (rc == TK_SUCCESS) rc = f16 ? tk_mi355x_llm_model_fill_synthetic_f16(m, seed) : tk_mi355x_llm_model_fill_synthetic(m, seed);
         if (rc != TK_SUCCESS) { if (m) release_model(m); return rc; } /* g_models_mu is held here */
         m->path = path;
     } else {
-        rc = tk_mi355x_llm_model_load_gguf(&m, path.c_str(), device);
+        rc = tk_mi355x_llm_model_load_gguf_lora(&m, file.c_str(), lora.c_str(), device);
         if (rc != TK_SUCCESS) return rc;
+        m->path = path;
     }
     if (!params->force_reload) g_models.push_back(m); /* a force-reloaded copy stays private to its handle */
     loader->held.push_back(m);

@@ -56,6 +56,10 @@ public:
     /* f16: the fp16 checkpoint recipe (every matrix and the embedding IEEE f16, norms f32) instead of Q4_K_M */
     bool fill_synthetic(uint64_t seed, bool f16 = false);
     bool has_f16 = false; /* some matrix is f16: sessions also keep f16-rounded f32 activations */
+    /* a LoRA adapter to merge into every matrix it names WHILE that matrix is installed (set before set_tensor / fill_synthetic; tk_lora.h);
+     * not owned, only read during those calls */
+    const struct TkLoraAdapter* lora = nullptr;
+    int lora_merged = 0; /* matrices the adapter changed */
     /* `host_blocks` is the tensor in GGUF layout (F32 for norms) */
     bool set_tensor(int layer, int which, int type, const void* host_blocks, size_t nbytes);
     bool ready() const;
@@ -64,7 +68,7 @@ public:
 
 private:
     TkDevTensor* slot(int layer, int which);
-    bool install(TkDevTensor* t, int type, int64_t rows, int64_t cols, const void* dev_blocks, hipStream_t s);
+    bool install(TkDevTensor* t, int type, int64_t rows, int64_t cols, void* dev_blocks, hipStream_t s, int layer, int which);
 };
 
 class TkLlmPipe;

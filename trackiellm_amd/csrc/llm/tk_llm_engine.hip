@@ -3,6 +3,7 @@
  * scheduling and hipGraph capture.  See tk_llm_engine.h for the reference call sites replaced.
  */
 #include "tk_llm_engine.h"
+#include "tk_lora.h"
 
 #include <math.h>
 #include <algorithm>
@@ -90,10 +91,26 @@ TkLlmModel::~TkLlmModel() {
 }
 
 /* dev_blocks: tensor in GGUF layout already in device memory */
-bool TkLlmModel::install(TkDevTensor* t, int type, int64_t rows, int64_t cols, const void* dev_blocks, hipStream_t s) {
+bool TkLlmModel::install(TkDevTensor* t, int type, int64_t rows, int64_t cols, void* dev_blocks, hipStream_t s, int layer, int which) {
     if (t->data) { (void)hipFree(t->data); t->data = nullptr; }
     t->type = type; t->rows = rows; t->cols = cols;
     const bool is_matrix = rows > 1 && t != &token_embd;
+    if (const TkLoraTensor* lt = (lora && is_matrix) ? lora->find(layer, which) : nullptr) {
+        /* the reference's llama_model_apply_lora_from_file (tk_model_loader.c:259-270): W += (alpha / r) B A on the blocks as the file holds them */
+        if (lt->n_out != rows || lt->k_in != cols) { error = "LoRA adapter does not fit this model (factor shapes against the base matrix)"; return false; }
+        float *dA = nullptr, *dB = nullptr;
+        HIPQ(hipMalloc((void**)&dA, lt->A.size() * 4));
+        if (hipMalloc((void**)&dB, lt->B.size() * 4) != hipSuccess) { (void)hipFree(dA); error = "out of device memory (LoRA factors)"; return false; }
+        bool ok = hipMemcpyAsync(dA, lt->A.data(), lt->A.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(dB, lt->B.data(), lt->B.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+        const bool taken = ok && tk_launch_lora_merge(type, dev_blocks, rows, cols, dA, dB, lt->r, lora->scale_of(*lt), s);
+        const bool done = hipStreamSynchronize(s) == hipSuccess; /* the factors' host copies and dA / dB live until here */
+        (void)hipFree(dA);
+        (void)hipFree(dB);
+        if (ok && !taken) { error = "LoRA merge needs a Q4_K, Q6_K or F16 matrix with columns % 256 == 0"; return false; }
+        if (!ok || !done) { error = "LoRA merge failed on the device"; return false; }
+        lora_merged++;
+    }
     if (type == TK_TYPE_F32) {
         t->bytes = (size_t)rows * cols * 4;
         HIPQ(hipMalloc((void**)&t->data, t->bytes));
@@ -137,7 +154,7 @@ bool TkLlmModel::set_tensor(int layer, int which, int type, const void* host_blo
     void* tmp = nullptr;
     HIPQ(hipMalloc(&tmp, nbytes));
     HIPQ(hipMemcpy(tmp, host_blocks, nbytes, hipMemcpyHostToDevice));
-    bool ok = install(t, type, rows, cols, tmp, nullptr);
+    bool ok = install(t, type, rows, cols, tmp, nullptr, layer, which);
     (void)hipDeviceSynchronize();
     (void)hipFree(tmp);
     return ok;
@@ -171,7 +188,7 @@ bool TkLlmModel::fill_synthetic(uint64_t seed, bool f16) {
             if (type == TK_TYPE_F32) tk_launch_synth_f32(seed, tid, r * c, (float*)tmp, nullptr);
             else if (type == TK_TYPE_F16) tk_launch_synth_f16(seed, tid, r * c, 0.02f, (uint16_t*)tmp, nullptr);
             else tk_launch_synth_blocks(type, seed, tid, r * c / 256, 0.02f, tmp, nullptr);
-            ok = install(slot(l, w), type, r, c, tmp, nullptr);
+            ok = install(slot(l, w), type, r, c, tmp, nullptr, l, w);
             if (ok && hipStreamSynchronize(nullptr) != hipSuccess) { error = "synthetic weight generation failed"; ok = false; }
         }
     (void)hipFree(tmp);

@@ -63,6 +63,9 @@ struct TkActQ8 { /* quantised-activation buffers for one K */
 /* weights */
 void tk_launch_synth_blocks(int type, uint64_t seed, uint64_t tensor_id, int64_t nblocks, float scale, void* out, hipStream_t s);
 void tk_launch_synth_f32(uint64_t seed, uint64_t tensor_id, int64_t n, float* out, hipStream_t s);
+/* W += scale (B A) on a matrix in GGUF layout (Q4_K / Q6_K blocks or f16), quantised back to its own type; A [r][K], B [rows][r] on the device.
+ * false: arguments the kernel does not take (type, K % 256, more than 2^31 blocks) */
+bool tk_launch_lora_merge(int type, void* blocks, int64_t rows, int64_t K, const float* A, const float* B, int r, float scale, hipStream_t s);
 void tk_launch_repack(int type, const void* blocks, int64_t rows, int64_t K, uint8_t* tiles, hipStream_t s);
 
 /* step kernels */

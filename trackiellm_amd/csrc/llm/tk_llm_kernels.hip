@@ -70,6 +70,40 @@ void tk_launch_synth_f32(uint64_t seed, uint64_t tensor_id, int64_t n, float* ou
 }
 
 /* ------------------------------------------------------------------------------------------
+ * LoRA merge at load (tk_lora.h; the reference applies an adapter once, in place, right after the model is loaded:
+ * src/ai_models/tk_model_loader.c:259-270).  W' = W + scale (B A), per 256-weight block of a row:
+ *     delta[k] = fma chain over j = 0 .. r-1 of B[n][j] * A[j][k] (from 0.0f),   w'[k] = w[k] + scale * delta[k]   (multiply, then add)
+ * and the block is quantised back to its own type by the build's block quantiser (a quantised destination without a base model: what
+ * ggml's add does on one).  One wave per block: every lane finishes four weights, lane 0 quantises.  Load-time only.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(64) void k_lora_merge(int type, void* blocks, int64_t K, const float* A, const float* B, int r, float scale) {
+    __shared__ float x[256];
+    const int64_t nblk = K / 256, b = blockIdx.x, n = b / nblk, k0 = (b % nblk) * 256;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 256; e += 64) {
+        float w;
+        if (type == TK_TYPE_Q4_K) w = tk_q4k_dequant((const tk_block_q4_K*)blocks + b, e);
+        else if (type == TK_TYPE_Q6_K) w = tk_q6k_dequant((const tk_block_q6_K*)blocks + b, e);
+        else w = tk_f16_to_f32(((const uint16_t*)blocks)[b * 256 + e]);
+        float delta = 0.0f;
+        for (int j = 0; j < r; ++j) delta = tk_fmaf(B[n * r + j], A[(int64_t)j * K + k0 + e], delta);
+        x[e] = w + scale * delta;
+    }
+    __syncthreads();
+    if (type == TK_TYPE_F16) {
+        for (int e = lane; e < 256; e += 64) ((uint16_t*)blocks)[b * 256 + e] = tk_f32_to_f16(x[e]);
+    } else if (lane == 0) {
+        if (type == TK_TYPE_Q4_K) { tk_block_q4_K blk; tk_quantize_q4_K(x, &blk); ((tk_block_q4_K*)blocks)[b] = blk; }
+        else { tk_block_q6_K blk; tk_quantize_q6_K(x, &blk); ((tk_block_q6_K*)blocks)[b] = blk; }
+    }
+}
+bool tk_launch_lora_merge(int type, void* blocks, int64_t rows, int64_t K, const float* A, const float* B, int r, float scale, hipStream_t s) {
+    if ((type != TK_TYPE_Q4_K && type != TK_TYPE_Q6_K && type != TK_TYPE_F16) || K % 256 || rows < 1 || r < 1 || rows * (K / 256) > 0x7fffffffLL) return false;
+    hipLaunchKernelGGL(k_lora_merge, dim3((unsigned)(rows * (K / 256))), dim3(64), 0, s, type, blocks, K, A, B, r, scale);
+    return true;
+}
+
+/* ------------------------------------------------------------------------------------------
  * GGUF blocks -> MFMA-fragment tiles (tk_llm_layout.h).  One wave per tile.
  * ------------------------------------------------------------------------------------------ */
 __global__ void k_repack_q4k(const tk_block_q4_K* src, int64_t nblk, uint8_t* tiles) {

@@ -15,6 +15,13 @@ class LlmHParams(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+def lora_probe(path):
+    """(rank, alpha, tensor pairs) of a LoRA adapter file; no GPU involved"""
+    r, a, n = C.c_int32(0), C.c_float(0), C.c_int32(0)
+    check(lib().tk_mi355x_lora_probe(path.encode(), C.byref(r), C.byref(a), C.byref(n)))
+    return r.value, a.value, n.value
+
+
 def attention_plan(nrows, n_head, n_kv_head, head_dim, max_ctx, fused=True, device=0):
     """the attention launch a pass takes on `device`: (kernel, query heads per workgroup, positions per slot / resident chunk, slots);
     kernel 0 = k_attention, 1 = k_attention_narrow (tk_mi355x_attention_plan)"""
@@ -41,10 +48,10 @@ def _p(a):
 
 
 class LlmModel:
-    def __init__(self, hparams=None, device=0, gguf=None):
+    def __init__(self, hparams=None, device=0, gguf=None, lora=None):
         self.h = C.c_void_p()
         if gguf is not None:
-            check(lib().tk_mi355x_llm_model_load_gguf(C.byref(self.h), gguf.encode(), device))
+            check(lib().tk_mi355x_llm_model_load_gguf_lora(C.byref(self.h), gguf.encode(), lora.encode() if lora else None, device))
         else:
             check(lib().tk_mi355x_llm_model_create(C.byref(self.h), C.byref(hparams), device))
 
@@ -67,6 +74,15 @@ class LlmModel:
     def set_tensor(self, layer, which, ttype, data):
         data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
         check(lib().tk_mi355x_llm_model_set_tensor(self.h, layer, which, ttype, _p(data), C.c_size_t(data.size)))
+
+    def set_lora(self, adapter_path):
+        """the adapter merged into every matrix installed from now on (set_tensor, fill_synthetic); None = none"""
+        check(lib().tk_mi355x_llm_model_set_lora(self.h, adapter_path.encode() if adapter_path else None))
+        return self
+
+    @property
+    def lora_merged(self):
+        return lib().tk_mi355x_llm_model_lora_merged(self.h)
 
     def close(self):
         if self.h:
@@ -268,10 +284,11 @@ class ModelLoader:
         cfg = _LoaderConfig(max_models, 1)
         check(lib().tk_model_loader_create(C.byref(self.h), C.byref(cfg)))
 
-    def load(self, path):
+    def load(self, path, lora_adapter=None, force_reload=False):
+        """tk_model_loader_load_model; lora_adapter: a "ggla" or GGUF adapter file merged into the weights at load"""
         lib().tk_path_create.restype = C.POINTER(_Path)
         p = lib().tk_path_create(path.encode())
-        params = _LoadParams(p, 1, False, 99, 1, True, False, False, 0, None)
+        params = _LoadParams(p, 1, bool(force_reload), 99, 1, True, False, False, 0, lora_adapter.encode() if lora_adapter else None)
         handle = C.c_void_p()
         try:
             check(lib().tk_model_loader_load_model(self.h, C.byref(params), C.byref(handle)))
