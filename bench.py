@@ -450,6 +450,12 @@ def reference_abi_batched_cortex(tk, K, N):
         t.join()
     dt = max(done) - t0
     st = [cx.stats() for cx in cxs]
+    # the shared model's scheduler counters (the registry hands this loader the cortices' own model): how wide the LLM passes really were
+    ld = tk.ModelLoader()
+    hm = ld.load("synthetic://mistral-7b?seed=4")
+    passes, rows, widest = tk.ModelLoader.batch_stats(hm)
+    ld.unload(hm)
+    ld.close()
     for cx in cxs:
         cx.stop()
     for cx in cxs:
@@ -457,7 +463,8 @@ def reference_abi_batched_cortex(tk, K, N):
     return {"cortices": K, "host_threads": K, "wall_s": round(dt, 3), "cycles_per_s": round(K / dt, 3), "create_s": round(t_create, 2),
             "llm_responses": int(sum(s.llm_responses for s in st)), "llm_tokens": int(sum(s.llm_tokens for s in st)),
             "speech_segments": int(sum(s.speech_segments for s in st)), "frames_with_objects": int(sum(s.frames_with_objects for s in st)),
-            "last_prompt_bytes_mean": int(np.mean(plen)), "data_dependent": True}
+            "last_prompt_bytes_mean": int(np.mean(plen)), "llm_passes": int(passes), "llm_rows_per_pass": round(rows / max(passes, 1), 1), "widest_pass": int(widest),
+            "data_dependent": True}
 
 
 def reference_abi_runners(tk, K, N):

@@ -102,7 +102,10 @@ TK_API void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_
  *   set_decode_policy: tk_asr_whisper_process_audio then decodes a FINAL result at temperatures 0, inc, 2 inc, ... <= 1 until the decode passes
  *     whisper.cpp's test (mean log-probability of the tokens up to and including end-of-text >= logprob_thold, and — past 32 tokens — entropy of
  *     the histogram of the last 32 tokens >= entropy_thold); attempt a uses seed + a; a partial result decodes once at temperature 0;
- *   last_decode: temperature, mean log-probability and attempt count of the decode the last process_audio returned. */
+ *   last_decode: temperature, mean log-probability and attempt count of the decode the last process_audio returned.
+ * TK_MI355X_ASR_POLICY=1 in the environment arms the policy with the reference's three numbers in tk_asr_whisper_create (for hosts that only
+ * know the reference's entry points).  Not restated from whisper.cpp: its logit filters (blank / non-speech / timestamp rules), the no-speech
+ * probability and the best-of-5 decoders it runs at temperature > 0 — one decoder per temperature here. */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_transcribe_policy(tk_asr_whisper_context_t* ctx, int batch, const int16_t* pcm, int n_samples,
                                                                     int n_steps, float temperature, uint64_t seed, int32_t* tokens_out,
                                                                     float* logprobs_out);

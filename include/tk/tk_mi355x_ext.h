@@ -180,7 +180,10 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_time_attention(tk_mi355x_llm_s
 
 /* which attention launch a pass of `nrows` rows takes on `device` (the choice depends on its CU count): out = {kernel, query heads per
  * workgroup, positions per ring slot / resident chunk, ring slots}; kernel 0 = k_attention (ring of chunks), 1 = k_attention_narrow (<= one
- * workgroup per CU, the context resident in LDS).  fused != 0: a decode pass (every sequence once), else a prefill-shaped pass.  The parity
+ * workgroup per CU, the context resident in LDS), 2 = k_attention_prefill (fused == 0 only: 16 rows of a sequence per workgroup on the fp32
+ * matrix pipe, taken by passes that reach position 128 or beyond; the other three numbers describe the k_attention form that shorter contexts
+ * take and that TK_MI355X_NO_PREFILL_ATT=1 puts back everywhere — the two forms are bit-identical).  fused != 0: a decode
+ * pass (every sequence once), else a pass that holds several positions of a sequence (prompt chunks).  The parity
  * tests assert the instantiation they exercise from this answer (csrc/llm/tk_llm_kernels.hip: tk_attention_plan). */
 TK_API int tk_mi355x_device_cu_count(int device); /* compute units of a HIP device (256 on an MI355X), -1 when there is no such device */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_attention_plan(int device, int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, int fused, int32_t out[4]);

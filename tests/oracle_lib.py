@@ -141,6 +141,7 @@ class OracleLlm:
         return k, v
 
     def forward(self, seq, pos, tok, want_logits=True):
+        assert np.max(pos) < self.cfg.max_ctx and np.min(pos) >= 0 and np.max(seq) < self.cfg.max_seq and np.min(seq) >= 0, "row outside the oracle's cache"
         seq = np.ascontiguousarray(seq, dtype=np.int32)
         pos = np.ascontiguousarray(pos, dtype=np.int32)
         tok = np.ascontiguousarray(tok, dtype=np.int32)

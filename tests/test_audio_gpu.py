@@ -442,3 +442,24 @@ def test_asr_decode_policy_fallback_on_the_reference_surface(gpu):
     asr.set_decode_policy(False)
     text, _, _, _ = asr.process_audio(pcm, True)
     assert text == text_of(greedy[0])
+
+
+def test_asr_decode_policy_from_the_environment(gpu, monkeypatch):
+    """TK_MI355X_ASR_POLICY=1: tk_asr_whisper_create arms the policy with the reference's numbers (0.2 / 2.4 / -1.0, tk_asr_whisper.c:126-138)"""
+    rng = np.random.default_rng(23)
+    pcm = np.clip(rng.normal(0, 3000, 16000), -32768, 32767).astype(np.int16)
+    plain = gpu.Asr()
+    plain.set_decode_steps(4)
+    plain.process_audio(pcm, True)
+    assert plain.last_decode()[2] == 0
+    monkeypatch.setenv("TK_MI355X_ASR_POLICY", "1")
+    armed = gpu.Asr()
+    armed.set_decode_steps(4)
+    armed.process_audio(pcm, True)
+    temp, avg, attempts = armed.last_decode()
+    assert attempts >= 1 and avg < 0.0
+    # synthetic weights give near-uniform logits: mean log-probability far below -1, so the whole ladder runs and ends at temperature 1
+    assert attempts == 6 and abs(temp - 1.0) < 1e-5
+    armed.process_audio(pcm, False)                                   # partial: one decode
+    assert armed.last_decode()[2] == 1
+    plain.close(); armed.close()

@@ -131,11 +131,11 @@ def test_decode_attention_past_2048_cached_positions(mistral_long, nrows, ctx):
 
 
 def test_prefill_chunk_starting_past_2048_positions(mistral_long):
-    """8 sequences x 32 new positions in ONE pass over 2048 cached positions each (k_qkv_rope_append + k_attention<4, not fused, 128, 32, 2>):
-    T runs from 2049 to 2080 inside one launch"""
+    """8 sequences x 32 new positions in ONE pass over 2048 cached positions each (k_qkv_rope_append + k_attention_prefill: two 16-row tiles
+    per sequence, 33 key blocks of 64 positions): T runs from 2049 to 2080 inside one launch"""
     gpu, model, sess, orc, hp = mistral_long
     nseq, npos, ctx0 = 8, 32, 2048
-    assert gpu.attention_plan(nseq * npos, hp.n_head, hp.n_kv_head, hp.head_dim, LONG_CTX, False)[0] == 0
+    assert gpu.attention_plan(nseq * npos, hp.n_head, hp.n_kv_head, hp.head_dim, LONG_CTX, False)[0] == 2   # k_attention_prefill
     rng = np.random.default_rng(4242)
     load_kv(sess, orc, hp, rng, range(nseq), ctx0)
     seq = np.repeat(np.arange(nseq, dtype=np.int32), npos)
@@ -150,7 +150,8 @@ def test_prefill_chunk_starting_past_2048_positions(mistral_long):
 @pytest.mark.parametrize("ctx0", [0, 31, 97, 159])
 def test_prefill_shaped_attention_at_mistral_geometry_bit_exact(mistral1, ctx0):
     """8 sequences x 32 new positions = 256 rows in ONE pass over `ctx0` cached positions each: rows of one sequence see each other causally,
-    so the pass takes k_qkv_rope_append + k_attention<4, not fused, 128, 32>; T runs from ctx0 + 1 to ctx0 + 32 inside one launch."""
+    so the pass takes k_qkv_rope_append + k_attention_prefill (16 rows of a sequence per workgroup); T runs from ctx0 + 1 to ctx0 + 32 inside
+    one launch."""
     gpu, model, sess, orc, hp = mistral1
     nseq, npos = 8, 32
     rng = np.random.default_rng(77 + ctx0)
@@ -207,3 +208,64 @@ def test_full_7b_prompt64_decode128_ids_match_oracle(gpu):
     orc.close()
     assert got == want
     assert len(set(got)) > 8
+
+
+def _ragged_pass(hp, rng, runs, ctx0s):
+    seq = np.concatenate([np.full(n, s, np.int32) for s, n in enumerate(runs)])
+    pos = np.concatenate([np.arange(c, c + n, dtype=np.int32) for c, n in zip(ctx0s, runs)])
+    tok = rng.integers(3, hp.vocab, seq.size).astype(np.int32)
+    return seq, pos, tok
+
+
+@pytest.mark.parametrize("runs,ctx0s", [
+    ([1, 5, 16, 17, 33, 63, 100, 21], [0, 150, 7, 64, 33, 0, 91, 128]),        # tiles of 1 .. 16 rows, runs that end mid-tile, 256 rows
+    ([180, 76], [0, 60]),                                                       # one long prompt chunk: 12 tiles of one sequence
+    ([3, 2, 40], [5, 0, 129]),                                                  # a narrow pass (45 rows)
+    ([2] * 32, [(37 * i) % 150 for i in range(32)]),                            # 32 tiles on a grid of 12 tile slots: workgroups walk tiles
+])
+def test_multi_position_passes_ragged_runs_bit_exact(mistral1, runs, ctx0s, monkeypatch):
+    """k_attention_prefill on passes as the batcher builds them — prompt chunks of several sequences, run lengths that are no multiple of
+    16, every sequence over its own cached context — against the oracle bit for bit, and the k_attention form
+    (TK_MI355X_NO_PREFILL_ATT=1, a fresh session: passes are captured per session) gives the same bits"""
+    gpu, model, sess, orc, hp = mistral1
+    rng = np.random.default_rng(9000 + sum(runs))
+    for s, c in enumerate(ctx0s):
+        if c:
+            load_kv(sess, orc, hp, rng, [s], c)
+    seq, pos, tok = _ragged_pass(hp, rng, runs, ctx0s)
+    assert gpu.attention_plan(seq.size, hp.n_head, hp.n_kv_head, hp.head_dim, MAX_CTX, False)[0] == 2
+    want, wam = orc.forward(seq, pos, tok)
+    got, gam = sess.forward(seq, pos, tok)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.array_equal(gam, wam)
+    # the per-row form on the same pass
+    monkeypatch.setenv("TK_MI355X_NO_PREFILL_ATT", "1")
+    assert gpu.attention_plan(seq.size, hp.n_head, hp.n_kv_head, hp.head_dim, MAX_CTX, False)[0] == 0
+    old = gpu.LlmSession(model, len(runs), MAX_CTX)
+    for s, c in enumerate(ctx0s):
+        if c:
+            k, v = sess.kv_read(0, s, 0, c)
+            old.kv_write(0, s, 0, k, v)
+    ogot, oam = old.forward(seq, pos, tok)
+    old.close()
+    assert np.array_equal(ogot.view(np.uint32), want.view(np.uint32)) and np.array_equal(oam, wam)
+
+
+def test_prompt_chunks_of_a_long_prompt_bit_exact(mistral_long):
+    """a 700-token prompt fed as the runner feeds it — chunks of 256, 256 and 188 rows of ONE sequence, each chunk attending to everything before
+    it (k_attention_prefill: 16 tiles per chunk, up to 11 key blocks) — logits of the last chunk and the cache rows equal to the oracle's"""
+    gpu, model, sess, orc, hp = mistral_long
+    rng = np.random.default_rng(31337)
+    n = 700
+    tok = rng.integers(3, hp.vocab, n).astype(np.int32)
+    for lo in range(0, n, 256):
+        hi = min(n, lo + 256)
+        seq = np.full(hi - lo, 3, np.int32)
+        pos = np.arange(lo, hi, dtype=np.int32)
+        want, wam = orc.forward(seq, pos, tok[lo:hi])
+        got, gam = sess.forward(seq, pos, tok[lo:hi])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (lo, np.abs(got - want).max())
+        assert np.array_equal(gam, wam)
+    gk, gv = sess.kv_read(0, 3, 0, n)
+    wk, wv = orc.kv_read(0, 3, 0, n)
+    assert np.array_equal(gk, wk) and np.array_equal(gv, wv)

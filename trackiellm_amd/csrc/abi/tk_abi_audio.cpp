@@ -132,6 +132,10 @@ tk_error_code_t tk_asr_whisper_create(tk_asr_whisper_context_t** out_context, co
     tk_error_code_t rc = asr_new(out_context, tk_whisper_tiny_en(), path, seed_of(path, 6), tk_mi355x_get_default_device(), 1);
     if (rc == TK_SUCCESS && config->language) (*out_context)->language = config->language;
     if (rc == TK_SUCCESS) (*out_context)->translate = config->translate_to_en;
+    /* TK_MI355X_ASR_POLICY=1: a reference host that cannot call tk_mi355x_asr_set_decode_policy gets whisper.cpp's temperature fallback armed
+     * with the numbers process_with_whisper sets (tk_asr_whisper.c:126-138) from create on */
+    const char* pol = getenv("TK_MI355X_ASR_POLICY");
+    if (rc == TK_SUCCESS && pol && pol[0] == '1') (*out_context)->policy_on = true;
     return rc;
 }
 

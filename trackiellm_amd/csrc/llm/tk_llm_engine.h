@@ -131,9 +131,17 @@ private:
     std::string launch_error; /* set by enqueue_* when a launcher refuses its arguments (no HIP error is raised for that) */
     int hist_cap = 0;
     hipGraphExec_t graph_exec[TK_MAX_ROWS + 1] = {};    /* decode pass (head + sampling, fused attention), by row count */
-    hipGraphExec_t graph_prefill[TK_MAX_ROWS + 1] = {}; /* prompt pass (no head, rope/append as its own kernel), by row count */
-    hipGraphExec_t graph_head_nf[TK_MAX_ROWS + 1] = {}; /* sampling pass that holds several positions of one sequence (a prompt's last chunk) */
+    /* [tiled_pass][row count]: prompt pass (no head, rope/append as its own kernel); sampling pass that holds several positions of one sequence
+     * (a prompt's last chunk) */
+    hipGraphExec_t graph_prefill[2][TK_MAX_ROWS + 1] = {};
+    hipGraphExec_t graph_head_nf[2][TK_MAX_ROWS + 1] = {};
+    /* set by whoever describes a pass, read by enqueue_range: a multi-position pass that reaches position TK_TILED_ATT_MIN_POS or beyond takes
+     * k_attention_prefill (16 rows of a sequence per workgroup), shorter contexts k_attention's per-row form (3 us per launch quicker below ~128
+     * positions, profiles/r05_prefill_attention.txt); the two are bit-identical, so the choice never shows in a result */
+    bool tiled_pass = false;
+    void choose_attention(const int32_t* pos, int nrows);
     int32_t* d_tab = nullptr;                           /* prefill schedule: [3][total rows] = seq, pos, tok */
+    int32_t* d_tiles = nullptr;                         /* [1 + TK_MAX_ROWS] 16-row tiles of a multi-position pass (k_att_tiles) */
     size_t tab_cap = 0;
     bool capture_pass(hipGraphExec_t* slot, int nrows, bool lm_head, bool fused_attn);
 };

@@ -273,6 +273,8 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     HIPQ(hipMemset(d_nsteps, 0, TK_MAX_ROWS * 4));
     hist_cap = mctx;
     HIPQ(hipMalloc((void**)&d_hist, (size_t)hist_cap * TK_MAX_ROWS * 4));
+    HIPQ(hipMalloc((void**)&d_tiles, (size_t)(1 + TK_MAX_ROWS) * 4));
+    HIPQ(hipMemset(d_tiles, 0, (size_t)(1 + TK_MAX_ROWS) * 4));
     HIPQ(hipMalloc((void**)&d_mask, (size_t)TK_MAX_ROWS * (((size_t)h.vocab + 31) / 32) * 4));
     HIPQ(hipMalloc((void**)&d_mask_row, TK_MAX_ROWS * 4));
     HIPQ(hipMemset(d_mask_row, 0xFF, TK_MAX_ROWS * 4));
@@ -304,9 +306,9 @@ TkLlmSession::~TkLlmSession() {
     if (model) (void)hipSetDevice(model->device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto& g : graph_exec) if (g) (void)hipGraphExecDestroy(g);
-    for (auto& g : graph_prefill) if (g) (void)hipGraphExecDestroy(g);
-    for (auto& g : graph_head_nf) if (g) (void)hipGraphExecDestroy(g);
-    void* ptrs[] = {kcache, vcache, x, x2, qbuf, partial, partial2, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_mask_row, d_samp, d_tab};
+    for (auto& v : graph_prefill) for (auto& g : v) if (g) (void)hipGraphExecDestroy(g);
+    for (auto& v : graph_head_nf) for (auto& g : v) if (g) (void)hipGraphExecDestroy(g);
+    void* ptrs[] = {kcache, vcache, x, x2, qbuf, partial, partial2, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_mask_row, d_samp, d_tab, d_tiles};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     free_act(&act_d); free_act(&act_qd); free_act(&act_ff);
     if (stream) (void)hipStreamDestroy(stream);
@@ -417,6 +419,10 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         tk_launch_gemv(a, s);
         return ks;
     };
+    /* passes that hold several positions of a sequence (prompt chunks): 16 rows of a sequence per attention workgroup on the fp32 matrix pipe
+     * (k_attention_prefill, bit-identical to k_attention); the row -> tile table is built once per pass from the sequence ids on the device */
+    const bool tiled_attn = !fused_attn && l1 > l0 && tiled_pass && tk_attention_prefill_applies(h.n_head, h.n_kv_head, h.head_dim);
+    if (tiled_attn) tk_launch_att_tiles(d_seq, nrows, d_tiles, s);
     int ks_res = 1; /* slabs of the pending residual update (the previous layer's down projection) */
     for (int l = l0; l < l1; ++l) {
         const TkLlmLayer& L = model->layers[l];
@@ -429,8 +435,9 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
             if (!fused_attn)
                 tk_launch_qkv_rope_append(partial2, ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
                                           qbuf, kcache, vcache, l, max_seq, max_ctx, s);
-            tk_launch_attention(qbuf, partial2, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
-                                h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
+            if (tiled_attn) tk_launch_attention_prefill(qbuf, kcache, vcache, d_seq, d_pos, d_tiles, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
+            else tk_launch_attention(qbuf, partial2, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
+                                     h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
             const int ks_o = enqueue_matmul(ot, 1, QD, h.ks_o, D, act_qd, partial, nrows);
             const int ks_gu = fused_gemv(gu, 2, D, h.ks_gateup, 2 * FF, partial2, 1, x2, x, partial, ks_o, D, (const float*)L.ffn_norm.data);
             ks_res = fused_gemv(dn, 1, FF, h.ks_down, D, partial, 2, nullptr, nullptr, partial2, ks_gu, 2 * FF, nullptr);
@@ -441,8 +448,9 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         if (!fused_attn)
             tk_launch_qkv_rope_append(partial, ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
                                       qbuf, kcache, vcache, l, max_seq, max_ctx, s);
-        tk_launch_attention(qbuf, partial, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
-                            h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
+        if (tiled_attn) tk_launch_attention_prefill(qbuf, kcache, vcache, d_seq, d_pos, d_tiles, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
+        else tk_launch_attention(qbuf, partial, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
+                                 h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
         const int ks_o = enqueue_matmul(ot, 1, QD, h.ks_o, D, act_qd, partial, nrows);
         tk_launch_rmsnorm_q8(x, partial, ks_o, D, (const float*)L.ffn_norm.data, h.rms_eps, D, nrows, act_d, s);
         if (tk_gemv_fuses_swiglu(nrows, h.ks_gateup, L.gate.type, L.up.type)) { /* wide pass: SwiGLU in the launch's epilogue, `partial` holds h [rows][FF] */
@@ -482,6 +490,15 @@ static bool graphs_enabled() {
  * APIs while this stream records */
 static std::mutex g_capture_mu;
 
+#ifndef TK_TILED_ATT_MIN_POS
+#define TK_TILED_ATT_MIN_POS 128
+#endif
+void TkLlmSession::choose_attention(const int32_t* pos, int nrows) {
+    int top = 0;
+    for (int r = 0; r < nrows; ++r) top = pos[r] > top ? pos[r] : top;
+    tiled_pass = top >= TK_TILED_ATT_MIN_POS;
+}
+
 bool TkLlmSession::capture_pass(hipGraphExec_t* slot, int nrows, bool lm_head, bool fused_attn) {
     if (*slot) return true;
     std::lock_guard<std::mutex> lk(g_capture_mu);
@@ -519,6 +536,7 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
     HIPQ(hipMemcpyAsync(d_pos, pos, nrows * 4, hipMemcpyHostToDevice, stream));
     HIPQ(hipMemcpyAsync(d_tok, tok, nrows * 4, hipMemcpyHostToDevice, stream));
     HIPQ(hipMemsetAsync(d_nsteps, 0, TK_MAX_ROWS * 4, stream));
+    choose_attention(pos, nrows);
     bool distinct = true; /* every sequence at most once in the pass -> rope/append can be fused into attention */
     for (int a = 0; a < nrows && distinct; ++a)
         for (int b = a + 1; b < nrows; ++b)
@@ -555,7 +573,7 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
     /* a pass replays a captured graph (one per (row count, form)): a host that asks for one token at a time — the reference's runner
      * API — pays one graph launch, not ~260 kernel launches, per token; masked rows ride the same graphs (the table above is data) */
     hipGraphExec_t* slot = !graphs_enabled() ? nullptr
-                           : !lm_head ? &graph_prefill[nrows] : distinct ? &graph_exec[nrows] : &graph_head_nf[nrows];
+                           : !lm_head ? &graph_prefill[tiled_pass][nrows] : distinct ? &graph_exec[nrows] : &graph_head_nf[tiled_pass][nrows];
     if (slot) {
         if (!capture_pass(slot, nrows, lm_head, lm_head && distinct)) return false;
         HIPQ(hipGraphLaunch(*slot, stream));
@@ -598,6 +616,7 @@ bool TkLlmSession::forward_stage(int nrows, const int32_t* seq, const int32_t* p
         for (int b = a + 1; b < nrows; ++b)
             if (seq[a] == seq[b]) { distinct = false; break; }
     launch_error.clear();
+    choose_attention(pos, nrows);
     enqueue_range(nrows, l0, l1, tok != nullptr, !head, head, distinct);
     if (!launch_error.empty()) { error = launch_error; (void)hipStreamSynchronize(stream); return false; }
     HIPQ(hipGetLastError());
@@ -642,9 +661,10 @@ bool TkLlmSession::prefill(int nseq, int n_prompt, const int32_t* tokens, int32_
         const bool use_graph = graphs_enabled();
         for (int64_t off = 0; off < total; off += TK_MAX_ROWS) {
             const int n = (int)std::min<int64_t>(TK_MAX_ROWS, total - off);
-            if (use_graph && !capture_pass(&graph_prefill[n], n, false, false)) return false;
+            choose_attention(tab.data() + total + off, n);
+            if (use_graph && !capture_pass(&graph_prefill[tiled_pass][n], n, false, false)) return false;
             hipLaunchKernelGGL(k_stage_rows, dim3((n + 255) / 256), dim3(256), 0, stream, d_tab + off, n, (int)total, d_seq, d_pos, d_tok);
-            if (use_graph) HIPQ(hipGraphLaunch(graph_prefill[n], stream));
+            if (use_graph) HIPQ(hipGraphLaunch(graph_prefill[tiled_pass][n], stream));
             else { launch_error.clear(); enqueue_pass(n, false, false); if (!launch_error.empty()) { error = launch_error; return false; } }
         }
         HIPQ(hipGetLastError());

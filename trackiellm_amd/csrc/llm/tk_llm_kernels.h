@@ -98,6 +98,14 @@ void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t*
 struct TkAttentionPlan { int kernel, gq, chunk, slots; size_t lds_bytes; };
 TkAttentionPlan tk_attention_plan(int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, bool fused);
 
+/* multi-position passes (prompt chunks): 16 rows of a sequence per workgroup on the fp32 matrix pipe, bit-identical to k_attention's non-fused
+ * form.  tiles: 1 + TK_MAX_ROWS ints built by tk_launch_att_tiles from the pass's sequence ids (once per pass); the cache must already hold
+ * the pass's own K / V rows (tk_launch_qkv_rope_append) */
+bool tk_attention_prefill_applies(int n_head, int n_kv_head, int head_dim);
+void tk_launch_att_tiles(const int32_t* seq, int nrows, int32_t* tiles, hipStream_t s);
+void tk_launch_attention_prefill(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq, const int32_t* pos,
+                                 const int32_t* tiles, int nrows, int n_head, int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out,
+                                 hipStream_t s);
 size_t tk_gemv_lds_bytes(int K, int ks, int mtiles);
 /* dynamic LDS of one k_attention workgroup; must stay below 160 KiB (the session checks it against its max_ctx) */
 size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk /* positions per ring slot: 32 or 64 */, int slots = 2 /* ring depth: 2 or 5 */);

@@ -2093,6 +2093,293 @@ __global__ __launch_bounds__(1024) void k_attention_narrow(const float* __restri
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-position passes (prompt chunks: several positions of one sequence in a pass; the reference feeds whole prompts —
+ * src/ai_models/tk_runner_streaming.c:20-40 — and the cortex's context strings run to hundreds of tokens, budget 2 048:
+ * src/cortex/tk_cortex_main.c:1334).  k_attention gives every row a workgroup of its own that streams the sequence's keys and values and
+ * walks them with one fma chain per thread: 256 rows of ONE sequence read the same rows 256 times and spend 256 VALU fmas per (row, head,
+ * position) — 177 us per layer for 256 rows over 450 positions (profiles/r05_prefill_attention.txt).  Here 16 consecutive rows of a
+ * sequence share a workgroup and the arithmetic moves to the fp32 matrix pipe WITHOUT changing a bit of it:
+ *   - v_mfma_f32_16x16x4_f32 is a k-ascending fma chain per output (what tk_gemm_tiled relies on), so a score — one fma chain over
+ *     head_dim from 0.0f, then * scale — is 32 chained MFMAs of a [16 rows] x [16 positions] tile; an output element depends only on its
+ *     own row and column, so which rows share a tile changes nothing;
+ *   - the canonical PV order — four interleaved partial sums over positions (t mod 4 = j), each an ascending fma chain, joined in j order
+ *     — is wave j's job: one MFMA step takes positions (t0 + j, + 4, + 8, + 12) of a 16-position tile, ascending, for all 16 rows;
+ *     probabilities of positions a row does not see (causal mask, padding) enter as 0: fma(0, v, acc) == acc and l + 0 == l exactly;
+ *   - no score storage: pass 1 walks the keys for the row maxima, pass 2 recomputes the (identical) scores block by block, so LDS does
+ *     not grow with the context.
+ * Workgroup = one 16-row tile of one sequence (table built on the device by k_att_tiles from the pass's sequence ids) x one 256-wide
+ * block of the attention output (256 / head_dim query heads of one KV head: whole Q8 blocks for the o-projection); 4 waves per head:
+ * wave w computes score tile w of every 64-position block and owns PV class j = w.  Keys sit in LDS in B-operand order (lane group g's
+ * dims g, g + 4, ... contiguous), values row-major with padded rows; both are fetched one block ahead into registers.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_att_tiles(const int32_t* __restrict__ seq, int nrows, int32_t* __restrict__ tiles) {
+    __shared__ int sq[TK_MAX_ROWS], run0[TK_MAX_ROWS], cnt[TK_MAX_ROWS];
+    const int t = threadIdx.x;
+    sq[t] = t < nrows ? seq[t] : -1;
+    __syncthreads();
+    run0[t] = (t < nrows && (t == 0 || sq[t] != sq[t - 1])) ? t : 0; /* start of the run a row belongs to: running maximum of the starts */
+    __syncthreads();
+    for (int d = 1; d < TK_MAX_ROWS; d <<= 1) {
+        const int v = t >= d ? (run0[t] > run0[t - d] ? run0[t] : run0[t - d]) : run0[t];
+        __syncthreads();
+        run0[t] = v;
+        __syncthreads();
+    }
+    const bool head = t < nrows && ((t - run0[t]) & 15) == 0; /* a tile starts every 16 rows of a run */
+    int len = 0;
+    if (head) { len = 1; while (len < 16 && t + len < nrows && sq[t + len] == sq[t]) ++len; }
+    cnt[t] = head ? 1 : 0;
+    __syncthreads();
+    for (int d = 1; d < TK_MAX_ROWS; d <<= 1) { /* inclusive prefix sum: the tile's index */
+        const int v = t >= d ? cnt[t] + cnt[t - d] : cnt[t];
+        __syncthreads();
+        cnt[t] = v;
+        __syncthreads();
+    }
+    if (head) tiles[cnt[t]] = t | (len << 16); /* tiles[1 ..] */
+    if (t == TK_MAX_ROWS - 1) tiles[0] = cnt[t];
+}
+
+template <int HD>
+struct TkPrefillLds {
+    static constexpr int HPB = 256 / HD;                 /* query heads per workgroup */
+    static constexpr int KCH = HD / 2 + 16;              /* bytes of one (position, lane group) key run: HD / 4 halves + 16 B of padding */
+    static constexpr int VROW = HD * 2 + 16;             /* bytes of a padded value row */
+    static constexpr int EROW = 20;                      /* floats of a padded probability row (16 rows of the tile per position) */
+    static constexpr size_t k_off = 0;
+    static constexpr size_t v_off = (size_t)64 * 4 * KCH;
+    static constexpr size_t e_off = v_off + (size_t)64 * VROW;
+    static constexpr size_t o_off = e_off + (size_t)HPB * 64 * EROW * 4;
+    static constexpr size_t l_off = o_off + (size_t)16 * 256 * 4;     /* [HPB][16] denominators */
+    static constexpr size_t m_off = l_off + (size_t)HPB * 16 * 4;     /* [HPB][4][16] per-wave maxima */
+    static constexpr size_t bytes = m_off + (size_t)HPB * 4 * 16 * 4;
+};
+
+template <int HD>
+__global__ __launch_bounds__((256 / HD) * 256) void k_attention_prefill(const float* __restrict__ qbuf, const uint16_t* __restrict__ kcache,
+                                                                      const uint16_t* __restrict__ vcache, const int32_t* __restrict__ seq,
+                                                                      const int32_t* __restrict__ pos, const int32_t* __restrict__ tiles, int n_head,
+                                                                      int n_kv_head, int layer, int max_seq, int max_ctx, TkActQ8 out) {
+    using L = TkPrefillLds<HD>;
+    constexpr int HPB = L::HPB, NT = HPB * 256, KCH = L::KCH, VROW = L::VROW, EROW = L::EROW;
+    constexpr int PIECES = 64 * HD / 8, PPT = (PIECES + NT - 1) / NT, PPR = HD / 8; /* 16-byte pieces of a 64-position block, per thread, per row */
+    extern __shared__ __attribute__((aligned(16))) uint8_t pf_lds[];
+    const int n_tiles = tiles[0];
+    /* the grid holds rows / 16 + 8 tile slots (a graph fixes it at capture); a pass of many short runs has more tiles: they are walked */
+    for (int tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
+    const int tw = tiles[1 + tile];
+    const int row0 = tw & 0xffff, nr = tw >> 16;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hsel = wid >> 2, w = wid & 3;
+    const int n16 = lane & 15, G = lane >> 4;
+    const int head = blockIdx.x * HPB + hsel, QD = n_head * HD;
+    const int kvh = (blockIdx.x * HPB) / (n_head / n_kv_head);
+    const int sq = seq[row0];
+    uint8_t* kbuf = pf_lds + L::k_off;
+    uint8_t* vbuf = pf_lds + L::v_off;
+    float* ebuf = (float*)(pf_lds + L::e_off) + (size_t)hsel * 64 * EROW;
+    float* obuf = (float*)(pf_lds + L::o_off);
+    float* lbuf = (float*)(pf_lds + L::l_off) + hsel * 16;
+    float* mred = (float*)(pf_lds + L::m_off) + hsel * 64;
+    const int64_t run0 = (((int64_t)layer * max_seq + sq) * n_kv_head + kvh) * (int64_t)max_ctx * HD;
+    const uint16_t* krun = kcache + run0;
+    const uint16_t* vrun = vcache + run0;
+
+    int Trow[4], Tmax = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Trow[i] = 4 * G + i < nr ? pos[row0 + 4 * G + i] + 1 : 0;
+    for (int m = 0; m < nr; ++m) { const int T = pos[row0 + m] + 1; Tmax = T > Tmax ? T : Tmax; }
+    const int NB = (Tmax + 63) / 64;
+    const float att_scale = tk_divf(1.0f, tk_sqrtf((float)HD));
+
+    /* this head's queries as the A operand: lane (row n16, group G) holds q[4 s + G], s = 0 .. HD / 4 - 1 */
+    float qa[HD / 4];
+    {
+        const float* qr = qbuf + (int64_t)(row0 + (n16 < nr ? n16 : 0)) * QD + head * HD + G;
+#pragma unroll
+        for (int s = 0; s < HD / 4; ++s) qa[s] = n16 < nr ? qr[4 * s] : 0.0f;
+    }
+
+    uint4 kreg[PPT], vreg[PPT];
+    auto fetch = [&](const uint16_t* run, int b, uint4* dst) { /* block b's rows (clamped to the last one any row of the tile sees) into registers */
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int pid = t + u * NT;
+            if (PIECES % NT == 0 || pid < PIECES) {
+                int pr = 64 * b + pid / PPR;
+                pr = pr < Tmax ? pr : Tmax - 1;
+                dst[u] = *(const uint4*)(run + (int64_t)pr * HD + 8 * (pid % PPR));
+            }
+        }
+    };
+    auto put_k = [&]() { /* dims 8 q + e of position pn: group g = e & 3 takes (e = g, e = 4 + g) = its steps 2 q, 2 q + 1 */
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int pid = t + u * NT;
+            if (PIECES % NT == 0 || pid < PIECES) {
+                const int pn = pid / PPR, q8 = pid % PPR;
+                const uint32_t wv[4] = {kreg[u].x, kreg[u].y, kreg[u].z, kreg[u].w};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t lo = (wv[g >> 1] >> (16 * (g & 1))) & 0xffffu, hi = (wv[2 + (g >> 1)] >> (16 * (g & 1))) & 0xffffu;
+                    *(uint32_t*)(kbuf + (size_t)(pn * 4 + g) * KCH + 4 * q8) = lo | (hi << 16);
+                }
+            }
+        }
+    };
+    auto put_v = [&]() {
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int pid = t + u * NT;
+            if (PIECES % NT == 0 || pid < PIECES) *(uint4*)(vbuf + (size_t)(pid / PPR) * VROW + 16 * (pid % PPR)) = vreg[u];
+        }
+    };
+    auto score_tile = [&]() -> v4f { /* rows x positions 16 w .. 16 w + 15 of the staged block: one fma chain over head_dim per element */
+        v4f d = {0.0f, 0.0f, 0.0f, 0.0f};
+        const uint8_t* kp = kbuf + (size_t)((16 * w + n16) * 4 + G) * KCH;
+#pragma unroll
+        for (int q = 0; q < HD / 32; ++q) {
+            const uint4 kk = *(const uint4*)(kp + 16 * q);
+            const uint32_t wv[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[8 * q + e], f16bits_to_f32((wv[e >> 1] >> (16 * (e & 1))) & 0xffffu), d, 0, 0, 0);
+        }
+        return d;
+    };
+
+    /* ---- pass 1: row maxima ---- */
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    v4f d_one = {0.0f, 0.0f, 0.0f, 0.0f}; /* a context of one block (<= 64 positions): its scores and its staged keys serve pass 2 as they are */
+    fetch(krun, 0, kreg);
+    if (NB == 1) fetch(vrun, 0, vreg);
+    for (int b = 0; b < NB; ++b) {
+        __syncthreads(); /* the previous block's (or tile's) readers are done */
+        put_k();
+        if (b + 1 < NB) fetch(krun, b + 1, kreg);
+        __syncthreads();
+        const v4f d = score_tile();
+        d_one = d;
+        const int tp = 64 * b + 16 * w + n16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (tp < Trow[i]) mx[i] = tk_fmaxf(mx[i], d[i] * att_scale);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        for (int s = 8; s >= 1; s >>= 1) mx[i] = tk_fmaxf(mx[i], wave_xor_f(mx[i], s));
+        if (n16 == 0) mred[w * 16 + 4 * G + i] = mx[i];
+    }
+    __syncthreads();
+    float rowmax[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        rowmax[i] = tk_fmaxf(tk_fmaxf(mred[4 * G + i], mred[16 + 4 * G + i]), tk_fmaxf(mred[32 + 4 * G + i], mred[48 + 4 * G + i]));
+
+    /* ---- pass 2: probabilities and PV, class j = w ---- */
+    v4f acc[HD / 16];
+#pragma unroll
+    for (int c = 0; c < HD / 16; ++c) acc[c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    float l = 0.0f; /* lanes G == 0: row n16's denominator of class w */
+    if (NB > 1) { fetch(krun, 0, kreg); fetch(vrun, 0, vreg); }
+    for (int b = 0; b < NB; ++b) {
+        __syncthreads(); /* the previous block's keys, values and probabilities are consumed */
+        if (NB > 1) put_k();
+        put_v();
+        if (b + 1 < NB) { fetch(krun, b + 1, kreg); fetch(vrun, b + 1, vreg); }
+        __syncthreads();
+        {
+            const v4f d = NB > 1 ? score_tile() : d_one;
+            const int tp = 64 * b + 16 * w + n16;
+            v4f e;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = tp < Trow[i] ? tk_expf(d[i] * att_scale - rowmax[i]) : 0.0f;
+            *(v4f*)(ebuf + (size_t)(16 * w + n16) * EROW + 4 * G) = e;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int prow = 16 * st + w + 4 * G; /* this lane group's position of the step: t0 + j + 4 g */
+            const float a = ebuf[(size_t)prow * EROW + n16];
+            const uint8_t* vp = vbuf + (size_t)prow * VROW + 4 * n16;
+#pragma unroll
+            for (int c = 0; c < HD / 32; ++c) {
+                const uint32_t vv = *(const uint32_t*)(vp + 64 * c);
+                acc[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f16bits_to_f32(vv & 0xffffu), acc[2 * c], 0, 0, 0);
+                acc[2 * c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, f16bits_to_f32(vv >> 16), acc[2 * c + 1], 0, 0, 0);
+            }
+            if (G == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) l = l + ebuf[(size_t)(16 * st + w + 4 * g) * EROW + n16];
+            }
+        }
+    }
+    /* ---- the four classes joined in order: ((p0 + p1) + p2) + p3, divided by ((l0 + l1) + l2) + l3 ---- */
+    for (int step = 0; step < 4; ++step) {
+        __syncthreads();
+        if (w == step) {
+            if (G == 0) lbuf[n16] = step == 0 ? l : lbuf[n16] + l;
+            if (step < 3) {
+#pragma unroll
+                for (int c = 0; c < HD / 16; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* o = obuf + (size_t)(4 * G + i) * 256 + hsel * HD + 32 * (c >> 1) + 2 * n16 + (c & 1);
+                        *o = step == 0 ? acc[c][i] : *o + acc[c][i];
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    if (w == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ll = lbuf[4 * G + i];
+#pragma unroll
+            for (int c = 0; c < HD / 16; ++c) {
+                float* o = obuf + (size_t)(4 * G + i) * 256 + hsel * HD + 32 * (c >> 1) + 2 * n16 + (c & 1);
+                *o = tk_divf(*o + acc[c][i], ll);
+            }
+        }
+    }
+    __syncthreads();
+    /* the o-projection's input: whole Q8 blocks (256 outputs of a row = this workgroup's heads), 32 lanes per block */
+    for (int idx = t; idx < nr * 32; idx += NT) {
+        const int m = idx >> 5, ch = idx & 31;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = obuf[(size_t)m * 256 + 8 * ch + i];
+        quantize_chunk8(v, blockIdx.x * 32 + ch, row0 + m, out);
+    }
+    } /* tiles */
+}
+
+bool tk_attention_prefill_applies(int n_head, int n_kv_head, int head_dim) {
+    /* TK_MI355X_NO_PREFILL_ATT=1: multi-position passes keep k_attention's one-workgroup-per-row form (A/B timing, parity tests of both) */
+    const char* np = getenv("TK_MI355X_NO_PREFILL_ATT");
+    if (np && np[0] == '1') return false;
+    if (head_dim != 64 && head_dim != 128) return false;
+    const int hpb = 256 / head_dim, grp = n_kv_head > 0 ? n_head / n_kv_head : 0;
+    return grp > 0 && grp % hpb == 0 && n_head % hpb == 0;
+}
+
+void tk_launch_att_tiles(const int32_t* seq, int nrows, int32_t* tiles, hipStream_t s) {
+    hipLaunchKernelGGL(k_att_tiles, dim3(1), dim3(TK_MAX_ROWS), 0, s, seq, nrows, tiles);
+}
+
+void tk_launch_attention_prefill(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq, const int32_t* pos,
+                                 const int32_t* tiles, int nrows, int n_head, int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out,
+                                 hipStream_t s) {
+    if (head_dim == 128)
+        hipLaunchKernelGGL((k_attention_prefill<128>), dim3(n_head / 2, nrows / 16 + 8), dim3(512), TkPrefillLds<128>::bytes, s, qbuf, kcache, vcache, seq, pos, tiles, n_head,
+                           n_kv_head, layer, max_seq, max_ctx, out);
+    else
+        hipLaunchKernelGGL((k_attention_prefill<64>), dim3(n_head / 4, nrows / 16 + 8), dim3(1024), TkPrefillLds<64>::bytes, s, qbuf, kcache, vcache, seq, pos, tiles, n_head,
+                           n_kv_head, layer, max_seq, max_ctx, out);
+}
+
 static size_t tk_attention_narrow_fixed_lds(int max_ctx) { /* everything but the key / value rows: q, scores, maxima, own row */
     return (size_t)(2 * 128 + 2 * (size_t)((max_ctx + 3) & ~3) + 32) * sizeof(float) + 2 * 128 * 2;
 }
@@ -2153,6 +2440,9 @@ TkAttentionPlan tk_attention_plan(int nrows, int n_head, int n_kv_head, int head
      * one-row launch already takes 9.8 us, the launch is a chain of ~10 barrier-separated phases, not of DMA latencies */
     pl.kernel = 0; pl.gq = gq; pl.chunk = chunk; pl.slots = chunk == 32 ? TK_ATT_WIDE_SLOTS : 2;
     pl.lds_bytes = tk_attention_lds_bytes(gq, head_dim, max_ctx, chunk, pl.slots);
+    /* a pass that is not fused holds several positions of a sequence: the session runs k_attention_prefill (kernel 2) where it applies; the
+     * other fields keep describing the k_attention form it replaces (TK_MI355X_NO_PREFILL_ATT=1, or a caller of tk_launch_attention itself) */
+    if (!fused && tk_attention_prefill_applies(n_head, n_kv_head, head_dim)) pl.kernel = 2;
     return pl;
 }
 
@@ -2359,6 +2649,8 @@ const char* tk_llm_prepare_device(int device) {
 #define TK_OPT_ATT_N(H) do { TK_OPT((k_attention<1, true, H, 128, 2>)); TK_OPT((k_attention<2, true, H, 128, 2>)); TK_OPT((k_attention<1, false, H, 128, 2>)); TK_OPT((k_attention<2, false, H, 128, 2>)); } while (0)
     TK_OPT_ATT_N(64); TK_OPT_ATT_N(128);
     TK_OPT(k_attention_narrow);
+    TK_OPT((k_attention_prefill<128>));
+    TK_OPT((k_attention_prefill<64>));
 #undef TK_OPT_ATT_N
 #undef TK_OPT_ATT
 #undef TK_OPT_GEMV

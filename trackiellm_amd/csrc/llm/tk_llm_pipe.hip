@@ -466,6 +466,7 @@ bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const in
     if (take) { --ids_outstanding_; if (rccl_comm_ && !id_msg_rows_.empty()) id_msg_rows_.pop_front(); }
     if (head && n_stages > 1) { ++ids_outstanding_; if (rccl_comm_ && stage == 0) id_msg_rows_.push_back(nrows); }
     /* host-described passes go eagerly (their row tables differ); distinct rows take the fused-attention form, as forward() does */
+    s_->choose_attention(pos, nrows);
     enqueue_stage(nrows, take, head, head, distinct);
     if (!s_->launch_error.empty()) { error = s_->launch_error; return false; }
     PQ(hipGetLastError());
