@@ -406,7 +406,7 @@ def reference_abi_batched_cortex(tk, K, N):
     # the runners the cortices create share ONE decode session of K sequence slots (the library's default is 16 per session: 256 cortices would
     # decode in sixteen separate 16-row streams); read when the first runner of the model is created
     prev_slots = os.environ.get("TK_MI355X_RUNNER_SLOTS")
-    os.environ["TK_MI355X_RUNNER_SLOTS"] = str(min(K, 256))
+    os.environ["TK_MI355X_RUNNER_SLOTS"] = os.environ.get("TK_BENCH_CORTEX_SLOTS") or str(min(K, 256))
     t_create = time.time()
     cxs = [tk.Cortex(llm="synthetic://mistral-7b?seed=4", detector="synthetic://yolov8n?seed=5&cls_bias=-0.45", asr="synthetic://whisper-tiny.en?seed=6",
                      vad="synthetic://vad?seed=7") for _ in range(K)]
