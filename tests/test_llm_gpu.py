@@ -1052,3 +1052,34 @@ def test_lora_adapter_through_the_reference_loader(gpu, tmp_path):
     for h in (h_again, h_lora, h_plain):
         loader.unload(h)
     loader.close()
+
+
+def test_tiny_long_prompt_chunks_head_dim_64(gpu):
+    """k_attention_prefill at head_dim 64 (four query heads per workgroup, 1 024 threads): a 300-token prompt of the tiny geometry in passes of
+    200 + 100 rows plus a ragged pass over three sequences, all reaching past position 128 (below it the per-row form runs) — logits = oracle"""
+    hp = gpu.TINY()
+    model = gpu.LlmModel(hp)
+    hp = model.hparams
+    assert gpu.attention_plan(200, hp.n_head, hp.n_kv_head, hp.head_dim, 320, False)[0] == 2
+    orc = O.OracleLlm(oracle_cfg_from(hp, 320, 4), seed=4)
+    copy_oracle_weights(orc, model, hp.n_layer)
+    sess = gpu.LlmSession(model, 4, 320)
+    rng = np.random.default_rng(41)
+    tok = rng.integers(3, hp.vocab, 300).astype(np.int32)
+    for lo, hi in ((0, 200), (200, 300)):
+        seq, pos = np.zeros(hi - lo, np.int32), np.arange(lo, hi, dtype=np.int32)
+        want, wam = orc.forward(seq, pos, tok[lo:hi])
+        got, gam = sess.forward(seq, pos, tok[lo:hi])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (lo, np.abs(got - want).max())
+        assert np.array_equal(gam, wam)
+    # ragged: sequence 1 gets 150 rows from position 0, sequence 2 gets 21, sequence 0 continues with 7 rows at 300
+    seq = np.array([1] * 150 + [2] * 21 + [0] * 7, np.int32)
+    pos = np.concatenate([np.arange(150), np.arange(21), np.arange(300, 307)]).astype(np.int32)
+    tk = rng.integers(3, hp.vocab, seq.size).astype(np.int32)
+    want, wam = orc.forward(seq, pos, tk)
+    got, gam = sess.forward(seq, pos, tk)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.array_equal(gam, wam)
+    sess.close()
+    model.close()
+    orc.close()
