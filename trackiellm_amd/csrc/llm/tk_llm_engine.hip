@@ -750,8 +750,9 @@ bool TkLlmSession::time_gemv(int layer, int which, int nrows, int iters, float* 
      * cold HBM lines (32 layers x 66 MB >> the 256 MiB Infinity Cache), as in a real decode step */
     std::vector<TkGemvArgs> set;
     double bytes = 0.0;
+    const char* hot = getenv("TK_MI355X_TIME_HOT"); /* =1: the SAME layer's launch back to back (weights resident in L2 / Infinity Cache): the bound a prefetch could reach */
     for (int l = 0; l < h.n_layer; ++l) {
-        if (which == 3 && l != layer) continue;
+        if ((which == 3 || (hot && hot[0] == '1')) && l != layer) continue;
         if (model->layers[l].v.type != model->layers[layer].v.type || model->layers[l].down.type != model->layers[layer].down.type) continue;
         double b;
         set.push_back(args_for(l, &b));
