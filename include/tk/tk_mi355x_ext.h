@@ -72,7 +72,11 @@ TK_API void tk_mi355x_llm_model_destroy(tk_mi355x_llm_model_t** m);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_model_set_runner_slots(void* model_handle, int slots);
 /* Passes of one or two rows (one runner stepping alone) run their RMS-norm and SwiGLU producers inside the mat-vec launches that consume
  * them (five launches per layer instead of eight; same values); $TK_MI355X_NO_FUSE=1, read when a pass is recorded, keeps them as launches of
- * their own.  $TK_MI355X_NO_GRAPH=1 launches every pass eagerly instead of replaying hipGraphs (profilers). */
+ * their own.  $TK_MI355X_NO_GRAPH=1 launches every pass eagerly instead of replaying hipGraphs (profilers).
+ * Passes that hold several positions of a sequence (prompt chunks) and reach position 128 run their attention with 16 rows of a sequence per
+ * workgroup on the fp32 matrix pipe (k_attention_prefill; same values as the per-row kernel): $TK_MI355X_NO_PREFILL_ATT=1 keeps the per-row
+ * kernel everywhere.  $TK_MI355X_TIME_HOT=1 makes the stand-alone mat-vec timing (tk_mi355x_llm_time_gemv) repeat ONE layer's launch — weights
+ * resident in the caches — instead of cycling through the layers.  $TK_MI355X_ASR_POLICY=1: include/tk/tk_audio.h. */
 /* what the schedulers of a model have done so far: passes run, rows processed, the widest pass */
 TK_API void tk_mi355x_llm_model_batch_stats(void* model_handle, uint64_t* passes, uint64_t* rows, int32_t* max_rows_in_a_pass);
 /* run-ahead rows (csrc/llm/tk_llm_batcher.h) that no owner came back for: the scheduler feeds a sequence's sampled id one position ahead

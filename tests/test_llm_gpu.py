@@ -1083,3 +1083,34 @@ def test_tiny_long_prompt_chunks_head_dim_64(gpu):
     sess.close()
     model.close()
     orc.close()
+
+
+def test_lora_merge_at_mistral_geometry_bit_exact(gpu, tmp_path):
+    """the merge kernel at the real matrix sizes: one Mistral-7B-shaped layer, rank-8 adapter on attn_q (Q4_K, 4096 x 4096), ffn_down (Q6_K,
+    4096 x 14336: 56 blocks per row) and output.weight (Q6_K, 32000 x 4096: 512 000 blocks) — merged blocks and logits equal to the oracle's"""
+    import gguf_util
+    hp = gpu.MISTRAL_7B()
+    hp.n_layer = 1
+    model = gpu.LlmModel(hp)
+    hp = model.hparams
+    cfg = oracle_cfg_from(hp, 16, 2)
+    base = O.OracleLlm(cfg, seed=4)
+    rng = np.random.default_rng(51)
+    shapes = {(0, 1): (hp.n_head * hp.head_dim, hp.d_model), (0, 8): (hp.d_model, hp.d_ff), (-1, O.T_OUTPUT): (hp.vocab, hp.d_model)}
+    fs = {k: (rng.normal(0, 0.02, (8, kk)).astype(np.float32), rng.normal(0, 0.02, (n, 8)).astype(np.float32)) for k, (n, kk) in shapes.items()}
+    path = str(tmp_path / "m.gguf")
+    gguf_util.write_lora_gguf(path, 16.0, fs)
+    model.set_lora(path)
+    copy_oracle_weights(base, model, 1)
+    assert model.lora_merged == 3
+    for (layer, w), (A, B) in fs.items():
+        base.apply_lora(layer, w, A, B, 2.0)
+    sess = gpu.LlmSession(model, 2, 16)
+    seq, pos, tok = [0, 0, 1], [0, 1, 0], [1, 777, 31999]
+    want, wam = base.forward(seq, pos, tok)
+    got, gam = sess.forward(seq, pos, tok)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.array_equal(gam, wam)
+    sess.close()
+    model.close()
+    base.close()
