@@ -8,5 +8,5 @@ OUT=$ROOT/build/variants; mkdir -p $OUT
 cd $ROOT/trackiellm_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=hidden -I$ROOT/include -I. -Wall -Wno-unused-function "$@" -c ${SRC:-llm/tk_llm_kernels.hip} -o $OUT/k_$NAME.o
 OBJS=$(find $ROOT/build/obj -name '*.o' | grep -v 'llm/tk_llm_kernels.hip.o')
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libtrackie_$NAME.so $OBJS $OUT/k_$NAME.o -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libtrackie_$NAME.so $OBJS $OUT/k_$NAME.o -lpthread -ldl
 echo built $OUT/libtrackie_$NAME.so
