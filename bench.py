@@ -18,6 +18,7 @@ What the line carries besides the contract keys (all measured live in this run, 
   north_star_point    a second, short timed run at 3 x 16 rows per pass: the configuration that meets north_star's
                       ">= 30 cycles/s at >= 40 % of the HBM roofline" together, reported beside the throughput-optimal headline
   reference_abi_b1    batch 1 through the reference's own entry points only (tk_llm_runner_*, tk_cortex_*)
+  prompt_processing   one prompt of 64 / 448 / 2 048 tokens through the session's prefill (time to the first token's logits)
   reference_abi_batched_cortex   K cortex handles on one model file, one DATA-DEPENDENT cycle each through tk_cortex_* only
   cpu_baseline        one whole fused cycle on the CPU oracle ("port"), at the box's core share and at 1 core
 """
@@ -395,6 +396,30 @@ def reference_abi_b1(tk, hp, N, roof1):
     return out
 
 
+def prompt_processing(tk, model, lengths=(64, 448, 2048)):
+    """one prompt of n tokens through TkLlmSession::prefill (passes of up to 256 rows; from position 128 on the attention of a pass runs 16 rows
+    of the sequence per workgroup on the fp32 matrix pipe, csrc/llm/tk_llm_kernels.hip: k_attention_prefill) — the reference feeds whole prompts
+    (src/ai_models/tk_runner_streaming.c:20-40) and budgets 2 048 tokens for them (src/cortex/tk_cortex_main.c:1334).  Best of two timed runs
+    after the capture run; ids of both runs equal."""
+    hp = model.hparams
+    rng = np.random.default_rng(5)
+    out = []
+    for n in lengths:
+        sess = tk.LlmSession(model, 1, n + 8)
+        toks = rng.integers(3, hp.vocab, (1, n)).astype(np.int32)
+        first = sess.prefill(toks)
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            again = sess.prefill(toks)
+            best = min(best, time.perf_counter() - t0)
+            if not np.array_equal(first, again):
+                raise RuntimeError("prompt processing is not reproducible")
+        out.append({"prompt_tokens": n, "ms": round(1e3 * best, 2), "tok_per_s": round(n / best, 1)})
+        sess.close()
+    return out
+
+
 def reference_abi_batched_cortex(tk, K, N):
     """K cortex handles (tk_cortex_create ... tk_cortex_destroy only) that share one LLM model file, each driven by its own host thread through
     ONE data-dependent cycle of the reference's loop (/root/reference/src/cortex/tk_cortex_main.c:1149-1237, 1323-1379): 1 s of PCM + the
@@ -710,6 +735,7 @@ def main():
         roof1 = gemv_roofline(s1, hp, 1, model.weight_bytes)
         s1.close()
         out["reference_abi_b1"] = reference_abi_b1(tk, hp, N, roof1)
+        out["prompt_processing"] = prompt_processing(tk, model)
         out["reference_abi_batched"] = [reference_abi_runners(tk, K, N) for K in (16, 64, 256)]
         # the same runners from a C host: the difference is the Python driver (GIL hand-offs between K threads that each make one ctypes call per token)
         out["reference_abi_batched_c_host"] = [reference_abi_runners_c_host(K, N) for K in (16, 256)]
