@@ -57,7 +57,7 @@ bool parse_tensor(Span s, std::string* name, TkOnnxTensor* t) {
         } else if (num == 2 && wt == 0) t->dtype = (int)v;
         else if (num == 4) {
             if (wt == 5) { float f; uint32_t u = (uint32_t)v; memcpy(&f, &u, 4); fdata.push_back(f); }
-            else if (wt == 2) { const size_t n = (size_t)(sub.e - sub.p) / 4, o = fdata.size(); fdata.resize(o + n); memcpy(fdata.data() + o, sub.p, n * 4); }
+            else if (wt == 2) { const size_t n = (size_t)(sub.e - sub.p) / 4, o = fdata.size(); fdata.resize(o + n); if (n) memcpy(fdata.data() + o, sub.p, n * 4); }
         } else if (num == 5 || num == 7) { /* int32_data / int64_data: varints, packed or not */
             if (wt == 0) idata.push_back((int64_t)v);
             else if (wt == 2) { uint64_t d; while (sub.p < sub.e) { if (!varint(sub, &d)) return false; idata.push_back((int64_t)d); } }
@@ -68,7 +68,7 @@ bool parse_tensor(Span s, std::string* name, TkOnnxTensor* t) {
     for (int64_t d : t->dims) { if (d < 0 || d > (1 << 26)) return false; count *= d; if (count > (1 << 28)) return false; }
     const int64_t rawn = raw.p ? (int64_t)(raw.e - raw.p) : -1;
     if (t->dtype == 1) {
-        if (rawn == count * 4) { t->f.resize((size_t)count); memcpy(t->f.data(), raw.p, (size_t)count * 4); }
+        if (rawn == count * 4) { t->f.resize((size_t)count); if (count) memcpy(t->f.data(), raw.p, (size_t)count * 4); } /* an empty tensor has no bytes to copy (and no buffer to copy into) */
         else if ((int64_t)fdata.size() == count) t->f.swap(fdata);
         else return count == 0;
     } else if (t->dtype == 10) {
@@ -76,7 +76,7 @@ bool parse_tensor(Span s, std::string* name, TkOnnxTensor* t) {
         t->f.resize((size_t)count);
         for (int64_t i = 0; i < count; ++i) { uint16_t h; memcpy(&h, raw.p + 2 * i, 2); t->f[(size_t)i] = tk_f16_to_f32(h); }
     } else if (t->dtype == 7) {
-        if (rawn == count * 8) { t->i.resize((size_t)count); memcpy(t->i.data(), raw.p, (size_t)count * 8); }
+        if (rawn == count * 8) { t->i.resize((size_t)count); if (count) memcpy(t->i.data(), raw.p, (size_t)count * 8); }
         else if ((int64_t)idata.size() == count) t->i.swap(idata);
         else return count == 0;
     } else if (t->dtype == 6) {
