@@ -1,5 +1,5 @@
 // Mutation fuzzing of the host-side file readers under AddressSanitizer + UBSan (CPU build only; no HIP device involved):
-//   LoRA adapters (ggla / GGUF), GGUF checkpoints, whisper.cpp ggml checkpoints, ONNX graphs and ONNX conv weights, GBNF grammars.
+//   LoRA adapters (ggla / GGUF), GGUF checkpoints, whisper.cpp ggml checkpoints, ONNX graphs and ONNX conv weights, GBNF grammars; the SentencePiece tokenizer on the vocabularies of accepted GGUF files.
 // Every reader takes untrusted files from tk_*_create / tk_model_loader_load_model paths.  Build + run: tools/fuzz/run.sh
 #include <stdio.h>
 #include <stdlib.h>
@@ -12,6 +12,7 @@
 #include "llm/tk_gguf.h"
 #include "llm/tk_grammar.h"
 #include "llm/tk_lora.h"
+#include "llm/tk_tokenizer.h"
 #include "nn/tk_onnx_graph.h"
 #include "vision/tk_onnx_weights.h"
 
@@ -54,7 +55,20 @@ int main(int argc, char** argv) {
             }
             wr(scratch, b);
             { TkLoraAdapter r; (r.load(scratch) ? ok : bad)++; }
-            { TkGgufFile r; (r.open(scratch) ? ok : bad)++; }
+            {
+                TkGgufFile r;
+                if (r.open(scratch)) {
+                    ++ok;
+                    if (!r.tokens.empty()) { /* a vocabulary the file brought (damaged scores / types / ids included) must tokenise and render without faults */
+                        TkTokenizer tok;
+                        tok.init_spm(r.tokens, r.scores, r.token_type, (int)r.get("tokenizer.ggml.bos_token_id", 1), (int)r.get("tokenizer.ggml.eos_token_id", 2));
+                        const std::vector<int32_t> ids = tok.encode(" hello world \xe2\x96\x81 \xff\x00x", true);
+                        for (int32_t id : ids) (void)tok.piece(id);
+                        (void)tok.piece(-1);
+                        (void)tok.piece((int32_t)r.tokens.size());
+                    }
+                } else ++bad;
+            }
             { TkWhisperGgml r; (r.open(scratch) ? ok : bad)++; }
             { TkOnnxGraph r; (r.load(scratch) ? ok : bad)++; }
             { TkOnnxWeights r; (r.load(scratch) ? ok : bad)++; }

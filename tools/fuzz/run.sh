@@ -24,5 +24,5 @@ open(W + "/g.gbnf", "w").write('root ::= "{" ws item ("," ws item)* "}"\nitem ::
 PY
 cd $ROOT/trackiellm_amd/csrc
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I. -I$ROOT/include \
-    $ROOT/tools/fuzz/fuzz_readers.cpp llm/tk_lora.cpp llm/tk_gguf.cpp llm/tk_grammar.cpp audio/tk_whisper_ggml.cpp nn/tk_onnx_graph.cpp vision/tk_onnx_weights.cpp -o $W/fuzz_readers
+    $ROOT/tools/fuzz/fuzz_readers.cpp llm/tk_lora.cpp llm/tk_gguf.cpp llm/tk_grammar.cpp llm/tk_tokenizer.cpp audio/tk_whisper_ggml.cpp nn/tk_onnx_graph.cpp vision/tk_onnx_weights.cpp -o $W/fuzz_readers
 $W/fuzz_readers $W/scratch.bin ${1:-1500} $(ls $W/a.ggla $W/b.gguf $W/model.gguf $W/g.gbnf $W/y.onnx 2>/dev/null)
