@@ -265,6 +265,7 @@ tk_error_code_t tk_mi355x_llm_model_load_gguf_lora(tk_mi355x_llm_model_t** out, 
     /* `m` is private to this call (never registered, no runner holds it): freed directly.  NOT tk_mi355x_llm_model_destroy — that takes
      * g_models_mu, which tk_model_loader_load_model holds across this call (a GGUF with a missing tensor hung the loader) */
     if (!ok) { delete m; return TK_ERROR_MODEL_LOAD_FAILED; }
+    if (m->lora) { m->model.lora = nullptr; m->lora->drop_factors(); } /* every matrix is installed: nothing reads the factors any more */
     if (!f.tokens.empty()) m->tok.init_spm(f.tokens, f.scores, f.token_type, (int)f.get("tokenizer.ggml.bos_token_id", 1), (int)f.get("tokenizer.ggml.eos_token_id", 2));
     auto it = f.str.find("general.architecture");
     m->context_length = (int)f.get((it == f.str.end() ? std::string("llama") : it->second) + ".context_length", 4096);
@@ -588,6 +589,7 @@ tk_error_code_t tk_model_loader_load_model(tk_model_loader_t* loader, const tk_m
         if (rc == TK_SUCCESS && !lora.empty()) rc = tk_mi355x_llm_model_set_lora(m, lora.c_str());
         if (rc == TK_SUCCESS) rc = f16 ? tk_mi355x_llm_model_fill_synthetic_f16(m, seed) : tk_mi355x_llm_model_fill_synthetic(m, seed);
         if (rc != TK_SUCCESS) { if (m) release_model(m); return rc; } /* g_models_mu is held here */
+        if (m->lora) { m->model.lora = nullptr; m->lora->drop_factors(); }
         m->path = path;
     } else {
         rc = tk_mi355x_llm_model_load_gguf_lora(&m, file.c_str(), lora.c_str(), device);

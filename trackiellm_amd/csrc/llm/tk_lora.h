@@ -40,6 +40,10 @@ struct TkLoraAdapter {
     bool load(const char* path);
     const TkLoraTensor* find(int layer, int which) const;
     float scale_of(const TkLoraTensor& t) const { return alpha / (float)t.r; }
+    /* a loaded model has the adapter inside its weights: the factors (tens to hundreds of MB of host memory for a 7B model) can go */
+    void drop_factors() {
+        for (auto& t : tensors) { std::vector<float>().swap(t.A); std::vector<float>().swap(t.B); }
+    }
 };
 
 #endif
