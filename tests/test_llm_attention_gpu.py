@@ -119,15 +119,41 @@ def mistral_long(gpu):
     orc.close()
 
 
-@pytest.mark.parametrize("nrows,ctx", [(1, 2048), (16, 2047), (16, 2100), (16, 4000), (32, 2048), (32, 3001)])
-def test_decode_attention_past_2048_cached_positions(mistral_long, nrows, ctx):
-    """a decode step over 2047 .. 4000 cached positions inside a 4096-position window: the narrow kernel walks the context chunk by chunk
-    (its resident chunk is ~220 positions at this window: ten to eighteen chunks), the ring kernel wraps its two slots 30 to 60 times"""
+@pytest.mark.parametrize("nrows,ctx", [(1, 2048), (16, 2047), (16, 2100), (16, 4000), (32, 2048), (32, 3001), (1, 640), (2, 777), (1, 4094), (4, 2049), (3, 1023),
+                                       (8, 1280), (8, 3001), (5, 1279)])
+def test_decode_attention_past_2048_cached_positions(mistral_long, nrows, ctx, monkeypatch):
+    """a decode step over 640 .. 4094 cached positions inside a 4096-position window, both ways.  The session's choice — 1 .. 2 rows from
+    position 640, 3 .. 4 rows from 1 024, 5 .. 8 rows from 1 280 — is the long-context form (kernel 3: append + scores over (row, KV head, 64-position block)
+    workgroups + one PV chain per (row, head, class) wave + join).  Wider passes, and every pass under TK_MI355X_NO_LONG_ATT=1 (a fresh session:
+    passes are captured per session), run the fused kernels: the narrow kernel walks the context chunk by chunk (its resident chunk is ~220
+    positions at this window: up to eighteen chunks), the ring kernel wraps its two slots 30 to 60 times.  All equal the oracle bit for bit."""
     gpu, model, sess, orc, hp = mistral_long
-    plan = check_plan(gpu, hp, nrows, LONG_CTX)
+    long_form = nrows <= 8 and ctx >= (1280 if nrows > 4 else 1024 if nrows > 2 else 640)
+    assert (gpu.attention_plan(nrows, hp.n_head, hp.n_kv_head, hp.head_dim, LONG_CTX, True, top_position=ctx)[0] == 3) == long_form
+    assert gpu.attention_plan(nrows, hp.n_head, hp.n_kv_head, hp.head_dim, LONG_CTX, True, top_position=639)[0] != 3
+    decode_step_case(gpu, sess, orc, hp, nrows, ctx, LONG_CTX, 7000 * nrows + ctx)
+    if not long_form or (ctx % 2 == 0 and ctx != 2048):
+        return                                                       # the fused kernels' share: wide passes, the odd contexts and the 2048 cases
+    monkeypatch.setenv("TK_MI355X_NO_LONG_ATT", "1")
+    assert gpu.attention_plan(nrows, hp.n_head, hp.n_kv_head, hp.head_dim, LONG_CTX, True, top_position=ctx)[0] != 3
+    plan = check_plan(gpu, hp, nrows, LONG_CTX) if nrows in EXPECTED_PLAN else gpu.attention_plan(nrows, hp.n_head, hp.n_kv_head, hp.head_dim, LONG_CTX, True)
     if plan[0] == 1:
         assert plan[2] < 2047  # several chunks
-    decode_step_case(gpu, sess, orc, hp, nrows, ctx, LONG_CTX, 7000 * nrows + ctx)
+    fused = gpu.LlmSession(model, nrows, LONG_CTX)
+    seq = np.arange(nrows, dtype=np.int32)
+    for sq in seq:
+        k, v = sess.kv_read(0, int(sq), 0, ctx)
+        fused.kv_write(0, int(sq), 0, k, v)
+    rng = np.random.default_rng(7000 * nrows + ctx)
+    for sq in seq:                                                   # decode_step_case drew the cache rows first: skip past them
+        f16_bits(rng, (ctx, hp.n_kv_head, hp.head_dim), 0.6); f16_bits(rng, (ctx, hp.n_kv_head, hp.head_dim), 1.0)
+    tok = rng.integers(3, hp.vocab, nrows).astype(np.int32)
+    pos = np.full(nrows, ctx, np.int32)
+    want, wam = orc.forward(seq, pos, tok)                           # the same row again: the oracle's cache row at `ctx` is rewritten with itself
+    got, gam = fused.forward(seq, pos, tok)
+    fused.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (nrows, ctx, np.abs(got - want).max())
+    assert np.array_equal(gam, wam)
 
 
 def test_prefill_chunk_starting_past_2048_positions(mistral_long):

@@ -1114,3 +1114,51 @@ def test_lora_merge_at_mistral_geometry_bit_exact(gpu, tmp_path):
     sess.close()
     model.close()
     base.close()
+
+
+def test_tiny_long_context_decode_head_dim_64(gpu):
+    """the long-context decode form at head_dim 64 (scores per 64-position block on the matrix pipe, one PV chain per (row, head, class) wave):
+    three sequences prefilled to 700 / 801 / 650 positions through prompt chunks, then decode rows at those positions, alone and together,
+    logits = oracle; and a short device-side decode loop that crosses the switch position (636 .. 643) gives the oracle's ids"""
+    hp = gpu.TINY()
+    model = gpu.LlmModel(hp)
+    hp = model.hparams
+    assert gpu.attention_plan(3, hp.n_head, hp.n_kv_head, hp.head_dim, 1024, True, top_position=801)[0] == 3
+    orc = O.OracleLlm(oracle_cfg_from(hp, 1024, 4), seed=4)
+    copy_oracle_weights(orc, model, hp.n_layer)
+    sess = gpu.LlmSession(model, 4, 1024)
+    rng = np.random.default_rng(43)
+    lens = {0: 700, 1: 801, 2: 650, 3: 636}
+    for sq, n in lens.items():
+        tok = rng.integers(3, hp.vocab, n).astype(np.int32)
+        for lo in range(0, n, 256):
+            hi = min(n, lo + 256)
+            seq, pos = np.full(hi - lo, sq, np.int32), np.arange(lo, hi, dtype=np.int32)
+            orc.forward(seq, pos, tok[lo:hi], want_logits=False)
+            sess.forward(seq, pos, tok[lo:hi], want_logits=False)
+    for rows in ([1], [0, 1, 2], [2]):
+        seq = np.array(rows, np.int32)
+        pos = np.array([lens[r] for r in rows], np.int32)
+        tok = rng.integers(3, hp.vocab, len(rows)).astype(np.int32)
+        want, wam = orc.forward(seq, pos, tok)
+        got, gam = sess.forward(seq, pos, tok)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rows, np.abs(got - want).max())
+        assert np.array_equal(gam, wam)
+        for r in rows:
+            lens[r] += 1
+    # sequence 3 alone through the device-side loop: positions 636 .. 643 cross the 640 switch inside one decode() call
+    tok = rng.integers(3, hp.vocab, 1).astype(np.int32)
+    _, am = orc.forward([3], [636], tok, want_logits=False)
+    _, gam = sess.forward([3], [636], tok, want_logits=False)
+    assert np.array_equal(am, gam)
+    want = []
+    cur = int(am[0])
+    for i in range(7):
+        _, am = orc.forward([3], [637 + i], [cur], want_logits=False)
+        cur = int(am[0])
+        want.append(cur)
+    toks, _ = sess.decode(1, 7)
+    assert [int(t) for t in toks[:7, 0]] == want
+    sess.close()
+    model.close()
+    orc.close()

@@ -424,6 +424,21 @@ tk_error_code_t tk_mi355x_attention_plan(int device, int nrows, int n_head, int 
     return TK_SUCCESS;
 }
 
+tk_error_code_t tk_mi355x_attention_plan_at(int device, int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, int fused, int top_position, int32_t out[4]) {
+    const tk_error_code_t rc = tk_mi355x_attention_plan(device, nrows, n_head, n_kv_head, head_dim, max_ctx, fused, out);
+    if (rc != TK_SUCCESS) return rc;
+    if (top_position < 0 || top_position >= max_ctx) return TK_ERROR_INVALID_ARGUMENT;
+    /* the session's per-pass choices (TkLlmSession::choose_attention_top) on top of the launcher's */
+    if (fused) {
+        if (max_ctx > TK_LONG_ATT_MIN_POS && tk_attention_long_applies(nrows, n_head, n_kv_head, head_dim) && top_position >= tk_long_att_min_pos(nrows)) {
+            out[0] = 3; out[1] = n_head / n_kv_head; out[2] = 64; out[3] = 1;
+        }
+    } else if (out[0] == 2 && top_position < 128) {
+        out[0] = 0;
+    }
+    return TK_SUCCESS;
+}
+
 tk_error_code_t tk_mi355x_llm_time_attention(tk_mi355x_llm_session_t* s, int nrows, int ctx, int iters, float* avg_ms, double* kv_bytes) {
     if (!s || !avg_ms || !kv_bytes) return TK_ERROR_INVALID_ARGUMENT;
     if (!s->session.time_attention(nrows, ctx, iters, avg_ms, kv_bytes)) return fail(TK_ERROR_GPU_ROCM_ERROR, s->session.error);

@@ -130,7 +130,7 @@ private:
     bool samp_dirty = false;        /* d_samp holds a stochastic row */
     std::string launch_error; /* set by enqueue_* when a launcher refuses its arguments (no HIP error is raised for that) */
     int hist_cap = 0;
-    hipGraphExec_t graph_exec[TK_MAX_ROWS + 1] = {};    /* decode pass (head + sampling, fused attention), by row count */
+    hipGraphExec_t graph_exec[2][TK_MAX_ROWS + 1] = {}; /* [long_pass][row count]: decode pass (head + sampling, every sequence once) */
     /* [tiled_pass][row count]: prompt pass (no head, rope/append as its own kernel); sampling pass that holds several positions of one sequence
      * (a prompt's last chunk) */
     hipGraphExec_t graph_prefill[2][TK_MAX_ROWS + 1] = {};
@@ -139,7 +139,12 @@ private:
      * k_attention_prefill (16 rows of a sequence per workgroup), shorter contexts k_attention's per-row form (3 us per launch quicker below ~128
      * positions, profiles/r05_prefill_attention.txt); the two are bit-identical, so the choice never shows in a result */
     bool tiled_pass = false;
+    /* a decode pass (every sequence once) of at most TK_LONG_ATT_MAX_ROWS rows that reaches position TK_LONG_ATT_MIN_POS runs its attention as
+     * append + scores + PV launches spread over the chip (tk_launch_attention_long) instead of one latency chain per pair of heads; bit-identical */
+    bool long_pass = false;
+    float* d_scores = nullptr; /* [TK_LONG_ATT_MAX_ROWS][n_head][max_ctx], allocated when the window can reach TK_LONG_ATT_MIN_POS */
     void choose_attention(const int32_t* pos, int nrows);
+    void choose_attention_top(int top, int nrows);
     int32_t* d_tab = nullptr;                           /* prefill schedule: [3][total rows] = seq, pos, tok */
     int32_t* d_tiles = nullptr;                         /* [1 + TK_MAX_ROWS] 16-row tiles of a multi-position pass (k_att_tiles) */
     size_t tab_cap = 0;

@@ -275,6 +275,8 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     HIPQ(hipMalloc((void**)&d_hist, (size_t)hist_cap * TK_MAX_ROWS * 4));
     HIPQ(hipMalloc((void**)&d_tiles, (size_t)(1 + TK_MAX_ROWS) * 4));
     HIPQ(hipMemset(d_tiles, 0, (size_t)(1 + TK_MAX_ROWS) * 4));
+    if (mctx > TK_LONG_ATT_MIN_POS && tk_attention_long_applies(1, h.n_head, h.n_kv_head, h.head_dim))
+        HIPQ(hipMalloc((void**)&d_scores, tk_attention_long_scratch_floats(h.n_head, h.head_dim, mctx) * sizeof(float)));
     HIPQ(hipMalloc((void**)&d_mask, (size_t)TK_MAX_ROWS * (((size_t)h.vocab + 31) / 32) * 4));
     HIPQ(hipMalloc((void**)&d_mask_row, TK_MAX_ROWS * 4));
     HIPQ(hipMemset(d_mask_row, 0xFF, TK_MAX_ROWS * 4));
@@ -305,10 +307,10 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
 TkLlmSession::~TkLlmSession() {
     if (model) (void)hipSetDevice(model->device);
     if (stream) (void)hipStreamSynchronize(stream);
-    for (auto& g : graph_exec) if (g) (void)hipGraphExecDestroy(g);
+    for (auto& v : graph_exec) for (auto& g : v) if (g) (void)hipGraphExecDestroy(g);
     for (auto& v : graph_prefill) for (auto& g : v) if (g) (void)hipGraphExecDestroy(g);
     for (auto& v : graph_head_nf) for (auto& g : v) if (g) (void)hipGraphExecDestroy(g);
-    void* ptrs[] = {kcache, vcache, x, x2, qbuf, partial, partial2, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_mask_row, d_samp, d_tab, d_tiles};
+    void* ptrs[] = {kcache, vcache, x, x2, qbuf, partial, partial2, logits, rope_cos, rope_sin, d_seq, d_pos, d_tok, d_nsteps, d_hist, d_mask, d_mask_row, d_samp, d_tab, d_tiles, d_scores};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     free_act(&act_d); free_act(&act_qd); free_act(&act_ff);
     if (stream) (void)hipStreamDestroy(stream);
@@ -422,6 +424,8 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
     /* passes that hold several positions of a sequence (prompt chunks): 16 rows of a sequence per attention workgroup on the fp32 matrix pipe
      * (k_attention_prefill, bit-identical to k_attention); the row -> tile table is built once per pass from the sequence ids on the device */
     const bool tiled_attn = !fused_attn && l1 > l0 && tiled_pass && tk_attention_prefill_applies(h.n_head, h.n_kv_head, h.head_dim);
+    /* few rows over a long context: the fused kernels would walk it as one latency chain per pair of heads */
+    const bool long_attn = fused_attn && l1 > l0 && long_pass && d_scores && tk_attention_long_applies(nrows, h.n_head, h.n_kv_head, h.head_dim);
     if (tiled_attn) tk_launch_att_tiles(d_seq, nrows, d_tiles, s);
     int ks_res = 1; /* slabs of the pending residual update (the previous layer's down projection) */
     for (int l = l0; l < l1; ++l) {
@@ -432,10 +436,11 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         const TkDevTensor* dn[1] = {&L.down};
         if (fuse) {
             const int ks_qkv = fused_gemv(qkv, 3, D, h.ks_qkv, QD + 2 * KVD, partial2, 1, x, x2, l == l0 ? nullptr : partial, ks_res, D, (const float*)L.attn_norm.data);
-            if (!fused_attn)
+            if (!fused_attn || long_attn)
                 tk_launch_qkv_rope_append(partial2, ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
                                           qbuf, kcache, vcache, l, max_seq, max_ctx, s);
-            if (tiled_attn) tk_launch_attention_prefill(qbuf, kcache, vcache, d_seq, d_pos, d_tiles, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
+            if (long_attn) tk_launch_attention_long(qbuf, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, d_scores, act_qd, s);
+            else if (tiled_attn) tk_launch_attention_prefill(qbuf, kcache, vcache, d_seq, d_pos, d_tiles, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
             else tk_launch_attention(qbuf, partial2, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
                                      h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
             const int ks_o = enqueue_matmul(ot, 1, QD, h.ks_o, D, act_qd, partial, nrows);
@@ -445,10 +450,11 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         }
         tk_launch_rmsnorm_q8(x, l == l0 ? nullptr : partial, ks_res, D, (const float*)L.attn_norm.data, h.rms_eps, D, nrows, act_d, s);
         const int ks_qkv = enqueue_matmul(qkv, 3, D, h.ks_qkv, QD + 2 * KVD, act_d, partial, nrows);
-        if (!fused_attn)
+        if (!fused_attn || long_attn)
             tk_launch_qkv_rope_append(partial, ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
                                       qbuf, kcache, vcache, l, max_seq, max_ctx, s);
-        if (tiled_attn) tk_launch_attention_prefill(qbuf, kcache, vcache, d_seq, d_pos, d_tiles, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
+        if (long_attn) tk_launch_attention_long(qbuf, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, d_scores, act_qd, s);
+        else if (tiled_attn) tk_launch_attention_prefill(qbuf, kcache, vcache, d_seq, d_pos, d_tiles, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
         else tk_launch_attention(qbuf, partial, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
                                  h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
         const int ks_o = enqueue_matmul(ot, 1, QD, h.ks_o, D, act_qd, partial, nrows);
@@ -496,7 +502,11 @@ static std::mutex g_capture_mu;
 void TkLlmSession::choose_attention(const int32_t* pos, int nrows) {
     int top = 0;
     for (int r = 0; r < nrows; ++r) top = pos[r] > top ? pos[r] : top;
+    choose_attention_top(top, nrows);
+}
+void TkLlmSession::choose_attention_top(int top, int nrows) {
     tiled_pass = top >= TK_TILED_ATT_MIN_POS;
+    long_pass = d_scores != nullptr && nrows <= TK_LONG_ATT_MAX_ROWS && top >= tk_long_att_min_pos(nrows);
 }
 
 bool TkLlmSession::capture_pass(hipGraphExec_t* slot, int nrows, bool lm_head, bool fused_attn) {
@@ -573,7 +583,7 @@ bool TkLlmSession::forward(int nrows, const int32_t* seq, const int32_t* pos, co
     /* a pass replays a captured graph (one per (row count, form)): a host that asks for one token at a time — the reference's runner
      * API — pays one graph launch, not ~260 kernel launches, per token; masked rows ride the same graphs (the table above is data) */
     hipGraphExec_t* slot = !graphs_enabled() ? nullptr
-                           : !lm_head ? &graph_prefill[tiled_pass][nrows] : distinct ? &graph_exec[nrows] : &graph_head_nf[tiled_pass][nrows];
+                           : !lm_head ? &graph_prefill[tiled_pass][nrows] : distinct ? &graph_exec[long_pass][nrows] : &graph_head_nf[tiled_pass][nrows];
     if (slot) {
         if (!capture_pass(slot, nrows, lm_head, lm_head && distinct)) return false;
         HIPQ(hipGraphLaunch(*slot, stream));
@@ -686,7 +696,8 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     for (int r = 0; r < nrows; ++r)
         if (hpos[r] + n_steps > max_ctx) { error = "decode would run past max_ctx"; return false; }
     const bool use_graph = graphs_enabled();
-    if (use_graph && !capture_pass(&graph_exec[nrows], nrows, true, true)) return false;
+    int top0 = 0;
+    for (int r = 0; r < nrows; ++r) top0 = hpos[r] > top0 ? hpos[r] : top0;
     HIPQ(hipMemsetAsync(d_nsteps, 0, TK_MAX_ROWS * 4, stream));
     if (mask_rows_dirty) { HIPQ(hipMemsetAsync(d_mask_row, 0xFF, TK_MAX_ROWS * 4, stream)); mask_rows_dirty = false; } /* the loop samples unconstrained */
     hipEvent_t e0, e1;
@@ -694,8 +705,11 @@ bool TkLlmSession::decode(int nrows, int n_steps, int32_t* out_tokens_host) {
     HIPQ(hipEventCreate(&e1));
     HIPQ(hipEventRecord(e0, stream));
     for (int i = 0; i < n_steps; ++i) {
-        if (use_graph) HIPQ(hipGraphLaunch(graph_exec[nrows], stream));
-        else { launch_error.clear(); enqueue_pass(nrows, true, true); if (!launch_error.empty()) { error = launch_error; break; } }
+        choose_attention_top(top0 + i, nrows); /* positions advance on the device; the host knows where the loop stands */
+        if (use_graph) {
+            if (!capture_pass(&graph_exec[long_pass][nrows], nrows, true, true)) { (void)hipStreamSynchronize(stream); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return false; }
+            HIPQ(hipGraphLaunch(graph_exec[long_pass][nrows], stream));
+        } else { launch_error.clear(); enqueue_pass(nrows, true, true); if (!launch_error.empty()) { error = launch_error; break; } }
     }
     if (!launch_error.empty()) { (void)hipStreamSynchronize(stream); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); launch_error.clear(); return false; }
     HIPQ(hipGetLastError());
@@ -806,8 +820,16 @@ bool TkLlmSession::time_attention(int nrows, int ctx, int iters, float* avg_ms, 
     /* TK_MI355X_TIME_UNFUSED=1: time the two-launch form instead (k_qkv_rope_append + k_attention<.., not fused>): what a decode pass would
      * cost without the fused prologue */
     const char* uf = getenv("TK_MI355X_TIME_UNFUSED");
-    const bool unfused = uf && uf[0] == '1';
+    const char* lf = getenv("TK_MI355X_TIME_LONG"); /* =1: the three-launch long-context form (tk_launch_attention_long) where it applies */
+    const bool longf = lf && lf[0] == '1' && d_scores && tk_attention_long_applies(nrows, h.n_head, h.n_kv_head, h.head_dim);
+    const bool unfused = (uf && uf[0] == '1') || longf;
     auto launch = [&](int l) {
+        if (longf) {
+            tk_launch_qkv_rope_append(partial, h.ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows, qbuf, kcache,
+                                      vcache, l % h.n_layer, max_seq, max_ctx, stream);
+            tk_launch_attention_long(qbuf, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l % h.n_layer, max_seq, max_ctx, d_scores, act_qd, stream);
+            return;
+        }
         if (unfused)
             tk_launch_qkv_rope_append(partial, h.ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows, qbuf, kcache,
                                       vcache, l % h.n_layer, max_seq, max_ctx, stream);

@@ -2356,6 +2356,208 @@ __global__ __launch_bounds__((256 / HD) * 256) void k_attention_prefill(const fl
     } /* tiles */
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Decode passes of few rows over LONG contexts (the reference runs a 4 096-position window with a 2 048-token prompt budget:
+ * src/ai_models/tk_runner_lifecycle.c:48, src/cortex/tk_cortex_main.c:1334).  k_attention_narrow walks a long context chunk by chunk inside
+ * one workgroup per pair of heads — ten to eighteen barrier-separated DMA round trips at 2 048 .. 4 000 positions: 51 / 96 us per layer at one
+ * row (164 GB/s: a latency chain), as much as the whole step's mat-vec launches.  Here the same arithmetic is spread over the chip in three
+ * launches, none of which waits on a chunk loop:
+ *   k_qkv_rope_append   q / k / v of the pass's rows (K-split sums, RoPE, f16 rounding, cache append), as for multi-position passes;
+ *   k_att_scores_long   workgroup = (row, KV head, 64-position block): the block's scores of the group's query heads on
+ *                       v_mfma_f32_16x16x4_f32 (the heads are the tile's rows; a score is the canonical fma chain over head_dim, * scale),
+ *                       written to a [row][head][position] fp32 buffer;
+ *   k_att_pv_chain      workgroup = one wave = (row, head, class j): row maximum (order-free), e = exp(s - m), then the canonical class
+ *                       chain — positions j, j + 4, ... ascending, acc = fma(e, v, acc), l = l + e — as ONE sequential chain per lane (a lane
+ *                       owns two dims), 32 value rows requested ahead; partial outputs and denominators to a scratch buffer;
+ *   k_att_pv_join       the four classes joined in order, division, Q8 quantisation.
+ * Bit-identical to k_attention / k_attention_narrow (tests/test_llm_attention_gpu.py: the decode cases past 2 048 positions run both).
+ * The session takes this form for passes of <= 32 rows that reach position TK_LONG_ATT_MIN_POS.
+ * ------------------------------------------------------------------------------------------ */
+template <int HD>
+__global__ __launch_bounds__(256) void k_att_scores_long(const float* __restrict__ qbuf, const uint16_t* __restrict__ kcache, const int32_t* __restrict__ seq,
+                                                         const int32_t* __restrict__ pos, int n_head, int n_kv_head, int layer, int max_seq, int max_ctx,
+                                                         float* __restrict__ scores) {
+    constexpr int KCH = HD / 2 + 16, PPR = HD / 8, PIECES = 64 * PPR, PPT = (PIECES + 255) / 256;
+    __shared__ __attribute__((aligned(16))) uint8_t kbuf[64 * 4 * KCH];
+    const int kvh = blockIdx.x, b = blockIdx.y, r = blockIdx.z;
+    const int T = pos[r] + 1;
+    if (64 * b >= T) return; /* the grid covers the whole window: blocks past this row's context leave at once */
+    const int t = threadIdx.x, lane = t & 63, n16 = lane & 15, G = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int GQ = n_head / n_kv_head, QD = n_head * HD;
+    float qa[HD / 4]; /* A operand: tile row = query head of the group (rows GQ .. 15 are zero), lane group G holds dims 4 s + G */
+    {
+        const float* qr = qbuf + (int64_t)r * QD + (kvh * GQ + (n16 < GQ ? n16 : 0)) * HD + G;
+#pragma unroll
+        for (int s = 0; s < HD / 4; ++s) qa[s] = n16 < GQ ? qr[4 * s] : 0.0f;
+    }
+    const uint16_t* krun = kcache + (((int64_t)layer * max_seq + seq[r]) * n_kv_head + kvh) * (int64_t)max_ctx * HD;
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) { /* the block's key rows into B-operand order (k_attention_prefill: put_k) */
+        const int pid = t + u * 256;
+        if (PIECES % 256 == 0 || pid < PIECES) {
+            const int pn = pid / PPR, q8 = pid % PPR;
+            int pr = 64 * b + pn;
+            pr = pr < T ? pr : T - 1;
+            const uint4 kk = *(const uint4*)(krun + (int64_t)pr * HD + 8 * q8);
+            const uint32_t wv[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t lo = (wv[g >> 1] >> (16 * (g & 1))) & 0xffffu, hi = (wv[2 + (g >> 1)] >> (16 * (g & 1))) & 0xffffu;
+                *(uint32_t*)(kbuf + (size_t)(pn * 4 + g) * KCH + 4 * q8) = lo | (hi << 16);
+            }
+        }
+    }
+    __syncthreads();
+    v4f d = {0.0f, 0.0f, 0.0f, 0.0f};
+    const uint8_t* kp = kbuf + (size_t)((16 * w + n16) * 4 + G) * KCH;
+#pragma unroll
+    for (int q = 0; q < HD / 32; ++q) {
+        const uint4 kk = *(const uint4*)(kp + 16 * q);
+        const uint32_t wv[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[8 * q + e], f16bits_to_f32((wv[e >> 1] >> (16 * (e & 1))) & 0xffffu), d, 0, 0, 0);
+    }
+    const int tp = 64 * b + 16 * w + n16;
+    if (G == 0 && tp < T) { /* lane group 0 holds tile rows 0 .. 3 = the group's heads */
+        const float att_scale = tk_divf(1.0f, tk_sqrtf((float)HD));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < GQ) scores[((int64_t)r * n_head + kvh * GQ + i) * max_ctx + tp] = d[i] * att_scale;
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void k_att_pv_chain(const float* __restrict__ scores, const uint16_t* __restrict__ vcache, const int32_t* __restrict__ seq,
+                                                     const int32_t* __restrict__ pos, int n_head, int n_kv_head, int layer, int max_seq, int max_ctx,
+                                                     float* __restrict__ pv_part, float* __restrict__ l_part) {
+    /* one wave = one (row, head, class) chain: 128 x rows workgroups, so the value rows arrive through as many CUs' memory pipes (a CU
+     * pulls ~25 - 40 GB/s: sixteen workgroups of eight chains each — the first form of this launch — took 29 us at 2 048 positions) */
+    const int j = blockIdx.x, head = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
+    const int kvh = head / (n_head / n_kv_head);
+    const int T = pos[r] + 1;
+    const float* s = scores + ((int64_t)r * n_head + head) * max_ctx;
+    const uint16_t* vrun = vcache + (((int64_t)layer * max_seq + seq[r]) * n_kv_head + kvh) * (int64_t)max_ctx * HD;
+    float m = -INFINITY;
+    for (int t0 = 0; t0 < T; t0 += 16 * 64) { /* sixteen loads in flight per lane: a load per iteration would be a chain of cache latencies */
+        float sv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int tt = t0 + 64 * u + lane; sv[u] = tt < T ? s[tt] : -INFINITY; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) m = tk_fmaxf(m, sv[u]);
+    }
+    for (int sft = 32; sft >= 1; sft >>= 1) m = tk_fmaxf(m, wave_xor_f(m, sft));
+    const int nj = T > j ? (T - j + 3) / 4 : 0; /* positions j, j + 4, ... of this class */
+    /* The chain: a lane owns two dims (head_dim 64: the upper half-wave mirrors the lower).  Chunks of 32 class positions, two register
+     * sets: a chunk's value rows are requested a chunk before the chain reaches them; the scores of a chunk are requested two chunks ahead
+     * and BEFORE the value rows of the chunk in between (vmcnt counts in order: waiting for a score requested after 32 row loads would
+     * drain them).  Probabilities reach every lane through LDS broadcast reads issued before the chunk's chain starts.  Measured and
+     * dropped: two rows per request with v_permlane32_swap (64 positions in flight; 19.1 us against 15.8 at 2 048 positions: the swaps and
+     * the four-dim owners' longer steps cost more than the deeper prefetch saves), v_readlane per step (16.7 us). */
+    const int dl = lane % (HD / 2);
+    float acc0 = 0.0f, acc1 = 0.0f, l = 0.0f;
+    uint32_t va[32], vb[32];
+    auto fetch = [&](uint32_t (&v)[32], int c) { /* value rows of class positions 32 c .. 32 c + 31 (clamped: their probability is 0 past the end) */
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            int tt = j + 4 * (32 * c + k);
+            tt = tt < T ? tt : T - 1;
+            v[k] = *(const uint32_t*)(vrun + (int64_t)tt * HD + 2 * dl);
+        }
+    };
+    auto score_of = [&](int c) -> float { /* lane i < 32: score of class position 32 c + i */
+        const int i = 32 * c + (lane & 31);
+        return i < nj ? s[j + 4 * i] : -INFINITY;
+    };
+    auto probs = [&](float sc, int c) -> float { return 32 * c + (lane & 31) < nj ? tk_expf(sc - m) : 0.0f; };
+    __shared__ float ebuf[2][32];
+    int eslot = 0;
+    auto eat = [&](const uint32_t (&v)[32], float e32) {
+        if (lane < 32) ebuf[eslot][lane] = e32;
+        __syncthreads();
+        float ek[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) ek[k] = ebuf[eslot][k];
+        eslot ^= 1;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            acc0 = tk_fmaf(ek[k], f16bits_to_f32(v[k] & 0xffffu), acc0);
+            acc1 = tk_fmaf(ek[k], f16bits_to_f32(v[k] >> 16), acc1);
+            l = l + ek[k];
+        }
+    };
+    const int nch = (nj + 31) / 32;
+    float sa = score_of(0), sb = score_of(1);
+    if (nch > 0) fetch(va, 0);
+    for (int c = 0; c < nch; c += 2) {
+        const float ea = probs(sa, c);
+        sa = score_of(c + 2);
+        fetch(vb, c + 1); /* past the end: clamped rows, probabilities 0 */
+        eat(va, ea);
+        if (c + 1 >= nch) break;
+        const float eb = probs(sb, c + 1);
+        sb = score_of(c + 3);
+        if (c + 2 < nch) fetch(va, c + 2);
+        eat(vb, eb);
+    }
+    float* pp = pv_part + (((int64_t)r * n_head + head) * TK_ATT_TSPLIT + j) * HD;
+    if (lane < HD / 2) { pp[2 * dl] = acc0; pp[2 * dl + 1] = acc1; }
+    if (lane == 0) l_part[((int64_t)r * n_head + head) * TK_ATT_TSPLIT + j] = l;
+}
+
+/* the four classes of every head joined in order, divided, quantised: workgroup = (row, the 256 / head_dim heads of a Q8 block) */
+template <int HD>
+__global__ __launch_bounds__(256) void k_att_pv_join(const float* __restrict__ pv_part, const float* __restrict__ l_part, int n_head, TkActQ8 out) {
+    __shared__ float obuf[256];
+    constexpr int HPB = 256 / HD;
+    const int r = blockIdx.y, t = threadIdx.x;
+    const int head = blockIdx.x * HPB + t / HD, dd = t % HD;
+    const float* pp = pv_part + ((int64_t)r * n_head + head) * TK_ATT_TSPLIT * HD + dd;
+    const float* lp = l_part + ((int64_t)r * n_head + head) * TK_ATT_TSPLIT;
+    const float a = ((pp[0] + pp[HD]) + pp[2 * HD]) + pp[3 * HD];
+    const float ll = ((lp[0] + lp[1]) + lp[2]) + lp[3];
+    obuf[t] = tk_divf(a, ll);
+    __syncthreads();
+    if (t < 32) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = obuf[8 * t + i];
+        quantize_chunk8(v, blockIdx.x * 32 + t, r, out);
+    }
+}
+
+void tk_launch_attention_long(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows, int n_head,
+                              int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, float* scores, TkActQ8 out, hipStream_t s) {
+    const dim3 gs(n_kv_head, (max_ctx + 63) / 64, nrows);
+    /* the scratch buffer: scores, then the classes' partial outputs and denominators (tk_attention_long_scratch_floats) */
+    float* pv_part = scores + (size_t)TK_LONG_ATT_MAX_ROWS * n_head * max_ctx;
+    float* l_part = pv_part + (size_t)TK_LONG_ATT_MAX_ROWS * n_head * TK_ATT_TSPLIT * head_dim;
+    const dim3 gc(TK_ATT_TSPLIT, n_head, nrows);
+    if (head_dim == 128) {
+        hipLaunchKernelGGL((k_att_scores_long<128>), gs, dim3(256), 0, s, qbuf, kcache, seq, pos, n_head, n_kv_head, layer, max_seq, max_ctx, scores);
+        hipLaunchKernelGGL((k_att_pv_chain<128>), gc, dim3(64), 0, s, scores, vcache, seq, pos, n_head, n_kv_head, layer, max_seq, max_ctx, pv_part, l_part);
+        hipLaunchKernelGGL((k_att_pv_join<128>), dim3(n_head / 2, nrows), dim3(256), 0, s, pv_part, l_part, n_head, out);
+    } else {
+        hipLaunchKernelGGL((k_att_scores_long<64>), gs, dim3(256), 0, s, qbuf, kcache, seq, pos, n_head, n_kv_head, layer, max_seq, max_ctx, scores);
+        hipLaunchKernelGGL((k_att_pv_chain<64>), gc, dim3(64), 0, s, scores, vcache, seq, pos, n_head, n_kv_head, layer, max_seq, max_ctx, pv_part, l_part);
+        hipLaunchKernelGGL((k_att_pv_join<64>), dim3(n_head / 4, nrows), dim3(256), 0, s, pv_part, l_part, n_head, out);
+    }
+}
+
+size_t tk_attention_long_scratch_floats(int n_head, int head_dim, int max_ctx) {
+    return (size_t)TK_LONG_ATT_MAX_ROWS * n_head * ((size_t)max_ctx + (size_t)TK_ATT_TSPLIT * head_dim + TK_ATT_TSPLIT);
+}
+
+bool tk_attention_long_applies(int nrows, int n_head, int n_kv_head, int head_dim) {
+    /* TK_MI355X_NO_LONG_ATT=1: decode passes keep the fused kernels whatever the context (A/B timing, parity tests of both) */
+    const char* np = getenv("TK_MI355X_NO_LONG_ATT");
+    if (np && np[0] == '1') return false;
+    if (nrows < 1 || nrows > TK_LONG_ATT_MAX_ROWS || (head_dim != 64 && head_dim != 128)) return false;
+    const int hpb = 256 / head_dim, grp = n_kv_head > 0 ? n_head / n_kv_head : 0;
+    return grp >= 1 && grp <= 4 && grp % hpb == 0 && n_head % hpb == 0;
+}
+
 bool tk_attention_prefill_applies(int n_head, int n_kv_head, int head_dim) {
     /* TK_MI355X_NO_PREFILL_ATT=1: multi-position passes keep k_attention's one-workgroup-per-row form (A/B timing, parity tests of both) */
     const char* np = getenv("TK_MI355X_NO_PREFILL_ATT");

@@ -22,11 +22,15 @@ def lora_probe(path):
     return r.value, a.value, n.value
 
 
-def attention_plan(nrows, n_head, n_kv_head, head_dim, max_ctx, fused=True, device=0):
+def attention_plan(nrows, n_head, n_kv_head, head_dim, max_ctx, fused=True, device=0, top_position=None):
     """the attention launch a pass takes on `device`: (kernel, query heads per workgroup, positions per slot / resident chunk, slots);
-    kernel 0 = k_attention, 1 = k_attention_narrow (tk_mi355x_attention_plan)"""
+    kernel 0 = k_attention, 1 = k_attention_narrow, 2 = k_attention_prefill, 3 = the long-context decode form (tk_mi355x_attention_plan;
+    with top_position — the pass's highest position — tk_mi355x_attention_plan_at: the session's per-pass choice)"""
     out = (C.c_int32 * 4)()
-    check(lib().tk_mi355x_attention_plan(device, nrows, n_head, n_kv_head, head_dim, max_ctx, 1 if fused else 0, out))
+    if top_position is None:
+        check(lib().tk_mi355x_attention_plan(device, nrows, n_head, n_kv_head, head_dim, max_ctx, 1 if fused else 0, out))
+    else:
+        check(lib().tk_mi355x_attention_plan_at(device, nrows, n_head, n_kv_head, head_dim, max_ctx, 1 if fused else 0, int(top_position), out))
     return tuple(out)
 
 
