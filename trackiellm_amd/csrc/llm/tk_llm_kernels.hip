@@ -2458,9 +2458,15 @@ __global__ __launch_bounds__(64) void k_att_pv_chain(const float* __restrict__ s
     const int dl = lane % (HD / 2);
     float acc0 = 0.0f, acc1 = 0.0f, l = 0.0f;
     uint32_t va[32], vb[32];
-    auto fetch = [&](uint32_t (&v)[32], int c) { /* value rows of class positions 32 c .. 32 c + 31 (clamped: their probability is 0 past the end) */
+    auto fetch = [&](uint32_t (&v)[32], int c) { /* value rows of class positions 32 c .. 32 c + 31 */
+        if (32 * c + 32 <= nj) { /* a whole chunk: one base address, rows 4 * head_dim halves apart (two scalar adds per request instead of six) */
+            const uint16_t* base = vrun + (int64_t)(j + 128 * c) * HD + 2 * dl;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
+            for (int k = 0; k < 32; ++k) v[k] = *(const uint32_t*)(base + (int64_t)k * 4 * HD);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { /* the last chunk, or past the end: clamped rows (their probability is 0) */
             int tt = j + 4 * (32 * c + k);
             tt = tt < T ? tt : T - 1;
             v[k] = *(const uint32_t*)(vrun + (int64_t)tt * HD + 2 * dl);
