@@ -19,6 +19,7 @@ What the line carries besides the contract keys (all measured live in this run, 
                       ">= 30 cycles/s at >= 40 % of the HBM roofline" together, reported beside the throughput-optimal headline
   reference_abi_b1    batch 1 through the reference's own entry points only (tk_llm_runner_*, tk_cortex_*)
   prompt_processing   one prompt of 64 / 448 / 2 048 tokens through the session's prefill (time to the first token's logits)
+  long_context_decode one sequence decoding at ~2 100 and ~4 000 cached positions (ms per token)
   reference_abi_batched_cortex   K cortex handles on one model file, one DATA-DEPENDENT cycle each through tk_cortex_* only
   cpu_baseline        one whole fused cycle on the CPU oracle ("port"), at the box's core share and at 1 core
 """
@@ -420,6 +421,24 @@ def prompt_processing(tk, model, lengths=(64, 448, 2048)):
     return out
 
 
+def long_context_decode(tk, model, contexts=(2000, 3900), steps=64):
+    """one sequence with a `ctx`-token prompt, then 2 x `steps` greedy tokens through the device-side loop (the second `steps` timed): decode at
+    the context lengths the reference budgets for (2 048-token prompts in a 4 096-position window: src/cortex/tk_cortex_main.c:1334,
+    src/ai_models/tk_runner_lifecycle.c:48).  From position 640 on a one-row pass runs its attention as scores + PV chains spread over the chip
+    (csrc/llm/tk_llm_kernels.hip: k_att_scores_long / k_att_pv_chain) instead of one latency chain per pair of heads."""
+    hp = model.hparams
+    rng = np.random.default_rng(9)
+    out = []
+    for ctx in contexts:
+        sess = tk.LlmSession(model, 1, ctx + 2 * steps + 8)
+        sess.prefill(rng.integers(3, hp.vocab, (1, ctx)).astype(np.int32))
+        sess.decode(1, steps)
+        _, ms = sess.decode(1, steps)
+        out.append({"positions": [ctx + steps, ctx + 2 * steps], "ms_per_token": round(ms, 3), "tok_per_s": round(1000.0 / ms, 1)})
+        sess.close()
+    return out
+
+
 def reference_abi_batched_cortex(tk, K, N):
     """K cortex handles (tk_cortex_create ... tk_cortex_destroy only) that share one LLM model file, each driven by its own host thread through
     ONE data-dependent cycle of the reference's loop (/root/reference/src/cortex/tk_cortex_main.c:1149-1237, 1323-1379): 1 s of PCM + the
@@ -736,6 +755,7 @@ def main():
         s1.close()
         out["reference_abi_b1"] = reference_abi_b1(tk, hp, N, roof1)
         out["prompt_processing"] = prompt_processing(tk, model)
+        out["long_context_decode"] = long_context_decode(tk, model)
         out["reference_abi_batched"] = [reference_abi_runners(tk, K, N) for K in (16, 64, 256)]
         # the same runners from a C host: the difference is the Python driver (GIL hand-offs between K threads that each make one ctypes call per token)
         out["reference_abi_batched_c_host"] = [reference_abi_runners_c_host(K, N) for K in (16, 256)]
