@@ -192,7 +192,7 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_llm_time_attention(tk_mi355x_llm_s
 TK_API int tk_mi355x_device_cu_count(int device); /* compute units of a HIP device (256 on an MI355X), -1 when there is no such device */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_attention_plan(int device, int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, int fused, int32_t out[4]);
 /* the same for a pass whose highest position is `top_position` (a session picks per pass from the positions it is handed): kernel 3 = the
- * long-context decode form (fused != 0; 1 .. 2 rows from position 640, 3 .. 4 rows from 1 024, 5 .. 8 rows from 1 280: k_qkv_rope_append + k_att_scores_long +
+ * long-context decode form (fused != 0; 1 .. 4 rows from position 512, 5 .. 8 rows from 768: k_att_scores_long +
  * k_att_pv_chain + k_att_pv_join — scores over (row, KV head, 64-position block) workgroups, one PV chain per (row, head, class) wave — instead
  * of one latency chain per pair of heads; $TK_MI355X_NO_LONG_ATT=1 keeps the fused kernels), kernel 2 only from position 128 on.  All forms
  * are bit-identical. */

@@ -119,18 +119,18 @@ def mistral_long(gpu):
     orc.close()
 
 
-@pytest.mark.parametrize("nrows,ctx", [(1, 2048), (16, 2047), (16, 2100), (16, 4000), (32, 2048), (32, 3001), (1, 640), (2, 777), (1, 4094), (4, 2049), (3, 1023),
-                                       (8, 1280), (8, 3001), (5, 1279)])
+@pytest.mark.parametrize("nrows,ctx", [(1, 2048), (16, 2047), (16, 2100), (16, 4000), (32, 2048), (32, 3001), (1, 512), (2, 777), (1, 4094), (4, 2049), (3, 511),
+                                       (8, 768), (8, 3001), (5, 767), (1, 447)])
 def test_decode_attention_past_2048_cached_positions(mistral_long, nrows, ctx, monkeypatch):
-    """a decode step over 640 .. 4094 cached positions inside a 4096-position window, both ways.  The session's choice — 1 .. 2 rows from
-    position 640, 3 .. 4 rows from 1 024, 5 .. 8 rows from 1 280 — is the long-context form (kernel 3: append + scores over (row, KV head, 64-position block)
-    workgroups + one PV chain per (row, head, class) wave + join).  Wider passes, and every pass under TK_MI355X_NO_LONG_ATT=1 (a fresh session:
+    """a decode step over 447 .. 4094 cached positions inside a 4096-position window, both ways.  The session's choice — 1 .. 4 rows from
+    position 512, 5 .. 8 rows from 768 — is the long-context form (kernel 3: q / k / v finishing + scores over (row, KV head,
+    64-position block) workgroups, one PV chain per (row, head, class) wave, join).  Wider passes, and every pass under TK_MI355X_NO_LONG_ATT=1 (a fresh session:
     passes are captured per session), run the fused kernels: the narrow kernel walks the context chunk by chunk (its resident chunk is ~220
     positions at this window: up to eighteen chunks), the ring kernel wraps its two slots 30 to 60 times.  All equal the oracle bit for bit."""
     gpu, model, sess, orc, hp = mistral_long
-    long_form = nrows <= 8 and ctx >= (1280 if nrows > 4 else 1024 if nrows > 2 else 640)
+    long_form = nrows <= 8 and ctx >= (768 if nrows > 4 else 512)
     assert (gpu.attention_plan(nrows, hp.n_head, hp.n_kv_head, hp.head_dim, LONG_CTX, True, top_position=ctx)[0] == 3) == long_form
-    assert gpu.attention_plan(nrows, hp.n_head, hp.n_kv_head, hp.head_dim, LONG_CTX, True, top_position=639)[0] != 3
+    assert gpu.attention_plan(nrows, hp.n_head, hp.n_kv_head, hp.head_dim, LONG_CTX, True, top_position=511)[0] != 3
     decode_step_case(gpu, sess, orc, hp, nrows, ctx, LONG_CTX, 7000 * nrows + ctx)
     if not long_form or (ctx % 2 == 0 and ctx != 2048):
         return                                                       # the fused kernels' share: wide passes, the odd contexts and the 2048 cases

@@ -1118,20 +1118,20 @@ def test_lora_merge_at_mistral_geometry_bit_exact(gpu, tmp_path):
 
 def test_tiny_long_context_decode_head_dim_64(gpu):
     """the long-context decode form at head_dim 64 (scores per 64-position block on the matrix pipe, one PV chain per (row, head, class) wave):
-    three sequences prefilled to 1030 / 1101 / 1050 positions through prompt chunks, then decode rows at those positions, alone (one row: the
-    form from position 640) and together (three rows: from 1 024), logits = oracle; and a short device-side decode loop that crosses the
-    one-row switch position (636 .. 643) gives the oracle's ids"""
+    three sequences prefilled to 530 / 601 / 550 positions through prompt chunks, then decode rows at those positions, alone and together (one to
+    four rows: the form from position 512), logits = oracle; and a short device-side decode loop that crosses the switch position
+    (508 .. 515) gives the oracle's ids"""
     hp = gpu.TINY()
     model = gpu.LlmModel(hp)
     hp = model.hparams
-    assert gpu.attention_plan(3, hp.n_head, hp.n_kv_head, hp.head_dim, 1536, True, top_position=1101)[0] == 3
-    assert gpu.attention_plan(3, hp.n_head, hp.n_kv_head, hp.head_dim, 1536, True, top_position=801)[0] != 3
-    assert gpu.attention_plan(1, hp.n_head, hp.n_kv_head, hp.head_dim, 1536, True, top_position=801)[0] == 3
-    orc = O.OracleLlm(oracle_cfg_from(hp, 1536, 4), seed=4)
+    assert gpu.attention_plan(3, hp.n_head, hp.n_kv_head, hp.head_dim, 768, True, top_position=601)[0] == 3
+    assert gpu.attention_plan(3, hp.n_head, hp.n_kv_head, hp.head_dim, 768, True, top_position=500)[0] != 3
+    assert gpu.attention_plan(1, hp.n_head, hp.n_kv_head, hp.head_dim, 768, True, top_position=512)[0] == 3
+    orc = O.OracleLlm(oracle_cfg_from(hp, 768, 4), seed=4)
     copy_oracle_weights(orc, model, hp.n_layer)
-    sess = gpu.LlmSession(model, 4, 1536)
+    sess = gpu.LlmSession(model, 4, 768)
     rng = np.random.default_rng(43)
-    lens = {0: 1030, 1: 1101, 2: 1050, 3: 636}
+    lens = {0: 530, 1: 601, 2: 550, 3: 508}
     for sq, n in lens.items():
         tok = rng.integers(3, hp.vocab, n).astype(np.int32)
         for lo in range(0, n, 256):
@@ -1149,15 +1149,15 @@ def test_tiny_long_context_decode_head_dim_64(gpu):
         assert np.array_equal(gam, wam)
         for r in rows:
             lens[r] += 1
-    # sequence 3 alone through the device-side loop: positions 636 .. 643 cross the 640 switch inside one decode() call
+    # sequence 3 alone through the device-side loop: positions 508 .. 515 cross the 512 switch inside one decode() call
     tok = rng.integers(3, hp.vocab, 1).astype(np.int32)
-    _, am = orc.forward([3], [636], tok, want_logits=False)
-    _, gam = sess.forward([3], [636], tok, want_logits=False)
+    _, am = orc.forward([3], [508], tok, want_logits=False)
+    _, gam = sess.forward([3], [508], tok, want_logits=False)
     assert np.array_equal(am, gam)
     want = []
     cur = int(am[0])
     for i in range(7):
-        _, am = orc.forward([3], [637 + i], [cur], want_logits=False)
+        _, am = orc.forward([3], [509 + i], [cur], want_logits=False)
         cur = int(am[0])
         want.append(cur)
     toks, _ = sess.decode(1, 7)

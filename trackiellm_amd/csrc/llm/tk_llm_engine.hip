@@ -436,10 +436,10 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         const TkDevTensor* dn[1] = {&L.down};
         if (fuse) {
             const int ks_qkv = fused_gemv(qkv, 3, D, h.ks_qkv, QD + 2 * KVD, partial2, 1, x, x2, l == l0 ? nullptr : partial, ks_res, D, (const float*)L.attn_norm.data);
-            if (!fused_attn || long_attn)
+            if (!fused_attn)
                 tk_launch_qkv_rope_append(partial2, ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
                                           qbuf, kcache, vcache, l, max_seq, max_ctx, s);
-            if (long_attn) tk_launch_attention_long(qbuf, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, d_scores, act_qd, s);
+            if (long_attn) tk_launch_attention_long(partial2, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, d_scores, act_qd, s);
             else if (tiled_attn) tk_launch_attention_prefill(qbuf, kcache, vcache, d_seq, d_pos, d_tiles, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
             else tk_launch_attention(qbuf, partial2, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
                                      h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
@@ -450,10 +450,10 @@ void TkLlmSession::enqueue_range(int nrows, int l0, int l1, bool embed, bool fol
         }
         tk_launch_rmsnorm_q8(x, l == l0 ? nullptr : partial, ks_res, D, (const float*)L.attn_norm.data, h.rms_eps, D, nrows, act_d, s);
         const int ks_qkv = enqueue_matmul(qkv, 3, D, h.ks_qkv, QD + 2 * KVD, act_d, partial, nrows);
-        if (!fused_attn || long_attn)
+        if (!fused_attn)
             tk_launch_qkv_rope_append(partial, ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows,
                                       qbuf, kcache, vcache, l, max_seq, max_ctx, s);
-        if (long_attn) tk_launch_attention_long(qbuf, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, d_scores, act_qd, s);
+        if (long_attn) tk_launch_attention_long(partial, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, d_scores, act_qd, s);
         else if (tiled_attn) tk_launch_attention_prefill(qbuf, kcache, vcache, d_seq, d_pos, d_tiles, nrows, h.n_head, h.n_kv_head, h.head_dim, l, max_seq, max_ctx, act_qd, s);
         else tk_launch_attention(qbuf, partial, ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head,
                                  h.head_dim, l, max_seq, max_ctx, act_qd, fused_attn, s);
@@ -825,9 +825,8 @@ bool TkLlmSession::time_attention(int nrows, int ctx, int iters, float* avg_ms, 
     const bool unfused = (uf && uf[0] == '1') || longf;
     auto launch = [&](int l) {
         if (longf) {
-            tk_launch_qkv_rope_append(partial, h.ks_qkv, QD + 2 * KVD, h.n_head, h.n_kv_head, h.head_dim, rope_cos, rope_sin, d_seq, d_pos, nrows, qbuf, kcache,
-                                      vcache, l % h.n_layer, max_seq, max_ctx, stream);
-            tk_launch_attention_long(qbuf, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l % h.n_layer, max_seq, max_ctx, d_scores, act_qd, stream);
+            tk_launch_attention_long(partial, h.ks_qkv, QD + 2 * KVD, rope_cos, rope_sin, kcache, vcache, d_seq, d_pos, nrows, h.n_head, h.n_kv_head, h.head_dim, l % h.n_layer,
+                                     max_seq, max_ctx, d_scores, act_qd, stream);
             return;
         }
         if (unfused)

@@ -107,17 +107,18 @@ void tk_launch_attention_prefill(const float* qbuf, const uint16_t* kcache, cons
                                  const int32_t* tiles, int nrows, int n_head, int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, TkActQ8 out,
                                  hipStream_t s);
 /* decode passes of few rows over long contexts: scores spread over (row, KV head, 64-position block) workgroups, then one sequential PV chain per
- * (row, head, class) wave — bit-identical to the fused kernels.  scores: tk_attention_long_scratch_floats() floats; the cache must already hold the pass's own
- * K / V rows and qbuf its rotated queries (tk_launch_qkv_rope_append) */
-/* by measurement (profiles/r05_attention_long_ctx.txt): 1 .. 2 rows from position 640, 3 .. 4 rows from 1 024, 5 .. 8 rows from 1 280; at 16 rows
- * the fused kernels' 256 workgroups already cover the chip */
+ * (row, head, class) wave — bit-identical to the fused kernels.  scores: tk_attention_long_scratch_floats() floats; `partial` holds the
+ * q | k | v projection's K-split slabs (the launch finishes q / k / v itself and appends this pass's rows to the cache) */
+/* by measurement, end to end (profiles/r05_attention_long_ctx.txt): 1 .. 4 rows from position 512, 5 .. 8 rows from 768 (the isolated launch
+ * already wins from ~384 at one row; a whole step does not before ~500); at 16 rows the fused kernels' 256 workgroups already cover the chip */
 #define TK_LONG_ATT_MAX_ROWS 8
-#define TK_LONG_ATT_MIN_POS 640
-static inline int tk_long_att_min_pos(int nrows) { return nrows > 4 ? 1280 : nrows > 2 ? 1024 : TK_LONG_ATT_MIN_POS; }
+#define TK_LONG_ATT_MIN_POS 512
+static inline int tk_long_att_min_pos(int nrows) { return nrows > 4 ? 768 : TK_LONG_ATT_MIN_POS; }
 bool tk_attention_long_applies(int nrows, int n_head, int n_kv_head, int head_dim);
 size_t tk_attention_long_scratch_floats(int n_head, int head_dim, int max_ctx); /* floats of the `scores` scratch buffer */
-void tk_launch_attention_long(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows, int n_head,
-                              int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, float* scores, TkActQ8 out, hipStream_t s);
+void tk_launch_attention_long(const float* partial, int ks, int n_total, const float* rope_cos, const float* rope_sin, uint16_t* kcache, uint16_t* vcache,
+                              const int32_t* seq, const int32_t* pos, int nrows, int n_head, int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx,
+                              float* scores, TkActQ8 out, hipStream_t s);
 size_t tk_gemv_lds_bytes(int K, int ks, int mtiles);
 /* dynamic LDS of one k_attention workgroup; must stay below 160 KiB (the session checks it against its max_ctx) */
 size_t tk_attention_lds_bytes(int gq, int head_dim, int max_ctx, int chunk /* positions per ring slot: 32 or 64 */, int slots = 2 /* ring depth: 2 or 5 */);

@@ -2362,8 +2362,9 @@ __global__ __launch_bounds__((256 / HD) * 256) void k_attention_prefill(const fl
  * one workgroup per pair of heads — ten to eighteen barrier-separated DMA round trips at 2 048 .. 4 000 positions: 51 / 96 us per layer at one
  * row (164 GB/s: a latency chain), as much as the whole step's mat-vec launches.  Here the same arithmetic is spread over the chip in three
  * launches, none of which waits on a chunk loop:
- *   k_qkv_rope_append   q / k / v of the pass's rows (K-split sums, RoPE, f16 rounding, cache append), as for multi-position passes;
- *   k_att_scores_long   workgroup = (row, KV head, 64-position block): the block's scores of the group's query heads on
+ *   k_att_scores_long   workgroup = (row, KV head, 64-position block): first the group's queries (K-split sums, RoPE) and — in the
+ *                       context's last block — this row's own key and value (f16 rounding, cache append, the key patched into the staged
+ *                       block from LDS): k_qkv_rope_append's arithmetic; then the block's scores of the group's query heads on
  *                       v_mfma_f32_16x16x4_f32 (the heads are the tile's rows; a score is the canonical fma chain over head_dim, * scale),
  *                       written to a [row][head][position] fp32 buffer;
  *   k_att_pv_chain      workgroup = one wave = (row, head, class j): row maximum (order-free), e = exp(s - m), then the canonical class
@@ -2371,34 +2372,53 @@ __global__ __launch_bounds__((256 / HD) * 256) void k_attention_prefill(const fl
  *                       owns two dims), 32 value rows requested ahead; partial outputs and denominators to a scratch buffer;
  *   k_att_pv_join       the four classes joined in order, division, Q8 quantisation.
  * Bit-identical to k_attention / k_attention_narrow (tests/test_llm_attention_gpu.py: the decode cases past 2 048 positions run both).
- * The session takes this form for passes of <= 32 rows that reach position TK_LONG_ATT_MIN_POS.
+ * The session takes this form for passes of at most TK_LONG_ATT_MAX_ROWS rows that reach tk_long_att_min_pos(rows) (tk_llm_kernels.h).
  * ------------------------------------------------------------------------------------------ */
 template <int HD>
-__global__ __launch_bounds__(256) void k_att_scores_long(const float* __restrict__ qbuf, const uint16_t* __restrict__ kcache, const int32_t* __restrict__ seq,
-                                                         const int32_t* __restrict__ pos, int n_head, int n_kv_head, int layer, int max_seq, int max_ctx,
-                                                         float* __restrict__ scores) {
-    constexpr int KCH = HD / 2 + 16, PPR = HD / 8, PIECES = 64 * PPR, PPT = (PIECES + 255) / 256;
+__global__ __launch_bounds__(256) void k_att_scores_long(const float* __restrict__ partial, int ks, int n_total, const float* __restrict__ rope_cos,
+                                                         const float* __restrict__ rope_sin, uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache,
+                                                         const int32_t* __restrict__ seq, const int32_t* __restrict__ pos, int n_head, int n_kv_head, int layer,
+                                                         int max_seq, int max_ctx, float* __restrict__ scores) {
+    constexpr int KCH = HD / 2 + 16, PPR = HD / 8, PIECES = 64 * PPR, PPT = (PIECES + 255) / 256, HALF = HD / 2;
     __shared__ __attribute__((aligned(16))) uint8_t kbuf[64 * 4 * KCH];
+    __shared__ float qs[4 * HD];      /* the group's rotated queries */
+    __shared__ uint16_t own_k[HD];    /* this row's own key (the workgroup of the context's last block appends it, and the value) */
     const int kvh = blockIdx.x, b = blockIdx.y, r = blockIdx.z;
-    const int T = pos[r] + 1;
+    const int p = pos[r], T = p + 1;
     if (64 * b >= T) return; /* the grid covers the whole window: blocks past this row's context leave at once */
     const int t = threadIdx.x, lane = t & 63, n16 = lane & 15, G = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int GQ = n_head / n_kv_head, QD = n_head * HD;
-    float qa[HD / 4]; /* A operand: tile row = query head of the group (rows GQ .. 15 are zero), lane group G holds dims 4 s + G */
-    {
-        const float* qr = qbuf + (int64_t)r * QD + (kvh * GQ + (n16 < GQ ? n16 : 0)) * HD + G;
-#pragma unroll
-        for (int s = 0; s < HD / 4; ++s) qa[s] = n16 < GQ ? qr[4 * s] : 0.0f;
+    const int GQ = n_head / n_kv_head, QD = n_head * HD, KVD = n_kv_head * HD;
+    const bool last = 64 * b + 64 >= T; /* this block holds position p */
+    uint16_t* krun = kcache + (((int64_t)layer * max_seq + seq[r]) * n_kv_head + kvh) * (int64_t)max_ctx * HD;
+    {   /* q (every block) and k, v of this row (the last block): K-split sums, RoPE on adjacent pairs, f16 rounding — k_qkv_rope_append's
+         * arithmetic, inside this launch (a launch of its own cost 4.8 us per layer) */
+        const float* cs = rope_cos + (int64_t)p * HALF;
+        const float* sn = rope_sin + (int64_t)p * HALF;
+        for (int idx = t; idx < (GQ + (last ? 2 : 0)) * HALF; idx += 256) {
+            const int hsel = idx / HALF, i = idx % HALF;
+            const int col = hsel < GQ ? (kvh * GQ + hsel) * HD + 2 * i : (hsel == GQ ? QD : QD + KVD) + kvh * HD + 2 * i;
+            const float a = sum_partials(partial, ks, n_total, r, col), bb = sum_partials(partial, ks, n_total, r, col + 1);
+            if (hsel < GQ) {
+                qs[hsel * HD + 2 * i] = tk_fmaf(-bb, sn[i], a * cs[i]);
+                qs[hsel * HD + 2 * i + 1] = tk_fmaf(a, sn[i], bb * cs[i]);
+            } else if (hsel == GQ) {
+                const uint16_t k0 = tk_f32_to_f16(tk_fmaf(-bb, sn[i], a * cs[i])), k1 = tk_f32_to_f16(tk_fmaf(a, sn[i], bb * cs[i]));
+                own_k[2 * i] = k0; own_k[2 * i + 1] = k1;
+                *(uint32_t*)(krun + (int64_t)p * HD + 2 * i) = (uint32_t)k0 | ((uint32_t)k1 << 16);
+            } else {
+                uint16_t* vrow = vcache + (((int64_t)layer * max_seq + seq[r]) * n_kv_head + kvh) * (int64_t)max_ctx * HD + (int64_t)p * HD;
+                *(uint32_t*)(vrow + 2 * i) = (uint32_t)tk_f32_to_f16(a) | ((uint32_t)tk_f32_to_f16(bb) << 16);
+            }
+        }
     }
-    const uint16_t* krun = kcache + (((int64_t)layer * max_seq + seq[r]) * n_kv_head + kvh) * (int64_t)max_ctx * HD;
 #pragma unroll
     for (int u = 0; u < PPT; ++u) { /* the block's key rows into B-operand order (k_attention_prefill: put_k) */
         const int pid = t + u * 256;
         if (PIECES % 256 == 0 || pid < PIECES) {
             const int pn = pid / PPR, q8 = pid % PPR;
             int pr = 64 * b + pn;
-            pr = pr < T ? pr : T - 1;
+            pr = pr < p ? pr : (p > 0 ? p - 1 : 0); /* cached rows only: position p itself is patched in from LDS below (its store may still be on its way) */
             const uint4 kk = *(const uint4*)(krun + (int64_t)pr * HD + 8 * q8);
             const uint32_t wv[4] = {kk.x, kk.y, kk.z, kk.w};
 #pragma unroll
@@ -2408,7 +2428,15 @@ __global__ __launch_bounds__(256) void k_att_scores_long(const float* __restrict
             }
         }
     }
-    __syncthreads();
+    __syncthreads(); /* the staged block, qs and own_k are written */
+    if (last && t < HD) { /* this row's own key into its slot of the block: dim t = 8 q8 + e sits at group e & 3, step 2 q8 + (e >> 2) */
+        const int pn = p - 64 * b, q8 = t >> 3, e = t & 7;
+        *(uint16_t*)(kbuf + (size_t)(pn * 4 + (e & 3)) * KCH + 2 * (2 * q8 + (e >> 2))) = own_k[t];
+    }
+    float qa[HD / 4]; /* A operand: tile row = query head of the group (rows GQ .. 15 are zero), lane group G holds dims 4 s + G */
+#pragma unroll
+    for (int s = 0; s < HD / 4; ++s) qa[s] = n16 < GQ ? qs[n16 * HD + 4 * s + G] : 0.0f;
+    if (last) __syncthreads();
     v4f d = {0.0f, 0.0f, 0.0f, 0.0f};
     const uint8_t* kp = kbuf + (size_t)((16 * w + n16) * 4 + G) * KCH;
 #pragma unroll
@@ -2533,19 +2561,22 @@ __global__ __launch_bounds__(256) void k_att_pv_join(const float* __restrict__ p
     }
 }
 
-void tk_launch_attention_long(const float* qbuf, const uint16_t* kcache, const uint16_t* vcache, const int32_t* seq, const int32_t* pos, int nrows, int n_head,
-                              int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx, float* scores, TkActQ8 out, hipStream_t s) {
+void tk_launch_attention_long(const float* partial, int ks, int n_total, const float* rope_cos, const float* rope_sin, uint16_t* kcache, uint16_t* vcache,
+                              const int32_t* seq, const int32_t* pos, int nrows, int n_head, int n_kv_head, int head_dim, int layer, int max_seq, int max_ctx,
+                              float* scores, TkActQ8 out, hipStream_t s) {
     const dim3 gs(n_kv_head, (max_ctx + 63) / 64, nrows);
     /* the scratch buffer: scores, then the classes' partial outputs and denominators (tk_attention_long_scratch_floats) */
     float* pv_part = scores + (size_t)TK_LONG_ATT_MAX_ROWS * n_head * max_ctx;
     float* l_part = pv_part + (size_t)TK_LONG_ATT_MAX_ROWS * n_head * TK_ATT_TSPLIT * head_dim;
     const dim3 gc(TK_ATT_TSPLIT, n_head, nrows);
     if (head_dim == 128) {
-        hipLaunchKernelGGL((k_att_scores_long<128>), gs, dim3(256), 0, s, qbuf, kcache, seq, pos, n_head, n_kv_head, layer, max_seq, max_ctx, scores);
+        hipLaunchKernelGGL((k_att_scores_long<128>), gs, dim3(256), 0, s, partial, ks, n_total, rope_cos, rope_sin, kcache, vcache, seq, pos, n_head, n_kv_head, layer,
+                           max_seq, max_ctx, scores);
         hipLaunchKernelGGL((k_att_pv_chain<128>), gc, dim3(64), 0, s, scores, vcache, seq, pos, n_head, n_kv_head, layer, max_seq, max_ctx, pv_part, l_part);
         hipLaunchKernelGGL((k_att_pv_join<128>), dim3(n_head / 2, nrows), dim3(256), 0, s, pv_part, l_part, n_head, out);
     } else {
-        hipLaunchKernelGGL((k_att_scores_long<64>), gs, dim3(256), 0, s, qbuf, kcache, seq, pos, n_head, n_kv_head, layer, max_seq, max_ctx, scores);
+        hipLaunchKernelGGL((k_att_scores_long<64>), gs, dim3(256), 0, s, partial, ks, n_total, rope_cos, rope_sin, kcache, vcache, seq, pos, n_head, n_kv_head, layer,
+                           max_seq, max_ctx, scores);
         hipLaunchKernelGGL((k_att_pv_chain<64>), gc, dim3(64), 0, s, scores, vcache, seq, pos, n_head, n_kv_head, layer, max_seq, max_ctx, pv_part, l_part);
         hipLaunchKernelGGL((k_att_pv_join<64>), dim3(n_head / 4, nrows), dim3(256), 0, s, pv_part, l_part, n_head, out);
     }
