@@ -1165,3 +1165,40 @@ def test_tiny_long_context_decode_head_dim_64(gpu):
     sess.close()
     model.close()
     orc.close()
+
+
+def test_runner_long_prompt_through_the_reference_surface(gpu):
+    """tk_llm_runner_prepare_generation with a 700-byte prompt (701 tokens: prompt chunks of 256 rows through k_attention_prefill) and
+    tk_llm_runner_generate_next_token past position 701 (one-row passes in the long-context decode form), behind the batcher: every id the
+    oracle's"""
+    loader = gpu.ModelLoader()
+    h = loader.load("synthetic://tiny?seed=4")
+    hp = gpu.LlmHParams()
+    gpu.lib().tk_mi355x_llm_model_get_hparams(h, __import__("ctypes").byref(hp))
+    assert gpu.attention_plan(1, hp.n_head, hp.n_kv_head, hp.head_dim, 1024, True, top_position=701)[0] == 3
+    runner = gpu.LlmRunner(h, context_size=1024)
+    text = "".join(chr(97 + (i * 7) % 26) for i in range(700))
+    runner.prepare(text)
+    pieces = []
+    for _ in range(10):
+        p = runner.next_token()
+        if p is None:
+            break
+        pieces.append(p)
+    orc = O.OracleLlm(oracle_cfg_from(hp, 1024, 1), seed=4)
+    ids = [1] + [3 + ord(ch) for ch in text]
+    am = None
+    for lo in range(0, len(ids), 256):
+        hi = min(len(ids), lo + 256)
+        _, am = orc.forward(np.zeros(hi - lo, np.int32), np.arange(lo, hi, dtype=np.int32), ids[lo:hi], want_logits=False)
+    cur, want = int(am[-1]), []
+    for i in range(len(pieces)):
+        want.append(cur)
+        _, am = orc.forward([0], [len(ids) + i], [cur], want_logits=False)
+        cur = int(am[0])
+    got = [3 + p[0] if len(p) == 1 else int(p.decode().strip()[1:]) for p in pieces]
+    assert len(pieces) >= 4 and got == want
+    runner.close()
+    loader.unload(h)
+    loader.close()
+    orc.close()
