@@ -1116,7 +1116,8 @@ def test_lora_merge_at_mistral_geometry_bit_exact(gpu, tmp_path):
     base.close()
 
 
-def test_tiny_long_context_decode_head_dim_64(gpu):
+@pytest.mark.parametrize("f16", [False, True])
+def test_tiny_long_context_decode_head_dim_64(gpu, f16):
     """the long-context decode form at head_dim 64 (scores per 64-position block on the matrix pipe, one PV chain per (row, head, class) wave):
     three sequences prefilled to 530 / 601 / 550 positions through prompt chunks, then decode rows at those positions, alone and together (one to
     four rows: the form from position 512), logits = oracle; and a short device-side decode loop that crosses the switch position
@@ -1127,7 +1128,7 @@ def test_tiny_long_context_decode_head_dim_64(gpu):
     assert gpu.attention_plan(3, hp.n_head, hp.n_kv_head, hp.head_dim, 768, True, top_position=601)[0] == 3
     assert gpu.attention_plan(3, hp.n_head, hp.n_kv_head, hp.head_dim, 768, True, top_position=500)[0] != 3
     assert gpu.attention_plan(1, hp.n_head, hp.n_kv_head, hp.head_dim, 768, True, top_position=512)[0] == 3
-    orc = O.OracleLlm(oracle_cfg_from(hp, 768, 4), seed=4)
+    orc = O.OracleLlm(oracle_cfg_from(hp, 768, 4), seed=4, f16=f16)   # f16: the fp16 checkpoint recipe (the attention output also feeds the tiled GEMM's f16-rounded image)
     copy_oracle_weights(orc, model, hp.n_layer)
     sess = gpu.LlmSession(model, 4, 768)
     rng = np.random.default_rng(43)
