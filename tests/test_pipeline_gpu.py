@@ -185,6 +185,36 @@ def test_second_generation_on_the_same_pipes_takes_fresh_ids(gpu):
         s.close()
 
 
+def test_ten_generations_on_one_set_of_pipes(gpu):
+    """the id-mailbox bookkeeping is stage 0's alone — on the other stages the count of outstanding sampled ids only
+    ever grew, and the 8th prompt's sampling pass of a long-lived pipe was refused there while stage 0 carried on and then timed out.  Ten
+    generations on one connect_local set of three stages, each compared with a single session."""
+    hp = gpu.TINY()
+    hp.n_layer = 3
+    model = gpu.LlmModel(hp).fill_synthetic(37)
+    hp = model.hparams
+    sess = [gpu.LlmSession(model, 2, 40) for _ in range(3)]
+    pipes = [gpu.LlmPipe(sess[s], s, 3, s, s + 1) for s in range(3)]
+    for s in range(3):
+        pipes[s].connect_local(pipes[(s + 1) % 3], pipes[(s - 1) % 3])
+    rng = np.random.default_rng(12)
+    for gen in range(10):
+        n_prompt, n_dec = 3 + gen % 4, 2 + gen % 3
+        prompts = rng.integers(3, hp.vocab, (2, n_prompt)).astype(np.int32)
+        for s in range(3):
+            _drive_stage(pipes[s], prompts, n_dec, rows_per_pass=4)
+        fed = pipes[0].sync(2, n_dec)
+        pipes[1].sync(2, 0)
+        sampled = pipes[2].sync(2, n_dec)
+        want = _single_session_reference(gpu, model, [prompts], n_dec + 1)[0]
+        assert np.array_equal(sampled, want[1:n_dec + 1]), "generation %d: samples differ from a single session's" % gen
+        assert np.array_equal(fed, want[:n_dec]), "generation %d: stage 0 fed stale ids" % gen
+    for p in pipes:
+        p.close()
+    for s in sess:
+        s.close()
+
+
 @pytest.mark.timeout(120)
 def test_pipe_wait_is_bounded_fails_fast_and_stays_failed(gpu, monkeypatch):
     """a stage whose producer never publishes must not hang: the first device-side wait gives up after the pipe's timeout

@@ -2626,6 +2626,10 @@ static size_t tk_attention_narrow_fixed_lds(int max_ctx) { /* everything but the
 static int tk_attention_narrow_cap(int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, bool fused) {
     const int grp = n_kv_head > 0 ? n_head / n_kv_head : 0;
     if (!fused || head_dim != 128 || (grp != 2 && grp != 4) || (n_head / 2) * nrows > TK_NUM_CU) return 0;
+    /* TK_MI355X_NO_NARROW_ATT=1: narrow passes keep k_attention's ring form (A/B timing: a narrow workgroup takes a whole CU — 16 waves and
+     * most of its LDS — so it cannot share the CU with another stream's mat-vec workgroups) */
+    const char* nn = getenv("TK_MI355X_NO_NARROW_ATT");
+    if (nn && nn[0] == '1') return 0;
     const size_t fixed = tk_attention_narrow_fixed_lds(max_ctx);
     if (fixed + 64 * 512 > (size_t)TK_MAX_DYN_LDS) return 0;
     int cap = (int)(((size_t)TK_MAX_DYN_LDS - fixed) / 512);

@@ -140,7 +140,8 @@ private:
     int ids_outstanding_ = 0;          /* id messages the last stage has been asked to send minus those stage 0 has been asked to take */
     int32_t* h_rows_ = nullptr;        /* pinned staging ring for (seq, pos, tok) of host-described passes */
     int h_next_ = 0;
-    hipGraphExec_t graph_[TK_MAX_ROWS + 1] = {};
+    hipGraphExec_t graph_[2][TK_MAX_ROWS + 1] = {}; /* [long-context attention form][row count] */
+    int host_top_ = 0;                 /* highest position of the rows decode() continues (host-side count; the device advances its own) */
     void* rccl_comm_ = nullptr;        /* ncclComm_t when the RCCL transport is selected */
     int32_t* rccl_scratch_ = nullptr;  /* [TK_MAX_ROWS] ids of a drained message */
     std::deque<int> id_msg_rows_;      /* RCCL transport, stage 0: row counts of the id messages not yet received (sends and receives must pair) */

@@ -217,6 +217,24 @@ struct RcclApi {
     std::string why;
 };
 enum { TK_NCCL_INT32 = 2, TK_NCCL_FLOAT32 = 7 }; /* ncclDataType_t (rccl.h: ncclInt32 = 2, ncclFloat32 = 7) */
+}  // namespace
+/* the prototypes and constants above are restated by hand so that the library does not LINK librccl; where the header is installed they
+ * are checked against it at build time (a mismatch would corrupt data or hang silently at run time) */
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#include <type_traits>
+static_assert(NCCL_UNIQUE_ID_BYTES == 128 && sizeof(ncclUniqueId) == sizeof(tk_nccl_id), "ncclUniqueId is not 128 opaque bytes");
+static_assert((int)ncclInt32 == TK_NCCL_INT32 && (int)ncclFloat32 == TK_NCCL_FLOAT32, "ncclDataType_t values moved");
+static_assert(sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) && (int)ncclSuccess == 0, "nccl enums are not int-sized / ncclSuccess != 0");
+static_assert(std::is_same<decltype(&ncclGetUniqueId), ncclResult_t (*)(ncclUniqueId*)>::value, "ncclGetUniqueId prototype");
+static_assert(std::is_same<decltype(&ncclCommInitRank), ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>::value, "ncclCommInitRank prototype");
+static_assert(std::is_same<decltype(&ncclCommDestroy), ncclResult_t (*)(ncclComm_t)>::value, "ncclCommDestroy prototype");
+static_assert(std::is_same<decltype(&ncclSend), ncclResult_t (*)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>::value, "ncclSend prototype");
+static_assert(std::is_same<decltype(&ncclRecv), ncclResult_t (*)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>::value, "ncclRecv prototype");
+static_assert(std::is_same<decltype(&ncclGetErrorString), const char* (*)(ncclResult_t)>::value, "ncclGetErrorString prototype");
+static_assert(std::is_pointer<ncclComm_t>::value, "ncclComm_t is not a pointer");
+#endif
+namespace {
 RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
@@ -279,7 +297,7 @@ static const char* const kFailedMsg =
 TkLlmPipe::~TkLlmPipe() {
     if (s_ && s_->model) (void)hipSetDevice(s_->model->device);
     if (s_ && s_->stream) (void)hipStreamSynchronize(s_->stream);
-    for (auto& g : graph_) if (g) (void)hipGraphExecDestroy(g);
+    for (auto& gs : graph_) for (auto& g : gs) if (g) (void)hipGraphExecDestroy(g);
     if (next_ && next_ipc_) (void)hipIpcCloseMemHandle(next_);
     if (prev_ && prev_ipc_ && prev_ != next_) (void)hipIpcCloseMemHandle(prev_);
     if (rccl_comm_) (void)rccl().CommDestroy(rccl_comm_);
@@ -459,14 +477,19 @@ bool TkLlmPipe::pass(int nrows, const int32_t* seq, const int32_t* pos, const in
     /* the id FIFO has TK_PIPE_SLOTS slots and stage 0 only returns credits when it takes a message: more sampling passes than that without a
      * take in between would park the last stage on credits until the next generation's drain.  One row group per pipe (LibPipeline, bench.py)
      * keeps at most two outstanding; a host that interleaves many sampled prompts on one pipe is told so instead of being slowed silently. */
-    if (head && n_stages > 1 && !take && ids_outstanding_ >= TK_PIPE_SLOTS - 1) {
+    /* the count is stage 0's: it is the only stage that takes or drains, so only there does the number mean anything (on the other stages it
+     * would grow by one per generation and refuse the 8th prompt of a long-lived pipe) */
+    if (stage == 0 && head && n_stages > 1 && !take && ids_outstanding_ >= TK_PIPE_SLOTS - 1) {
         error = "more than " + std::to_string(TK_PIPE_SLOTS - 1) + " sampled ids are waiting in the id mailbox: decode (or feed host tokens) before sampling further prompts on this pipe";
         return false;
     }
     if (take) { --ids_outstanding_; if (rccl_comm_ && !id_msg_rows_.empty()) id_msg_rows_.pop_front(); }
-    if (head && n_stages > 1) { ++ids_outstanding_; if (rccl_comm_ && stage == 0) id_msg_rows_.push_back(nrows); }
+    if (stage == 0 && head && n_stages > 1) { ++ids_outstanding_; if (rccl_comm_) id_msg_rows_.push_back(nrows); }
     /* host-described passes go eagerly (their row tables differ); distinct rows take the fused-attention form, as forward() does */
     s_->choose_attention(pos, nrows);
+    host_top_ = 0; /* where decode() continues from: the rows' positions advance on the device after a sampling pass */
+    for (int r = 0; r < nrows; ++r) host_top_ = pos[r] > host_top_ ? pos[r] : host_top_;
+    if (head) ++host_top_;
     enqueue_stage(nrows, take, head, head, distinct);
     if (!s_->launch_error.empty()) { error = s_->launch_error; return false; }
     PQ(hipGetLastError());
@@ -483,7 +506,10 @@ bool TkLlmPipe::decode(int nrows, int n_steps) {
     PQ(hipMemsetAsync(s_->d_nsteps, 0, TK_MAX_ROWS * 4, s_->stream));
     const char* ng = getenv("TK_MI355X_NO_GRAPH");
     const bool use_graph = !(ng && ng[0] == '1') && !rccl_comm_; /* collective calls are launched eagerly */
-    if (use_graph && !graph_[nrows]) {
+    /* the attention form (fused / long-context three-launch form) follows the position the loop stands at, as TkLlmSession::decode does: the
+     * host knows it from the last pass() and counts the steps; one graph per (form, row count) */
+    auto capture = [&](hipGraphExec_t* slot) -> bool {
+        if (*slot) return true;
         std::lock_guard<std::mutex> lk(g_pipe_capture_mu);
         hipGraph_t g = nullptr;
         PQ(hipStreamBeginCapture(s_->stream, hipStreamCaptureModeRelaxed));
@@ -491,21 +517,27 @@ bool TkLlmPipe::decode(int nrows, int n_steps) {
         enqueue_stage(nrows, true, true, true, true);
         const hipError_t e_end = hipStreamEndCapture(s_->stream, &g);
         hipError_t e_inst = hipSuccess;
-        if (e_end == hipSuccess && s_->launch_error.empty()) e_inst = hipGraphInstantiate(&graph_[nrows], g, nullptr, nullptr, 0);
+        if (e_end == hipSuccess && s_->launch_error.empty()) e_inst = hipGraphInstantiate(slot, g, nullptr, nullptr, 0);
         if (g) (void)hipGraphDestroy(g);
         if (e_end != hipSuccess || e_inst != hipSuccess || !s_->launch_error.empty()) {
-            graph_[nrows] = nullptr;
+            *slot = nullptr;
             (void)hipGetLastError();
             error = !s_->launch_error.empty() ? s_->launch_error : std::string("graph capture of a pipeline pass failed: ") + hipGetErrorString(e_end != hipSuccess ? e_end : e_inst);
             return false;
         }
-    }
+        return true;
+    };
     /* a step takes one id message and (the last stage) sends one: the FIFO's length is unchanged, its row counts all become nrows */
     if (rccl_comm_ && stage == 0 && n_stages > 1) { id_msg_rows_.assign(id_msg_rows_.size(), nrows); }
     for (int i = 0; i < n_steps; ++i) {
-        if (use_graph) PQ(hipGraphLaunch(graph_[nrows], s_->stream));
-        else { s_->launch_error.clear(); enqueue_stage(nrows, true, true, true, true); if (!s_->launch_error.empty()) { error = s_->launch_error; return false; } }
+        s_->choose_attention_top(host_top_ + i, nrows);
+        if (use_graph) {
+            hipGraphExec_t* slot = &graph_[s_->long_pass ? 1 : 0][nrows];
+            if (!capture(slot)) return false;
+            PQ(hipGraphLaunch(*slot, s_->stream));
+        } else { s_->launch_error.clear(); enqueue_stage(nrows, true, true, true, true); if (!s_->launch_error.empty()) { error = s_->launch_error; return false; } }
     }
+    host_top_ += n_steps;
     PQ(hipGetLastError());
     return true;
 }

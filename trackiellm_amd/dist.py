@@ -82,45 +82,143 @@ def pack_perception(dets, tokens):
     return out
 
 
-class PerceptionExchange:
-    """The cycle's data dependency across ranks (model-per-gpu and combined placements): every step ends with ONE gather of the
-    perception ranks' results of the batch they just finished to the LLM's first rank (rank `dst`), which must hold them before it
-    generates for that batch — the software pipeline of the one-GPU bench (LLM of batch k beside the perception of batch k + 1) with its
-    hand-off made explicit.  Every rank of the job calls hand_over() once per step, in the same place; the payload is a few hundred
-    bytes per cycle and goes through torch.distributed (gather_object: any backend)."""
+def perception_plan(vision_ranks, audio_ranks, cycles, tok_steps):
+    """{rank: (frames, utterances, token ids per utterance)} a perception rank hands over per step: `cycles` split evenly (ceil) over the
+    ranks of each stream — the shares bench.py gives its PerceptionBench objects.  Every rank computes the same table, so message sizes
+    are known on both ends without a size exchange."""
+    plan = {}
+    for r in vision_ranks:
+        f, u, t = plan.get(r, (0, 0, 0))
+        plan[r] = (-(-cycles // len(vision_ranks)), u, t)
+    for r in audio_ranks:
+        f, u, t = plan.get(r, (0, 0, 0))
+        plan[r] = (f, -(-cycles // len(audio_ranks)), tok_steps)
+    return plan
 
-    def __init__(self, dist, dst=0):
+
+def _message_words(frames, utts, tok_steps):
+    return frames * (1 + MAX_DETS * 6) + utts * tok_steps
+
+
+class PerceptionExchange:
+    """The cycle's data dependency across ranks (model-per-gpu and combined placements): the perception ranks' results of a batch must be on
+    the LLM's first rank (`dst`) before it generates for that batch — the software pipeline of the one-GPU bench (LLM of batch k beside the
+    perception of batch k + 1) with its hand-off made explicit.
+
+    Point to point and never blocking a sender on the LLM: messages have a FIXED size known to both ends from `plan`
+    (perception_plan: per frame a count + MAX_DETS x 6 floats, per utterance tok_steps ids, as 32-bit words), a perception rank's
+    hand_over() is one isend from one of two buffers (it only ever waits for its own send of two steps ago), dst's hand_over() posts the
+    irecvs of the batch that has just been computed and returns, and require() — called right before generating — is the only wait.  A
+    slow LLM rank therefore never serialises the perception ranks, and the perception ranks never wait inside a collective for ranks that
+    have nothing to contribute (what one gather_object per step did).  `device`: where the message tensors live ("cuda" under the nccl
+    backend = RCCL, None = host tensors for gloo)."""
+
+    def __init__(self, dist, dst=0, plan=None, device=None):
+        import torch
         self.dist, self.dst = dist, dst
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
-        self.received = None      # on dst: what the perception ranks produced last step
+        self.plan = dict(plan or {})
+        if self.dst in self.plan and any(self.plan[self.dst]):
+            raise ValueError("the LLM's first rank cannot also be a perception rank of the exchange")
+        self.received = None      # on dst: what the perception ranks produced for the batch last required
         self.bytes_last = 0
         self.checksum = 0
+        self._torch = torch
+        self._device = device
+        self._step = 0
+        self._sends = [None, None]
+        self._posted = None       # on dst: [(rank, tensor, work)] of the newest batch
+        mk = lambda n: torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+        if self.rank == self.dst:
+            self._rbuf = [{r: mk(_message_words(*self.plan[r])) for r in sorted(self.plan)} for _ in range(2)]
+        elif self.rank in self.plan:
+            self._sbuf = [mk(_message_words(*self.plan[self.rank])) for _ in range(2)]
+
+    def _encode(self, payload):
+        import numpy as np
+        f, u, t = self.plan[self.rank]
+        words = np.zeros(max(_message_words(f, u, t), 1), np.int32)
+        payload = payload or {}
+        if f:
+            n = np.asarray(payload.get("n_dets", np.zeros(0, np.int32)), np.int32)
+            d = np.asarray(payload.get("dets", np.zeros((0, MAX_DETS, 6), np.float32)), np.float32)
+            if len(n) != f or d.shape != (f, MAX_DETS, 6):
+                raise ValueError("this rank hands over %d frames per step (plan), got %d" % (f, len(n)))
+            words[:f] = n
+            words[f:f + f * MAX_DETS * 6] = d.reshape(-1).view(np.int32)
+        if u:
+            tk = np.asarray(payload.get("tokens", np.zeros((0, t), np.int32)), np.int32)
+            if tk.shape != (u, t):
+                raise ValueError("this rank hands over %d x %d token ids per step (plan), got %s" % (u, t, tk.shape))
+            words[f * (1 + MAX_DETS * 6):f * (1 + MAX_DETS * 6) + u * t] = tk.reshape(-1)
+        return words
+
+    def _decode(self, rank, words):
+        import numpy as np
+        f, u, t = self.plan[rank]
+        out = {}
+        if f:
+            out["n_dets"] = words[:f].copy()
+            out["dets"] = words[f:f + f * MAX_DETS * 6].view(np.float32).reshape(f, MAX_DETS, 6).copy()
+        if u:
+            o = f * (1 + MAX_DETS * 6)
+            out["tokens"] = words[o:o + u * t].reshape(u, t).copy()
+        return out
 
     def hand_over(self, payload):
-        """payload: pack_perception(...) on perception ranks, None elsewhere.  On `dst` the gathered results become `received`."""
+        """once per step on every rank, at the step's end.  Perception ranks: payload = pack_perception(...) of the batch just computed,
+        sent without waiting for the receiver.  dst: posts the receives of that batch (payload ignored) and returns at once."""
+        slot = self._step & 1
+        self._step += 1
+        if self.rank == self.dst:
+            self._posted = [(r, self._rbuf[slot][r], self.dist.irecv(self._rbuf[slot][r], src=r)) for r in sorted(self.plan)]
+            return None
+        if self.rank not in self.plan:
+            return None
+        if self._sends[slot] is not None:
+            self._sends[slot].wait()                       # the send of two steps ago: its buffer is reused now
+            self._sends[slot] = None
+        self._sbuf[slot].copy_(self._torch.from_numpy(self._encode(payload)))
+        self._sends[slot] = self.dist.isend(self._sbuf[slot], dst=self.dst)
+        return None
+
+    def require(self, n_frames, n_utts):
+        """on dst, before generating for a batch: wait for that batch's messages (posted by the previous hand_over) and check they are
+        complete; the results become `received`"""
         import numpy as np
-        box = [None] * self.world if self.rank == self.dst else None
-        self.dist.gather_object(payload, box, dst=self.dst)
         if self.rank != self.dst:
             return None
-        got = [b for b in box if b]
+        if self._posted is None:
+            raise RuntimeError("perception results of this batch are missing: nothing has been handed over yet")
+        got = []
+        for r, buf, work in self._posted:
+            work.wait()
+            got.append(self._decode(r, buf.cpu().numpy()))
+        self._posted = None
         self.received = got
         self.bytes_last = int(sum(v.nbytes for b in got for v in b.values()))
         cs = 0
         for b in got:  # consumed: every value is read once (the prompt builder's stand-in; the token ids of the prompt stay the fixed
-            for v in b.values():  # seeded ones of SURVEY.md 8d, so the numbers compare with the one-GPU run)
-                cs = (cs * 1000003 + int(np.asarray(v, np.float64).sum() * 16)) % (1 << 61)
+            for k in sorted(b):  # seeded ones of SURVEY.md 8d, so the numbers compare with the one-GPU run)
+                cs = (cs * 1000003 + int(np.asarray(b[k], np.float64).sum() * 16)) % (1 << 61)
         self.checksum = cs
-        return got
-
-    def require(self, n_frames, n_utts):
-        """on dst, before generating for a batch: its perception results are here and complete"""
-        got = self.received or []
         f = sum(len(b["n_dets"]) for b in got if "n_dets" in b)
         u = sum(len(b["tokens"]) for b in got if "tokens" in b)
         if f < n_frames or u < n_utts:
             raise RuntimeError("perception results of this batch are missing: %d / %d frames, %d / %d utterances" % (f, n_frames, u, n_utts))
+        return got
+
+    def finish(self):
+        """before the process group goes away: a sender's last isends complete, dst takes the batch nobody generated for"""
+        for w in self._sends:
+            if w is not None:
+                w.wait()
+        self._sends = [None, None]
+        if self.rank == self.dst and self._posted is not None:
+            for _, _, work in self._posted:
+                work.wait()
+            self._posted = None
 
 
 def combined_roles(world):
@@ -185,6 +283,10 @@ class LibPipeline:
         self.bounds = stage_bounds(n_layer, self.n_stages)
         self.pipes = []
         mine = []
+        if rccl and n_groups > 1 and self.n_stages > 1:
+            # several communicators on one device with eager send / recv on separate streams is the pattern RCCL documents as
+            # deadlock-prone; the collective transport carries ONE row group per stage (the mailbox transport has no such limit)
+            raise ValueError("the RCCL transport carries one row group per pipeline (got %d): use --sessions 1 with --pipe-rccl" % n_groups)
         if self.stage is not None:
             for g in range(n_groups):
                 self.pipes.append(make_pipe(g, self.stage, self.n_stages, self.bounds[self.stage], self.bounds[self.stage + 1]))
