@@ -94,6 +94,23 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_transcribe_tokens(tk_asr_whisp
                                                                     int n_steps, int32_t* tokens_out, float* mel_out, float* enc_out,
                                                                     float* logits_out);
 TK_API void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_steps);
+/* tk_asr_whisper_process_audio decodes the way whisper_full does under the reference's parameters (src/audio/tk_asr_whisper.c:89-110:
+ * suppress_blank off, suppress_non_speech_tokens on, timestamps on): whisper.cpp's whisper_process_logits and the token bookkeeping of its decode
+ * loop run on the device, the text is the text tokens of the sequence up to its result length, at most `decode_steps` tokens per call.
+ * enable = 0 restores the earlier rounds' decode (<|notimestamps|> prompt, bare arg max, exactly decode_steps tokens); vocabularies without
+ * whisper's special-token layout (fewer than 51864 tokens) always decode that way. */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_set_reference_decode(tk_asr_whisper_context_t* ctx, int enable);
+/* one utterance through that decode: tokens [n_steps] (eot behind the row's end), log-probabilities [n_steps] (may be NULL), *result_len = tokens that
+ * make up the text, *status = 0 (n_steps reached), 1 (completed), 2 (failed: whisper.cpp would fall back to the next temperature) */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_transcribe_ref(tk_asr_whisper_context_t* ctx, const int16_t* pcm, int n_samples, int n_steps, float temperature,
+                                                                 uint64_t seed, int32_t* tokens_out, float* logprobs_out, int32_t* result_len, int32_t* status);
+/* the static suppression table of that decode ([n_vocab], 1 = never sampled) and the ids of the first timestamp / end-of-text tokens; returns the
+ * table's length (0: the vocabulary has no timestamp tokens) */
+TK_API int32_t tk_mi355x_asr_suppress_table(tk_asr_whisper_context_t* ctx, uint8_t* out, int32_t cap, int32_t* token_beg, int32_t* token_eot);
+/* the per-model-file registry behind tk_asr_whisper_create: contexts opened on the same checkpoint / device share the weights and one batched
+ * engine whose scheduler coalesces their one-utterance calls (tk_asr_whisper_process_audio).  Counters of this context's shared engine: live
+ * contexts, batched jobs run, utterances they carried, the widest job.  Any pointer may be NULL. */
+TK_API void tk_mi355x_asr_share_stats(const tk_asr_whisper_context_t* ctx, uint64_t* handles, uint64_t* batches, uint64_t* utterances, uint64_t* widest);
 /* whisper.cpp's decoding policy, which the reference's wrapper arms with temperature_inc 0.2 / entropy_thold 2.4 / logprob_thold -1.0
  * (src/audio/tk_asr_whisper.c:126-138; partial results: no fallback, :137).  OFF by default: the plain greedy decode is what the parity suite pins.
  *   transcribe_policy: the forced decode of transcribe_tokens with the token of every step picked by temperature (0 = arg max; > 0 = one draw from

@@ -126,6 +126,10 @@ TK_API void tk_vision_result_destroy(tk_vision_result_t** result);
 /* ---- extensions (no reference counterpart) ---- */
 /* B frames of identical geometry in one pass (one per concurrent cortex cycle); results[i] / counts[i] per frame; max_batch in [1, 256] */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_set_max_batch(tk_object_detector_t* detector, int max_batch);
+/* the per-model-file registry behind tk_object_detector_create: handles opened on the same file / device / geometry share the weights and one
+ * batched engine whose scheduler coalesces their one-frame calls (tk_object_detector_detect, tk_vision_pipeline_process_frame).  Counters of
+ * this handle's shared engine: live handles, batched jobs run, frames they carried, the widest job.  Any pointer may be NULL. */
+TK_API void tk_mi355x_detector_share_stats(const tk_object_detector_t* detector, uint64_t* handles, uint64_t* batches, uint64_t* frames, uint64_t* widest);
 /* ONNX detector file (tk_object_detector_config_t.model_path, src/vision/tk_object_detector.c:93-152): parse the Conv initialisers
  * (no ONNX Runtime, no GPU) and check them against the YOLOv8n graph this path runs; n_convs / n_params optional */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_onnx_probe(const char* path, int32_t* n_convs, int64_t* n_params);

@@ -33,6 +33,110 @@ static float sum256(const float* partial) {
     return ((w[0] + w[1]) + w[2]) + w[3];
 }
 
+extern "C" int32_t orc_sample_row(const float* logits, int vocab, const uint32_t* allow, float temp, int32_t top_k, float top_p, float min_p, uint64_t seed, uint32_t counter);
+
+/* 1024 strided chains of `term(i)` over i in [0, n) with keep(i), each wave of 64 chains joined by the xor butterfly (32 .. 1), then waves 0 .. 15 in
+ * order: the order k_pick_rows / k_pick_rows_filtered sum in */
+template <typename Keep, typename Term>
+static float chain_sum_1024(int n, Keep keep, Term term) {
+    float chain[1024];
+    for (int t = 0; t < 1024; ++t) {
+        float s = 0.0f;
+        for (int i = t; i < n; i += 1024)
+            if (keep(i)) s = s + term(i);
+        chain[t] = s;
+    }
+    float S = 0.0f;
+    for (int w = 0; w < 16; ++w) {
+        float a[64], nx[64];
+        for (int j = 0; j < 64; ++j) a[j] = chain[w * 64 + j];
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            for (int j = 0; j < 64; ++j) nx[j] = a[j] + a[j ^ sft];
+            for (int j = 0; j < 64; ++j) a[j] = nx[j];
+        }
+        S = w == 0 ? a[0] : S + a[0];
+    }
+    return S;
+}
+
+/* One sampled position of whisper.cpp's decoder under the reference's parameters (TEST INFRASTRUCTURE, like everything under oracle/).  Follows
+ * whisper.cpp's published whisper_process_logits and the token bookkeeping of whisper_full_with_state's decode loop — whisper.cpp is a dependency
+ * the reference calls (src/audio/tk_asr_whisper.c:89-110,142-147) but does not vendor or pin: PARITY UNPINNED against it.  Parameters as the
+ * reference's wrapper leaves them: suppress_blank = false, suppress_non_speech_tokens = true (in `suppress`, with the special tokens
+ * whisper.cpp always masks: <|notimestamps|>, <|startoftranscript|>, <|nospeech|>, <|startoflm|>, <|startofprev|>, task and language tokens),
+ * no_timestamps = false, max_initial_ts = 1.0 (tid0 = 50), single_segment = false, max_tokens = 0, seek = 0.
+ * state[8] = {tokens sampled, last was a timestamp, the one before was, has_ts, seek_delta, result_len, status (0 running, 1 completed, 2 failed),
+ * seek_end}.  Returns the token (eot for a row that stands still), *logprob = its log-probability under the filtered distribution.
+ * Stated deviations: the sums run in this build's canonical order (1024 chains) instead of index order, exp / log are the build's exact-math
+ * sequences, the greedy pick is the first index of the largest LOGIT (whisper.cpp takes the first index of the largest exp(logprob): equal unless
+ * two allowed logits differ by less than an ulp of their probability), a draw at temperature > 0 is the build's canonical sampler over the 64
+ * largest allowed logits (whisper.cpp: std::discrete_distribution over all). */
+extern "C" int32_t orc_whisper_filter_pick(const float* x, int cols, const uint8_t* suppress, int32_t* st, int32_t beg, int32_t eot, int32_t tid0, float temperature,
+                                           uint64_t seed, uint32_t counter, float* logprob) {
+    if (st[6] != 0) { if (logprob) *logprob = 0.0f; return eot; }
+    const int n_tok = st[0];
+    const bool last_ts = n_tok > 0 && st[1] != 0, prev_ts = n_tok < 2 || st[2] != 0, has_ts = st[3] != 0;
+    const int seek_delta = st[4];
+    std::vector<uint8_t> ok((size_t)cols);
+    for (int i = 0; i < cols; ++i) {
+        bool a = suppress[i] == 0;
+        if (last_ts) { /* timestamps have to appear in pairs, except directly before EOT */
+            if (prev_ts) { if (i >= beg) a = false; }
+            else if (i < eot) a = false;
+        }
+        if (n_tok == 0 && tid0 >= 0 && i > beg + tid0) a = false;      /* the initial timestamp cannot be larger than max_initial_ts */
+        if (has_ts && i >= beg && i < beg + seek_delta / 2) a = false; /* condition timestamp tokens to be increasing */
+        ok[(size_t)i] = a ? 1 : 0;
+    }
+    const bool hot = temperature > 0.0f;
+    std::vector<float> z((size_t)cols);
+    for (int i = 0; i < cols; ++i) z[(size_t)i] = hot ? tk_divf(x[i], temperature) : x[i];
+    float m_all = -INFINITY, m_tx = -INFINITY, m_ts = -INFINITY;
+    for (int i = 0; i < cols; ++i)
+        if (ok[(size_t)i]) {
+            m_all = tk_fmaxf(m_all, z[(size_t)i]);
+            if (i < beg) m_tx = tk_fmaxf(m_tx, z[(size_t)i]); else m_ts = tk_fmaxf(m_ts, z[(size_t)i]);
+        }
+    const float S = chain_sum_1024(cols, [&](int i) { return ok[(size_t)i] != 0; }, [&](int i) { return tk_expf(z[(size_t)i] - m_all); });
+    const float logS = tk_logf(S);
+    auto lp = [&](int i) { return (z[(size_t)i] - m_all) - logS; };
+    /* if sum of probability over timestamps is above any other token, sample timestamp */
+    const float lp_mts = (m_ts - m_all) - logS, lp_mtx = (m_tx - m_all) - logS;
+    const float S_ts = chain_sum_1024(cols, [&](int i) { return i >= beg && ok[(size_t)i] != 0; }, [&](int i) { return tk_expf(lp(i) - lp_mts); });
+    const float lp_ts = S_ts > 0.0f ? tk_logf(S_ts) + lp_mts : -INFINITY;
+    if (lp_ts > lp_mtx)
+        for (int i = 0; i < beg && i < cols; ++i) ok[(size_t)i] = 0;
+    int tok = -1;
+    if (!hot) {
+        for (int i = 0; i < cols; ++i)
+            if (ok[(size_t)i] && (tok < 0 || x[i] > x[tok])) tok = i;
+    } else {
+        std::vector<uint32_t> allow((size_t)(cols + 31) / 32, 0u);
+        for (int i = 0; i < cols; ++i)
+            if (ok[(size_t)i]) allow[(size_t)i >> 5] |= 1u << (i & 31);
+        tok = orc_sample_row(x, cols, allow.data(), temperature, 0, 1.0f, 0.0f, seed, counter);
+    }
+    if (logprob) *logprob = lp(tok);
+    /* whisper_full_with_state, "update sliding window" / "end of segment", i = the token's index in the sequence */
+    const int i = n_tok, seek_end = st[7];
+    int hts = has_ts ? 1 : 0, sd = seek_delta, rl = st[5], status = 0;
+    if (tok > beg) {
+        const int sd_new = 2 * (tok - beg);
+        if (hts && sd > sd_new && rl < i) status = 2; /* do not allow to go back in time */
+        else { sd = sd_new; rl = i + 1; hts = 1; }
+    }
+    if (status == 0 && (tok == eot || (hts && sd + 100 >= seek_end))) {
+        if (rl == 0) {
+            if (sd + 100 >= seek_end) rl = i + 1;
+            else status = 2;
+        }
+        if (status == 0) status = 1;
+    }
+    const int was_last = last_ts ? 1 : 0;
+    st[0] = i + 1; st[1] = tok >= beg ? 1 : 0; st[2] = was_last; st[3] = hts; st[4] = sd; st[5] = rl; st[6] = status;
+    return tok;
+}
+
 struct CpuAudioOps {
     std::vector<std::vector<float>> bufs;
     float* alloc(size_t n) { bufs.emplace_back(n ? n : 1, 0.0f); return bufs.back().data(); }
@@ -98,12 +202,29 @@ struct CpuAudioOps {
     /* whisper.cpp's decoding policy (the reference arms it: src/audio/tk_asr_whisper.c:126-138), restating k_pick_rows of
      * csrc/nn/tk_nn_kernels.hip: token by temperature (0 = first index of the maximum; > 0 = one draw of the canonical sampler over the 64
      * largest logits, counter = position x rows + row) and its log-probability under softmax(l / temperature) over the whole vocabulary */
+    /* the reference-parameter decode (orc_whisper_filter_pick below): logits of the sampled positions go through whisper.cpp's filters */
+    bool filt_on = false;
+    int filt_first_step = 0;
+    const uint8_t* filt_suppress = nullptr;
+    int32_t* filt_state = nullptr; /* [rows][8] */
+    int32_t filt_beg = 0, filt_eot = 0, filt_tid0 = 50;
     bool pick_on = false;
     float pick_temp = 0.0f;
     uint64_t pick_seed = 0;
     float* pick_lp = nullptr; /* [positions][rows] */
     int pick_step = 0;
     void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out) {
+        if (filt_on) {
+            if (pick_step >= filt_first_step)
+                for (int r = 0; r < rows; ++r) {
+                    float lp = 0.0f;
+                    out[r] = orc_whisper_filter_pick(x + (int64_t)r * ld, cols, filt_suppress, filt_state + (int64_t)r * 8, filt_beg, filt_eot, filt_tid0, pick_temp, pick_seed,
+                                                     (uint32_t)(pick_step * rows + r), &lp);
+                    if (pick_lp) pick_lp[(int64_t)pick_step * rows + r] = lp;
+                }
+            pick_step++;
+            return;
+        }
         for (int r = 0; r < rows; ++r) {
             const float* xr = x + (int64_t)r * ld;
             int best = 0;
@@ -242,6 +363,42 @@ void orc_whisper_transcribe_policy(orc_whisper* m, int B, const int16_t* pcm, in
                 if (logprobs_out) logprobs_out[(size_t)b * n_steps + step] = lp[(size_t)p * B + b];
             }
         }
+    }
+}
+
+/* same contract as TkAsr::transcribe_ref: the decode under the reference's whisper.cpp parameters, at most n_steps tokens per utterance */
+void orc_whisper_transcribe_ref(orc_whisper* m, int B, const int16_t* pcm, int n_samples, const int32_t* n_samples_row, const int32_t* prompt, int n_prompt, int n_steps,
+                                float temperature, uint64_t seed, const uint8_t* suppress, int32_t token_beg, int32_t token_eot, int32_t* tokens_out, float* logprobs_out,
+                                int32_t* result_len, int32_t* status) {
+    const TkWhisperHP& h = m->hp;
+    CpuAudioOps ops;
+    ops.bufs.reserve(4096);
+    TkWhisperGraph<CpuAudioOps> g{h, m->man, m->wp.data()};
+    float* ml = g.mel(ops, pcm, B, n_samples, n_samples);
+    float* enc = g.encode(ops, ml, B);
+    auto st = g.begin_decode(ops, enc, B);
+    const int total = n_prompt + n_steps - 1;
+    std::vector<float> lp((size_t)total * B, 0.0f);
+    std::vector<int32_t> state((size_t)B * 8, 0);
+    for (int b = 0; b < B; ++b) state[(size_t)b * 8 + 7] = n_samples_row[b] / TK_WH_HOP;
+    ops.filt_on = true; ops.filt_first_step = n_prompt - 1; ops.filt_suppress = suppress; ops.filt_state = state.data(); ops.filt_beg = token_beg; ops.filt_eot = token_eot;
+    ops.filt_tid0 = 50;
+    ops.pick_temp = temperature; ops.pick_seed = seed; ops.pick_lp = lp.data(); ops.pick_step = 0;
+    for (int p = 0; p < total; ++p) {
+        for (int b = 0; b < B; ++b) { st.tok[b] = p < n_prompt ? prompt[p] : st.next[b]; st.pos[b] = p; }
+        g.decode_step(ops, st, p);
+        if (p >= n_prompt - 1) {
+            const int step = p - (n_prompt - 1);
+            for (int b = 0; b < B; ++b) {
+                tokens_out[(size_t)b * n_steps + step] = st.next[b];
+                if (logprobs_out) logprobs_out[(size_t)b * n_steps + step] = lp[(size_t)p * B + b];
+            }
+        }
+    }
+    for (int b = 0; b < B; ++b) {
+        const int32_t* sb = &state[(size_t)b * 8];
+        if (status) status[b] = sb[6];
+        if (result_len) result_len[b] = sb[6] == 0 ? sb[0] : sb[5];
     }
 }
 

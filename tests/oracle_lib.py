@@ -414,6 +414,25 @@ class OracleWhisper:
         return toks[:, :n_steps], mel, enc, lg
 
 
+    def transcribe_ref(self, pcm, lengths, n_steps, suppress, token_beg, token_eot, prompt, temperature=0.0, seed=0):
+        """the decode under the reference's whisper.cpp parameters (orc_whisper_transcribe_ref): pcm [B][n] zero padded, lengths [B] ->
+        (tokens [B][n_steps], logprobs [B][n_steps], result_len [B], status [B])"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        B, n = pcm.shape
+        lengths = np.ascontiguousarray(lengths, np.int32)
+        suppress = np.ascontiguousarray(suppress, np.uint8)
+        prompt = np.ascontiguousarray(prompt, np.int32)
+        toks = np.zeros((B, n_steps), np.int32)
+        lp = np.zeros((B, n_steps), np.float32)
+        rl = np.zeros(B, np.int32)
+        st = np.zeros(B, np.int32)
+        L = lib()
+        L.orc_whisper_transcribe_ref.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_void_p,
+                                                 C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_whisper_transcribe_ref(self.h, B, ptr(pcm), n, ptr(lengths), ptr(prompt), len(prompt), n_steps, temperature, seed, ptr(suppress), token_beg, token_eot,
+                                     ptr(toks), ptr(lp), ptr(rl), ptr(st))
+        return toks, lp, rl, st
+
     def transcribe_policy(self, pcm, n_steps, temperature, seed, prompt=None):
         """forced decode with the token picked by temperature -> (tokens [B][n_steps], logprobs [B][n_steps])"""
         pcm = np.ascontiguousarray(pcm, np.int16)
@@ -466,3 +485,17 @@ def vad_run(probs, threshold=0.5, min_silence_ms=300.0, min_speech_ms=250.0, dt_
         if e >= 0:
             ev.append((i, e))
     return ev, s
+
+
+def whisper_filter_pick(logits, suppress, state, beg, eot, tid0=50, temperature=0.0, seed=0, counter=0):
+    """one sampled position of whisper.cpp's decoder under the reference's parameters (orc_whisper_filter_pick): logits [n_vocab], suppress [n_vocab]
+    uint8, state int32[8] (updated in place) -> (token, logprob)"""
+    logits = np.ascontiguousarray(logits, np.float32)
+    suppress = np.ascontiguousarray(suppress, np.uint8)
+    assert state.dtype == np.int32 and state.shape == (8,) and state.flags.c_contiguous
+    lp = C.c_float(0)
+    L = lib()
+    L.orc_whisper_filter_pick.restype = C.c_int32
+    L.orc_whisper_filter_pick.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]
+    tok = L.orc_whisper_filter_pick(ptr(logits), len(logits), ptr(suppress), ptr(state), beg, eot, tid0, temperature, seed, counter, C.byref(lp))
+    return int(tok), float(lp.value)

@@ -111,6 +111,7 @@ def test_whisper_ggml_checkpoint_end_to_end(gpu, tmp_path):
 
 def test_asr_reference_surface_buffering(gpu):
     asr = gpu.Asr()
+    asr.set_reference_decode(False)   # the buffering rules, on the forced decode: exactly decode_steps words per result
     asr.set_decode_steps(3)
     rng = np.random.default_rng(5)
     chunk = np.clip(rng.normal(0, 3000, 8000), -32768, 32767).astype(np.int16)
@@ -463,3 +464,145 @@ def test_asr_decode_policy_from_the_environment(gpu, monkeypatch):
     armed.process_audio(pcm, False)                                   # partial: one decode
     assert armed.last_decode()[2] == 1
     plain.close(); armed.close()
+
+
+def test_asr_contexts_on_one_file_share_an_engine_and_give_the_solo_results(gpu):
+    """round 6: tk_asr_whisper_context_t handles opened on the same checkpoint share the weights and ONE batched engine; their
+    one-utterance calls (src/audio/tk_asr_whisper.c:282-344) are coalesced by a scheduler, shorter utterances padded with the zeros the 30 s
+    window holds behind them anyway.  Five contexts fed utterances of DIFFERENT lengths at once return the text each returns alone."""
+    import threading
+    rng = np.random.default_rng(78)
+    K = 5
+    utts = [np.clip(rng.normal(0, 3000, 16000 + 1777 * i), -32768, 32767).astype(np.int16) for i in range(K)]
+    solo = []
+    for u in utts:
+        a = gpu.Asr()
+        a.set_reference_decode(False)   # six words per utterance whatever the (random-weight) decoder says; the default decode: test_asr_reference_parameter_decode
+        a.set_decode_steps(6)
+        assert a.share_stats()[0] == 1
+        solo.append(a.process_audio(u, True)[0])
+        a.close()
+    assert len(set(solo)) > 1
+    ctx = [gpu.Asr() for _ in range(K)]
+    for a in ctx:
+        a.set_reference_decode(False)
+        a.set_decode_steps(6)
+    assert ctx[0].share_stats()[0] == K
+    got = [None] * K
+    bar = threading.Barrier(K)
+
+    def run(i):
+        bar.wait()
+        for rep in range(2):
+            got[i] = ctx[i].process_audio(utts[i], True)[0]
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == solo
+    handles, batches, n, widest = ctx[0].share_stats()
+    assert n == 2 * K and batches < n and widest >= 2, (handles, batches, n, widest)
+    # the policy decode (temperature ladder) goes through the same engine one utterance at a time and equals a private context's
+    ctx[0].set_decode_policy(True, seed=3)
+    priv = gpu.Asr()
+    priv_alone = None
+    for a in ctx[1:]:
+        a.close()
+    t_shared = ctx[0].process_audio(utts[0], True)[0]
+    ctx[0].close()
+    priv.set_reference_decode(False)
+    priv.set_decode_steps(6)
+    priv.set_decode_policy(True, seed=3)
+    assert priv.process_audio(utts[0], True)[0] == t_shared
+    priv.close()
+
+
+NON_SPEECH = ['"', "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~", "「", "」", "『", "』", "<<", ">>", "<<<",
+              ">>>", "--", "---", "-(", "-[", "('", '("', "((", "))", "(((", ")))", "[[", "]]", "{{", "}}", "♪♪", "♪♪♪", "♩", "♪", "♫", "♬", "♭", "♮", "♯"]
+
+
+def test_asr_reference_parameter_decode(gpu, tmp_path):
+    """tk_asr_whisper_process_audio decodes the way whisper_full does under the parameters the reference's wrapper sets
+    (/root/reference/src/audio/tk_asr_whisper.c:89-110: suppress_blank off, suppress_non_speech_tokens on, timestamps on; :142-181: segment texts
+    concatenated).  A ggml checkpoint with whisper's real vocabulary layout (51864 ids: text, eot 50256, sot, language / task / special tokens,
+    timestamps from 50363) and a small decoder: the product's suppression table equals the one built here from the vocabulary strings, tokens,
+    log-probabilities, result lengths and statuses of utterances of several lengths equal the oracle's (orc_whisper_transcribe_ref) — alone,
+    coalesced by the shared engine, and at a temperature — and process_audio's text is the text tokens of the accepted run."""
+    import threading
+    import ggml_whisper_util as G
+    ohp = O.WhisperHP(80, 1500, 64, 2, 1, 448, 64, 2, 1, 51864)
+    orc = O.OracleWhisper(ohp, seed=12)
+    T = orc.tensors()
+    rounded, file_t = G.checkpoint_tensors(T, ohp)
+    orc.set_tensors(rounded)
+    EOT, SOT, BEG = 50256, 50257, 50363
+    vocab = [(" w%d" % i).encode() for i in range(EOT)]
+    planted = {}
+    for k, tok in enumerate(NON_SPEECH + [" -", " '"]):                     # plant the strings whisper.cpp looks up, bare and " "-prefixed
+        for j, form in enumerate(([tok, " " + tok] if tok not in (" -", " '") else [tok])):
+            i = 100 + 7 * (2 * k + j)
+            vocab[i] = form.encode()
+            planted[i] = form
+    vocab[90] = b" ("                                                        # a second id of the same string: whisper.cpp's map keeps one, so does the table
+    path = tmp_path / "ggml-ref.bin"
+    G.write_ggml(path, ohp, T["frontend.mel_filters"], vocab, file_t)
+    asr = gpu.Asr(model=str(path))
+    tab, beg, eot = asr.suppress_table()
+    want_tab = np.zeros(ohp.n_vocab, np.uint8)
+    want_tab[SOT:BEG] = 1                                                    # sot, 99 language slots, translate, transcribe, solm, prev, nosp, notimestamps
+    for i in planted:
+        want_tab[i] = 1
+    want_tab[100 + 7 * (2 * NON_SPEECH.index("(") + 1)] = 0                  # " (" is found at its FIRST id (90), the planted copy stays free
+    want_tab[90] = 1
+    assert (beg, eot) == (BEG, EOT) and np.array_equal(tab, want_tab), np.nonzero(tab != want_tab)
+    rng = np.random.default_rng(41)
+    lens = [16000, 16000 + 3000, 5 * 16000, 25 * 16000, 12 * 16000 + 123]
+    utts = [np.clip(rng.normal(0, 3000, n), -32768, 32767).astype(np.int16) for n in lens]
+    prompt = np.array([SOT], np.int32)                                       # English-only vocabulary: <|startoftranscript|> alone, timestamps on
+    STEPS = 20
+    want = []
+    for u in utts:
+        want.append(orc.transcribe_ref(u[None], [len(u)], STEPS, want_tab, BEG, EOT, prompt))
+    statuses = [int(w[3][0]) for w in want]
+    for u, w in zip(utts, want):                                             # one at a time
+        toks, lp, rl, st = asr.transcribe_ref(u, STEPS)
+        assert np.array_equal(toks, w[0][0]) and np.array_equal(lp, w[1][0]) and (rl, st) == (int(w[2][0]), int(w[3][0]))
+    assert len(set(statuses)) > 1 or max(int(w[2][0]) for w in want) > 2, statuses   # the cases are not all the same one-token story
+    # every rule leaves its trace: no suppressed token is ever sampled, timestamps never decrease
+    for w in want:
+        t = w[0][0][: int(w[2][0])]
+        assert not want_tab[t].any()
+        ts = t[t >= BEG]
+        assert np.all(np.diff(ts) >= 0)
+    # coalesced: five contexts of the same file at once, different lengths in one batch (each row its own seek_end)
+    ctx = [gpu.Asr(model=str(path)) for _ in utts]
+    got = [None] * len(utts)
+    bar = threading.Barrier(len(utts))
+
+    def run(i):
+        bar.wait()
+        got[i] = ctx[i].transcribe_ref(utts[i], STEPS)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(len(utts))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g, w in zip(got, want):
+        assert np.array_equal(g[0], w[0][0]) and np.array_equal(g[1], w[1][0]) and (g[2], g[3]) == (int(w[2][0]), int(w[3][0]))
+    assert ctx[0].share_stats()[3] >= 2
+    # at a temperature: the canonical draw over the allowed set, same seed and counter on both sides
+    wt = orc.transcribe_ref(utts[2][None], [len(utts[2])], STEPS, want_tab, BEG, EOT, prompt, temperature=0.6, seed=9)
+    gt = asr.transcribe_ref(utts[2], STEPS, temperature=0.6, seed=9)
+    assert np.array_equal(gt[0], wt[0][0]) and np.array_equal(gt[1], wt[1][0]) and (gt[2], gt[3]) == (int(wt[2][0]), int(wt[3][0]))
+    # the reference surface: the text tokens of the accepted run, specials and timestamps rendered as nothing; less than a second of audio gives no text
+    asr.set_decode_steps(STEPS)
+    for u, w in zip(utts, want):
+        text = asr.process_audio(u, True)[0] or ""
+        run_ = w[0][0][: int(w[2][0])]
+        assert text == "".join(vocab[t].decode() for t in run_ if t < EOT)
+    assert (asr.process_audio(utts[0][:15000], True)[0] or "") == ""
+    for a in ctx + [asr]:
+        a.close()

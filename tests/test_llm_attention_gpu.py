@@ -27,6 +27,14 @@ MAX_CTX = 192
 CTXS = [31, 32, 33, 63, 64, 65, 127, 128, 191]
 
 
+@pytest.fixture(autouse=True)
+def narrow_attention_even_when_sessions_share_the_device(monkeypatch):
+    """two module-scoped sessions of this file are alive at once; with more than one decode session on a device the launcher prefers the ring
+    form (it shares a CU with other streams' launches: test_narrow_attention_yields_when_sessions_share_the_device).  This file is about the
+    instantiations a LONE runner takes, so the narrow form is asked for explicitly."""
+    monkeypatch.setenv("TK_MI355X_NO_NARROW_ATT", "0")
+
+
 def f16_bits(rng, shape, scale):
     return (rng.standard_normal(shape, dtype=np.float32) * scale).astype(np.float16).view(np.uint16)
 
@@ -205,6 +213,28 @@ def test_kv_hook_argument_errors(mistral1):
     with pytest.raises(gpu.TkError):
         sess.kv_write(0, 0, MAX_CTX - 3, k, k)  # runs past the context
     assert gpu.lib().tk_mi355x_llm_session_kv_write(None, 0, 0, 0, 1, None, None) == 1001
+
+
+def test_narrow_attention_yields_when_sessions_share_the_device(mistral1, monkeypatch):
+    """round 6: a narrow-attention workgroup takes a whole CU, so with several decode sessions alive on a device (the fused bench's three groups)
+    the launcher's answer is the ring form, which co-resides with the other streams' mat-vec workgroups; one session alone keeps the narrow
+    form.  Both are bit-identical (every case of this file runs whichever the plan names), so only the plan is asserted here."""
+    gpu, model, sess, orc, hp = mistral1
+    ncu = gpu.lib().tk_mi355x_device_cu_count(0)
+    if ncu != 256:
+        pytest.skip("plan expectations are for 256 CUs")
+    monkeypatch.delenv("TK_MI355X_NO_NARROW_ATT", raising=False)
+    alive_before = gpu.attention_plan(16, hp.n_head, hp.n_kv_head, hp.head_dim, MAX_CTX, True)
+    extra = [gpu.LlmSession(model, 16, MAX_CTX) for _ in range(2)]
+    shared = gpu.attention_plan(16, hp.n_head, hp.n_kv_head, hp.head_dim, MAX_CTX, True)
+    assert shared[0] == 0 and shared[1] == 2 and shared[2] == 128           # k_attention<2, fused, 128, 128, 2>
+    for s in extra:
+        s.close()
+    assert gpu.attention_plan(16, hp.n_head, hp.n_kv_head, hp.head_dim, MAX_CTX, True) == alive_before
+    monkeypatch.setenv("TK_MI355X_NO_NARROW_ATT", "0")
+    assert gpu.attention_plan(16, hp.n_head, hp.n_kv_head, hp.head_dim, MAX_CTX, True)[0] == 1   # asked for explicitly
+    monkeypatch.setenv("TK_MI355X_NO_NARROW_ATT", "1")
+    assert gpu.attention_plan(16, hp.n_head, hp.n_kv_head, hp.head_dim, MAX_CTX, True)[0] == 0
 
 
 def test_full_7b_prompt64_decode128_ids_match_oracle(gpu):

@@ -483,7 +483,8 @@ def _ids_of(pieces):
 def test_7b_through_reference_runner_32_tokens(gpu):
     """BASELINE configs[0] (tests/tk_cortex_test.cpp's model + token count) through the reference entry points only:
     tk_model_loader_load_model -> tk_llm_runner_prepare_generation -> 32 x tk_llm_runner_generate_next_token on the full 32-layer
-    Mistral-7B Q4_K_M geometry; ids equal tk_mi355x_llm_forward (the entry the oracle pins) on the same weights."""
+    Mistral-7B Q4_K_M geometry; every id equal to the ORACLE's on the same weights and token stream (the prompt's rows in one oracle pass
+    + 31 single-row passes, ~10 s of CPU)."""
     loader = gpu.ModelLoader()
     h = loader.load("synthetic://mistral-7b?seed=4")
     runner = gpu.LlmRunner(h, context_size=128)
@@ -495,23 +496,24 @@ def test_7b_through_reference_runner_32_tokens(gpu):
         assert p is not None and p != "<tool_call>"
         pieces.append(p)
     got = _ids_of(pieces)
-    model = _BorrowedModel(gpu, h)
-    assert model.hparams.n_layer == 32 and model.hparams.d_model == 4096
-    sess = gpu.LlmSession(model, 1, 128)
-    ids = [1] + [3 + b for b in prompt.encode()]
-    n = len(ids)
-    _, am = sess.forward(np.zeros(n, np.int32), np.arange(n, dtype=np.int32), ids, want_logits=False)
-    cur, want = int(am[-1]), []
-    for i in range(32):
-        want.append(cur)
-        _, am = sess.forward([0], [n + i], [cur], want_logits=False)
-        cur = int(am[0])
-    assert got == want
-    assert len(set(got)) > 1
-    sess.close()
+    hp = _BorrowedModel(gpu, h).hparams
+    assert hp.n_layer == 32 and hp.d_model == 4096
     runner.close()
     loader.unload(h)
     loader.close()
+    ids = np.array([1] + [3 + b for b in prompt.encode()], np.int32)   # BOS + the byte vocabulary's ids (csrc/llm/tk_tokenizer.h)
+    n = len(ids)
+    orc = O.OracleLlm(oracle_cfg_from(hp, 128, 1), seed=4)
+    _, am = orc.forward(np.zeros(n, np.int32), np.arange(n, dtype=np.int32), ids, want_logits=False)
+    cur, want = int(am[-1]), []
+    for i in range(32):
+        want.append(cur)
+        if i + 1 < 32:
+            _, am = orc.forward([0], [n + i], [cur], want_logits=False)
+            cur = int(am[0])
+    orc.close()
+    assert got == want
+    assert len(set(got)) > 1
 
 
 def test_runner_add_tool_response_continues_the_context(gpu):

@@ -98,3 +98,71 @@ def test_decode_policy_restatement_properties():
     assert O.whisper_decode_failed(cut, lp2 * 8, eot, logprob_thold=-2.5) == (False, -2.0)   # judged up to and including end-of-text only
     half = np.array([i % 4 for i in range(40)], np.int32)                      # four tokens, eight times each: entropy ln 4 = 1.386
     assert O.whisper_decode_failed(half, lp, eot, entropy_thold=1.38)[0] is False and O.whisper_decode_failed(half, lp, eot, entropy_thold=1.39)[0] is True
+
+
+def test_whisper_logit_filters_on_hand_made_logits():
+    """whisper.cpp's whisper_process_logits + the decode loop's token bookkeeping under the reference's parameters
+    (/root/reference/src/audio/tk_asr_whisper.c:89-110: suppress_blank off, suppress_non_speech_tokens on, timestamps on, max_initial_ts 1.0),
+    restated in orc_whisper_filter_pick, on a toy vocabulary: text 0..19, eot 20, specials 21..29 (always suppressed), timestamps 30..39, the
+    first timestamp at most beg + 3.  Every rule is driven by logits built to tempt it."""
+    V, EOT, BEG, TID0 = 40, 20, 30, 3
+    sup = np.zeros(V, np.uint8)
+    sup[21:30] = 1
+    sup[7] = 1                                           # a "non-speech" text token
+    st = np.zeros(8, np.int32)
+    st[7] = 1000                                         # seek_end: a 10 s utterance
+    base = np.full(V, -5.0, np.float32)
+
+    def logsoftmax_at(x, allowed, i):
+        a = x.astype(np.float64)[allowed]
+        return float(x[i] - (np.log(np.exp(a - a.max()).sum()) + a.max()))
+
+    # (a) first token: the best timestamp lies beyond max_initial_ts, the suppressed text token is the largest logit of all, and the timestamps'
+    #     summed probability beats every text token -> the best timestamp <= beg + tid0
+    x = base.copy(); x[7] = 30.0; x[38] = 10.0; x[32] = 5.0; x[3] = 4.0
+    tok, lp = O.whisper_filter_pick(x, sup, st, BEG, EOT, TID0)
+    allowed = np.array([i for i in range(V) if not sup[i] and not (i > BEG + TID0)])
+    assert tok == 32 and abs(lp - logsoftmax_at(x, allowed, 32)) < 1e-5
+    assert st.tolist() == [1, 1, 0, 1, 4, 1, 0, 1000]    # seek_delta 2 * 2, result_len 1, still running
+    # (b) the last token was a timestamp and so (fewer than two tokens) was "the one before": no timestamp now, however large
+    x = base.copy(); x[35] = 50.0; x[5] = 1.0; x[6] = 0.5
+    tok, lp = O.whisper_filter_pick(x, sup, st, BEG, EOT, TID0)
+    assert tok == 5 and st.tolist() == [2, 0, 1, 1, 4, 1, 0, 1000]
+    # (c) timestamps must not go back: 31 < beg + seek_delta / 2 is masked although it is the largest; 35 wins because the timestamps' sum beats the text
+    x = base.copy(); x[31] = 40.0; x[35] = 6.0; x[36] = 5.9; x[4] = 6.2
+    tok, lp = O.whisper_filter_pick(x, sup, st, BEG, EOT, TID0)
+    assert tok == 35 and st.tolist() == [3, 1, 0, 1, 10, 3, 0, 1000]
+    # (d) a timestamp after a text token: only its pair or the end of text may follow -> eot although text logits are larger; the segment is complete
+    x = base.copy(); x[2] = 20.0; x[EOT] = 3.0; x[37] = 1.0
+    tok, lp = O.whisper_filter_pick(x, sup, st, BEG, EOT, TID0)
+    assert tok == EOT and st.tolist() == [4, 0, 1, 1, 10, 3, 1, 1000]
+    allowed = np.array([EOT] + list(range(35, 40)))
+    assert abs(lp - logsoftmax_at(x, allowed, EOT)) < 1e-5
+    # (e) a finished row stands still and emits eot
+    before = st.copy()
+    assert O.whisper_filter_pick(x, sup, st, BEG, EOT, TID0)[0] == EOT and np.array_equal(st, before)
+    # (f) text wins when its best token beats the timestamps' sum: nothing is masked, the arg max is that token
+    st = np.zeros(8, np.int32); st[7] = 1000
+    x = base.copy(); x[9] = 8.0; x[30] = 5.0; x[31] = 5.0
+    assert O.whisper_filter_pick(x, sup, st, BEG, EOT, TID0)[0] == 9 and st.tolist() == [1, 0, 0, 0, 0, 0, 0, 1000]
+    # (g) end of text before any timestamp: a failure on a long utterance (whisper.cpp falls back to the next temperature), a one-token result on a
+    #     short one (seek + seek_delta + 100 >= seek_end)
+    for seek_end, want in ((1000, [1, 0, 0, 0, 0, 0, 2, 1000]), (100, [1, 0, 0, 0, 0, 1, 1, 100])):
+        st = np.zeros(8, np.int32); st[7] = seek_end
+        x = base.copy(); x[EOT] = 9.0
+        assert O.whisper_filter_pick(x, sup, st, BEG, EOT, TID0)[0] == EOT and st.tolist() == want
+    # (h) a short utterance ends with its first closing timestamp: seek_delta + 100 >= seek_end
+    st = np.array([3, 0, 0, 0, 0, 0, 0, 110], np.int32)
+    x = base.copy(); x[36] = 9.0
+    assert O.whisper_filter_pick(x, sup, st, BEG, EOT, TID0)[0] == 36 and st.tolist() == [4, 1, 0, 1, 12, 4, 1, 110]
+    # (i) at a temperature the draw stays inside the allowed set and is a pure function of (seed, counter)
+    st0 = np.array([1, 1, 0, 1, 4, 1, 0, 1000], np.int32)   # after (a): no timestamps allowed
+    x = np.linspace(-1, 1, V).astype(np.float32)
+    draws = set()
+    for counter in range(40):
+        s1, s2 = st0.copy(), st0.copy()
+        t1, l1 = O.whisper_filter_pick(x, sup, s1, BEG, EOT, TID0, temperature=1.0, seed=5, counter=counter)
+        t2, l2 = O.whisper_filter_pick(x, sup, s2, BEG, EOT, TID0, temperature=1.0, seed=5, counter=counter)
+        assert (t1, l1) == (t2, l2) and t1 <= EOT and not sup[t1]
+        draws.add(t1)
+    assert len(draws) > 5

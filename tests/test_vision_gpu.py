@@ -229,3 +229,53 @@ def test_detector_errors(gpu):
         gpu.ObjectDetector(width=100)
     with pytest.raises(gpu.TkError):
         gpu.ObjectDetector(model="/nonexistent/weights.tkyolo")
+
+
+def test_detectors_on_one_file_share_an_engine_and_give_the_solo_results(gpu):
+    """round 6: tk_object_detector_t / tk_vision_pipeline_t handles opened on the same model file share the weights and ONE
+    batched engine; their one-frame calls (the reference's API shape, src/vision/tk_object_detector.c:182-219) are coalesced by a scheduler.
+    Six handles driven at once from six threads each return exactly what a lone handle returns for that frame — detections, boxes and the
+    pipeline's per-box attributes — and the engine's counters show that frames really travelled together."""
+    import threading
+    rng = np.random.default_rng(77)
+    K = 6
+    frames = [rng.integers(0, 256, (480, 640, 3), dtype=np.uint8) for _ in range(K)]
+    model = "synthetic://yolov8n?seed=5&cls_bias=-0.40"
+    solo_det, solo_pipe = [], []
+    for f in frames:                                   # one handle alive at a time: nothing to coalesce with
+        d = gpu.ObjectDetector(model=model, conf=0.5)
+        assert d.share_stats()[0] == 1
+        solo_det.append(d.detect(f))
+        d.close()
+        p = gpu.VisionPipeline(model=model, conf=0.5, max_objects=20)
+        solo_pipe.append(p.process(f, flags=1)[2])
+        p.close()
+    assert sum(len(r) for r in solo_det) > K and len({len(r) for r in solo_det}) > 1
+    dets = [gpu.ObjectDetector(model=model, conf=0.5) for _ in range(K // 2)]
+    pipes = [gpu.VisionPipeline(model=model, conf=0.5, max_objects=20) for _ in range(K - K // 2)]
+    assert dets[0].share_stats()[0] == K               # detector handles and pipelines' detectors: one engine
+    other = gpu.ObjectDetector(model="synthetic://yolov8n?seed=6&cls_bias=-0.40", conf=0.5)
+    assert other.share_stats()[0] == 1                 # another file, another engine
+    got = [None] * K
+    bar = threading.Barrier(K)
+
+    def run(i):
+        bar.wait()
+        for rep in range(3):                           # the same frame thrice: every round coalesces anew
+            got[i] = dets[i].detect(frames[i]) if i < len(dets) else pipes[i - len(dets)].process(frames[i], flags=1)[2]
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(K):
+        assert got[i] == (solo_det[i] if i < len(dets) else solo_pipe[i]), "handle %d differs from its solo result" % i
+    handles, batches, nframes, widest = dets[0].share_stats()
+    assert nframes == 3 * K and batches < nframes and widest >= 2, (handles, batches, nframes, widest)
+    # thresholds are per handle: a stricter handle does not change its neighbours' results
+    dets[0].set_thresholds(0.9, 0.5)
+    strict = dets[0].detect(frames[0])
+    assert len(strict) < len(solo_det[0]) and dets[1].detect(frames[1]) == solo_det[1]
+    for h in dets + pipes + [other]:
+        h.close()

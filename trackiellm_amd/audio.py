@@ -84,6 +84,36 @@ class Asr:
         lib().tk_mi355x_asr_last_decode(self.h, C.byref(t), C.byref(a), C.byref(n))
         return t.value, a.value, n.value
 
+    def set_reference_decode(self, enable=True):
+        """process_audio decodes under the reference's whisper.cpp parameters (logit filters, timestamps) — the default; False = the forced-greedy decode"""
+        check(lib().tk_mi355x_asr_set_reference_decode(self.h, int(enable)))
+
+    def transcribe_ref(self, pcm, n_steps, temperature=0.0, seed=0):
+        """one utterance through the reference-parameter decode -> (tokens [n_steps], logprobs [n_steps], result_len, status)"""
+        pcm = np.ascontiguousarray(pcm, np.int16).reshape(-1)
+        toks = np.zeros(n_steps, np.int32)
+        lp = np.zeros(n_steps, np.float32)
+        rl, st = C.c_int32(0), C.c_int32(0)
+        check(lib().tk_mi355x_asr_transcribe_ref(self.h, pcm.ctypes.data_as(C.c_void_p), pcm.size, n_steps, C.c_float(temperature), C.c_uint64(seed),
+                                                 toks.ctypes.data_as(C.c_void_p), lp.ctypes.data_as(C.c_void_p), C.byref(rl), C.byref(st)))
+        return toks, lp, rl.value, st.value
+
+    def suppress_table(self):
+        """(table uint8 [n_vocab] or None, token_beg, token_eot) of the reference-parameter decode"""
+        beg, eot = C.c_int32(0), C.c_int32(0)
+        n = lib().tk_mi355x_asr_suppress_table(self.h, None, 0, C.byref(beg), C.byref(eot))
+        if n <= 0:
+            return None, 0, 0
+        tab = np.zeros(n, np.uint8)
+        lib().tk_mi355x_asr_suppress_table(self.h, tab.ctypes.data_as(C.c_void_p), n, C.byref(beg), C.byref(eot))
+        return tab, beg.value, eot.value
+
+    def share_stats(self):
+        """(live contexts, batched jobs, utterances, widest job) of the engine this context shares with the others opened on the same file"""
+        v = [C.c_uint64(0) for _ in range(4)]
+        lib().tk_mi355x_asr_share_stats(self.h, *[C.byref(x) for x in v])
+        return tuple(int(x.value) for x in v)
+
     def set_language(self, lang):
         return lib().tk_asr_whisper_set_language(self.h, lang.encode() if lang is not None else None)
 

@@ -18,13 +18,165 @@
 #include "tk/tk_depth.h"
 #include "../vision/tk_fusion.h"
 
-struct tk_object_detector_s {
+#include <string>
+#include <sys/stat.h>
+/* a registry key names a FILE, not a path: a path rewritten while an older handle is alive (size, modification time or inode differ) is another model */
+static std::string file_identity(const std::string& path) {
+    struct stat st;
+    if (path.compare(0, 12, "synthetic://") == 0 || stat(path.c_str(), &st) != 0) return path;
+    return path + "|" + std::to_string((long long)st.st_size) + "|" + std::to_string((long long)st.st_mtim.tv_sec) + "." + std::to_string((long long)st.st_mtim.tv_nsec) + "|" +
+           std::to_string((unsigned long long)st.st_ino);
+}
+
+/* ---- per-model-file registry: every tk_object_detector_t opened on the same file / device / geometry shares ONE set of weights
+ * and ONE batched engine.  The reference's API is one frame per call and per handle (src/vision/tk_object_detector.c:182-219); K cortex
+ * handles that each own a detector at batch 1 ran K small networks side by side.  Here a call enqueues its frame, a scheduler thread coalesces
+ * the frames that are waiting (same geometry and thresholds) into one batched detect() — the way csrc/llm/tk_llm_batcher does for runners — and
+ * every caller gets exactly what it would get alone: the engine's arithmetic is per frame (tests/test_vision_gpu.py: batch == singles).
+ * The per-box attributes of tk_vision_pipeline_process_frame run inside the same job, while the batch's frames are still on the device. */
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <thread>
+
+#define TK_DET_SHARED_MAX_BATCH 32
+
+struct DetReq {
+    const uint8_t* frame = nullptr;
+    uint32_t w = 0, h = 0, stride = 0, bpp = 3;
+    float conf = 0.5f, iou = 0.5f;
+    bool want_attr = false;      /* classify the first `max_objects` boxes (0 = all) while the frame is resident */
+    uint32_t max_objects = 0;
+    std::vector<TkDetection> dets;
+    std::vector<int32_t> color, door;
+    bool have_attr = false, ok = false, done = false;
+    std::string err;
+};
+
+/* the reference's box conversion (detector space -> frame pixels, truncated): one definition for results and attribute rectangles */
+static inline void box_to_rect(const TkDetection& v, float sx, float sy, int32_t* r) {
+    r[0] = (int)(v.x1 * sx); r[1] = (int)(v.y1 * sy); r[2] = (int)((v.x2 - v.x1) * sx); r[3] = (int)((v.y2 - v.y1) * sy);
+}
+
+struct SharedDetector {
+    std::string key;
     TkYoloModel model;
-    std::unique_ptr<TkDetector> det;
+    int in_w = 640, in_h = 640;
+    std::unique_ptr<TkDetector> eng; /* grows with the number of handles (1, 2, 4 ... TK_DET_SHARED_MAX_BATCH frames per call) */
+    std::mutex mu;
+    std::condition_variable cv_req, cv_done;
+    std::deque<DetReq*> q;
+    std::thread th;
+    bool stop = false;
+    int handles = 0;
+    uint64_t n_batches = 0, n_frames = 0, widest = 0;
+
+    ~SharedDetector() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_req.notify_all();
+        if (th.joinable()) th.join();
+    }
+    bool ensure_engine(int want, std::string* err) {
+        if (eng && eng->max_batch >= want) return true;
+        std::unique_ptr<TkDetector> nd(new TkDetector());
+        if (!nd->init(&model, in_w, in_h, want)) { *err = nd->error; return false; }
+        eng.swap(nd);
+        return true;
+    }
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_req.wait(lk, [&] { return stop || !q.empty(); });
+            if (stop) break;
+            /* give the other handles' callers a moment to arrive: a few hundred microseconds against a network of ~1.5 ms per frame */
+            if (handles > 1) {
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+                while ((int)q.size() < (handles < TK_DET_SHARED_MAX_BATCH ? handles : TK_DET_SHARED_MAX_BATCH) && !stop)
+                    if (cv_req.wait_until(lk, until) == std::cv_status::timeout) break;
+                if (stop) break;
+            }
+            std::vector<DetReq*> job;
+            DetReq* first = q.front();
+            for (auto it = q.begin(); it != q.end() && (int)job.size() < TK_DET_SHARED_MAX_BATCH;) {
+                DetReq* r = *it;
+                if (r->w == first->w && r->h == first->h && r->stride == first->stride && r->bpp == first->bpp && r->conf == first->conf && r->iou == first->iou) {
+                    job.push_back(r);
+                    it = q.erase(it);
+                } else ++it;
+            }
+            int cap = 1;
+            while (cap < (int)job.size() || (cap < handles && cap < TK_DET_SHARED_MAX_BATCH)) cap *= 2;
+            lk.unlock();
+            std::string err;
+            bool ok = ensure_engine(cap, &err);
+            std::vector<std::vector<TkDetection>> out;
+            if (ok) {
+                std::vector<const uint8_t*> ptrs(job.size());
+                for (size_t i = 0; i < job.size(); ++i) ptrs[i] = job[i]->frame;
+                eng->conf = first->conf;
+                eng->iou = first->iou;
+                ok = eng->detect((int)job.size(), ptrs.data(), first->w, first->h, first->stride, first->bpp, &out);
+                if (!ok) err = eng->error;
+            }
+            for (size_t i = 0; i < job.size(); ++i) {
+                DetReq* r = job[i];
+                r->ok = ok;
+                if (!ok) { r->err = err; continue; }
+                r->dets.swap(out[i]);
+                size_t n = r->dets.size();
+                if (r->max_objects && n > r->max_objects) n = r->max_objects;
+                if (r->want_attr && n > 0) {
+                    std::vector<int32_t> rects(4 * n);
+                    const float sx = (float)r->w / (float)in_w, sy = (float)r->h / (float)in_h;
+                    for (size_t k = 0; k < n; ++k) box_to_rect(r->dets[k], sx, sy, &rects[4 * k]);
+                    r->color.assign(n, -1);
+                    r->door.assign(n, 0);
+                    r->have_attr = eng->classify_boxes((int)i, (int)n, rects.data(), r->color.data(), r->door.data());
+                }
+            }
+            lk.lock();
+            n_batches++;
+            n_frames += job.size();
+            if (job.size() > widest) widest = job.size();
+            for (DetReq* r : job) r->done = true;
+            cv_done.notify_all();
+        }
+        /* whoever is still waiting is told so */
+        for (DetReq* r : q) { r->ok = false; r->err = "the detector was destroyed"; r->done = true; }
+        q.clear();
+        cv_done.notify_all();
+    }
+    void submit(DetReq* r) {
+        std::unique_lock<std::mutex> lk(mu);
+        q.push_back(r);
+        cv_req.notify_all();
+        cv_done.wait(lk, [&] { return r->done; });
+    }
+};
+
+static std::mutex g_det_mu;
+static std::map<std::string, std::weak_ptr<SharedDetector>> g_det_registry;
+
+struct tk_object_detector_s {
+    std::shared_ptr<SharedDetector> sh; /* weights + the coalescing engine, shared by every handle of the same file */
+    std::unique_ptr<TkDetector> own;    /* a private engine on the shared weights: only for the batch / raw-tensor entry points (tk_mi355x_detector_*) */
     std::vector<const char*> labels;
     size_t class_count = 0;
     int in_w = 640, in_h = 640;
+    float conf = 0.5f, iou = 0.5f;
     std::vector<std::vector<TkDetection>> last;
+    ~tk_object_detector_s() {
+        own.reset(); /* before the weights it reads */
+        if (sh) { std::lock_guard<std::mutex> lk(sh->mu); sh->handles--; }
+    }
+    TkDetector* priv(int max_batch, std::string* err) {
+        if (own && own->max_batch >= max_batch) return own.get();
+        std::unique_ptr<TkDetector> nd(new TkDetector());
+        if (!nd->init(&sh->model, in_w, in_h, max_batch)) { *err = nd->error; return nullptr; }
+        own.swap(nd);
+        return own.get();
+    }
 };
 
 static tk_error_code_t vfail(tk_error_code_t code, const std::string& why) {
@@ -53,21 +205,39 @@ tk_error_code_t tk_object_detector_create(tk_object_detector_t** out_detector, c
     d->labels.assign(config->class_labels, config->class_labels + config->class_count);
     d->in_w = config->input_width ? (int)config->input_width : 640;
     d->in_h = config->input_height ? (int)config->input_height : 640;
-    if (!d->model.init(dev, (int)config->class_count)) return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
+    d->conf = config->confidence_threshold;
+    d->iou = config->iou_threshold;
     const std::string path = config->model_path->path_str;
-    if (path.compare(0, 12, "synthetic://") == 0) {
-        if (!d->model.fill_synthetic((uint64_t)query_param(path, "seed", 5), (float)query_param(path, "cls_bias", -4.0)))
-            return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
-    } else if (path.size() > 5 && path.compare(path.size() - 5, 5, ".onnx") == 0) {
-        /* the reference's detector file: its Conv initialisers feed this path's own YOLOv8n graph (no ONNX Runtime) */
-        if (!d->model.load_onnx(path.c_str())) return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
-    } else if (!d->model.load_file(path.c_str())) {
-        return vfail(TK_ERROR_MODEL_LOAD_FAILED, d->model.error);
+    const std::string key = file_identity(path) + "|dev" + std::to_string(dev) + "|nc" + std::to_string(config->class_count) + "|" + std::to_string(d->in_w) + "x" + std::to_string(d->in_h);
+    {
+        /* find-or-load under the registry lock: K handles created at once load the file once (the reference's model loader does the same for
+         * LLM files, src/ai_models/tk_model_loader.c:199-294) */
+        std::lock_guard<std::mutex> lk(g_det_mu);
+        std::shared_ptr<SharedDetector> sh = g_det_registry[key].lock();
+        if (!sh) {
+            sh.reset(new SharedDetector());
+            sh->key = key;
+            sh->in_w = d->in_w;
+            sh->in_h = d->in_h;
+            if (!sh->model.init(dev, (int)config->class_count)) return vfail(TK_ERROR_MODEL_LOAD_FAILED, sh->model.error);
+            if (path.compare(0, 12, "synthetic://") == 0) {
+                if (!sh->model.fill_synthetic((uint64_t)query_param(path, "seed", 5), (float)query_param(path, "cls_bias", -4.0)))
+                    return vfail(TK_ERROR_MODEL_LOAD_FAILED, sh->model.error);
+            } else if (path.size() > 5 && path.compare(path.size() - 5, 5, ".onnx") == 0) {
+                /* the reference's detector file: its Conv initialisers feed this path's own YOLOv8n graph (no ONNX Runtime) */
+                if (!sh->model.load_onnx(path.c_str())) return vfail(TK_ERROR_MODEL_LOAD_FAILED, sh->model.error);
+            } else if (!sh->model.load_file(path.c_str())) {
+                return vfail(TK_ERROR_MODEL_LOAD_FAILED, sh->model.error);
+            }
+            std::string err;
+            if (!sh->ensure_engine(1, &err)) return vfail(TK_ERROR_GPU_MEMORY, err);
+            SharedDetector* raw = sh.get();
+            sh->th = std::thread([raw] { raw->run(); });
+            g_det_registry[key] = sh;
+        }
+        { std::lock_guard<std::mutex> hl(sh->mu); sh->handles++; }
+        d->sh = sh;
     }
-    d->det.reset(new TkDetector());
-    if (!d->det->init(&d->model, d->in_w, d->in_h, 1)) return vfail(TK_ERROR_GPU_MEMORY, d->det->error);
-    d->det->conf = config->confidence_threshold;
-    d->det->iou = config->iou_threshold;
     *out_detector = d.release();
     return TK_SUCCESS;
 }
@@ -98,13 +268,20 @@ void tk_object_detector_destroy(tk_object_detector_t** detector) {
 }
 
 tk_error_code_t tk_mi355x_detector_set_max_batch(tk_object_detector_t* d, int max_batch) {
-    if (!d) return TK_ERROR_INVALID_ARGUMENT;
-    std::unique_ptr<TkDetector> nd(new TkDetector());
-    if (!nd->init(&d->model, d->in_w, d->in_h, max_batch)) return vfail(TK_ERROR_GPU_MEMORY, nd->error);
-    nd->conf = d->det->conf;
-    nd->iou = d->det->iou;
-    d->det.swap(nd);
+    if (!d || max_batch < 1) return TK_ERROR_INVALID_ARGUMENT;
+    std::string err;
+    d->own.reset();
+    if (!d->priv(max_batch, &err)) return vfail(TK_ERROR_GPU_MEMORY, err);
     return TK_SUCCESS;
+}
+
+void tk_mi355x_detector_share_stats(const tk_object_detector_t* d, uint64_t* handles, uint64_t* batches, uint64_t* frames, uint64_t* widest) {
+    if (!d || !d->sh) return;
+    std::lock_guard<std::mutex> lk(d->sh->mu);
+    if (handles) *handles = (uint64_t)d->sh->handles;
+    if (batches) *batches = d->sh->n_batches;
+    if (frames) *frames = d->sh->n_frames;
+    if (widest) *widest = d->sh->widest;
 }
 
 static tk_error_code_t to_results(tk_object_detector_s* d, const std::vector<TkDetection>& v, const tk_video_frame_t* f,
@@ -118,10 +295,9 @@ static tk_error_code_t to_results(tk_object_detector_s* d, const std::vector<TkD
         r.class_id = (uint32_t)v[i].cls;
         r.label = v[i].cls >= 0 && (size_t)v[i].cls < d->class_count ? d->labels[v[i].cls] : NULL;
         r.confidence = v[i].score;
-        r.bbox.x = (int)(v[i].x1 * sx);
-        r.bbox.y = (int)(v[i].y1 * sy);
-        r.bbox.w = (int)((v[i].x2 - v[i].x1) * sx);
-        r.bbox.h = (int)((v[i].y2 - v[i].y1) * sy);
+        int32_t rc4[4];
+        box_to_rect(v[i], sx, sy, rc4);
+        r.bbox.x = rc4[0]; r.bbox.y = rc4[1]; r.bbox.w = rc4[2]; r.bbox.h = rc4[3];
     }
     return TK_SUCCESS;
 }
@@ -143,8 +319,23 @@ tk_error_code_t tk_mi355x_detector_detect_batch(tk_object_detector_t* d, int n, 
             return vfail(TK_ERROR_INVALID_ARGUMENT, "frames of one batch must share geometry");
         ptrs[i] = frames[i].data;
     }
-    if (!d->det->detect(n, ptrs.data(), frames[0].width, frames[0].height, pitch(frames[0]), bpp, &d->last))
-        return vfail(TK_ERROR_INFERENCE_FAILED, d->det->error);
+    if (n == 1 && !d->own) {
+        /* the reference's one-frame call: through the shared engine, coalesced with the other handles' frames */
+        DetReq r;
+        r.frame = frames[0].data; r.w = frames[0].width; r.h = frames[0].height; r.stride = pitch(frames[0]); r.bpp = bpp; r.conf = d->conf; r.iou = d->iou;
+        if (r.w < 2 || r.h < 2 || r.stride < r.w * bpp) return vfail(TK_ERROR_INFERENCE_FAILED, "frame geometry invalid (need w,h >= 2 and stride >= w*bpp)");
+        d->sh->submit(&r);
+        if (!r.ok) return vfail(TK_ERROR_INFERENCE_FAILED, r.err);
+        d->last.assign(1, std::vector<TkDetection>());
+        d->last[0].swap(r.dets);
+    } else {
+        std::string err;
+        TkDetector* e = d->own ? d->own.get() : d->priv(n, &err);
+        if (!e) return vfail(TK_ERROR_GPU_MEMORY, err);
+        e->conf = d->conf;
+        e->iou = d->iou;
+        if (!e->detect(n, ptrs.data(), frames[0].width, frames[0].height, pitch(frames[0]), bpp, &d->last)) return vfail(TK_ERROR_INFERENCE_FAILED, e->error);
+    }
     for (int i = 0; i < n; ++i) {
         tk_error_code_t rc = to_results(d, d->last[i], &frames[i], &out_results[i], &out_counts[i]);
         if (rc != TK_SUCCESS) return rc;
@@ -166,21 +357,31 @@ void tk_object_detector_free_results(tk_detection_result_t** results) {
 
 void tk_object_detector_update_thresholds(tk_object_detector_t* detector, float confidence_threshold, float iou_threshold) {
     if (!detector) return;
-    detector->det->conf = confidence_threshold;
-    detector->det->iou = iou_threshold;
+    detector->conf = confidence_threshold;
+    detector->iou = iou_threshold;
 }
 
 tk_error_code_t tk_mi355x_detector_forward_raw(tk_object_detector_t* d, int batch, const float* nhwc, float* raw_out, size_t raw_floats) {
     if (!d || !nhwc || !raw_out) return TK_ERROR_INVALID_ARGUMENT;
     std::vector<float> raw;
-    if (!d->det->forward_tensor(batch, nhwc, &raw)) return vfail(TK_ERROR_INFERENCE_FAILED, d->det->error);
+    std::string err;
+    TkDetector* e = d->priv(batch > 1 ? batch : 1, &err);
+    if (!e) return vfail(TK_ERROR_GPU_MEMORY, err);
+    e->conf = d->conf;
+    e->iou = d->iou;
+    if (!e->forward_tensor(batch, nhwc, &raw)) return vfail(TK_ERROR_INFERENCE_FAILED, e->error);
     if (raw.size() > raw_floats) return vfail(TK_ERROR_BUFFER_TOO_SMALL, "raw_out too small");
     memcpy(raw_out, raw.data(), raw.size() * 4);
-    if (!d->det->fetch(batch, &d->last)) return vfail(TK_ERROR_INFERENCE_FAILED, d->det->error); /* for last_boxes */
+    if (!e->fetch(batch, &d->last)) return vfail(TK_ERROR_INFERENCE_FAILED, e->error); /* for last_boxes */
     return TK_SUCCESS;
 }
 
-int tk_mi355x_detector_anchor_count(const tk_object_detector_t* d) { return d ? d->det->n_anchors : 0; }
+int tk_mi355x_detector_anchor_count(const tk_object_detector_t* d) {
+    if (!d) return 0;
+    if (d->own) return d->own->n_anchors;
+    std::lock_guard<std::mutex> lk(d->sh->mu);
+    return d->sh->eng ? d->sh->eng->n_anchors : 0;
+}
 
 tk_error_code_t tk_mi355x_detector_last_boxes(tk_object_detector_t* d, int frame, float* boxes5, int32_t* cls, int32_t* anchors, int cap, int* count) {
     if (!d || !count || frame < 0 || frame >= (int)d->last.size()) return TK_ERROR_INVALID_ARGUMENT;
@@ -368,20 +569,48 @@ tk_error_code_t tk_vision_pipeline_process_frame(tk_vision_pipeline_t* pipeline,
          * logged and the frame goes on without this analysis (:190-197) */
         tk_detection_result_t* det = nullptr;
         size_t n = 0;
-        bool ok = video_frame->data && tk_object_detector_detect(pipeline->detector, video_frame, &det, &n) == TK_SUCCESS;
-        if (ok && pipeline->max_objects && n > pipeline->max_objects) n = pipeline->max_objects; /* results are score-descending */
+        std::vector<int32_t> color, door;
+        bool have_attr = false;
+        tk_object_detector_s* d = pipeline->detector;
+        bool ok = video_frame->data != nullptr;
+        if (ok && !d->own) {
+            /* one job of the shared engine: the network on this frame (batched with the other handles' frames) and, while the frame is still on
+             * the device, the attributes of the boxes that will be reported; RGBA / padded frames have no attribute pass (the reference reads
+             * them as packed RGB8 and classifies garbage) */
+            DetReq r;
+            const uint32_t bpp = (uint32_t)bytes_per_pixel(video_frame);
+            r.frame = video_frame->data; r.w = video_frame->width; r.h = video_frame->height; r.stride = video_frame->stride ? video_frame->stride : video_frame->width * bpp;
+            r.bpp = bpp; r.conf = d->conf; r.iou = d->iou; r.want_attr = bpp == 3 && r.stride == r.w * 3; r.max_objects = pipeline->max_objects;
+            ok = r.w >= 2 && r.h >= 2 && r.stride >= r.w * bpp;
+            if (ok) {
+                d->sh->submit(&r);
+                ok = r.ok;
+            }
+            if (ok) {
+                d->last.assign(1, std::vector<TkDetection>());
+                d->last[0].swap(r.dets);
+                ok = to_results(d, d->last[0], video_frame, &det, &n) == TK_SUCCESS;
+                have_attr = r.have_attr;
+                color.swap(r.color);
+                door.swap(r.door);
+            }
+            if (ok && pipeline->max_objects && n > pipeline->max_objects) n = pipeline->max_objects; /* results are score-descending */
+        } else if (ok) {
+            ok = tk_object_detector_detect(d, video_frame, &det, &n) == TK_SUCCESS;
+            if (ok && pipeline->max_objects && n > pipeline->max_objects) n = pipeline->max_objects;
+            if (ok && n > 0) {
+                std::vector<int32_t> rects(4 * n);
+                color.assign(n, -1);
+                door.assign(n, 0);
+                for (size_t i = 0; i < n; ++i) { rects[4 * i] = det[i].bbox.x; rects[4 * i + 1] = det[i].bbox.y; rects[4 * i + 2] = det[i].bbox.w; rects[4 * i + 3] = det[i].bbox.h; }
+                have_attr = d->own->classify_boxes(0, (int)n, rects.data(), color.data(), door.data());
+            }
+        }
         if (ok && n > 0) {
             result->objects = (tk_vision_object_t*)calloc(n, sizeof(tk_vision_object_t));
             ok = result->objects != nullptr;
         }
-        std::vector<int32_t> rects(4 * n), color(n, -1), door(n, 0);
-        bool have_attr = false;
-        if (ok && n > 0) {
-            for (size_t i = 0; i < n; ++i) { rects[4 * i] = det[i].bbox.x; rects[4 * i + 1] = det[i].bbox.y; rects[4 * i + 2] = det[i].bbox.w; rects[4 * i + 3] = det[i].bbox.h; }
-            /* the frame the detector just pre-processed is still on the device; RGBA / padded frames have no attribute pass (the
-             * reference reads them as packed RGB8 and classifies garbage) */
-            have_attr = pipeline->detector->det->classify_boxes(0, (int)n, rects.data(), color.data(), door.data());
-        }
+        if (have_attr && (color.size() < n || door.size() < n)) have_attr = false;
         if (ok) {
             for (size_t i = 0; i < n; ++i) {
                 tk_vision_object_t& o = result->objects[i];

@@ -52,6 +52,14 @@ public:
      * distribution (what the policy's logprob / entropy thresholds are taken on) */
     bool transcribe_policy(int B, const int16_t* pcm, int n_samples, const int32_t* prompt, int n_prompt, int n_steps, float temperature, uint64_t seed,
                            int32_t* tokens_out, float* logprobs_out);
+    /* the decode as whisper.cpp runs it under the reference's parameters (src/audio/tk_asr_whisper.c:89-110; csrc/nn/tk_nn_kernels.h: TkWhFilter):
+     * logit filters, timestamp rules and the per-token bookkeeping on the device, at most n_steps tokens per utterance.  n_samples_row [B] = each
+     * utterance's own length (rows are padded to `n_samples` with zeros): it sets the row's seek_end.  suppress [n_vocab] = 1 where a token is
+     * never sampled.  Out: tokens [B][n_steps] (eot behind a row's end), logprobs [B][n_steps] (may be null), result_len [B] = tokens that make
+     * up the row's text, status [B] = 0 (n_steps reached), 1 (completed), 2 (failed: whisper.cpp would fall back to the next temperature) */
+    bool transcribe_ref(int B, const int16_t* pcm, int n_samples, const int32_t* n_samples_row, const int32_t* prompt, int n_prompt, int n_steps, float temperature,
+                        uint64_t seed, const uint8_t* suppress, int32_t token_beg, int32_t token_eot, int32_t* tokens_out, float* logprobs_out, int32_t* result_len,
+                        int32_t* status);
 
 private:
     friend struct TkAudioGpuOps;
@@ -60,7 +68,11 @@ private:
     std::string launch_error; /* a launcher refused its arguments while the graph was being enqueued (no HIP error is raised for that) */
     int16_t* pcm_dev = nullptr;
     size_t pcm_cap = 0;
-    struct { bool on = false; float temp = 0.0f; uint64_t seed = 0; float* logprob = nullptr; int step = 0; } pick; /* token pick of the current transcribe */
+    struct { bool on = false; float temp = 0.0f; uint64_t seed = 0; float* logprob = nullptr; int step = 0;
+             bool filtered = false; int first_step = 0; const uint8_t* suppress = nullptr; int32_t* state = nullptr; int32_t beg = 0, eot = 0, tid0 = 0; } pick; /* token pick of the current transcribe */
+    uint8_t* suppress_dev = nullptr; /* [n_vocab] of the last transcribe_ref (uploaded again only when the table changes) */
+    std::vector<uint8_t> suppress_host;
+    int32_t* wh_state = nullptr;     /* [max_batch][TK_WH_STATE_INTS] */
     std::vector<float> pick_logprobs; /* [total steps][B], read back by transcribe_policy */
 };
 

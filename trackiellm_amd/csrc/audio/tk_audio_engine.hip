@@ -322,7 +322,15 @@ struct TkAudioGpuOps {
         if (!a->pick.on) { tk_launch_argmax_rows(x, rows, cols, ld, out, s); return; }
         /* whisper.cpp's decoding policy: the step's token by temperature, its log-probability noted (step p of the decode loop, row b: slot p * B + b) */
         TkPick pk{a->pick.temp, a->pick.seed, (uint32_t)(a->pick.step * rows), a->pick.logprob ? a->pick.logprob + (size_t)a->pick.step * rows : nullptr};
-        tk_launch_pick_rows(x, rows, cols, ld, out, pk, s);
+        if (a->pick.filtered) {
+            /* prompt positions before the last one produce logits nobody samples from: the rows' decode state must not move there */
+            if (a->pick.step >= a->pick.first_step) {
+                TkWhFilter f{a->pick.suppress, a->pick.state, a->pick.beg, a->pick.eot, a->pick.tid0};
+                tk_launch_pick_rows_filtered(x, rows, cols, ld, out, pk, f, s);
+            }
+        } else {
+            tk_launch_pick_rows(x, rows, cols, ld, out, pk, s);
+        }
         a->pick.step++;
     }
     void frames(const int16_t* pcm, int B, int n_samples, int pcm_stride, int n_total, int T, const float* window, float* out) {
@@ -475,6 +483,8 @@ TkAsr::~TkAsr() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (arena) (void)hipFree(arena);
     if (pcm_dev) (void)hipFree(pcm_dev);
+    if (suppress_dev) (void)hipFree(suppress_dev);
+    if (wh_state) (void)hipFree(wh_state);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -518,6 +528,53 @@ bool TkAsr::transcribe_policy(int B, const int16_t* pcm, int n_samples, const in
     (void)hipFree(d_lp);
     pick.logprob = nullptr;
     if (ok && !copied) error = "copy of the log-probabilities failed";
+    return ok && copied;
+}
+
+bool TkAsr::transcribe_ref(int B, const int16_t* pcm, int n_samples, const int32_t* n_samples_row, const int32_t* prompt, int n_prompt, int n_steps, float temperature,
+                           uint64_t seed, const uint8_t* suppress, int32_t token_beg, int32_t token_eot, int32_t* tokens_out, float* logprobs_out, int32_t* result_len,
+                           int32_t* status) {
+    const TkWhisperHP& h = model->hp;
+    if (!(temperature >= 0.0f) || h.n_vocab > 65536) { error = "temperature must be >= 0 and the vocabulary at most 65536 tokens"; return false; }
+    if (B < 1 || B > max_batch || !suppress || !n_samples_row || token_beg <= token_eot || token_beg >= h.n_vocab) { error = "bad arguments to the reference-parameter decode"; return false; }
+    const int total = n_prompt + n_steps - 1;
+    if (total < 1) { error = "nothing to decode"; return false; }
+    if (hipSetDevice(model->device) != hipSuccess) { error = "hipSetDevice failed"; return false; }
+    if (!suppress_dev) HIPQ(hipMalloc((void**)&suppress_dev, (size_t)h.n_vocab));
+    if (!wh_state) HIPQ(hipMalloc((void**)&wh_state, (size_t)max_batch * TK_WH_STATE_INTS * sizeof(int32_t)));
+    if (suppress_host.size() != (size_t)h.n_vocab || memcmp(suppress_host.data(), suppress, (size_t)h.n_vocab) != 0) {
+        HIPQ(hipStreamSynchronize(stream)); /* the previous decode may still read the table */
+        suppress_host.assign(suppress, suppress + h.n_vocab);
+        HIPQ(hipMemcpy(suppress_dev, suppress_host.data(), (size_t)h.n_vocab, hipMemcpyHostToDevice));
+    }
+    std::vector<int32_t> st0((size_t)B * TK_WH_STATE_INTS, 0);
+    for (int b = 0; b < B; ++b) st0[(size_t)b * TK_WH_STATE_INTS + 7] = n_samples_row[b] / TK_WH_HOP; /* seek_end: the utterance in 10 ms frames */
+    HIPQ(hipMemcpyAsync(wh_state, st0.data(), st0.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    float* d_lp = nullptr;
+    if (hipMalloc((void**)&d_lp, (size_t)total * B * sizeof(float)) != hipSuccess) { error = "out of device memory (log-probabilities)"; return false; }
+    HIPQ(hipMemsetAsync(d_lp, 0, (size_t)total * B * sizeof(float), stream));
+    pick.on = true; pick.temp = temperature; pick.seed = seed; pick.logprob = d_lp; pick.step = 0;
+    pick.filtered = true; pick.first_step = n_prompt - 1; pick.suppress = suppress_dev; pick.state = wh_state; pick.beg = token_beg; pick.eot = token_eot;
+    pick.tid0 = 50; /* max_initial_ts 1.0 s / (30 s / 1500 positions) */
+    const bool ok = transcribe(B, pcm, n_samples, prompt, n_prompt, n_steps, tokens_out, nullptr, nullptr, nullptr); /* synchronises the stream */
+    pick.on = false; pick.filtered = false;
+    bool copied = true;
+    std::vector<int32_t> st1((size_t)B * TK_WH_STATE_INTS);
+    if (ok) {
+        pick_logprobs.resize((size_t)total * B);
+        copied = hipMemcpy(pick_logprobs.data(), d_lp, pick_logprobs.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(st1.data(), wh_state, st1.size() * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+        for (int b = 0; copied && b < B; ++b) {
+            const int32_t* sb = &st1[(size_t)b * TK_WH_STATE_INTS];
+            if (status) status[b] = sb[6];
+            /* n_steps reached before the row ended: every sampled token counts (whisper.cpp would go on to n_text_ctx / 2 - 4 tokens) */
+            if (result_len) result_len[b] = sb[6] == 0 ? sb[0] : sb[5];
+            for (int step = 0; logprobs_out && step < n_steps; ++step) logprobs_out[(size_t)b * n_steps + step] = pick_logprobs[(size_t)(n_prompt - 1 + step) * B + b];
+        }
+    }
+    (void)hipFree(d_lp);
+    pick.logprob = nullptr;
+    if (ok && !copied) error = "copy of the decode state failed";
     return ok && copied;
 }
 

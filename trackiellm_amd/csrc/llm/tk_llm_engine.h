@@ -142,6 +142,7 @@ private:
     /* a decode pass (every sequence once) of at most TK_LONG_ATT_MAX_ROWS rows that reaches position TK_LONG_ATT_MIN_POS runs its attention as
      * append + scores + PV launches spread over the chip (tk_launch_attention_long) instead of one latency chain per pair of heads; bit-identical */
     bool long_pass = false;
+    bool counted_ = false; /* this session is in the device's count of live decode sessions (tk_attention_note_session) */
     float* d_scores = nullptr; /* [TK_LONG_ATT_MAX_ROWS][n_head][max_ctx], allocated when the window can reach TK_LONG_ATT_MIN_POS */
     void choose_attention(const int32_t* pos, int nrows);
     void choose_attention_top(int top, int nrows);

@@ -247,6 +247,8 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
     }
     HIPQ(hipSetDevice(m->device));
     HIPQ(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    tk_attention_note_session(m->device, +1);
+    counted_ = true;
     const int QD = h.n_head * h.head_dim, KVD = h.n_kv_head * h.head_dim, half = h.head_dim / 2;
     size_t kv = (size_t)h.n_layer * mseq * mctx * KVD;
     HIPQ(hipMalloc((void**)&kcache, kv * 2));
@@ -305,6 +307,7 @@ bool TkLlmSession::init(TkLlmModel* m, int mseq, int mctx) {
 }
 
 TkLlmSession::~TkLlmSession() {
+    if (model && counted_) tk_attention_note_session(model->device, -1);
     if (model) (void)hipSetDevice(model->device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto& v : graph_exec) for (auto& g : v) if (g) (void)hipGraphExecDestroy(g);

@@ -96,6 +96,8 @@ void tk_launch_argmax(const float* logits, int vocab, int nrows, const uint32_t*
 /* the attention launch a pass takes: kernel 0 = k_attention<gq, fused, head_dim, chunk, slots> (chunk = positions per ring slot), kernel 1 =
  * k_attention_narrow (gq 2, chunk = positions resident per chunk, the whole context when it fits) */
 struct TkAttentionPlan { int kernel, gq, chunk, slots; size_t lds_bytes; };
+/* a decode session on `device` came (+1) or went (-1): with more than one alive the plan prefers forms that share a CU with other streams' launches */
+void tk_attention_note_session(int device, int delta);
 TkAttentionPlan tk_attention_plan(int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, bool fused);
 
 /* multi-position passes (prompt chunks): 16 rows of a sequence per workgroup on the fp32 matrix pipe, bit-identical to k_attention's non-fused

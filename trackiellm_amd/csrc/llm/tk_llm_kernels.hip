@@ -1087,7 +1087,8 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = (m ^ rot) * TK_ROW_SLOTS + 4 * g + r; /* register slot m holds M-tile m ^ rot */
+                const int mt = rot == 0 ? m : (m < MT / 2 ? m + rot : m - rot); /* register slot m holds M-tile m ^ rot (the half-swap: MT = 6 is no power of two) */
+                const int row = mt * TK_ROW_SLOTS + 4 * g + r;
                 if (row < a.nrows) __builtin_nontemporal_store(acc[w][m][r], &a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n]);
             }
     }
@@ -1237,11 +1238,15 @@ __device__ __forceinline__ void load_atile32(ATile32& T, const Ptrs32& p, int t)
 
 /* one 256-k block: this wave's 32 weight rows x its four 32-row M-tiles.  T arrives holding tile 0's operands; the operands of tile
  * t + 1 are requested as soon as the MFMAs of tile t have issued — into the same registers — and land while tile t is finished on the VALU. */
-template <bool Q4, typename Hook>
-__device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const Ptrs32& p, float (&acc)[TK_G32_MTW][16], Hook&& after_mfmas) {
+/* MTW = 32-row M-tiles a workgroup's row range holds: 3 for passes of 129..192 rows (two halves of 96 rows), 4 for 193..256 — a pass of 160
+ * rows walks 3 + 3 tiles, not 4 + 4 (round 5: the 129th row cost + 63 %, profiles/r05_width_curve.txt).  A compile-time bound: 48 or 64
+ * accumulators and no branch in the loop.  (One tile fewer for the second half of 129..160- and 193..224-row passes as a scalar `break` in the
+ * unrolled loop was built too: 108 - 392 bytes of spill per lane at the 256-register budget of two workgroups per CU; not kept.) */
+template <bool Q4, int MTW, typename Hook>
+__device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const Ptrs32& p, float (&acc)[MTW][16], Hook&& after_mfmas) {
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < TK_G32_MTW; ++t) {
+    for (int t = 0; t < MTW; ++t) {
         /* P = 8 Ph + Pl (64 Ph + Pl for Q6_K) inside ONE accumulator: the high-digit chain first, its result shifted on the VALU, then the
          * low-digit chain on top of it (sixteen live registers fewer than two accumulators, and the finishing below needs no shift-add);
          * the independent min-term MFMA sits where the shift waits for the last high-digit MFMA */
@@ -1267,7 +1272,7 @@ __device__ __forceinline__ void gemm_block32(const Ops32& o, ATile32& T, const P
 #pragma unroll
         for (int u = 0; u < 8; ++u) pl = TK_MFMA32(A[u], o.bl[u], pl, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < TK_G32_MTW) load_atile32<Q4>(T, p, t + 1);
+        if (t + 1 < MTW) load_atile32<Q4>(T, p, t + 1);
         after_mfmas(t); /* a quarter of this wave's ring staging for the next block: LDS-DMA issue costs 60-180 cycles a piece, here they pass while
                          * the tile's MFMAs are still in the matrix pipe */
         __builtin_amdgcn_sched_barrier(0);
@@ -1315,9 +1320,9 @@ __device__ __forceinline__ void g32_unpack(const typename G32Frag<Q4>::type& f0,
 
 
 /* The K loop of one wave: its two weight tiles (32 weight rows) against its four 32-row M-tiles, block by block through the ring. */
-template <bool Q4, typename StageSmall, typename StagePart>
+template <bool Q4, int MTW, typename StageSmall, typename StagePart>
 __device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_bytes, ptrdiff_t tile_pitch, int nb, const uint8_t* ring, int slot_bytes, int lane,
-                                           float (&acc)[TK_G32_MTW][16], StageSmall&& stage_small, StagePart&& stage_part) {
+                                           float (&acc)[MTW][16], StageSmall&& stage_small, StagePart&& stage_part) {
     typedef typename G32Frag<Q4>::type F;
     F f0 = g32_load<Q4>(tile, lane), f1 = g32_load<Q4>(tile + tile_pitch, lane);
     stage_small(0, 0);
@@ -1349,7 +1354,14 @@ __device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_byte
         f1 = g32_load<Q4>(next + tile_pitch, lane);
         __builtin_amdgcn_sched_barrier(0);
         /* the last block restages itself into the slot nobody reads any more: no branch around the DMA issue */
-        gemm_block32<Q4>(o, T, bp, acc, [&](int t) { stage_part(more ? b + 1 : b, (b + 1) & 1, t); });
+        /* the ring's four staging parts ride on the tiles' MFMA phases: one per tile, the rest with the LAST tile when there are fewer than four
+         * (with the first tile the same code needs 148 bytes of spill per lane) */
+        gemm_block32<Q4, MTW>(o, T, bp, acc, [&](int t) {
+            stage_part(more ? b + 1 : b, (b + 1) & 1, t);
+            if (MTW < 4 && t == MTW - 1)
+#pragma unroll
+                for (int q = MTW; q < 4; ++q) stage_part(more ? b + 1 : b, (b + 1) & 1, q);
+        });
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -1362,7 +1374,7 @@ __device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_byte
  * 8750 cycles per block against 4352 of matrix pipe (profiles/r03_gemm32_segments.txt).
  * blockIdx -> (half, unit): consecutive workgroup ids go round the 8 XCDs, so the two halves of a unit are 8 ids apart: same XCD, same
  * L2 — the second half's weight requests hit the lines the first one brought in. */
-template <int TYPES>
+template <int TYPES, int MTW>
 __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups, int total_row_tiles, int n_halves) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int MT = TK_G32_MT;
@@ -1406,16 +1418,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
     const ptrdiff_t tile_pitch = a.swiglu ? a.seg[1].tiles - a.seg[0].tiles : (ptrdiff_t)((size_t)nblk_total * tile_bytes);
     const uint8_t* tile = a.seg[seg].tiles + ((size_t)rt * nblk_total + blk0) * tile_bytes;
 
-    float acc[TK_G32_MTW][16];
+    float acc[MTW][16];
 #pragma unroll
-    for (int t = 0; t < TK_G32_MTW; ++t)
+    for (int t = 0; t < MTW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     /* ring staging: of the half's eight 16-row M-tiles, `pair` and `pair + 4` belong to this wave.  The int8 image (4 x 1 KiB pieces per
      * tile, every lane takes part: no exec masking, so the issue can sit between the MFMA phases of the tile loop) in four parts of two
      * pieces; the f16 sub-block sums (32 lanes) and the block scales (4 lanes) separately at the top of a block */
-    const int m0 = half * MT; /* the half's first M-tile in the pass's activation images */
+    /* rows of the pass as 32-row tiles: each half takes MTW of them (rows beyond the pass are computed on whatever the image holds and never stored) */
+    const int t32_0 = half * MTW; /* this half's first 32-row tile */
+    const int m0 = 2 * t32_0;     /* the half's first 16-row M-tile in the pass's activation images */
+    /* the ring is staged whole (eight 16-row M-tiles per block) whatever MTW: the images of all sixteen M-tiles exist (TK_MAX_ROWS), a tile nobody
+     * reads costs L2 -> LDS bytes only, and a branch around the DMA issue inside the tile loop costs registers (148 bytes of spill per lane measured) */
     /* addresses = wave-uniform base (SGPR pair) + this lane's 32-bit offset, formed where they are used: the compiler otherwise hoists five
      * 64-bit per-lane addresses out of the K loop and holds ten registers for them across it (the asm keeps the offset opaque per use) */
     auto stage_part = [&](int c, int slot, int part) {
@@ -1455,8 +1471,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
         }
         return;
     }
-    if (HAS4 && is4) g32_k_loop<true>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, stage_small, stage_part);
-    if (HAS6 && !is4) g32_k_loop<false>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, stage_small, stage_part);
+    if (HAS4 && is4) g32_k_loop<true, MTW>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, stage_small, stage_part);
+    if (HAS6 && !is4) g32_k_loop<false, MTW>(tile, tile_bytes, tile_pitch, nb, lds, CH, lane, acc, stage_small, stage_part);
 
     /* Epilogue: 64 accumulator registers per lane.  Stored as they stand, a store instruction writes one dword per lane (two 128-byte row
      * segments): 64 store instructions per wave, and the tail of the launch is store-ISSUE bound (exit - loop end 4 us of gate|up's 76).
@@ -1470,7 +1486,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
         const int h = lane >> 5, n32 = lane & 31;
         const int n0 = a.col0 + row_base + rt * TK_TILE_ROWS + 4 * (lane & 7);
 #pragma unroll
-        for (int t = 0; t < TK_G32_MTW; ++t) {
+        for (int t = 0; t < MTW; ++t) {
             float* sp = (float*)scr[t & 1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + n32] = acc[t][r];
@@ -1482,7 +1498,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
                     v4f hv;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hv[j] = tk_siluf(g[j]) * u[j];
-                    const int row = (half * TK_G32_MTW + t) * 32 + rl;
+                    const int row = (t32_0 + t) * 32 + rl;
                     if (row < a.nrows) *(v4f*)&a.out[(size_t)row * a.n_total + rt * TK_TILE_ROWS + cg] = hv;
                 }
                 continue;
@@ -1491,7 +1507,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm32_w4a8(TkGemvArgs a, int groups
             for (int i = 0; i < 4; ++i) {
                 const int rl = 8 * i + (lane >> 3);
                 const v4f v = *(const v4f*)(sp + rl * 32 + 4 * (lane & 7));
-                const int row = (half * TK_G32_MTW + t) * 32 + rl;
+                const int row = (t32_0 + t) * 32 + rl;
                 if (row < a.nrows) *(v4f*)&a.out[((size_t)ksi * TK_MAX_ROWS + row) * a.n_total + n0] = v;
             }
         }
@@ -1522,6 +1538,16 @@ static int tk_num_cu() {
 template <typename F>
 static hipError_t opt_in_lds(F* fn) { return hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, TK_MAX_DYN_LDS); }
 
+#ifndef TK_G32_MIN_ROWS
+#define TK_G32_MIN_ROWS (8 * TK_ROW_SLOTS + 1)
+#endif
+/* rows per pass from which the 32x32x32 kernel takes over (narrower passes run k_gemm_w4a8 at 4 .. 12 M-tiles); TK_MI355X_G32_FROM=129 .. 257
+ * moves it (257 = never), read once */
+static int tk_g32_from() {
+    static const int v = [] { const char* e = getenv("TK_MI355X_G32_FROM"); const int x = e ? atoi(e) : 0; return x >= TK_G32_MIN_ROWS && x <= 257 ? x : 12 * TK_ROW_SLOTS + 1; }();
+    return v;
+}
+
 void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     int row_tiles = 0;
     for (int i = 0; i < a.nseg; ++i) row_tiles += a.seg[i].row_tiles;
@@ -1535,28 +1561,41 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
 #ifndef TK_G32_MIN_ROWS
 #define TK_G32_MIN_ROWS (8 * TK_ROW_SLOTS + 1)
 #endif
-    if (a.nrows >= TK_G32_MIN_ROWS) {
+    /* 129..192 rows: the 16x16x64 kernel at ten / twelve M-tiles (its time grows by ~0.4 ms per 32 rows: 3.3 / 3.7 ms per decode step's launch set
+     * against 4.2 of the 32x32x32 kernel at three tiles per half, profiles/r06_width_curve.txt); TK_MI355X_G32_FROM=129 keeps the round-5 split */
+    if (a.nrows >= tk_g32_from()) {
         /* 129..256 rows: the 32x32x32 kernel, one type per wave (a mixed q / k / v launch needs no split): four (weight-tile pair) slots per
          * workgroup, one workgroup per row half */
         const int pairs = a.swiglu ? a.seg[0].row_tiles : row_tiles / 2; /* every segment holds a multiple of 4 row tiles: pairs never straddle segments */
         const int g32 = (pairs + 3) / 4;
         const int n_halves = a.nrows > 8 * TK_ROW_SLOTS ? 2 : 1;
+        const int tiles32 = (a.nrows + 31) / 32; /* 5..8 at 129..256 rows: two halves of 3 (<= 192 rows) or 4 tiles */
         const size_t ldsb = (size_t)2 * TK_G32_MT * TK_RING_TILE_BYTES;
         const dim3 grid(g32 * a.ks * n_halves);
-        if (types == 1) hipLaunchKernelGGL((k_gemm32_w4a8<1>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
-        else if (types == 2) hipLaunchKernelGGL((k_gemm32_w4a8<2>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
-        else hipLaunchKernelGGL((k_gemm32_w4a8<3>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves);
+#define TK_G32_LAUNCH_M(TYV, MTWV) hipLaunchKernelGGL((k_gemm32_w4a8<TYV, MTWV>), grid, dim3(256), ldsb, s, a, g32, row_tiles, n_halves)
+#define TK_G32_LAUNCH(TYV) do { if (n_halves == 1 || tiles32 > 6) TK_G32_LAUNCH_M(TYV, 4); else TK_G32_LAUNCH_M(TYV, 3); } while (0)
+        if (types == 1) TK_G32_LAUNCH(1);
+        else if (types == 2) TK_G32_LAUNCH(2);
+        else TK_G32_LAUNCH(3);
+#undef TK_G32_LAUNCH
+#undef TK_G32_LAUNCH_M
         return;
     }
     if (a.nrows > 2 * TK_ROW_SLOTS) { /* batched passes of 33..128 rows: K-streamed activations, 4 or 8 M-tiles per weight tile */
-        const int mtb = a.nrows > 4 * TK_ROW_SLOTS ? 8 : 4;
+        /* 16-row M-tiles a weight tile is multiplied against: 65..96 rows walk six, not eight */
+        const int mtb = a.nrows > 14 * TK_ROW_SLOTS ? 16 : a.nrows > 12 * TK_ROW_SLOTS ? 14 : a.nrows > 10 * TK_ROW_SLOTS ? 12 : a.nrows > 8 * TK_ROW_SLOTS ? 10 : a.nrows > 6 * TK_ROW_SLOTS ? 8 : a.nrows > 4 * TK_ROW_SLOTS ? 6 : 4;
         const size_t ldsb = (size_t)2 * TK_RING_BLOCKS * mtb * TK_RING_TILE_BYTES;
         /* one weight tile per wave (two adjacent tiles per wave halve the LDS operand stream but leave one wave per SIMD: 25 % slower on
          * MI355X, profiles/r01_gemm_batched.txt) */
 #define TK_GEMM_LAUNCH(MTV, TYV) hipLaunchKernelGGL((k_gemm_w4a8<MTV, TYV, 1>), dim3(groups * a.ks), dim3(64 * waves), ldsb, s, a, groups, row_tiles)
 #define TK_GEMM_TY(MTV) do { if (types == 1) TK_GEMM_LAUNCH(MTV, 1); else if (types == 2) TK_GEMM_LAUNCH(MTV, 2); else TK_GEMM_LAUNCH(MTV, 3); } while (0)
         if (mtb == 4) TK_GEMM_TY(4);
-        else TK_GEMM_TY(8);
+        else if (mtb == 6) TK_GEMM_TY(6);
+        else if (mtb == 8) TK_GEMM_TY(8);
+        else if (mtb == 10) TK_GEMM_TY(10);
+        else if (mtb == 12) TK_GEMM_TY(12);
+        else if (mtb == 14) TK_GEMM_TY(14);
+        else TK_GEMM_TY(16);
 #undef TK_GEMM_TY
 #undef TK_GEMM_LAUNCH
         return;
@@ -2622,14 +2661,28 @@ void tk_launch_attention_prefill(const float* qbuf, const uint16_t* kcache, cons
 static size_t tk_attention_narrow_fixed_lds(int max_ctx) { /* everything but the key / value rows: q, scores, maxima, own row */
     return (size_t)(2 * 128 + 2 * (size_t)((max_ctx + 3) & ~3) + 32) * sizeof(float) + 2 * 128 * 2;
 }
+/* decode sessions alive per device: a narrow-attention workgroup takes a whole CU (16 waves, most of its LDS), so while it runs no other
+ * stream's mat-vec workgroup can share the CU and the launch itself waits until whole CUs drain.  Alone that is the fastest form; with
+ * several decode streams on the device the ring form (4 waves, <= 70 KiB) overlaps with their launches and the step is shorter
+ * (3 groups x 16 rows: 3.92 -> 3.75 ms per step and group, profiles/r06_northstar_explore.txt).  Both forms are bit-identical. */
+static std::atomic<int> g_sessions_alive[64];
+void tk_attention_note_session(int device, int delta) {
+    if (device >= 0 && device < 64) g_sessions_alive[device].fetch_add(delta, std::memory_order_relaxed);
+}
+static bool tk_device_is_shared_by_sessions() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    return g_sessions_alive[dev].load(std::memory_order_relaxed) > 1;
+}
 /* positions the narrow kernel keeps resident per chunk (a multiple of 32), 0 when it does not apply */
 static int tk_attention_narrow_cap(int nrows, int n_head, int n_kv_head, int head_dim, int max_ctx, bool fused) {
     const int grp = n_kv_head > 0 ? n_head / n_kv_head : 0;
     if (!fused || head_dim != 128 || (grp != 2 && grp != 4) || (n_head / 2) * nrows > TK_NUM_CU) return 0;
     /* TK_MI355X_NO_NARROW_ATT=1: narrow passes keep k_attention's ring form (A/B timing: a narrow workgroup takes a whole CU — 16 waves and
      * most of its LDS — so it cannot share the CU with another stream's mat-vec workgroups) */
-    const char* nn = getenv("TK_MI355X_NO_NARROW_ATT");
+    const char* nn = getenv("TK_MI355X_NO_NARROW_ATT"); /* =0: narrow even when the device is shared */
     if (nn && nn[0] == '1') return 0;
+    if (!(nn && nn[0] == '0') && tk_device_is_shared_by_sessions()) return 0;
     const size_t fixed = tk_attention_narrow_fixed_lds(max_ctx);
     if (fixed + 64 * 512 > (size_t)TK_MAX_DYN_LDS) return 0;
     int cap = (int)(((size_t)TK_MAX_DYN_LDS - fixed) / 512);
@@ -2763,7 +2816,7 @@ void tk_launch_quant_q8(const float* hbuf, int FF, int nrows, TkActQ8 out, hipSt
 }
 
 bool tk_gemv_fuses_swiglu(int nrows, int ks, int type_gate, int type_up) {
-    return nrows >= TK_G32_MIN_ROWS && ks == 1 && type_gate == type_up && (type_gate == TK_TYPE_Q4_K || type_gate == TK_TYPE_Q6_K);
+    return nrows >= tk_g32_from() && ks == 1 && type_gate == type_up && (type_gate == TK_TYPE_Q4_K || type_gate == TK_TYPE_Q6_K); /* the 32x32x32 kernel's epilogue */
 }
 
 void tk_launch_swiglu_q8(const float* partial, int ks, int FF, int nrows, TkActQ8 out, hipStream_t s) {
@@ -2880,8 +2933,10 @@ const char* tk_llm_prepare_device(int device) {
     hipError_t e = hipSuccess;
 #define TK_OPT(fn) do { if (e == hipSuccess) e = opt_in_lds(fn); } while (0)
 #define TK_OPT_GEMM(MTV) do { TK_OPT((k_gemm_w4a8<MTV, 1, 1>)); TK_OPT((k_gemm_w4a8<MTV, 2, 1>)); TK_OPT((k_gemm_w4a8<MTV, 3, 1>)); } while (0)
-    TK_OPT_GEMM(4); TK_OPT_GEMM(8);
-    TK_OPT((k_gemm32_w4a8<1>)); TK_OPT((k_gemm32_w4a8<2>)); TK_OPT((k_gemm32_w4a8<3>));
+    TK_OPT_GEMM(4); TK_OPT_GEMM(6); TK_OPT_GEMM(8); TK_OPT_GEMM(10); TK_OPT_GEMM(12); TK_OPT_GEMM(14); TK_OPT_GEMM(16);
+#define TK_OPT_G32(TYV) do { TK_OPT((k_gemm32_w4a8<TYV, 4>)); TK_OPT((k_gemm32_w4a8<TYV, 3>)); } while (0)
+    TK_OPT_G32(1); TK_OPT_G32(2); TK_OPT_G32(3);
+#undef TK_OPT_G32
 #define TK_OPT_GEMV_F(PFV, MTV, FUV) do { TK_OPT((k_gemv_w4a8<PFV, MTV, 1, FUV>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 2, FUV>)); TK_OPT((k_gemv_w4a8<PFV, MTV, 3, FUV>)); } while (0)
 #define TK_OPT_GEMV(PFV, MTV) TK_OPT_GEMV_F(PFV, MTV, 0)
     TK_OPT_GEMV(1, 1); TK_OPT_GEMV(2, 1); TK_OPT_GEMV(1, 2); TK_OPT_GEMV(2, 2); TK_OPT_GEMV_F(2, 1, 1); TK_OPT_GEMV_F(2, 1, 2);

@@ -46,6 +46,15 @@ void tk_launch_argmax_rows(const float* x, int rows, int cols, int ld, int32_t* 
  * that distribution per row (logprob may be null); the generator is keyed by (seed, counter0 + row) */
 struct TkPick { float temp; uint64_t seed; uint32_t counter0; float* logprob; };
 void tk_launch_pick_rows(const float* x, int rows, int cols, int ld, int32_t* out, const TkPick& pk, hipStream_t s);
+/* whisper.cpp's whisper_process_logits + the per-token bookkeeping of whisper_full's decode loop, as the reference's wrapper configures them
+ * (src/audio/tk_asr_whisper.c:89-110: suppress_blank off, suppress_non_speech_tokens on, timestamps on, max_initial_ts at its default 1.0 s):
+ * per row a static suppression table, the timestamp rules (pairs, initial cap, monotonic), "timestamps win when their summed probability beats
+ * every text token", then the pick (arg max or one draw) and its log-probability, then the row's decode state moves on.
+ * state[row][8] = {tokens sampled, last was a timestamp, the one before was, has_ts, seek_delta, result_len, status (0 running, 1 completed,
+ * 2 failed), seek_end (10 ms frames of the utterance)}; a row whose status is not 0 emits `eot` and stands still. */
+#define TK_WH_STATE_INTS 8
+struct TkWhFilter { const uint8_t* suppress; int32_t* state; int32_t beg, eot, tid0; };
+void tk_launch_pick_rows_filtered(const float* x, int rows, int cols, int ld, int32_t* out, const TkPick& pk, const TkWhFilter& f, hipStream_t s);
 void tk_launch_layernorm(const float* x, int rows, int D, const float* w, const float* b, float eps, float* y, hipStream_t s, float* img = nullptr /* optional: also the tiled GEMM's operand image of y */);
 void tk_launch_softmax_rows(float* x, int rows, int cols, int ld, hipStream_t s);
 void tk_launch_add_rows(float* x, const float* add, int rows, int D, int add_rows, hipStream_t s);

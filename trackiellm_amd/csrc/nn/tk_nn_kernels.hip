@@ -920,3 +920,148 @@ void tk_launch_pick_rows(const float* x, int rows, int cols, int ld, int32_t* ou
 void tk_launch_argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_argmax_rows, dim3(rows), dim3(1024), 0, s, x, cols, ld, out);
 }
+
+/* ---- whisper.cpp's logit filters and decode bookkeeping on the device (one workgroup per row; restated sequentially in
+ * oracle/tk_oracle_audio.cpp: orc_whisper_filter_pick).  Canonical arithmetic, with z_i = l_i (temperature 0) or l_i / temperature:
+ *   allowed set A0 = not in the static table, and by the row's state: first token -> no timestamp above beg + tid0; last token a timestamp ->
+ *     (the one before too: no timestamp) / (otherwise: nothing below eot); has_ts -> no timestamp below beg + seek_delta / 2
+ *   mx = max z over A0,  S = sum over A0 of exp(z_i - mx) as 1024 chains (chain t: i = t, t + 1024, ...) joined per wave by the xor butterfly
+ *     (32 .. 1), then waves 0 .. 15 in order,  lp_i = (z_i - mx) - log S
+ *   timestamps: m_ts = max lp over A0 above beg, S_ts = sum exp(lp_i - m_ts) the same way, lp_ts = log S_ts + m_ts; text: m_tx = max lp over A0
+ *     below beg;  lp_ts > m_tx -> A = A0 without the text tokens, else A = A0
+ *   token = first index of the maximum of z over A (temperature 0) or one draw of the canonical sampler over A; its log-probability = lp_token */
+__global__ __launch_bounds__(1024) void k_pick_rows_filtered(const float* x, int cols, int ld, int32_t* out, TkPick pk, TkWhFilter f) {
+    __shared__ uint32_t allow[2048]; /* vocabularies of at most 65536 tokens */
+    __shared__ float bv[16], bw[16];
+    __shared__ int bi[16];
+    __shared__ uint32_t sm[256 + 8 + 4 * TK_SAMPLE_MAX_K];
+    __shared__ int32_t picked;
+    const int r = blockIdx.x, t = threadIdx.x;
+    int32_t* st = f.state + (int64_t)r * TK_WH_STATE_INTS;
+    if (st[6] != 0) { if (t == 0) out[r] = f.eot; return; } /* completed or failed earlier: the row stands still */
+    const float* xr = x + (int64_t)r * ld;
+    const int n_tok = st[0], has_ts = st[3], seek_delta = st[4];
+    const int last_ts = n_tok > 0 ? st[1] : 0;  /* tokens_cur.size() > 0 && tokens_cur.back() is a timestamp */
+    const int prev_ts = n_tok < 2 ? 1 : st[2];  /* tokens_cur.size() < 2 || the one before it is */
+    const int nwords = (cols + 31) >> 5;
+    const int ts_lo = has_ts ? f.beg + seek_delta / 2 : f.beg;               /* timestamps below it would go back in time */
+    const int ts_hi = n_tok == 0 && f.tid0 >= 0 ? f.beg + f.tid0 : 0x7fffffff; /* the first timestamp cannot lie beyond max_initial_ts */
+    for (int w = t; w < nwords; w += 1024) {
+        uint32_t bits = 0;
+        for (int b = 0; b < 32; ++b) {
+            const int i = 32 * w + b;
+            if (i >= cols) break;
+            bool ok = f.suppress[i] == 0;
+            if (i >= f.beg) ok = ok && i >= ts_lo && i <= ts_hi && !(last_ts && prev_ts);
+            if (last_ts && !prev_ts && i < f.eot) ok = false;
+            bits |= ok ? (1u << b) : 0u;
+        }
+        allow[w] = bits;
+    }
+    __syncthreads();
+    auto allowed = [&](int i) { return (allow[i >> 5] >> (i & 31)) & 1u; };
+    const bool hot = pk.temp > 0.0f;
+    auto zof = [&](int i) { return hot ? tk_divf(xr[i], pk.temp) : xr[i]; };
+    /* maxima of z over A0: all, text, timestamps (a workgroup-wide max is order-free) */
+    float m_all = -INFINITY, m_tx = -INFINITY, m_ts = -INFINITY;
+    for (int i = t; i < cols; i += 1024) {
+        if (!allowed(i)) continue;
+        const float z = zof(i);
+        m_all = tk_fmaxf(m_all, z);
+        if (i < f.beg) m_tx = tk_fmaxf(m_tx, z); else m_ts = tk_fmaxf(m_ts, z);
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        m_all = tk_fmaxf(m_all, __shfl_xor(m_all, s, 64));
+        m_tx = tk_fmaxf(m_tx, __shfl_xor(m_tx, s, 64));
+        m_ts = tk_fmaxf(m_ts, __shfl_xor(m_ts, s, 64));
+    }
+    if ((t & 63) == 0) { bv[t >> 6] = m_all; bw[t >> 6] = m_tx; bi[t >> 6] = __float_as_int(m_ts); }
+    __syncthreads();
+    for (int w = 0; w < 16; ++w) { m_all = tk_fmaxf(m_all, bv[w]); m_tx = tk_fmaxf(m_tx, bw[w]); m_ts = tk_fmaxf(m_ts, __int_as_float(bi[w])); }
+    __syncthreads();
+    /* S over A0 */
+    float ssum = 0.0f;
+    for (int i = t; i < cols; i += 1024)
+        if (allowed(i)) ssum = ssum + tk_expf(zof(i) - m_all);
+    for (int s = 32; s >= 1; s >>= 1) ssum = ssum + __shfl_xor(ssum, s, 64);
+    if ((t & 63) == 0) bv[t >> 6] = ssum;
+    __syncthreads();
+    float S = bv[0];
+    for (int w = 1; w < 16; ++w) S = S + bv[w];
+    const float logS = tk_logf(S);
+    __syncthreads();
+    /* the timestamps' summed probability against the best text token */
+    const float lp_mts = (m_ts - m_all) - logS, lp_mtx = (m_tx - m_all) - logS;
+    float tsum = 0.0f;
+    for (int i = t; i < cols; i += 1024)
+        if (i >= f.beg && allowed(i)) tsum = tsum + tk_expf(((zof(i) - m_all) - logS) - lp_mts);
+    for (int s = 32; s >= 1; s >>= 1) tsum = tsum + __shfl_xor(tsum, s, 64);
+    if ((t & 63) == 0) bv[t >> 6] = tsum;
+    __syncthreads();
+    float S_ts = bv[0];
+    for (int w = 1; w < 16; ++w) S_ts = S_ts + bv[w];
+    const float lp_ts = S_ts > 0.0f ? tk_logf(S_ts) + lp_mts : -INFINITY;
+    __syncthreads();
+    if (lp_ts > lp_mtx) { /* sample a timestamp: the text tokens leave the allowed set */
+        for (int w = t; w < nwords; w += 1024) {
+            const int lo = 32 * w;
+            if (lo + 32 <= f.beg) allow[w] = 0;
+            else if (lo < f.beg) allow[w] &= ~((1u << (f.beg - lo)) - 1u);
+        }
+        __syncthreads();
+    }
+    /* the pick */
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = t; i < cols; i += 1024) {
+        if (!allowed(i)) continue;
+        const float v = xr[i];
+        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const float ov = __shfl_xor(best, s, 64);
+        const int oi = __shfl_xor(idx, s, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((t & 63) == 0) { bv[t >> 6] = best; bi[t >> 6] = idx; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        bi[0] = idx;
+    }
+    __syncthreads();
+    int tok = bi[0];
+    __syncthreads();
+    if (hot) {
+        TkSampleRow sp{};
+        sp.temp = pk.temp; sp.top_p = 1.0f; sp.min_p = 0.0f; sp.top_k = 0; sp.seed = pk.seed; sp.counter = pk.counter0 + (uint32_t)r;
+        sample_row(xr, cols, allow, sp, &picked, sm);
+        __syncthreads();
+        tok = picked;
+    }
+    if (t == 0) {
+        out[r] = tok;
+        if (pk.logprob) pk.logprob[r] = (zof(tok) - m_all) - logS;
+        /* whisper_full's bookkeeping of the sampled token (i = its index in the sequence) */
+        const int i = n_tok;
+        int hts = has_ts, sd = seek_delta, rl = st[5], status = 0;
+        const int seek_end = st[7];
+        if (tok > f.beg) {
+            const int sd_new = 2 * (tok - f.beg);
+            if (hts && sd > sd_new && rl < i) status = 2; /* "do not allow to go back in time" */
+            else { sd = sd_new; rl = i + 1; hts = 1; }
+        }
+        if (status == 0 && (tok == f.eot || (hts && sd + 100 >= seek_end))) {
+            if (rl == 0) {
+                if (sd + 100 >= seek_end) rl = i + 1;
+                else status = 2;
+            }
+            if (status == 0) status = 1;
+        }
+        st[0] = i + 1; st[1] = tok >= f.beg ? 1 : 0; st[2] = last_ts; st[3] = hts; st[4] = sd; st[5] = rl; st[6] = status;
+    }
+}
+void tk_launch_pick_rows_filtered(const float* x, int rows, int cols, int ld, int32_t* out, const TkPick& pk, const TkWhFilter& f, hipStream_t s) {
+    hipLaunchKernelGGL(k_pick_rows_filtered, dim3(rows), dim3(1024), 0, s, x, cols, ld, out, pk, f);
+}

@@ -113,6 +113,12 @@ class ObjectDetector:
     def set_thresholds(self, conf, iou):
         lib().tk_object_detector_update_thresholds(self.h, C.c_float(conf), C.c_float(iou))
 
+    def share_stats(self):
+        """(live handles, batched jobs, frames, widest job) of the engine this handle shares with the others opened on the same file"""
+        v = [C.c_uint64(0) for _ in range(4)]
+        lib().tk_mi355x_detector_share_stats(self.h, *[C.byref(x) for x in v])
+        return tuple(int(x.value) for x in v)
+
     def close(self):
         if self.h:
             lib().tk_object_detector_destroy(C.byref(self.h))
