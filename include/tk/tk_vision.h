@@ -135,6 +135,11 @@ TK_API void tk_mi355x_detector_share_stats(const tk_object_detector_t* detector,
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_onnx_probe(const char* path, int32_t* n_convs, int64_t* n_params);
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_detect_batch(tk_object_detector_t* detector, int n_frames, const tk_video_frame_t* frames,
                                                                     tk_detection_result_t** out_results, size_t* out_counts);
+/* A detector .onnx that is not the 63-convolution YOLOv8n topology (the reference names yolov5nu.onnx, src/cortex/tk_cortex_main.h:71) runs its own
+ * graph on the library's ONNX executor and its [1, 4 + nc, anchors] output is decoded and NMS-ed like the YOLOv8n head maps: 1 for such a handle */
+TK_API int tk_mi355x_detector_is_graph(const tk_object_detector_t* detector);
+/* test hook of that path: the graph on a pre-processed planar tensor [B][3][H][W]; out [B][4 + nc][anchors] = the file's own output */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_forward_graph(tk_object_detector_t* detector, int batch, const float* nchw, float* out, size_t out_floats);
 /* test hook: run the network on a pre-processed NHWC fp32 tensor [B][H][W][3]; raw head maps [B][anchors][64+nc] */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_forward_raw(tk_object_detector_t* detector, int batch, const float* nhwc, float* raw_out,
                                                                    size_t raw_floats);

@@ -210,6 +210,45 @@ int orc_yolo_post(const float* raw, int H, int W, int nc, float conf, float iou,
     return (int)kept.size();
 }
 
+/* out: [4 + nc][anchors] of ONE frame — a YOLO-class graph's own decoded output (Ultralytics export: box centre / size in input pixels, class
+ * probabilities) -> survivors of the same threshold / ordering / class-aware NMS as orc_yolo_post; returns count */
+int orc_yolo_post_out(const float* out, int nc, int n_anchors, float conf, float iou, float* boxes5, int32_t* cls, int32_t* anchors, int cap) {
+    std::vector<tk_yolo_cand_t> cand;
+    for (int a = 0; a < n_anchors; ++a) {
+        tk_yolo_cand_t c;
+        const float cx = out[a], cy = out[(size_t)n_anchors + a], w = out[(size_t)2 * n_anchors + a], h = out[(size_t)3 * n_anchors + a];
+        c.x1 = cx - 0.5f * w; c.y1 = cy - 0.5f * h; c.x2 = cx + 0.5f * w; c.y2 = cy + 0.5f * h;
+        c.score = -1.0f; c.cls = 0;
+        for (int k = 0; k < nc; ++k) {
+            const float p = out[(size_t)(4 + k) * n_anchors + a];
+            if (p > c.score) { c.score = p; c.cls = k; }
+        }
+        c.anchor = a;
+        if (c.score > conf) cand.push_back(c);
+    }
+    std::stable_sort(cand.begin(), cand.end(), [](const tk_yolo_cand_t& p, const tk_yolo_cand_t& q) {
+        return p.score > q.score || (p.score == q.score && p.anchor < q.anchor);
+    });
+    if ((int)cand.size() > TK_YOLO_MAX_CAND) cand.resize(TK_YOLO_MAX_CAND);
+    std::vector<tk_yolo_cand_t> kept;
+    for (const auto& c : cand) {
+        bool drop = false;
+        for (const auto& k : kept)
+            if (k.cls == c.cls && tk_yolo_iou(&k, &c) > iou) { drop = true; break; }
+        if (!drop) {
+            kept.push_back(c);
+            if ((int)kept.size() >= TK_OBJECT_DETECTOR_MAX_DETECTIONS) break;
+        }
+    }
+    for (int i = 0; i < (int)kept.size() && i < cap; ++i) {
+        boxes5[5 * i] = kept[i].x1; boxes5[5 * i + 1] = kept[i].y1; boxes5[5 * i + 2] = kept[i].x2; boxes5[5 * i + 3] = kept[i].y2;
+        boxes5[5 * i + 4] = kept[i].score;
+        cls[i] = kept[i].cls;
+        anchors[i] = kept[i].anchor;
+    }
+    return (int)kept.size();
+}
+
 /* plain fp32 GEMM oracle of tk_gemm_f32: C = act(alpha * sum_k A[m][k] B[n][k] + bias) + residual, k-ordered fma chain */
 void orc_gemm(const float* A, const float* B, float* C, const float* bias, const float* residual, int M, int N, int K, int lda, int ldb, int ldc,
               int ldr, int b_kn, int act, float alpha) {

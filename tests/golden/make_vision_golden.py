@@ -202,6 +202,153 @@ def make_yolo_dets():
     print("wrote yolo_tiny_dets.npz")
 
 
+def torch_yolo5(Wt, x, nc):
+    """the YOLOv5u-class detector as torch modules in the published Ultralytics definitions (Conv = Conv2d + SiLU, Bottleneck, C3, SPPF, the
+    anchor-free Detect head's inference path: make_anchors, DFL, dist2bbox(xywh), sigmoid) — written from those definitions, not from
+    tests/onnx_util.yolo5_spec(): it takes the weights by module path.  x NCHW -> [1, 4 + nc, anchors]."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import onnx_util as OX
+
+    mods = {m[0]: m for m in OX.yolo5_modules(nc)}
+
+    class Conv(nn.Module):
+        def __init__(self, name):
+            super().__init__()
+            _, ci, co, k, s, act = mods[name]
+            self.conv = nn.Conv2d(ci, co, k, s, 2 if k == 6 else k // 2)
+            self.conv.weight.data = torch.from_numpy(Wt[name + ".w"])
+            self.conv.bias.data = torch.from_numpy(Wt[name + ".b"])
+            self.act = nn.SiLU() if act else nn.Identity()
+
+        def forward(self, t):
+            return self.act(self.conv(t))
+
+    class Bottleneck(nn.Module):
+        def __init__(self, name, shortcut):
+            super().__init__()
+            self.cv1, self.cv2, self.add = Conv(name + ".cv1"), Conv(name + ".cv2"), shortcut
+
+        def forward(self, t):
+            return t + self.cv2(self.cv1(t)) if self.add else self.cv2(self.cv1(t))
+
+    class C3(nn.Module):
+        def __init__(self, name, n, shortcut=True):
+            super().__init__()
+            self.cv1, self.cv2, self.cv3 = Conv(name + ".cv1"), Conv(name + ".cv2"), Conv(name + ".cv3")
+            self.m = nn.Sequential(*[Bottleneck("%s.m%d" % (name, i), shortcut) for i in range(n)])
+
+        def forward(self, t):
+            return self.cv3(torch.cat((self.m(self.cv1(t)), self.cv2(t)), 1))
+
+    class SPPF(nn.Module):
+        def __init__(self, name):
+            super().__init__()
+            self.cv1, self.cv2, self.m = Conv(name + ".cv1"), Conv(name + ".cv2"), nn.MaxPool2d(5, 1, 2)
+
+        def forward(self, t):
+            y = [self.cv1(t)]
+            y.extend(self.m(y[-1]) for _ in range(3))
+            return self.cv2(torch.cat(y, 1))
+
+    class Detect(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.cv2 = nn.ModuleList(nn.Sequential(*[Conv("d.cv2.%d.%d" % (i, j)) for j in range(3)]) for i in range(3))
+            self.cv3 = nn.ModuleList(nn.Sequential(*[Conv("d.cv3.%d.%d" % (i, j)) for j in range(3)]) for i in range(3))
+
+        def forward(self, feats):
+            xs = [torch.cat((self.cv2[i](f), self.cv3[i](f)), 1) for i, f in enumerate(feats)]
+            pts, strides = [], []
+            for f, st in zip(xs, (8.0, 16.0, 32.0)):                    # make_anchors(feats, strides, 0.5)
+                h, w = f.shape[2:]
+                sy, sx = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5, torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
+                pts.append(torch.stack((sx, sy), -1).view(-1, 2))
+                strides.append(torch.full((h * w, 1), st))
+            anchors, strides = torch.cat(pts).transpose(0, 1), torch.cat(strides).transpose(0, 1)
+            cat = torch.cat([xi.view(1, 64 + nc, -1) for xi in xs], 2)
+            box, cls = cat.split((64, nc), 1)
+            b, _, a = box.shape                                          # DFL
+            dist = F.conv2d(box.view(b, 4, 16, a).transpose(2, 1).softmax(1), torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)).view(b, 4, a)
+            lt, rb = dist.chunk(2, 1)                                    # dist2bbox(xywh=True, dim=1)
+            x1y1, x2y2 = anchors.unsqueeze(0) - lt, anchors.unsqueeze(0) + rb
+            dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * strides
+            return torch.cat((dbox, cls.sigmoid()), 1)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            D = OX.YOLO5_DEPTH
+            self.b0, self.b1, self.b2, self.b3, self.b4 = Conv("b0"), Conv("b1"), C3("b2", D[0]), Conv("b3"), C3("b4", D[1])
+            self.b5, self.b6, self.b7, self.b8, self.b9 = Conv("b5"), C3("b6", D[2]), Conv("b7"), C3("b8", D[3]), SPPF("b9")
+            self.h10, self.h13, self.h14, self.h17 = Conv("h10"), C3("h13", 1, False), Conv("h14"), C3("h17", 1, False)
+            self.h18, self.h20, self.h21, self.h23 = Conv("h18"), C3("h20", 1, False), Conv("h21"), C3("h23", 1, False)
+            self.up, self.detect = nn.Upsample(None, 2, "nearest"), Detect()
+
+        def forward(self, t):
+            p3 = self.b4(self.b3(self.b2(self.b1(self.b0(t)))))
+            p4 = self.b6(self.b5(p3))
+            x9 = self.b9(self.b8(self.b7(p4)))
+            h10 = self.h10(x9)
+            h14 = self.h14(self.h13(torch.cat((self.up(h10), p4), 1)))
+            h17 = self.h17(torch.cat((self.up(h14), p3), 1))
+            h20 = self.h20(torch.cat((self.h18(h17), h14), 1))
+            h23 = self.h23(torch.cat((self.h21(h20), h10), 1))
+            return self.detect([h17, h20, h23])
+
+    with torch.no_grad():
+        return Net().eval()(torch.from_numpy(x)).numpy()
+
+
+def torch_post_decoded(out, nc, conf, iou, max_det=500, max_cand=2048):
+    """decode + class-aware NMS of an Ultralytics export's [4 + nc][anchors] output (xywh centre boxes in input pixels, probabilities): xyxy,
+    score = max over classes, candidates score > conf by (score desc, anchor asc), torchvision's batched-NMS coordinate-offset trick"""
+    import torch
+    o = torch.from_numpy(np.ascontiguousarray(out, np.float32))
+    cx, cy, w, h = o[0], o[1], o[2], o[3]
+    xyxy = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    scores, cls = o[4:4 + nc].max(0)
+    idx = torch.nonzero(scores > conf).reshape(-1)
+    idx = idx[torch.argsort(scores[idx], descending=True, stable=True)][:max_cand]
+    b, s, c = xyxy[idx], scores[idx], cls[idx]
+    off = b + (c.to(torch.float32) * (b.abs().max() + 1.0))[:, None] if len(b) else b
+    area = (off[:, 2] - off[:, 0]) * (off[:, 3] - off[:, 1])
+    wh = (torch.minimum(off[:, None, 2:], off[None, :, 2:]) - torch.maximum(off[:, None, :2], off[None, :, :2])).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    ioum = inter / (area[:, None] + area[None, :] - inter)
+    keep, dead = [], torch.zeros(len(b), dtype=torch.bool)
+    for i in range(len(b)):
+        if dead[i]:
+            continue
+        keep.append(i)
+        dead |= ioum[i] > iou
+    keep = torch.tensor(keep[:max_det], dtype=torch.long)
+    return torch.cat([b[keep], s[keep, None]], 1).numpy(), c[keep].numpy().astype(np.int32), idx[keep].numpy().astype(np.int32), int(len(b)), ioum.numpy(), c.numpy()
+
+
+def make_yolo5():
+    """yolo5nu_tiny.npz — the YOLOv5u-class graph (tests/onnx_util.yolo5_model: what the detector loads through the ONNX executor) evaluated by
+    the torch modules above on seeded weights and a seeded 128 x 128 input: the [1, 4 + nc, anchors] output and the detections of the
+    independent post-processor.  The IoU threshold is picked away from every same-class pair's IoU, as for yolo_tiny_dets.npz."""
+    import onnx_util as OX
+    nc, H, seed = 80, 128, 21
+    Wt = OX.yolo5_weights(seed, nc, cls_bias=-1.2)
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((1, 3, H, H)).astype(np.float32)
+    out = torch_yolo5(Wt, x, nc)[0]
+    conf = 0.3
+    _, _, _, _, ioum, candc = torch_post_decoded(out, nc, conf, 0.5)
+    same = (candc[:, None] == candc[None, :]) & ~np.eye(len(candc), dtype=bool)
+    iou, margin = max(((t, float(np.abs(ioum[same] - t).min()) if same.any() else 1.0) for t in (0.4, 0.45, 0.5, 0.55, 0.6, 0.65)), key=lambda p: p[1])
+    tb, tc, ta, ncand, _, _ = torch_post_decoded(out, nc, conf, iou)
+    print(f"yolo5: output {out.shape}, scale {np.abs(out).max():.3f}; iou {iou}: candidates {ncand}, kept {len(ta)}, closest same-class IoU to the threshold {margin:.2e}")
+    assert ncand >= 8 and ncand - len(ta) >= 2 and margin > 2e-4
+    np.savez_compressed(os.path.join(HERE, "yolo5nu_tiny.npz"), x=x, seed=np.int32(seed), cls_bias=np.float32(-1.2), out=out, conf=np.float32(conf), iou=np.float32(iou),
+                        torch_boxes=tb, torch_cls=tc, torch_anchors=ta, n_candidates=np.int32(ncand))
+    print("wrote yolo5nu_tiny.npz")
+
+
 def attribute_vector_frames():
     """the two frames of the reference's tests/tk_attribute_classifier_test.c:21-54 (pure red) and :56-91 (gray with two black column bands)"""
     red = np.zeros((100, 100, 3), np.uint8)
@@ -224,8 +371,12 @@ def make_attribute_vectors():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "yolo5":
+        make_yolo5()
+        sys.exit(0)
     make_attribute_vectors()
     make_preprocess()
     make_yolo()
     make_yolo_full()
     make_yolo_dets()
+    make_yolo5()

@@ -537,3 +537,158 @@ def swin_consts(W):
         a = np.asarray(vals, np.int64)
         c[k] = a.reshape(dims) if dims is not None else a
     return c
+
+
+# ---- a detector of the YOLOv5u class (the file the reference names: yolov5nu.onnx, src/cortex/tk_cortex_main.h:71, tests/tk_cortex_test.cpp:41):
+# C3 blocks + SPPF backbone, PAN head, the anchor-free decoupled Detect head with DFL — spelled the way an Ultralytics export spells it: every
+# Conv module = Conv (BN folded) -> Sigmoid -> Mul, Upsample = Resize(nearest, x2), Detect = per scale Concat(box, cls) -> Reshape -> Concat
+# over scales -> Split -> [Reshape, Transpose, Softmax(axis 1), Conv(arange 16), Reshape] -> Slice / Sub / Add / Div / Concat (dist2bbox, xywh)
+# -> Mul(strides) and Sigmoid(cls) -> Concat -> [1, 4 + nc, anchors].  Channel widths are a fraction of the nano model's: no checkpoint is
+# available offline, the graph class is what is tested. ----
+
+YOLO5_CH = (8, 16, 32, 64, 128)   # c1 .. c5 (the nano model: 16, 32, 64, 128, 256)
+YOLO5_DEPTH = (1, 2, 3, 1)        # bottlenecks of the backbone's four C3 blocks (nano: 1, 2, 3, 1)
+
+
+def yolo5_modules(nc):
+    """(module path, c_in, c_out, k, stride, activation) of every convolution, in no particular order"""
+    k1, k2, k3, k4, k5 = YOLO5_CH
+    out = []
+
+    def conv(name, ci, co, k=1, s=1, act=True):
+        out.append((name, ci, co, k, s, act))
+
+    def c3(name, ci, co, n):
+        h = co // 2
+        conv(name + ".cv1", ci, h); conv(name + ".cv2", ci, h); conv(name + ".cv3", 2 * h, co)
+        for i in range(n):
+            conv("%s.m%d.cv1" % (name, i), h, h, 1); conv("%s.m%d.cv2" % (name, i), h, h, 3)
+
+    conv("b0", 3, k1, 6, 2); conv("b1", k1, k2, 3, 2); c3("b2", k2, k2, YOLO5_DEPTH[0]); conv("b3", k2, k3, 3, 2); c3("b4", k3, k3, YOLO5_DEPTH[1])
+    conv("b5", k3, k4, 3, 2); c3("b6", k4, k4, YOLO5_DEPTH[2]); conv("b7", k4, k5, 3, 2); c3("b8", k5, k5, YOLO5_DEPTH[3])
+    conv("b9.cv1", k5, k5 // 2); conv("b9.cv2", 2 * k5, k5)
+    conv("h10", k5, k4); c3("h13", 2 * k4, k4, 1); conv("h14", k4, k3); c3("h17", 2 * k3, k3, 1)
+    conv("h18", k3, k3, 3, 2); c3("h20", 2 * k3, k4, 1); conv("h21", k4, k4, 3, 2); c3("h23", 2 * k4, k5, 1)
+    cb, cc = 16, max(k3, 16)
+    for i, ch in enumerate((k3, k4, k5)):
+        conv("d.cv2.%d.0" % i, ch, cb, 3); conv("d.cv2.%d.1" % i, cb, cb, 3); conv("d.cv2.%d.2" % i, cb, 64, 1, 1, False)
+        conv("d.cv3.%d.0" % i, ch, cc, 3); conv("d.cv3.%d.1" % i, cc, cc, 3); conv("d.cv3.%d.2" % i, cc, nc, 1, 1, False)
+    return out
+
+
+def yolo5_weights(seed, nc=80, cls_bias=-1.5):
+    rng = np.random.default_rng(seed)
+    W = {}
+    for name, ci, co, k, s, act in yolo5_modules(nc):
+        W[name + ".w"] = (rng.standard_normal((co, ci, k, k)) * 1.4 / np.sqrt(ci * k * k)).astype(np.float32)
+        W[name + ".b"] = (0.05 * rng.standard_normal(co)).astype(np.float32)
+        if name.startswith("d.cv3.") and name.endswith(".2"):
+            W[name + ".b"] = (W[name + ".b"] + cls_bias).astype(np.float32)
+    return W
+
+
+def yolo5_anchors(H, W):
+    """anchor centres [2, A] in grid units and strides [1, A], scale after scale (Ultralytics make_anchors, offset 0.5)"""
+    pts, strides = [], []
+    for st in (8, 16, 32):
+        h, w = H // st, W // st
+        ys, xs = np.meshgrid(np.arange(h, dtype=np.float32) + 0.5, np.arange(w, dtype=np.float32) + 0.5, indexing="ij")
+        pts.append(np.stack([xs.reshape(-1), ys.reshape(-1)], 0))
+        strides.append(np.full((1, h * w), float(st), np.float32))
+    return np.concatenate(pts, 1).astype(np.float32), np.concatenate(strides, 1)
+
+
+def yolo5_spec(nc, H, W):
+    """(nodes, float constants beside the weights, int64 constants) of the export"""
+    spec = []
+    floats, ints = {}, {}
+    mods = {m[0]: m for m in yolo5_modules(nc)}
+
+    def n(op, i, o, **attrs):
+        spec.append({"op": op, "in": i, "out": o if isinstance(o, list) else [o], "attrs": attrs})
+        return o
+
+    def conv(name, x):
+        _, ci, co, k, s, act = mods[name]
+        p = k // 2 if k != 6 else 2
+        y = n("Conv", [x, name + ".w", name + ".b"], name + "/c", strides=[s, s], pads=[p, p, p, p], kernel_shape=[k, k])
+        if not act:
+            return y
+        return n("Mul", [y, n("Sigmoid", [y], name + "/s")], name + "/y")
+
+    def c3(name, x, nb, shortcut):
+        a = conv(name + ".cv1", x)
+        for i in range(nb):
+            t = conv("%s.m%d.cv2" % (name, i), conv("%s.m%d.cv1" % (name, i), a))
+            a = n("Add", [a, t], "%s.m%d/add" % (name, i)) if shortcut else t
+        b = conv(name + ".cv2", x)
+        return conv(name + ".cv3", n("Concat", [a, b], name + "/cat", axis=1))
+
+    def up(x, name):
+        return n("Resize", [x, "roi", "up_scales"], name, mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+
+    floats["roi"] = np.zeros(0, np.float32)
+    floats["up_scales"] = np.array([1, 1, 2, 2], np.float32)
+    x = conv("b1", conv("b0", "images"))
+    x = c3("b2", x, YOLO5_DEPTH[0], True)
+    p3 = c3("b4", conv("b3", x), YOLO5_DEPTH[1], True)
+    p4 = c3("b6", conv("b5", p3), YOLO5_DEPTH[2], True)
+    x = c3("b8", conv("b7", p4), YOLO5_DEPTH[3], True)
+    y0 = conv("b9.cv1", x)
+    mp = dict(kernel_shape=[5, 5], strides=[1, 1], pads=[2, 2, 2, 2])
+    y1 = n("MaxPool", [y0], "b9/mp1", **mp); y2 = n("MaxPool", [y1], "b9/mp2", **mp); y3 = n("MaxPool", [y2], "b9/mp3", **mp)
+    x9 = conv("b9.cv2", n("Concat", [y0, y1, y2, y3], "b9/cat", axis=1))
+    h10 = conv("h10", x9)
+    h13 = c3("h13", n("Concat", [up(h10, "h11"), p4], "h12", axis=1), 1, False)
+    h14 = conv("h14", h13)
+    h17 = c3("h17", n("Concat", [up(h14, "h15"), p3], "h16", axis=1), 1, False)
+    h20 = c3("h20", n("Concat", [conv("h18", h17), h14], "h19", axis=1), 1, False)
+    h23 = c3("h23", n("Concat", [conv("h21", h20), h10], "h22", axis=1), 1, False)
+    flat = []
+    for i, f in enumerate((h17, h20, h23)):
+        box = conv("d.cv2.%d.2" % i, conv("d.cv2.%d.1" % i, conv("d.cv2.%d.0" % i, f)))
+        cls = conv("d.cv3.%d.2" % i, conv("d.cv3.%d.1" % i, conv("d.cv3.%d.0" % i, f)))
+        cat = n("Concat", [box, cls], "d/cat%d" % i, axis=1)
+        ints["d/shape%d" % i] = ([1, 64 + nc, -1], None)
+        flat.append(n("Reshape", [cat, "d/shape%d" % i], "d/flat%d" % i))
+    allc = n("Concat", flat, "d/all", axis=2)
+    ints["d/split"] = ([64, nc], None)
+    n("Split", [allc, "d/split"], ["d/box", "d/cls"], axis=1)
+    ints["d/dfl_shape"] = ([1, 4, 16, -1], None)
+    t = n("Transpose", [n("Reshape", ["d/box", "d/dfl_shape"], "d/dfl_r")], "d/dfl_t", perm=[0, 2, 1, 3])
+    t = n("Conv", [n("Softmax", [t], "d/dfl_s", axis=1), "d/dfl_w"], "d/dfl_c")
+    floats["d/dfl_w"] = np.arange(16, dtype=np.float32).reshape(1, 16, 1, 1)
+    ints["d/dist_shape"] = ([1, 4, -1], None)
+    dist = n("Reshape", [t, "d/dist_shape"], "d/dist")
+    for nm, v in (("k0", [0]), ("k2", [2]), ("k4", [4]), ("ax1", [1])):
+        ints["d/" + nm] = (v, None)
+    lt = n("Slice", [dist, "d/k0", "d/k2", "d/ax1"], "d/lt")
+    rb = n("Slice", [dist, "d/k2", "d/k4", "d/ax1"], "d/rb")
+    pts, strides = yolo5_anchors(H, W)
+    floats["d/anchors"] = pts[None]
+    floats["d/strides"] = strides
+    floats["d/two"] = np.array(2.0, np.float32)
+    x1y1 = n("Sub", ["d/anchors", lt], "d/x1y1")
+    x2y2 = n("Add", ["d/anchors", rb], "d/x2y2")
+    cxy = n("Div", [n("Add", [x1y1, x2y2], "d/sum"), "d/two"], "d/cxy")
+    wh = n("Sub", [x2y2, x1y1], "d/wh")
+    dbox = n("Mul", [n("Concat", [cxy, wh], "d/xywh", axis=1), "d/strides"], "d/dbox")
+    n("Concat", [dbox, n("Sigmoid", ["d/cls"], "d/prob")], "output", axis=1)
+    return spec, floats, ints
+
+
+def yolo5_model(W, nc, H, Wd, extra_op=None):
+    spec, floats, ints = yolo5_spec(nc, H, Wd)
+    fl = dict(W)
+    fl.update(floats)
+    nodes = []
+    for nd in spec:
+        attrs = []
+        for k, v in nd["attrs"].items():
+            attrs.append(attr_str(k, v) if isinstance(v, str) else attr_float(k, v) if isinstance(v, float) else attr_int(k, v) if isinstance(v, int) else attr_ints(k, v))
+        nodes.append(node(nd["op"], nd["in"], nd["out"], attrs, name=nd["out"][0] + "_node"))
+    if extra_op:
+        nodes.append(node(extra_op, ["output"], ["unused"], name="extra"))
+    inits = [tensor(k, v) for k, v in fl.items()] + [int_tensor(k, np.asarray(v[0]).reshape(-1), v[1]) for k, v in ints.items()]
+    A = (H // 8) * (Wd // 8) + (H // 16) * (Wd // 16) + (H // 32) * (Wd // 32)
+    return model(nodes, inits, [value_info("images", 1, [1, 3, H, Wd])], [value_info("output", 1, [1, 4 + nc, A])])

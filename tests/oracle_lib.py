@@ -323,6 +323,20 @@ class OracleYolo:
         return boxes[:n], cls[:n], anc[:n]
 
 
+def yolo_post_out(out, nc, conf, iou, cap=500):
+    """decode + NMS of a YOLO-class graph's decoded output [4 + nc][anchors] (orc_yolo_post_out) -> (boxes5, classes, anchors)"""
+    out = np.ascontiguousarray(out, np.float32)
+    assert out.shape[0] == 4 + nc
+    boxes = np.zeros((cap, 5), np.float32)
+    cls = np.zeros(cap, np.int32)
+    anc = np.zeros(cap, np.int32)
+    L = lib()
+    L.orc_yolo_post_out.restype = C.c_int
+    L.orc_yolo_post_out.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    n = L.orc_yolo_post_out(ptr(out), nc, out.shape[1], conf, iou, ptr(boxes), ptr(cls), ptr(anc), cap)
+    return boxes[:n], cls[:n], anc[:n]
+
+
 def gemm(A, B, bias=None, residual=None, b_kn=False, act=0, alpha=1.0):
     A = np.ascontiguousarray(A, np.float32)
     B = np.ascontiguousarray(B, np.float32)

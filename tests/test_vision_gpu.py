@@ -279,3 +279,63 @@ def test_detectors_on_one_file_share_an_engine_and_give_the_solo_results(gpu):
     assert len(strict) < len(solo_det[0]) and dets[1].detect(frames[1]) == solo_det[1]
     for h in dets + pipes + [other]:
         h.close()
+
+
+def test_detector_runs_a_yolov5u_class_onnx_through_the_graph_executor(gpu, tmp_path):
+    """the reference names yolov5nu.onnx (/root/reference/src/cortex/tk_cortex_main.h:71, tests/tk_cortex_test.cpp:41,
+    src/vision/tk_object_detector.c:93-152 hands any file to ONNX Runtime).  A file that is not the 63-convolution YOLOv8n topology — here a
+    seeded YOLOv5u-class graph (C3 blocks, SPPF, PAN, anchor-free DFL head; 262 nodes spelled as an Ultralytics export) — loads through
+    tk_object_detector_create and runs node by node on the library's ONNX executor; its [1, 4 + nc, anchors] output equals the INDEPENDENT torch
+    modules' (tests/golden/make_vision_golden.py: torch_yolo5) within 2e-5 of its scale, and the detections — decode + NMS on the device — have
+    the torch post-processor's indices."""
+    import onnx_util as X
+    d = np.load(os.path.join(GOLD, "yolo5nu_tiny.npz"))
+    nc, H = 80, d["x"].shape[2]
+    Wt = X.yolo5_weights(int(d["seed"]), nc, float(d["cls_bias"]))
+    path = tmp_path / "yolov5nu.onnx"
+    path.write_bytes(X.yolo5_model(Wt, nc, H, H))
+    conf, iou = float(d["conf"]), float(d["iou"])
+    det = gpu.ObjectDetector(model=str(path), width=H, height=H, conf=conf, iou=iou)
+    assert det.is_graph()
+    out = det.forward_graph(d["x"])
+    scale = float(np.abs(d["out"]).max())
+    assert out.shape == (1,) + d["out"].shape and np.abs(out[0] - d["out"]).max() <= 2e-5 * scale, np.abs(out[0] - d["out"]).max() / scale
+    boxes, cls, anc = det.last_boxes()
+    assert np.array_equal(anc, d["torch_anchors"]) and np.array_equal(cls, d["torch_cls"]) and len(anc) < int(d["n_candidates"])
+    assert np.abs(boxes - d["torch_boxes"]).max() <= 1e-3 * scale
+    ob, oc, oa = O.yolo_post_out(out[0], nc, conf, iou)                     # and the oracle's decode + NMS on the product's own output: bit for bit
+    assert np.array_equal(anc, oa) and np.array_equal(cls, oc) and np.array_equal(boxes, ob)
+    with pytest.raises(gpu.TkError):
+        det.forward_raw(np.zeros((1, H, H, 3), np.float32))                  # raw head maps are the hard-wired path's
+    # the reference's call: a frame through tk_object_detector_detect = pre-process (planar for a file's graph) + graph + decode + NMS
+    rng = np.random.default_rng(4)
+    frame = rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)
+    got = det.detect(frame)
+    chw = gpu.preprocess(frame, H, H)
+    det.forward_graph(chw[None])
+    b2, c2, a2 = det.last_boxes()
+    sx, sy = 160 / H, 96 / H
+    want = [(int(c), (int(b[0] * np.float32(sx)), int(b[1] * np.float32(sy)), int((b[2] - b[0]) * np.float32(sx)), int((b[3] - b[1]) * np.float32(sy)))) for b, c in zip(b2, c2)]
+    assert [(g[0], g[3]) for g in got] == want and len(got) > 0
+    # two frames in one call: the graph runs frame by frame, results per frame
+    frame2 = rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)
+    both = det.detect_batch([frame, frame2])
+    assert both[0] == got and both[1] == det.detect(frame2)
+    det.close()
+    # a YOLOv8n-topology file keeps the hard-wired path
+    orc = O.OracleYolo(nc=80, seed=11, cls_bias=-3.0)
+    p8 = tmp_path / "yolov8n.onnx"
+    p8.write_bytes(X.yolo_model(orc.layers()))
+    d8 = gpu.ObjectDetector(model=str(p8), width=64, height=64)
+    assert not d8.is_graph()
+    d8.close()
+    # a graph the executor cannot run is refused at create with the op's name; so is an output of another geometry at the first frame
+    bad = tmp_path / "bad.onnx"
+    bad.write_bytes(X.yolo5_model(Wt, nc, H, H, extra_op="NonMaxSuppression"))
+    with pytest.raises(gpu.TkError) as e:
+        gpu.ObjectDetector(model=str(bad), width=H, height=H)
+    assert "NonMaxSuppression" in e.value.detail
+    other = gpu.ObjectDetector(model=str(path), width=2 * H, height=2 * H)   # the file's anchor constants are for H x H
+    with pytest.raises(gpu.TkError):
+        other.detect(frame)
+    other.close()

@@ -376,6 +376,23 @@ tk_error_code_t tk_mi355x_detector_forward_raw(tk_object_detector_t* d, int batc
     return TK_SUCCESS;
 }
 
+tk_error_code_t tk_mi355x_detector_forward_graph(tk_object_detector_t* d, int batch, const float* nchw, float* out, size_t out_floats) {
+    if (!d || !nchw || !out) return TK_ERROR_INVALID_ARGUMENT;
+    std::vector<float> o;
+    std::string err;
+    TkDetector* e = d->priv(batch > 1 ? batch : 1, &err);
+    if (!e) return vfail(TK_ERROR_GPU_MEMORY, err);
+    e->conf = d->conf;
+    e->iou = d->iou;
+    if (!e->forward_graph(batch, nchw, &o)) return vfail(TK_ERROR_INFERENCE_FAILED, e->error);
+    if (o.size() > out_floats) return vfail(TK_ERROR_BUFFER_TOO_SMALL, "out too small");
+    memcpy(out, o.data(), o.size() * 4);
+    if (!e->fetch(batch, &d->last)) return vfail(TK_ERROR_INFERENCE_FAILED, e->error); /* for last_boxes */
+    return TK_SUCCESS;
+}
+
+int tk_mi355x_detector_is_graph(const tk_object_detector_t* d) { return d && d->sh && d->sh->model.generic ? 1 : 0; }
+
 int tk_mi355x_detector_anchor_count(const tk_object_detector_t* d) {
     if (!d) return 0;
     if (d->own) return d->own->n_anchors;

@@ -60,6 +60,23 @@ TK_HD void tk_yolo_decode_anchor(const float* o, int nc, float ax, float ay, flo
     c->cls = bi;
 }
 
+/* o: column `anchor` of a [4 + nc][n_anchors] decoded output (row pitch ld): centre x, centre y, width, height, then nc class probabilities */
+TK_HD void tk_yolo_decode_out_anchor(const float* o, int ld, int nc, tk_yolo_cand_t* c) {
+    const float cx = o[0], cy = o[(size_t)ld], w = o[(size_t)2 * ld], h = o[(size_t)3 * ld];
+    c->x1 = cx - 0.5f * w;
+    c->y1 = cy - 0.5f * h;
+    c->x2 = cx + 0.5f * w;
+    c->y2 = cy + 0.5f * h;
+    float best = -1.0f;
+    int bi = 0;
+    for (int k = 0; k < nc; ++k) {
+        const float s = o[(size_t)(4 + k) * ld];
+        if (s > best) { best = s; bi = k; }
+    }
+    c->score = best;
+    c->cls = bi;
+}
+
 TK_HD float tk_yolo_iou(const tk_yolo_cand_t* a, const tk_yolo_cand_t* b) {
     const float iw = tk_fminf(a->x2, b->x2) - tk_fmaxf(a->x1, b->x1);
     const float ih = tk_fminf(a->y2, b->y2) - tk_fmaxf(a->y1, b->y1);

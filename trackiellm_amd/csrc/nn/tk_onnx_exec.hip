@@ -66,6 +66,18 @@ __global__ void k_vg_binary(int op, const float* a, const float* b, float* y, Vg
     y[i] = v;
 }
 
+/* softmax over an inner axis of n entries `inner` elements apart: max, exp and sum in index order, divide */
+__global__ void k_oe_softmax_axis(const float* x, float* y, int64_t pairs, int64_t n, int64_t inner) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pairs) return;
+    const int64_t base = (i / inner) * n * inner + i % inner;
+    float m = -INFINITY;
+    for (int64_t k = 0; k < n; ++k) m = tk_fmaxf(m, x[base + k * inner]);
+    float s = 0.0f;
+    for (int64_t k = 0; k < n; ++k) { const float e = tk_expf(x[base + k * inner] - m); y[base + k * inner] = e; s = s + e; }
+    for (int64_t k = 0; k < n; ++k) y[base + k * inner] = tk_divf(y[base + k * inner], s);
+}
+
 /* generic gather: out element i (coordinates over dim[]) reads x[off + sum c_d * sa[d]] — Transpose, Slice, Concat pieces */
 __global__ void k_vg_gather(const float* x, float* y, VgIdx ix, int64_t off, int64_t n, int64_t y_off, VgIdx oy) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -358,7 +370,7 @@ float* TkOnnxExec::alloc(int64_t n) {
 static const char* kSupported[] = {"Conv", "Relu", "Sigmoid", "Tanh", "Sqrt", "Abs", "Neg", "Exp", "Log", "Add", "Sub", "Mul", "Div", "Pow", "Slice", "Concat",
                                    "Pad", "Transpose", "ReduceMean", "LSTM", "Unsqueeze", "Squeeze", "Reshape", "Flatten", "Identity", "Cast", "Constant",
                                    "Clip", "LeakyRelu", "HardSigmoid", "HardSwish", "Resize", "Upsample", "MaxPool", "AveragePool", "GlobalAveragePool",
-                                   "BatchNormalization", "MatMul", "Gemm", "Softmax", "Dropout",
+                                   "BatchNormalization", "MatMul", "Gemm", "Softmax", "Dropout", "Split",
                                    /* tk_onnx_exec_seq.hip */
                                    "LayerNormalization", "Erf", "Gelu", "Gather", "ReduceSum", "ReduceL2", "ReduceMax", "ReduceMin", "Expand", "Max", "Min", "Where",
                                    "ConvTranspose", "Shape", "If", "Equal", "Less", "Greater", "Not", "And", "Or"};
@@ -622,6 +634,40 @@ bool TkOnnxExec::exec(const TkOnnxNode& nd, std::map<std::string, Val>& v) {
         Val* y = out_f(0, os);
         if (!y) return false;
         if (y->count() > 0) hipLaunchKernelGGL(k_vg_gather, grid_for(y->count()), dim3(128), 0, stream_, xc.d, y->d, ix, off, y->count(), (int64_t)0, oy);
+        return true;
+    }
+    if (op == "Split") { /* equal parts or the sizes in `split` (attribute up to opset 12, second input from 13): one strided copy per output */
+        Val* x = need(0, false);
+        if (!x) return false;
+        const Val xc = *x;
+        const size_t r = xc.shape.size();
+        if (r == 0 || r > TK_VG_RANK) { error = "rank outside 1..6"; return false; }
+        int64_t ax = nd.ai("axis", 0);
+        if (ax < 0) ax += (int64_t)r;
+        if (ax < 0 || ax >= (int64_t)r) { error = "Split axis outside the rank of its input"; return false; }
+        std::vector<int64_t> sizes;
+        if (!ints_arg("split", 1, &sizes)) {
+            const int64_t n = (int64_t)nd.out.size(), dim = xc.shape[(size_t)ax];
+            const int64_t each = (dim + n - 1) / n;
+            for (int64_t i = 0; i < n; ++i) sizes.push_back(i + 1 < n ? each : dim - each * (n - 1));
+        }
+        int64_t tot = 0;
+        for (int64_t z : sizes) { if (z < 0) { error = "negative split size"; return false; } tot += z; }
+        if (sizes.size() != nd.out.size() || tot != xc.shape[(size_t)ax]) { error = "split sizes do not add up to the axis"; return false; }
+        const std::vector<int64_t> si = strides_of(xc.shape);
+        int64_t at = 0;
+        for (size_t k = 0; k < sizes.size(); ++k) {
+            std::vector<int64_t> os = xc.shape;
+            os[(size_t)ax] = sizes[k];
+            Val* y = out_f(k, os);
+            if (!y) return false;
+            const std::vector<int64_t> so = strides_of(os);
+            VgIdx ix{}, oy{};
+            for (int d = 0; d < TK_VG_RANK; ++d) { ix.dim[d] = 1; ix.sa[d] = 0; oy.sa[d] = 0; }
+            for (size_t i = 0; i < r; ++i) { const size_t d = TK_VG_RANK - r + i; ix.dim[d] = os[i]; ix.sa[d] = si[i]; oy.sa[d] = so[i]; }
+            if (y->count() > 0) hipLaunchKernelGGL(k_vg_gather, grid_for(y->count()), dim3(128), 0, stream_, xc.d, y->d, ix, at * si[(size_t)ax], y->count(), (int64_t)0, oy);
+            at += sizes[k];
+        }
         return true;
     }
     if (op == "Concat") {
@@ -1029,7 +1075,16 @@ bool TkOnnxExec::exec_image_op(const TkOnnxNode& nd, std::map<std::string, Val>&
         const int64_t r = (int64_t)xc.shape.size();
         int64_t ax = nd.ai("axis", -1);
         if (ax < 0) ax += r;
-        if (ax != r - 1 || r < 1) { error = "only the last axis"; return false; }
+        if (r < 1 || ax < 0 || ax >= r) { error = "Softmax axis outside the rank of its input"; return false; }
+        if (ax != r - 1) { /* an inner axis (the DFL of a YOLO head: [1, 16, 4, anchors] over axis 1): one thread per (outer, inner) pair walks the axis in index order */
+            Val* y = out_f(0, xc.shape);
+            if (!y) return false;
+            int64_t inner = 1;
+            for (int64_t i = ax + 1; i < r; ++i) inner *= xc.shape[(size_t)i];
+            const int64_t n = xc.shape[(size_t)ax], pairs = n > 0 ? xc.count() / n : 0;
+            if (pairs > 0) hipLaunchKernelGGL(k_oe_softmax_axis, grid_for(pairs), dim3(128), 0, stream_, xc.d, y->d, pairs, n, inner);
+            return true;
+        }
         Val* y = out_f(0, xc.shape);
         if (!y) return false;
         const int cols = (int)xc.shape.back();

@@ -12,9 +12,12 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
 #include "../common/tk_ggml_blocks.h"
 #include "../common/tk_yolo_post.h"
 #include "../common/tk_yolov8n_graph.h"
+#include "../nn/tk_onnx_exec.h"
 
 struct TkPreprocessArgs {
     const uint8_t* src;  /* device, interleaved */
@@ -42,8 +45,14 @@ public:
     bool fill_synthetic(uint64_t seed, float cls_bias);
     bool set_layer(int idx, const float* w_host, const float* b_host);
     bool load_file(const char* path); /* "TKYOLO1\0" flat container: see INTEGRATION.md */
-    /* Conv initialisers of an Ultralytics YOLOv8 ONNX export, in execution order (vision/tk_onnx_weights.h); the trailing DFL conv is skipped */
+    /* Conv initialisers of an Ultralytics YOLOv8 ONNX export, in execution order (vision/tk_onnx_weights.h); the trailing DFL conv is skipped.
+     * A file that is not the 63-convolution YOLOv8n topology — the reference names yolov5nu.onnx (src/cortex/tk_cortex_main.h:71,
+     * tests/tk_cortex_test.cpp:41): C3 blocks, the same [1, 4 + nc, anchors] output — becomes a `generic` model: every engine runs the file's own
+     * graph node by node (csrc/nn/tk_onnx_exec) and decodes its decoded-box output (k_yolo_decode_out) instead of the raw head maps. */
     bool load_onnx(const char* path);
+    bool generic = false;    /* the graph executor path */
+    std::string onnx_path;   /* generic: the file every engine loads */
+    std::string graph_in, graph_out; /* generic: the graph's float input / first output */
     size_t param_count() const;
 };
 
@@ -62,6 +71,8 @@ public:
     bool detect(int B, const uint8_t* const* frames, uint32_t w, uint32_t h, uint32_t stride, uint32_t bpp, std::vector<std::vector<TkDetection>>* out);
     /* test hooks: run the network on an already pre-processed NHWC tensor / fetch the raw head maps */
     bool forward_tensor(int B, const float* nhwc_host, std::vector<float>* raw_out /* [B][8400][64+nc] */);
+    /* generic models: the graph on a pre-processed planar tensor [B][3][H][W]; out [B][4 + nc][anchors] = the file's own output */
+    bool forward_graph(int B, const float* nchw_host, std::vector<float>* out);
     bool fetch(int B, std::vector<std::vector<TkDetection>>* out); /* download the NMS survivors of the last enqueue */
     /* per-box attributes on frame b of the last detect() batch, still resident on the device (reference: the CPU loops of
      * src/vision/tk_attribute_classifier.c run per detection, tk_vision_pipeline.c:462-485): rects[n] = {x, y, w, h} in frame pixels;
@@ -81,6 +92,8 @@ private:
     int32_t* attr_dev = nullptr; /* [cap][4] rects then [cap][2] results */
     int attr_cap = 0;
     bool run_attributes(const uint8_t* frame, uint32_t w, uint32_t h, int n, const int32_t* rects, int32_t* color, int32_t* door_closed);
+    std::unique_ptr<TkOnnxExec> exec; /* generic models: this engine's own instance of the file's graph (constants resident, one arena per run) */
+    bool run_graph(int B, float* host_out); /* generic: `input` holds B planar frames -> cand[b][anchor]; host_out (optional) [B][4 + nc][anchors] */
     float* arena = nullptr;
     size_t arena_floats = 0, arena_used = 0;
     float* col = nullptr;

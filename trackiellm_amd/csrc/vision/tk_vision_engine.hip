@@ -144,20 +144,47 @@ bool TkYoloModel::load_file(const char* path) {
     return ok;
 }
 
+/* a YOLO-class file that is not the YOLOv8n topology: accepted when its graph is one the executor can run — every op supported, one float image
+ * input [N, 3, H, W], a first output [N, 4 + nc, anchors] (checked against the engine's geometry at the first run) */
+static bool yolo_generic_graph(const char* path, TkYoloModel* m, const std::string& why_not_v8n) {
+    TkOnnxGraph g;
+    if (!g.load(path)) { m->error = why_not_v8n + "; and as a graph: " + g.error; return false; }
+    std::string err;
+    if (!TkOnnxExec::ops_supported(g, &err)) { m->error = why_not_v8n + "; and the graph executor cannot run it: " + err; return false; }
+    std::string in;
+    for (const auto& vi : g.inputs) {
+        if (g.init.count(vi.name) == 0 && (vi.elem_type == 1 || vi.elem_type == 0)) { /* (the reader already leaves initialisers out of `inputs`) */ if (!in.empty()) { m->error = why_not_v8n + "; and the graph has more than one float input"; return false; } in = vi.name; }
+    }
+    if (in.empty() || g.outputs.empty()) { m->error = why_not_v8n + "; and the graph has no float image input / no output"; return false; }
+    m->generic = true;
+    m->onnx_path = path;
+    m->graph_in = in;
+    m->graph_out = g.outputs[0].name;
+    return true;
+}
+
 bool TkYoloModel::load_onnx(const char* path) {
     TkOnnxWeights ox;
     if (!ox.load(path)) { error = ox.error; return false; }
     /* 63 graph convolutions, optionally followed by the DFL projection conv [1][16][1][1] */
     size_t n = ox.convs.size();
     if (n == specs.size() + 1 && ox.convs.back().cout == 1 && ox.convs.back().cin == TK_YOLO_REG_MAX && ox.convs.back().kh == 1) --n;
-    if (n != specs.size()) { error = "the ONNX graph has " + std::to_string(ox.convs.size()) + " Conv nodes, YOLOv8n has " + std::to_string(specs.size()) + " (+ DFL)"; return false; }
+    if (n != specs.size())
+        return yolo_generic_graph(path, this, "the ONNX graph has " + std::to_string(ox.convs.size()) + " Conv nodes, YOLOv8n has " + std::to_string(specs.size()) + " (+ DFL)");
+    for (size_t i = 0; i < n; ++i) { /* the hard-wired graph is the fast path: only a file that IS that topology takes it */
+        const TkConvSpec& s = specs[i];
+        const TkOnnxConv& c = ox.convs[i];
+        if (c.cout != s.cout || c.cin != s.cin || c.kh != s.k || c.kw != s.k)
+            return yolo_generic_graph(path, this, "Conv " + std::to_string(i) + " is [" + std::to_string(c.cout) + "][" + std::to_string(c.cin) + "][" + std::to_string(c.kh) + "][" +
+                                                      std::to_string(c.kw) + "], the YOLOv8n graph expects [" + std::to_string(s.cout) + "][" + std::to_string(s.cin) + "][" +
+                                                      std::to_string(s.k) + "][" + std::to_string(s.k) + "]");
+    }
     std::vector<float> hw;
     for (size_t i = 0; i < n; ++i) {
         const TkConvSpec& s = specs[i];
         const TkOnnxConv& c = ox.convs[i];
         if (c.cout != s.cout || c.cin != s.cin || c.kh != s.k || c.kw != s.k) {
-            error = "Conv " + std::to_string(i) + " is [" + std::to_string(c.cout) + "][" + std::to_string(c.cin) + "][" + std::to_string(c.kh) + "][" + std::to_string(c.kw) +
-                    "], the YOLOv8n graph expects [" + std::to_string(s.cout) + "][" + std::to_string(s.cin) + "][" + std::to_string(s.k) + "][" + std::to_string(s.k) + "]";
+            error = "Conv " + std::to_string(i) + " does not match the YOLOv8n graph";
             return false;
         }
         hw.resize(c.w.size());
@@ -248,6 +275,18 @@ __global__ void k_yolo_decode(TkT h0, TkT h1, TkT h2, int nc, int n_anchors, flo
     c.anchor = a;
     if (!(c.score > conf)) c.cls = -1; /* not a candidate */
     cand[(size_t)b * n_anchors + a] = c;
+}
+
+/* a YOLO-class graph's own output [4 + nc][anchors] (Ultralytics export: box centre / size in input pixels, class probabilities already through
+ * the sigmoid): xyxy = centre -/+ size / 2, score = max_c p_c (first class on ties), candidate iff score > confidence_threshold */
+__global__ void k_yolo_decode_out(const float* out, int nc, int n_anchors, float conf, tk_yolo_cand_t* cand) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_anchors) return;
+    tk_yolo_cand_t c;
+    tk_yolo_decode_out_anchor(out + a, n_anchors, nc, &c);
+    c.anchor = a;
+    if (!(c.score > conf)) c.cls = -1;
+    cand[a] = c;
 }
 
 /* rank of every candidate among the candidates: (score desc, anchor asc); the best MAX_CAND are kept.  Most anchors fall below the
@@ -344,6 +383,7 @@ TkDetector::~TkDetector() {
     if (stream) (void)hipStreamSynchronize(stream);
     void* ptrs[] = {frame_dev, arena, col, input, cand, order, n_cand, mask, kept, n_kept, attr_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (exec) exec->unload(); /* before its stream goes */
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -353,16 +393,23 @@ bool TkDetector::init(TkYoloModel* m, int w, int h, int mb) {
     if (mb < 1 || mb > 256) { error = "max_batch must be in [1,256]"; return false; }
     HIPQ(hipSetDevice(m->device));
     HIPQ(tk_create_perception_stream(&stream));
-    TkSizeOps so{&m->specs};
-    TkT x = so.alloc(mb, h, w, 3);
-    so.used = 0;
-    TkT o[3];
-    TkYoloV8n<TkSizeOps>::forward(so, x, o, m->nc);
-    arena_floats = so.used + 1024;
-    col_floats = so.col + 1024;
     n_anchors = (h / 8) * (w / 8) + (h / 16) * (w / 16) + (h / 32) * (w / 32);
-    HIPQ(hipMalloc((void**)&arena, arena_floats * 4));
-    HIPQ(hipMalloc((void**)&col, col_floats * 4));
+    if (m->generic) {
+        /* the file's own graph, one frame per run: every node's output of a run lives in the executor's arena (a YOLO-nano-class graph at 640 x 640
+         * holds ~25 M activation floats + im2col scratch; 320 floats per input pixel leaves a wide margin and is checked by the executor) */
+        exec.reset(new TkOnnxExec());
+        if (!exec->load(m->onnx_path.c_str(), m->device, stream, (size_t)320 * h * w + (1u << 22))) { error = "detector graph: " + exec->error; return false; }
+    } else {
+        TkSizeOps so{&m->specs};
+        TkT x = so.alloc(mb, h, w, 3);
+        so.used = 0;
+        TkT o[3];
+        TkYoloV8n<TkSizeOps>::forward(so, x, o, m->nc);
+        arena_floats = so.used + 1024;
+        col_floats = so.col + 1024;
+        HIPQ(hipMalloc((void**)&arena, arena_floats * 4));
+        HIPQ(hipMalloc((void**)&col, col_floats * 4));
+    }
     HIPQ(hipMalloc((void**)&input, (size_t)mb * h * w * 3 * 4));
     HIPQ(hipMalloc((void**)&cand, (size_t)mb * n_anchors * sizeof(tk_yolo_cand_t)));
     HIPQ(hipMalloc((void**)&order, (size_t)mb * TK_YOLO_MAX_CAND * 4));
@@ -373,7 +420,58 @@ bool TkDetector::init(TkYoloModel* m, int w, int h, int mb) {
     return true;
 }
 
+/* generic models: frame by frame through the file's graph (exports carry a batch dimension of one), each frame's output decoded before the next
+ * run reuses the arena (same stream: in order) */
+bool TkDetector::run_graph(int B, float* host_out) {
+    for (int b = 0; b < B; ++b) {
+        exec->begin();
+        TkOnnxExec::Val in;
+        in.d = input + (size_t)b * 3 * in_h * in_w;
+        in.shape = {1, 3, in_h, in_w};
+        exec->bind(model->graph_in, in);
+        if (!exec->run()) { error = "detector graph: " + exec->error; return false; }
+        const TkOnnxExec::Val* o = exec->value(model->graph_out);
+        if (!o || !o->d || o->is_int) { error = "detector graph: no float output"; return false; }
+        /* [1, 4 + nc, anchors] (or [4 + nc, anchors]) with this engine's anchor count */
+        const size_t r = o->shape.size();
+        if (r < 2 || o->shape[r - 1] != n_anchors || o->shape[r - 2] != 4 + model->nc || o->count() != (int64_t)(4 + model->nc) * n_anchors) {
+            std::string sh;
+            for (int64_t d : o->shape) sh += (sh.empty() ? "" : ", ") + std::to_string(d);
+            error = "detector graph: output [" + sh + "], expected [1, " + std::to_string(4 + model->nc) + ", " + std::to_string(n_anchors) + "] (4 + class_count rows, " +
+                    std::to_string(in_w) + " x " + std::to_string(in_h) + " at strides 8 / 16 / 32)";
+            return false;
+        }
+        hipLaunchKernelGGL(k_yolo_decode_out, dim3((n_anchors + 255) / 256), dim3(256), 0, stream, o->d, model->nc, n_anchors, conf, cand + (size_t)b * n_anchors);
+        if (host_out) HIPQ(hipMemcpyAsync(host_out + (size_t)b * o->count(), o->d, (size_t)o->count() * 4, hipMemcpyDeviceToHost, stream)); /* before the next run reuses the arena */
+    }
+    return true;
+}
+
+bool TkDetector::forward_graph(int B, const float* nchw_host, std::vector<float>* out) {
+    if (!model->generic) { error = "forward_graph is the graph-executor path's hook (this model runs the hard-wired YOLOv8n graph: forward_tensor)"; return false; }
+    if (B < 1 || B > max_batch) { error = "batch larger than the detector was created for"; return false; }
+    HIPQ(hipSetDevice(model->device));
+    HIPQ(hipMemcpyAsync(input, nchw_host, (size_t)B * 3 * in_h * in_w * 4, hipMemcpyHostToDevice, stream));
+    out->assign((size_t)B * (4 + model->nc) * n_anchors, 0.0f);
+    last_B = 0;
+    if (!run_graph(B, out->data())) return false;
+    hipLaunchKernelGGL(k_yolo_rank, dim3((n_anchors + 255) / 256, B), dim3(256), 0, stream, cand, n_anchors, order, n_cand);
+    hipLaunchKernelGGL(k_yolo_mask, dim3(TK_YOLO_MAX_CAND / 64 / 8, TK_YOLO_MAX_CAND / 8, B), dim3(8, 8), 0, stream, cand, n_anchors, order, n_cand, iou, mask);
+    hipLaunchKernelGGL(k_yolo_scan, dim3(B), dim3(64), 0, stream, cand, n_anchors, order, n_cand, mask, kept, n_kept);
+    HIPQ(hipGetLastError());
+    HIPQ(hipStreamSynchronize(stream));
+    return true;
+}
+
 bool TkDetector::enqueue(int B) {
+    if (model->generic) {
+        if (!run_graph(B, nullptr)) return false;
+        hipLaunchKernelGGL(k_yolo_rank, dim3((n_anchors + 255) / 256, B), dim3(256), 0, stream, cand, n_anchors, order, n_cand);
+        hipLaunchKernelGGL(k_yolo_mask, dim3(TK_YOLO_MAX_CAND / 64 / 8, TK_YOLO_MAX_CAND / 8, B), dim3(8, 8), 0, stream, cand, n_anchors, order, n_cand, iou, mask);
+        hipLaunchKernelGGL(k_yolo_scan, dim3(B), dim3(64), 0, stream, cand, n_anchors, order, n_cand, mask, kept, n_kept);
+        HIPQ(hipGetLastError());
+        return true;
+    }
     TkGpuOps ops{this, stream};
     arena_used = 0;
     TkT x;
@@ -402,7 +500,7 @@ bool TkDetector::detect(int B, const uint8_t* const* frames, uint32_t w, uint32_
         HIPQ(hipMemcpyAsync(frame_dev + fb * b, frames[b], fb, hipMemcpyHostToDevice, stream));
         TkPreprocessArgs a{};
         a.src = frame_dev + fb * b; a.in_w = w; a.in_h = h; a.in_stride = stride; a.bpp = bpp;
-        a.dst = input + (size_t)b * in_h * in_w * 3; a.out_w = in_w; a.out_h = in_h; a.nhwc = 1;
+        a.dst = input + (size_t)b * in_h * in_w * 3; a.out_w = in_w; a.out_h = in_h; a.nhwc = model->generic ? 0 : 1; /* a file's graph takes planar NCHW */
         for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std_dev[c] = std_dev[c]; }
         tk_launch_preprocess(a, stream);
     }
@@ -547,6 +645,7 @@ bool TkDetector::fetch(int B, std::vector<std::vector<TkDetection>>* out) {
 }
 
 bool TkDetector::forward_tensor(int B, const float* nhwc_host, std::vector<float>* raw_out) {
+    if (model->generic) { error = "raw head maps exist on the hard-wired YOLOv8n path only; this model runs its file's graph (forward_graph)"; return false; }
     if (B < 1 || B > max_batch) { error = "batch larger than the detector was created for"; return false; }
     HIPQ(hipSetDevice(model->device));
     HIPQ(hipMemcpyAsync(input, nhwc_host, (size_t)B * in_h * in_w * 3 * 4, hipMemcpyHostToDevice, stream));

@@ -101,6 +101,19 @@ class ObjectDetector:
         check(lib().tk_mi355x_detector_forward_raw(self.h, B, x.ctypes.data_as(C.c_void_p), raw.ctypes.data_as(C.c_void_p), C.c_size_t(raw.size)))
         return raw
 
+    def is_graph(self):
+        """True when the model file is not the YOLOv8n topology and runs its own graph on the ONNX executor"""
+        return bool(lib().tk_mi355x_detector_is_graph(self.h))
+
+    def forward_graph(self, x):
+        """the file's graph on pre-processed planar frames [B][3][H][W] -> its output [B][4 + nc][anchors]"""
+        x = np.ascontiguousarray(x, np.float32)
+        B = x.shape[0]
+        na = (self.height // 8) * (self.width // 8) + (self.height // 16) * (self.width // 16) + (self.height // 32) * (self.width // 32)
+        out = np.empty((B, 4 + self.nc, na), np.float32)
+        check(lib().tk_mi355x_detector_forward_graph(self.h, B, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)))
+        return out
+
     def last_boxes(self, frame=0, cap=500):
         boxes = np.zeros((cap, 5), np.float32)
         cls = np.zeros(cap, np.int32)
