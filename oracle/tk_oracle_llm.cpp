@@ -13,16 +13,11 @@
  *   - the published Mistral-7B-v0.1 decoder (RMSNorm eps 1e-5, GQA 32q/8kv x 128, RoPE
  *     theta 1e4 on adjacent pairs as the GGUF llama-arch convention stores q/k, SwiGLU);
  *   - llama.cpp's CPU numerics structure for k-quants: activations are quantised per
- *     256-block to int8 (Q8_K: d = amax/127, bsums) and the dot product is integer inside
+ *     256-block to int8 (Q8_K, bsums) and the dot product is integer inside
  *     a block, float across blocks (ggml_vec_dot_q4_K_q8_K / q6_K_q8_K as published).
- *     Q8_K scale convention, stated because it differs from the published quantize_row_q8_K
- *     by one rounding: here id = 127 / amax (one division), q = rint(x * id), d = amax / 127
- *     (a second, independent division).  Published ggml picks the signed extreme `max`,
- *     iscale = -127 / max (older revisions -128 / max), q = nearest_int(iscale * x) clamped to
- *     127, d = 1 / iscale: the same integers up to the sign convention of the extreme element
- *     and a d that is the reciprocal of the rounded iscale instead of amax / 127 — a relative
- *     difference of at most one ulp in d (<= 6e-8), far inside the 1e-3 logit tolerance north_star
- *     names; the HIP path and this oracle share THIS convention and agree bit for bit.
+ *     The Q8_K quantiser is the published quantize_row_q8_K_ref (iscale = -127 / max of the signed extreme, d = 1 / iscale; round 6 — earlier
+ *     rounds used d = amax / 127).  What still differs from the engine the reference calls is the K-split summation order of a matmul (part of
+ *     this build's canonical order, exported with the model) — and that llama.cpp itself is absent.
  * It is pinned by (i) an independent fp32 torch implementation on de-quantised weights
  * (tests/golden/make_llm_golden.py -> tests/golden/llm_tiny.npz) and (ii) the codec
  * round-trip fixtures.
@@ -97,20 +92,25 @@ void orc_rmsnorm(const float* x, const float* w, int n, float eps, float* out) {
     for (int i = 0; i < n; ++i) out[i] = (x[i] * scale) * w[i];
 }
 
-/* Q8_K-style activation quantisation of one row: q[n] int8, d[n/256], bsum32[n/32] */
+/* Q8_K activation quantisation of one row, as ggml publishes it (quantize_row_q8_K_ref): per 256-block the signed value `max` of the FIRST element
+ * of largest magnitude, iscale = -127 / max, q = min(127, nearest_int(iscale * x)), d = 1 / iscale (so d carries the sign of -max and the extreme
+ * element becomes -127); an all-zero block has d = 0, q = 0.  q[n] int8, d[n/256], bsum32[n/32] (ggml keeps sums of 16: a Q4_K sub-block of 32 adds
+ * two of them) */
 void orc_q8k_quantize(const float* x, int n, int8_t* q, float* d, int32_t* bsum32) {
     for (int b = 0; b < n / 256; ++b) {
         const float* xb = x + 256 * b;
-        float amax = 0.0f;
-        for (int i = 0; i < 256; ++i) amax = tk_fmaxf(amax, tk_fabsf(xb[i]));
-        float id = amax > 0.0f ? tk_divf(127.0f, amax) : 0.0f;
-        d[b] = amax > 0.0f ? tk_divf(amax, 127.0f) : 0.0f;
+        float amax = 0.0f, mx = 0.0f;
+        for (int i = 0; i < 256; ++i) {
+            const float ax = tk_fabsf(xb[i]);
+            if (ax > amax) { amax = ax; mx = xb[i]; }
+        }
+        const float iscale = amax > 0.0f ? tk_divf(-127.0f, mx) : 0.0f;
+        d[b] = amax > 0.0f ? tk_divf(1.0f, iscale) : 0.0f;
         for (int j = 0; j < 8; ++j) {
             int32_t s = 0;
             for (int i = 0; i < 32; ++i) {
-                float r = tk_rintf(xb[32 * j + i] * id);
-                int v = (int)r;
-                v = v > 127 ? 127 : (v < -127 ? -127 : v);
+                int v = (int)tk_rintf(iscale * xb[32 * j + i]); /* nearest_int: round to nearest, ties to even */
+                v = v > 127 ? 127 : v;
                 q[256 * b + 32 * j + i] = (int8_t)v;
                 s += v;
             }

@@ -90,9 +90,10 @@ def test_prefill_equals_incremental_decode():
 def test_ksplit_changes_only_rounding():
     a = O.OracleLlm(O.tiny_config(), seed=4)
     b = O.OracleLlm(O.tiny_config(ks_down=2, ks_o=2), seed=4)
-    la, _ = a.forward([0, 0], [0, 1], [11, 12])
-    lb, _ = b.forward([0, 0], [0, 1], [11, 12])
-    assert np.allclose(la, lb, atol=1e-5) and not np.array_equal(la, lb)
+    toks = [11, 12, 13, 200, 7, 99]
+    la, _ = a.forward([0] * 6, list(range(6)), toks)
+    lb, _ = b.forward([0] * 6, list(range(6)), toks)
+    assert np.allclose(la, lb, atol=1e-5) and not np.array_equal(la, lb)   # (two tokens alone happen to round the same way under ggml's Q8_K scale)
 
 
 def test_product_chosen_ksplit_plan_is_harmless_at_mistral_geometry():
@@ -214,12 +215,33 @@ def test_q6k_known_answer_block():
 
 
 def test_q8k_quantize_properties():
+    """ggml's published quantize_row_q8_K_ref (round 6: the convention of oracle and kernels): iscale = -127 / max of the signed extreme (the FIRST
+    element of largest magnitude), q = min(127, nearest_int(iscale * x)), d = 1 / iscale"""
     rng = np.random.default_rng(1)
     x = rng.standard_normal(512).astype(np.float32)
     q, d, bs = O.q8k_quantize(x)
-    assert np.abs(q).max() == 127
     assert np.array_equal(bs, q.reshape(-1, 32).sum(1))
-    assert np.abs(q.reshape(2, 256) * d[:, None] - x.reshape(2, 256)).max() <= d.max() * 0.5 + 1e-7
+    assert np.abs(q.reshape(2, 256) * d[:, None] - x.reshape(2, 256)).max() <= np.abs(d).max() * 0.5 + 1e-7
+    for b in range(2):                                                   # the extreme element becomes -127 and d carries the sign of -max
+        xb, qb = x[256 * b:256 * (b + 1)], q[256 * b:256 * (b + 1)]
+        i = int(np.argmax(np.abs(xb)))
+        assert qb[i] == -127 and np.sign(d[b]) == -np.sign(xb[i]) and qb.min() >= -127 and qb.max() <= 127
+        iscale = np.float32(-127.0) / xb[i]
+        assert d[b] == np.float32(1.0) / iscale
+        assert np.array_equal(qb, np.minimum(127, np.rint(iscale * xb)).astype(np.int8))
+    # a hand-computed block: extreme +2.0 at index 3 (and -2.0 later: the first one decides the sign), iscale = -63.5, d = -1 / 63.5
+    h = np.zeros(256, np.float32)
+    h[0], h[1], h[2], h[3], h[4], h[200] = 1.0, -0.5, 0.011811024, 2.0, 0.0078, -2.0
+    q, d, bs = O.q8k_quantize(h)
+    assert q[:5].tolist() == [-64, 32, -1, -127, 0] and q[200] == 127 and d[0] == np.float32(1.0) / np.float32(-63.5)
+    assert bs.tolist() == [-160, 0, 0, 0, 0, 0, 127, 0]
+    # ties to even (nearest_int): 0.5 / 63.5 * 2.5 -> -2.5 -> -2;  the positive side is clamped at 127, the negative side never passes -127
+    h = np.zeros(256, np.float32)
+    h[0], h[1], h[2] = -2.0, np.float32(2.5 / 63.5), np.float32(3.5 / 63.5)
+    q, d, _ = O.q8k_quantize(h)
+    assert q[:3].tolist() == [-127, 2, 4] and d[0] == np.float32(1.0) / np.float32(63.5)
+    z, dz, bz = O.q8k_quantize(np.zeros(256, np.float32))               # an all-zero block: d = 0, q = 0
+    assert not z.any() and dz[0] == 0.0 and not bz.any()
 
 
 def test_exact_math_accuracy():

@@ -223,18 +223,28 @@ __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot,
             dst[(k16 & 3) * 64 + (k16 >> 2)] = tk_f16_to_f32(tk_f32_to_f16(v[i]));
         }
     }
-    float amax = 0.0f;
+    /* ggml's quantize_row_q8_K_ref: the signed value of the block's FIRST element of largest magnitude (element index = 8 x chunk-in-block + i),
+     * iscale = -127 / max, q = min(127, nearest_int(iscale * x)), d = 1 / iscale */
+    float amax = 0.0f, mval = 0.0f;
+    int midx = 8 * (c & 31);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) amax = tk_fmaxf(amax, tk_fabsf(v[i]));
+    for (int i = 0; i < 8; ++i) {
+        const float ax = tk_fabsf(v[i]);
+        if (ax > amax) { amax = ax; mval = v[i]; midx = 8 * (c & 31) + i; }
+    }
 #pragma unroll
-    for (int s = 1; s <= 16; s <<= 1) amax = tk_fmaxf(amax, wave_xor_f(amax, s));
-    const float id = amax > 0.0f ? tk_divf(127.0f, amax) : 0.0f;
+    for (int s = 1; s <= 16; s <<= 1) {
+        const float oa = wave_xor_f(amax, s), ov = wave_xor_f(mval, s);
+        const int oi = __shfl_xor(midx, s, TK_WAVE);
+        if (oa > amax || (oa == amax && oi < midx)) { amax = oa; mval = ov; midx = oi; }
+    }
+    const float iscale = amax > 0.0f ? tk_divf(-127.0f, mval) : 0.0f;
     int q[8];
     int sum = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        int t = (int)tk_rintf(v[i] * id);
-        t = t > 127 ? 127 : (t < -127 ? -127 : t);
+        int t = (int)tk_rintf(iscale * v[i]);
+        t = t > 127 ? 127 : t;
         q[i] = t;
         sum += t;
     }
@@ -257,7 +267,7 @@ __device__ __forceinline__ void quantize_chunk8(const float* v, int c, int slot,
             hb[128] = tk_f32_to_f16((float)(sum & 1));
         }
     }
-    if ((c & 31) == 0) out.ad[mt * out.ad_ts + (size_t)(c >> 5) * TK_ROW_SLOTS + sl] = amax > 0.0f ? tk_divf(amax, 127.0f) : 0.0f;
+    if ((c & 31) == 0) out.ad[mt * out.ad_ts + (size_t)(c >> 5) * TK_ROW_SLOTS + sl] = amax > 0.0f ? tk_divf(1.0f, iscale) : 0.0f;
 }
 
 /* ------------------------------------------------------------------------------------------
