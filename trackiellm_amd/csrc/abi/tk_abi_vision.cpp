@@ -330,7 +330,7 @@ tk_error_code_t tk_mi355x_detector_detect_batch(tk_object_detector_t* d, int n, 
         d->last[0].swap(r.dets);
     } else {
         std::string err;
-        TkDetector* e = d->own ? d->own.get() : d->priv(n, &err);
+        TkDetector* e = d->priv(n, &err); /* the handle's private engine, grown when this batch is wider than it */
         if (!e) return vfail(TK_ERROR_GPU_MEMORY, err);
         e->conf = d->conf;
         e->iou = d->iou;

@@ -359,6 +359,8 @@ void tk_launch_rmsnorm_q8(float* x, const float* partial, int ks, int n_total_pa
                           TkActQ8 out, hipStream_t s) {
     int nthr = D / 4; /* one thread per 16-byte group of the row, 256 .. 1024 */
     nthr = nthr < 256 ? 256 : nthr > 1024 ? 1024 : (nthr + 255) / 256 * 256;
+    /* (round 6: four-wave workgroups while several decode streams share the device — so that the norm fits beside other streams' resident mat-vec
+     * workgroups instead of waiting for one to retire — measured SLOWER: 3.99 against 3.90 ms per step and group at 3 x 16 rows, profiles/r06_northstar_explore.txt) */
     hipLaunchKernelGGL(k_rmsnorm_q8, dim3(nrows), dim3(nthr), (D + 4) * sizeof(float), s, x, partial, ks, n_total_partial, w, eps, D, out);
 }
 

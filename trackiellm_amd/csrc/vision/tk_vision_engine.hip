@@ -165,7 +165,8 @@ static bool yolo_generic_graph(const char* path, TkYoloModel* m, const std::stri
 
 bool TkYoloModel::load_onnx(const char* path) {
     TkOnnxWeights ox;
-    if (!ox.load(path)) { error = ox.error; return false; }
+    /* the Conv-initialiser reader only understands what a YOLOv8n export holds; a file it cannot read may still be a graph the executor runs */
+    if (!ox.load(path)) return yolo_generic_graph(path, this, "as a YOLOv8n weight file: " + ox.error);
     /* 63 graph convolutions, optionally followed by the DFL projection conv [1][16][1][1] */
     size_t n = ox.convs.size();
     if (n == specs.size() + 1 && ox.convs.back().cout == 1 && ox.convs.back().cin == TK_YOLO_REG_MAX && ox.convs.back().kh == 1) --n;
