@@ -439,14 +439,15 @@ def long_context_decode(tk, model, contexts=(2000, 3900), steps=64):
     return out
 
 
-def reference_abi_batched_cortex(tk, K, N):
+def reference_abi_batched_cortex(tk, K, N, progress=False):
     """K cortex handles (tk_cortex_create ... tk_cortex_destroy only) that share one LLM model file, each driven by its own host thread through
     ONE data-dependent cycle of the reference's loop (/root/reference/src/cortex/tk_cortex_main.c:1149-1237, 1323-1379): 1 s of PCM + the
     silence that ends the segment -> VAD -> Whisper -> the transcript becomes a conversation turn -> reasoner context string -> LLM response;
     then a 640 x 640 frame -> detector -> the detections enter the context string -> LLM response.  The prompts are built from THAT
     cycle's transcript and detections (different frames / audio per cortex); the LLM rows of all cortices are decoded together behind the
-    runner API (csrc/llm/tk_llm_batcher.h).  Two responses of N / 2 tokens each = N tokens per cycle.  Perception runs per handle at batch 1,
-    as the reference's API shapes it.  The synthetic vocabulary is byte-level, so a context string costs one prompt token per byte."""
+    runner API (csrc/llm/tk_llm_batcher.h).  Two responses of N / 2 tokens each = N tokens per cycle.  Perception is called per handle, one frame /
+    utterance per call as the reference's API shapes it; the handles' calls are coalesced by the per-model-file engines behind it (round 6).  The
+    synthetic vocabulary is byte-level, so a context string costs one prompt token per byte."""
     # the runners the cortices create share ONE decode session of K sequence slots (the library's default is 16 per session: 256 cortices would
     # decode in sixteen separate 16-row streams); read when the first runner of the model is created
     prev_slots = os.environ.get("TK_MI355X_RUNNER_SLOTS")
@@ -477,8 +478,9 @@ def reference_abi_batched_cortex(tk, K, N):
         t_end = time.time() + 600
         while cx.stats().llm_responses < want and time.time() < t_end:
             time.sleep(0.002)
+        dropped = cx.stats().events_dropped
         cx.inject_frame(frame)
-        while cx.stats().frames_processed < 1 and time.time() < t_end:
+        while cx.stats().frames_processed < 1 and cx.stats().events_dropped == dropped and time.time() < t_end:  # (a frame the pipeline failed on is counted as dropped)
             time.sleep(0.002)
         want += 1 if cx.stats().frames_with_objects > 0 else 0
         while cx.stats().llm_responses < want and time.time() < t_end:
@@ -488,10 +490,23 @@ def reference_abi_batched_cortex(tk, K, N):
 
     th = [threading.Thread(target=drive, args=(i,)) for i in range(K)]
     t0 = time.time()
+    ticking = [progress]
+
+    def ticker():  # developer aid (tools/time_batched_cortex.py --progress): where the K cycles stand, every few seconds, on stderr
+        while ticking[0]:
+            time.sleep(5.0)
+            st = [cx.stats() for cx in cxs]
+            print("[%6.1f s] speech segments %d, frames processed %d (with objects %d), responses %d, tokens %d, dropped events %d" % (
+                time.time() - t0, sum(s.speech_segments for s in st), sum(s.frames_processed for s in st), sum(s.frames_with_objects for s in st),
+                sum(s.llm_responses for s in st), sum(s.llm_tokens for s in st), sum(s.events_dropped for s in st)), file=sys.stderr, flush=True)
+
+    tick = threading.Thread(target=ticker, daemon=True)
+    tick.start()
     for t in th:
         t.start()
     for t in th:
         t.join()
+    ticking[0] = False
     dt = max(done) - t0
     st = [cx.stats() for cx in cxs]
     # the shared model's scheduler counters (the registry hands this loader the cortices' own model): how wide the LLM passes really were
@@ -500,11 +515,20 @@ def reference_abi_batched_cortex(tk, K, N):
     passes, rows, widest = tk.ModelLoader.batch_stats(hm)
     ld.unload(hm)
     ld.close()
+    # the shared perception engines' counters (round 6: every cortex's detector / ASR handle on one model file shares one batched engine whose
+    # scheduler coalesces the handles' one-frame / one-utterance calls): a probe handle on the same file reads them
+    dprobe = tk.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", conf=0.5, iou=0.5)
+    aprobe = tk.Asr(model="synthetic://whisper-tiny.en?seed=6")
+    dshare, ashare = dprobe.share_stats(), aprobe.share_stats()
+    dprobe.close()
+    aprobe.close()
     for cx in cxs:
         cx.stop()
     for cx in cxs:
         cx.close()
     return {"cortices": K, "host_threads": K, "wall_s": round(dt, 3), "cycles_per_s": round(K / dt, 3), "create_s": round(t_create, 2),
+            "shared_perception": {"detector_jobs": dshare[1], "frames": dshare[2], "widest_detector_job": dshare[3], "asr_jobs": ashare[1], "utterances": ashare[2],
+                                  "widest_asr_job": ashare[3]},
             "llm_responses": int(sum(s.llm_responses for s in st)), "llm_tokens": int(sum(s.llm_tokens for s in st)),
             "speech_segments": int(sum(s.speech_segments for s in st)), "frames_with_objects": int(sum(s.frames_with_objects for s in st)),
             "last_prompt_bytes_mean": int(np.mean(plen)), "llm_passes": int(passes), "llm_rows_per_pass": round(rows / max(passes, 1), 1), "widest_pass": int(widest),
@@ -606,9 +630,9 @@ def main():
     ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     ap.add_argument("--ns-steps", type=int, default=4, help="timed steps of the north_star_point run")
     ap.add_argument("--cortices", type=lambda v: [int(x) for x in v.split(",") if x], default=[16, 64],
-                    help="cortex-handle counts of the reference_abi_batched_cortex extras.  256 handles (a 4096-position KV cache for 256 sequences = 137 GB, "
-                         "+ 256 private detector / ASR engines) only fit beside nothing else: run tools/time_batched_cortex.py 256 on its own "
-                         "(profiles/r05_batched_cortex.txt: 25 cycles/s); inside this process the GPU's memory is oversubscribed and the driver evicts")
+                    help="cortex-handle counts of the reference_abi_batched_cortex extras.  256 handles need a 4096-position KV cache for 256 sequences (137 GB) "
+                         "beside what this process already holds: measured on its own by tools/time_batched_cortex.py 256 (profiles/r06_batched_cortex_256.txt: "
+                         "33.7 cycles/s; the detector / ASR engines are shared per model file since round 6)")
     ap.add_argument("--weights", choices=["q4_k_m", "f16"], default="q4_k_m",
                     help="f16: BASELINE configs[4]'s fp16 checkpoint (14.2 GB of weights per decode step) on the exact fp32 MFMA GEMM; LLM stream only, "
                          "no W4A8 roofline object (other kernels)")

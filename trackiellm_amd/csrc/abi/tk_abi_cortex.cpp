@@ -261,7 +261,11 @@ tk_error_code_t tk_cortex_run(tk_cortex_t* c) {
             tk_vision_result_t* vr = nullptr;
             const tk_vision_analysis_flags_t flags = TK_VISION_ANALYZE_OBJECT_DETECTION | TK_VISION_ANALYZE_DEPTH_ESTIMATION |
                                                      TK_VISION_ANALYZE_FUSION_DISTANCE | TK_VISION_ANALYZE_NAVIGATION_CUES;
-            if (tk_vision_pipeline_process_frame(c->vis, &f, flags, nullptr, 0, &vr) != TK_SUCCESS || !vr) continue;
+            if (tk_vision_pipeline_process_frame(c->vis, &f, flags, nullptr, 0, &vr) != TK_SUCCESS || !vr) {
+                std::lock_guard<std::mutex> lk(c->stat_mu); /* the frame is lost: counted, like an event the queue refused */
+                c->stats.events_dropped++;
+                continue;
+            }
             const size_t n = vr->object_count;
             (void)tk_contextual_reasoner_update_vision_context(c->reasoner, vr);
             tk_vision_result_destroy(&vr);

@@ -301,6 +301,9 @@ tk_error_code_t tk_mi355x_llm_forward_sampled(tk_mi355x_llm_session_t* s, int nr
     TkSampleRow rows[TK_MAX_ROWS] = {};
     for (int r = 0; r < nrows; ++r) {
         const tk_mi355x_sampling_t& p = sampling[r];
+        /* the checks tk_mi355x_llm_runner_set_sampling makes, per row */
+        if (!(p.temperature >= 0.0f) || p.top_k < 0 || p.top_k > TK_SAMPLE_MAX_K || !(p.top_p > 0.0f) || p.top_p > 1.0f || !(p.min_p >= 0.0f) || p.min_p > 1.0f)
+            return fail(TK_ERROR_INVALID_ARGUMENT, "sampling parameters of row " + std::to_string(r) + " are out of range (temperature >= 0, 0 <= top_k <= 64, 0 < top_p <= 1, 0 <= min_p <= 1)");
         rows[r].temp = p.temperature; rows[r].top_p = p.top_p; rows[r].min_p = p.min_p; rows[r].top_k = p.top_k; rows[r].seed = p.seed; rows[r].counter = p.counter;
     }
     if (!s->session.forward(nrows, seq, pos, tok, logits, ids, true, nullptr, rows)) return fail(TK_ERROR_INFERENCE_FAILED, s->session.error);
@@ -690,6 +693,9 @@ const char* tk_mi355x_llm_runner_tool_call_text(tk_llm_runner_t* runner) { retur
 
 tk_error_code_t tk_mi355x_llm_runner_set_sampling(tk_llm_runner_t* runner, float temperature, int32_t top_k, float top_p, float min_p) {
     if (!runner || !(temperature >= 0.0f) || top_k < 0 || !(top_p > 0.0f) || top_p > 1.0f || !(min_p >= 0.0f) || min_p > 1.0f) return TK_ERROR_INVALID_ARGUMENT;
+    /* the device sampler draws from at most TK_SAMPLE_MAX_K = 64 candidates: llama.cpp's default top_k (40) fits; a larger top_k is refused rather than
+     * clamped silently, and top_k = 0 ("the whole vocabulary" in llama.cpp) means the 64 largest here (include/tk/tk_mi355x_ext.h) */
+    if (top_k > TK_SAMPLE_MAX_K) return fail(TK_ERROR_INVALID_ARGUMENT, "top_k above 64: the sampler keeps at most 64 candidates");
     if (temperature > 0.0f && runner->model->model.hp.vocab > 65536) return fail(TK_ERROR_NOT_IMPLEMENTED, "stochastic sampling supports vocabularies of at most 65536 tokens");
     runner->samp.temp = temperature; runner->samp.top_k = top_k; runner->samp.top_p = top_p; runner->samp.min_p = min_p;
     return TK_SUCCESS;

@@ -39,7 +39,8 @@ struct TkLoraAdapter {
 
     bool load(const char* path);
     const TkLoraTensor* find(int layer, int which) const;
-    float scale_of(const TkLoraTensor& t) const { return alpha / (float)t.r; }
+    /* alpha / r of THAT tensor; an adapter written with alpha = 0 scales by 1 (llama.cpp's llama_lora_adapter: `alpha ? alpha / rank : 1`) */
+    float scale_of(const TkLoraTensor& t) const { return alpha != 0.0f ? alpha / (float)t.r : 1.0f; }
     /* a loaded model has the adapter inside its weights: the factors (tens to hundreds of MB of host memory for a 7B model) can go */
     void drop_factors() {
         for (auto& t : tensors) { std::vector<float>().swap(t.A); std::vector<float>().swap(t.B); }
