@@ -89,6 +89,15 @@ struct SharedAsr {
         cv_req.notify_all();
         if (th.joinable()) th.join();
     }
+    std::mutex eng_mu; /* held while a job runs on `eng` and while `eng` is replaced */
+    /* called when a handle joins (under the registry lock): the engine is sized for the handles there are — 1, 2, 4 ... MAX frames / utterances per
+     * job — at CREATE time, so that nothing allocates or frees device memory while jobs and other streams' graph captures run */
+    bool grow_for_handles(std::string* err) {
+        int want = 1;
+        while (want < handles && want < TK_ASR_SHARED_MAX_BATCH) want *= 2;
+        std::lock_guard<std::mutex> lk(eng_mu);
+        return ensure_engine(want, err);
+    }
     bool ensure_engine(int want, std::string* err) {
         if (eng && eng->max_batch >= want) return true;
         std::unique_ptr<TkAsr> ne(new TkAsr());
@@ -120,7 +129,8 @@ struct SharedAsr {
             while (cap < (int)job.size() || (cap < handles && cap < TK_ASR_SHARED_MAX_BATCH)) cap *= 2;
             lk.unlock();
             std::string err;
-            bool ok = ensure_engine(cap, &err);
+            std::unique_lock<std::mutex> el(eng_mu);
+            bool ok = ensure_engine(cap, &err); /* a no-op after grow_for_handles(): the engine already takes this many */
             if (ok) {
                 const int B = (int)job.size();
                 int n_max = 0;
@@ -158,6 +168,7 @@ struct SharedAsr {
                 }
                 if (!ok) err = eng->error;
             }
+            el.unlock();
             lk.lock();
             n_batches++;
             n_utts += job.size();
@@ -328,6 +339,7 @@ static tk_error_code_t asr_new(tk_asr_whisper_context_t** out, const TkWhisperHP
     }
     { std::lock_guard<std::mutex> hl(sh->mu); sh->handles++; }
     c->sh = sh;
+    if (shared && !sh->grow_for_handles(&err)) return afail(TK_ERROR_GPU_MEMORY, err); /* (c's destructor takes the handle back) */
     c->buffer.assign(TK_ASR_MAX_BUFFER, 0);
     const int v = sh->model.hp.n_vocab;
     const int ml = v >= 51865 ? 1 : 0; /* multilingual vocabularies have one more text token: the special ids move up by one */
@@ -365,7 +377,7 @@ static tk_error_code_t asr_run_ref(tk_asr_whisper_context_s* c, const int16_t* p
         if (status) *status = r.status;
         return TK_SUCCESS;
     }
-    std::lock_guard<std::mutex> lk(sh->mu);
+    std::lock_guard<std::mutex> lk(sh->eng_mu);
     const int32_t len = n_samples;
     int32_t rl = 0, stt = 0;
     if (!sh->eng->transcribe_ref(1, pcm, n_samples, &len, prompt.data(), (int)prompt.size(), n_steps, temperature, seed, sh->suppress.data(), sh->token_beg, sh->token_eot,
@@ -392,7 +404,7 @@ static tk_error_code_t asr_run(tk_asr_whisper_context_s* c, int batch, const int
         return r.ok ? TK_SUCCESS : afail(TK_ERROR_INFERENCE_FAILED, r.err);
     }
     /* the test / bench entry points on a shared context (copies of the mel, batches): the engine itself, one caller at a time */
-    std::lock_guard<std::mutex> lk(sh->mu);
+    std::lock_guard<std::mutex> lk(sh->eng_mu);
     std::string err;
     if (!sh->ensure_engine(batch, &err)) return afail(TK_ERROR_GPU_MEMORY, err);
     const bool ok = policy ? sh->eng->transcribe_policy(batch, pcm, n_samples, prompt.data(), (int)prompt.size(), n_steps, temperature, seed, tokens_out, logprobs_out)

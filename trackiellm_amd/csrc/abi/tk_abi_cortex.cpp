@@ -85,12 +85,18 @@ static void run_llm(tk_cortex_s* c) {
     if (tk_contextual_reasoner_generate_context_string(c->reasoner, &ctx, 2048) != TK_SUCCESS || !ctx) { set_state(c, TK_STATE_IDLE); return; }
     const std::string prompt = ctx;
     (void)tk_contextual_reasoner_free_context_string(ctx);
-    if (tk_llm_runner_prepare_generation(c->runner, prompt.c_str(), false) != TK_SUCCESS) { set_state(c, TK_STATE_IDLE); return; }
+    static const bool debug = [] { const char* e = getenv("TK_MI355X_DEBUG"); return e && e[0] == '1'; }(); /* failures of the response thread on stderr */
+    if (tk_llm_runner_prepare_generation(c->runner, prompt.c_str(), false) != TK_SUCCESS) {
+        if (debug) fprintf(stderr, "tk_cortex: prepare_generation failed: %s\n", tk_error_get_detail());
+        set_state(c, TK_STATE_IDLE);
+        return;
+    }
     set_state(c, TK_STATE_RESPONDING);
     std::string resp;
     int n = 0;
     for (; n < c->max_tokens && !c->stop.load(); ++n) {
         const char* p = tk_llm_runner_generate_next_token(c->runner);
+        if (!p && debug) fprintf(stderr, "tk_cortex: generate_next_token returned NULL after %d tokens: %s\n", n, tk_error_get_detail());
         if (!p || p == TK_TOOL_CALL_TOKEN) break;
         resp += p;
     }

@@ -77,6 +77,15 @@ struct SharedDetector {
         cv_req.notify_all();
         if (th.joinable()) th.join();
     }
+    std::mutex eng_mu; /* held while a job runs on `eng` and while `eng` is replaced */
+    /* called when a handle joins (under the registry lock): the engine is sized for the handles there are — 1, 2, 4 ... MAX frames / utterances per
+     * job — at CREATE time, so that nothing allocates or frees device memory while jobs and other streams' graph captures run */
+    bool grow_for_handles(std::string* err) {
+        int want = 1;
+        while (want < handles && want < TK_DET_SHARED_MAX_BATCH) want *= 2;
+        std::lock_guard<std::mutex> lk(eng_mu);
+        return ensure_engine(want, err);
+    }
     bool ensure_engine(int want, std::string* err) {
         if (eng && eng->max_batch >= want) return true;
         std::unique_ptr<TkDetector> nd(new TkDetector());
@@ -109,7 +118,8 @@ struct SharedDetector {
             while (cap < (int)job.size() || (cap < handles && cap < TK_DET_SHARED_MAX_BATCH)) cap *= 2;
             lk.unlock();
             std::string err;
-            bool ok = ensure_engine(cap, &err);
+            std::unique_lock<std::mutex> el(eng_mu);
+            bool ok = ensure_engine(cap, &err); /* a no-op after grow_for_handles(): the engine already takes this many */
             std::vector<std::vector<TkDetection>> out;
             if (ok) {
                 std::vector<const uint8_t*> ptrs(job.size());
@@ -135,6 +145,7 @@ struct SharedDetector {
                     r->have_attr = eng->classify_boxes((int)i, (int)n, rects.data(), r->color.data(), r->door.data());
                 }
             }
+            el.unlock();
             lk.lock();
             n_batches++;
             n_frames += job.size();
@@ -237,6 +248,8 @@ tk_error_code_t tk_object_detector_create(tk_object_detector_t** out_detector, c
         }
         { std::lock_guard<std::mutex> hl(sh->mu); sh->handles++; }
         d->sh = sh;
+        std::string gerr;
+        if (!sh->grow_for_handles(&gerr)) return vfail(TK_ERROR_GPU_MEMORY, gerr); /* (d's destructor takes the handle back) */
     }
     *out_detector = d.release();
     return TK_SUCCESS;
@@ -396,7 +409,7 @@ int tk_mi355x_detector_is_graph(const tk_object_detector_t* d) { return d && d->
 int tk_mi355x_detector_anchor_count(const tk_object_detector_t* d) {
     if (!d) return 0;
     if (d->own) return d->own->n_anchors;
-    std::lock_guard<std::mutex> lk(d->sh->mu);
+    std::lock_guard<std::mutex> lk(d->sh->eng_mu);
     return d->sh->eng ? d->sh->eng->n_anchors : 0;
 }
 

@@ -73,6 +73,8 @@ private:
     uint8_t* suppress_dev = nullptr; /* [n_vocab] of the last transcribe_ref (uploaded again only when the table changes) */
     std::vector<uint8_t> suppress_host;
     int32_t* wh_state = nullptr;     /* [max_batch][TK_WH_STATE_INTS] */
+    float* lp_dev = nullptr;         /* [n_text_ctx][max_batch] log-probabilities of a policy / reference-parameter decode */
+    bool ensure_decode_buffers();
     std::vector<float> pick_logprobs; /* [total steps][B], read back by transcribe_policy */
 };
 

@@ -484,6 +484,7 @@ TkAsr::~TkAsr() {
     if (arena) (void)hipFree(arena);
     if (pcm_dev) (void)hipFree(pcm_dev);
     if (suppress_dev) (void)hipFree(suppress_dev);
+    if (lp_dev) (void)hipFree(lp_dev);
     if (wh_state) (void)hipFree(wh_state);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -513,22 +514,34 @@ bool TkAsr::transcribe_policy(int B, const int16_t* pcm, int n_samples, const in
     const int total = n_prompt + n_steps - 1;
     if (B < 1 || total < 1) { error = "nothing to decode"; return false; }
     if (hipSetDevice(model->device) != hipSuccess) { error = "hipSetDevice failed"; return false; }
-    float* d_lp = nullptr;
-    if (hipMalloc((void**)&d_lp, (size_t)total * B * sizeof(float)) != hipSuccess) { error = "out of device memory (log-probabilities)"; return false; }
+    if (!ensure_decode_buffers()) return false;
+    if (total > model->hp.n_text_ctx || B > max_batch) { error = "prompt + steps exceed the text context"; return false; }
+    float* d_lp = lp_dev;
     pick.on = true; pick.temp = temperature; pick.seed = seed; pick.logprob = d_lp; pick.step = 0;
     const bool ok = transcribe(B, pcm, n_samples, prompt, n_prompt, n_steps, tokens_out, nullptr, nullptr, nullptr); /* synchronises the stream */
     pick.on = false;
     bool copied = true;
     if (ok && logprobs_out) {
         pick_logprobs.resize((size_t)total * B);
-        copied = hipMemcpy(pick_logprobs.data(), d_lp, pick_logprobs.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+        copied = hipMemcpyAsync(pick_logprobs.data(), d_lp, pick_logprobs.size() * sizeof(float), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                 hipStreamSynchronize(stream) == hipSuccess;
         for (int step = 0; copied && step < n_steps; ++step)
             for (int b = 0; b < B; ++b) logprobs_out[(size_t)b * n_steps + step] = pick_logprobs[(size_t)(n_prompt - 1 + step) * B + b];
     }
-    (void)hipFree(d_lp);
     pick.logprob = nullptr;
     if (ok && !copied) error = "copy of the log-probabilities failed";
     return ok && copied;
+}
+
+/* the decode's small device buffers, allocated ONCE per engine: nothing on a call's path allocates or frees device memory or uses the null stream —
+ * hipFree synchronises the whole device and, issued while another host thread captures a hipGraph (the LLM's passes are captured at first use of
+ * every row count), was the prime suspect of an intermittent process-wide stall on cold boxes (round 6, 64 cortices) */
+bool TkAsr::ensure_decode_buffers() {
+    const TkWhisperHP& h = model->hp;
+    if (!lp_dev) HIPQ(hipMalloc((void**)&lp_dev, (size_t)max_batch * h.n_text_ctx * sizeof(float)));
+    if (!suppress_dev) HIPQ(hipMalloc((void**)&suppress_dev, (size_t)h.n_vocab));
+    if (!wh_state) HIPQ(hipMalloc((void**)&wh_state, (size_t)max_batch * TK_WH_STATE_INTS * sizeof(int32_t)));
+    return true;
 }
 
 bool TkAsr::transcribe_ref(int B, const int16_t* pcm, int n_samples, const int32_t* n_samples_row, const int32_t* prompt, int n_prompt, int n_steps, float temperature,
@@ -540,18 +553,17 @@ bool TkAsr::transcribe_ref(int B, const int16_t* pcm, int n_samples, const int32
     const int total = n_prompt + n_steps - 1;
     if (total < 1) { error = "nothing to decode"; return false; }
     if (hipSetDevice(model->device) != hipSuccess) { error = "hipSetDevice failed"; return false; }
-    if (!suppress_dev) HIPQ(hipMalloc((void**)&suppress_dev, (size_t)h.n_vocab));
-    if (!wh_state) HIPQ(hipMalloc((void**)&wh_state, (size_t)max_batch * TK_WH_STATE_INTS * sizeof(int32_t)));
+    if (!ensure_decode_buffers()) return false;
+    if (total > h.n_text_ctx) { error = "prompt + steps exceed the text context"; return false; }
     if (suppress_host.size() != (size_t)h.n_vocab || memcmp(suppress_host.data(), suppress, (size_t)h.n_vocab) != 0) {
         HIPQ(hipStreamSynchronize(stream)); /* the previous decode may still read the table */
         suppress_host.assign(suppress, suppress + h.n_vocab);
-        HIPQ(hipMemcpy(suppress_dev, suppress_host.data(), (size_t)h.n_vocab, hipMemcpyHostToDevice));
+        HIPQ(hipMemcpyAsync(suppress_dev, suppress_host.data(), (size_t)h.n_vocab, hipMemcpyHostToDevice, stream));
     }
     std::vector<int32_t> st0((size_t)B * TK_WH_STATE_INTS, 0);
     for (int b = 0; b < B; ++b) st0[(size_t)b * TK_WH_STATE_INTS + 7] = n_samples_row[b] / TK_WH_HOP; /* seek_end: the utterance in 10 ms frames */
     HIPQ(hipMemcpyAsync(wh_state, st0.data(), st0.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    float* d_lp = nullptr;
-    if (hipMalloc((void**)&d_lp, (size_t)total * B * sizeof(float)) != hipSuccess) { error = "out of device memory (log-probabilities)"; return false; }
+    float* d_lp = lp_dev;
     HIPQ(hipMemsetAsync(d_lp, 0, (size_t)total * B * sizeof(float), stream));
     pick.on = true; pick.temp = temperature; pick.seed = seed; pick.logprob = d_lp; pick.step = 0;
     pick.filtered = true; pick.first_step = n_prompt - 1; pick.suppress = suppress_dev; pick.state = wh_state; pick.beg = token_beg; pick.eot = token_eot;
@@ -562,8 +574,9 @@ bool TkAsr::transcribe_ref(int B, const int16_t* pcm, int n_samples, const int32
     std::vector<int32_t> st1((size_t)B * TK_WH_STATE_INTS);
     if (ok) {
         pick_logprobs.resize((size_t)total * B);
-        copied = hipMemcpy(pick_logprobs.data(), d_lp, pick_logprobs.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
-                 hipMemcpy(st1.data(), wh_state, st1.size() * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+        copied = hipMemcpyAsync(pick_logprobs.data(), d_lp, pick_logprobs.size() * sizeof(float), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                 hipMemcpyAsync(st1.data(), wh_state, st1.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                 hipStreamSynchronize(stream) == hipSuccess;
         for (int b = 0; copied && b < B; ++b) {
             const int32_t* sb = &st1[(size_t)b * TK_WH_STATE_INTS];
             if (status) status[b] = sb[6];
@@ -572,7 +585,6 @@ bool TkAsr::transcribe_ref(int B, const int16_t* pcm, int n_samples, const int32
             for (int step = 0; logprobs_out && step < n_steps; ++step) logprobs_out[(size_t)b * n_steps + step] = pick_logprobs[(size_t)(n_prompt - 1 + step) * B + b];
         }
     }
-    (void)hipFree(d_lp);
     pick.logprob = nullptr;
     if (ok && !copied) error = "copy of the decode state failed";
     return ok && copied;
@@ -585,7 +597,8 @@ bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* 
     if (n_samples < 0 || n_samples > h.n_samples()) { error = "audio longer than the model window"; return false; }
     if (n_prompt < 1 || n_prompt + n_steps > h.n_text_ctx) { error = "prompt + steps exceed the text context"; return false; }
     HIPQ(hipSetDevice(model->device));
-    const size_t need = (size_t)B * (n_samples > 0 ? n_samples : 1);
+    size_t need = (size_t)B * (n_samples > 0 ? n_samples : 1);
+    if (need > pcm_cap) need = (size_t)max_batch * (size_t)h.n_samples(); /* once: the engine's whole batch of full windows (0.96 MB each) */
     if (need > pcm_cap) {
         if (pcm_dev) (void)hipFree(pcm_dev);
         pcm_dev = nullptr;

@@ -491,11 +491,11 @@ bool TkDetector::detect(int B, const uint8_t* const* frames, uint32_t w, uint32_
     if (w < 2 || h < 2 || stride < w * bpp) { error = "frame geometry invalid (need w,h >= 2 and stride >= w*bpp)"; return false; }
     HIPQ(hipSetDevice(model->device));
     const size_t fb = (size_t)stride * h;
-    if (fb * B > frame_cap) {
+    if (fb * B > frame_cap) { /* once per frame geometry: room for the engine's whole batch, so a wider job later never re-allocates (hipFree synchronises the device) */
         if (frame_dev) (void)hipFree(frame_dev);
         frame_dev = nullptr;
-        HIPQ(hipMalloc((void**)&frame_dev, fb * B));
-        frame_cap = fb * B;
+        HIPQ(hipMalloc((void**)&frame_dev, fb * max_batch));
+        frame_cap = fb * max_batch;
     }
     for (int b = 0; b < B; ++b) {
         HIPQ(hipMemcpyAsync(frame_dev + fb * b, frames[b], fb, hipMemcpyHostToDevice, stream));
@@ -583,12 +583,13 @@ __global__ __launch_bounds__(256) void k_box_attributes(const uint8_t* frame, in
 
 bool TkDetector::run_attributes(const uint8_t* frame, uint32_t w, uint32_t h, int n, const int32_t* rects, int32_t* color, int32_t* door_closed) {
     if (n <= 0) return true;
-    if (n > attr_cap) {
+    if (n > attr_cap) { /* at least the detector's own cap of boxes at the first use: no regrowth afterwards */
+        const int want = n > TK_OBJECT_DETECTOR_MAX_DETECTIONS ? n : TK_OBJECT_DETECTOR_MAX_DETECTIONS;
         if (attr_dev) (void)hipFree(attr_dev);
         attr_dev = nullptr;
         attr_cap = 0;
-        HIPQ(hipMalloc((void**)&attr_dev, (size_t)n * 6 * 4));
-        attr_cap = n;
+        HIPQ(hipMalloc((void**)&attr_dev, (size_t)want * 6 * 4));
+        attr_cap = want;
     }
     int32_t* res = attr_dev + (size_t)attr_cap * 4;
     HIPQ(hipMemcpyAsync(attr_dev, rects, (size_t)n * 16, hipMemcpyHostToDevice, stream));
