@@ -439,6 +439,10 @@ def long_context_decode(tk, model, contexts=(2000, 3900), steps=64):
     return out
 
 
+BATCHED_CORTEX_DEADLINE_S = 120
+STALLED = []  # legs that hit their deadline: main() then exits without running destructors
+
+
 def reference_abi_batched_cortex(tk, K, N, progress=False):
     """K cortex handles (tk_cortex_create ... tk_cortex_destroy only) that share one LLM model file, each driven by its own host thread through
     ONE data-dependent cycle of the reference's loop (/root/reference/src/cortex/tk_cortex_main.c:1149-1237, 1323-1379): 1 s of PCM + the
@@ -488,7 +492,7 @@ def reference_abi_batched_cortex(tk, K, N, progress=False):
         done[i] = time.time()
         plen[i] = len(cx.last_prompt())
 
-    th = [threading.Thread(target=drive, args=(i,)) for i in range(K)]
+    th = [threading.Thread(target=drive, args=(i,), daemon=True) for i in range(K)]
     t0 = time.time()
     ticking = [progress]
 
@@ -504,9 +508,18 @@ def reference_abi_batched_cortex(tk, K, N, progress=False):
     tick.start()
     for t in th:
         t.start()
+    # an extra must never hang the bench: K cycles take seconds; after BATCHED_CORTEX_DEADLINE_S the leg is reported as an error, its handles are
+    # left alone (closing a wedged cortex could block) and main() leaves through os._exit once the JSON line is out
+    deadline = time.time() + BATCHED_CORTEX_DEADLINE_S
     for t in th:
-        t.join()
+        t.join(max(0.0, deadline - time.time()))
     ticking[0] = False
+    if any(t.is_alive() for t in th):
+        STALLED.append("reference_abi_batched_cortex(%d)" % K)
+        st = [cx.stats() for cx in cxs]
+        raise RuntimeError("stalled: after %d s only %d of %d cycles were complete (responses %d, frames %d, speech segments %d)" % (
+            BATCHED_CORTEX_DEADLINE_S, sum(1 for d_ in done if d_ > 0), K, sum(s_.llm_responses for s_ in st), sum(s_.frames_processed for s_ in st),
+            sum(s_.speech_segments for s_ in st)))
     dt = max(done) - t0
     st = [cx.stats() for cx in cxs]
     # the shared model's scheduler counters (the registry hands this loader the cortices' own model): how wide the LLM passes really were
@@ -795,7 +808,9 @@ def main():
                 out["reference_abi_batched_cortex"].append({"cortices": K, "error": str(e)[:200]})
     if extras and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(tk, model, hp, P, N, args.asr_steps)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if STALLED:  # a leg was abandoned with live handles: do not wait for their destructors
+        os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
 
