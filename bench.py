@@ -887,7 +887,7 @@ def run_pipeline(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N, com
                           "dtype": "f16 weights x f16-rounded f32 activations, fp32 MFMA chain" if f16 else DTYPE, "data": "synthetic",
                           "config": {"workload": wl, "concurrent_cycles": cycles, "layers_per_stage": [bounds[r + 1] - bounds[r] for r in range(n_st)],
                                      "roles": roles, "parallelism": par},
-                          **({"perception_handover": {"what": "detections (<= 20 per frame) + ASR token ids of every batch gathered to the pipeline's stage 0 per step, required before its generate",
+                          **({"perception_handover": {"what": "detections (<= 20 per frame) + ASR token ids of every batch sent to the pipeline's stage 0 per step as fixed-size isend / irecv messages, required before its generate",
                                                       "bytes_per_step": ex.bytes_last, "checksum": ex.checksum}} if ex is not None and rank == roles["llm"][0] else {}),
                           "llm_tok_per_s": round(cycles * N * args.steps / elapsed, 1)}))
     if ex is not None:
@@ -938,7 +938,7 @@ def run_model_per_gpu(args, tk, D, dist, hp, rank, local_rank, world, G, B, P, N
                                      "rows_per_llm_pass": B, "prompt_tokens": P, "decode_tokens": N,
                                      "parallelism": "model-per-gpu x%d: LLM on rank 0; detector on ranks %s; VAD+ASR on ranks %s" % (world, vis, aud)},
                           "llm_rank_ms_per_step": round(1000.0 * r["elapsed"] / args.steps, 2), "role_of_rank0": role,
-                          "perception_handover": {"what": "detections (<= 20 per frame) + ASR token ids of every batch gathered to rank 0 per step, required before its generate",
+                          "perception_handover": {"what": "detections (<= 20 per frame) + ASR token ids of every batch sent to rank 0 per step as fixed-size isend / irecv messages, required before its generate",
                                                   "bytes_per_step": ex.bytes_last, "checksum": ex.checksum}}))
     cb.close()
     ex.finish()
