@@ -594,6 +594,12 @@ def test_asr_reference_parameter_decode(gpu, tmp_path):
     for g, w in zip(got, want):
         assert np.array_equal(g[0], w[0][0]) and np.array_equal(g[1], w[1][0]) and (g[2], g[3]) == (int(w[2][0]), int(w[3][0]))
     assert ctx[0].share_stats()[3] >= 2
+    # a long cap (whisper.cpp's own is n_text_ctx / 2 - 4 = 220): every 16 steps the engine reads the rows' status words and stops enqueueing once all
+    # rows have ended; tokens behind a row's end are eot and its log-probabilities 0 on both sides
+    for i in (0, 2):
+        w48 = orc.transcribe_ref(utts[i][None], [len(utts[i])], 48, want_tab, BEG, EOT, prompt)
+        g48 = asr.transcribe_ref(utts[i], 48)
+        assert np.array_equal(g48[0], w48[0][0]) and np.array_equal(g48[1], w48[1][0]) and (g48[2], g48[3]) == (int(w48[2][0]), int(w48[3][0]))
     # at a temperature: the canonical draw over the allowed set, same seed and counter on both sides
     wt = orc.transcribe_ref(utts[2][None], [len(utts[2])], STEPS, want_tab, BEG, EOT, prompt, temperature=0.6, seed=9)
     gt = asr.transcribe_ref(utts[2], STEPS, temperature=0.6, seed=9)

@@ -634,6 +634,8 @@ bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* 
     for (int p = 0; p < total; ++p)
         for (int b = 0; b < B; ++b) host_tab[((size_t)n_prompt + p) * B + b] = p;
     HIPQ(hipMemcpyAsync(tok_tab, host_tab.data(), host_tab.size() * 4, hipMemcpyHostToDevice, stream));
+    int steps_run = n_steps; /* sampled positions really enqueued */
+    std::vector<int32_t> st_host;
     for (int p = 0; p < total; ++p) {
         st.tok = p < n_prompt ? tok_tab + (size_t)p * B : out_tab + (size_t)(p - 1) * B;
         st.pos = pos_tab + (size_t)p * B;
@@ -643,13 +645,26 @@ bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* 
             first_logits->resize((size_t)B * h.n_vocab);
             HIPQ(hipMemcpyAsync(first_logits->data(), st.logits, first_logits->size() * 4, hipMemcpyDeviceToHost, stream));
         }
+        /* the reference-parameter decode ends where the rows' own bookkeeping says (whisper.cpp: up to n_text_ctx / 2 - 4 tokens): every 16 sampled
+         * positions the rows' status words are read; once every row has completed or failed nothing more is enqueued — a finished row emits eot and
+         * stands still anyway (k_pick_rows_filtered), so stopping early changes no token */
+        const int step = p - (n_prompt - 1);
+        if (pick.filtered && step >= 0 && (step + 1) % 16 == 0 && p + 1 < total) {
+            ops.flush();
+            st_host.resize((size_t)B * TK_WH_STATE_INTS);
+            HIPQ(hipMemcpyAsync(st_host.data(), pick.state, st_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            HIPQ(hipStreamSynchronize(stream));
+            bool all_done = true;
+            for (int b = 0; b < B; ++b) all_done = all_done && st_host[(size_t)b * TK_WH_STATE_INTS + 6] != 0;
+            if (all_done) { steps_run = step + 1; break; }
+        }
     }
     ops.flush();
-    std::vector<int32_t> outs((size_t)n_steps * B);
+    std::vector<int32_t> outs((size_t)steps_run * B);
     HIPQ(hipMemcpyAsync(outs.data(), out_tab + (size_t)(n_prompt - 1) * B, outs.size() * 4, hipMemcpyDeviceToHost, stream));
     HIPQ(hipStreamSynchronize(stream)); /* host_tab and outs live until here */
     for (int step = 0; step < n_steps; ++step)
-        for (int b = 0; b < B; ++b) tokens_out[(size_t)b * n_steps + step] = outs[(size_t)step * B + b];
+        for (int b = 0; b < B; ++b) tokens_out[(size_t)b * n_steps + step] = step < steps_run ? outs[(size_t)step * B + b] : pick.eot;
     HIPQ(hipGetLastError());
     if (!launch_error.empty()) { error = launch_error; return false; }
     return true;
