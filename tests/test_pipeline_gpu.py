@@ -215,6 +215,43 @@ def test_ten_generations_on_one_set_of_pipes(gpu):
         s.close()
 
 
+def test_pipelined_decode_takes_the_long_context_form_past_512_positions(gpu):
+    """a pipe stage cached ONE decode graph per row count, captured with whatever attention form the first capture met, so a pipe
+    first captured on a short prompt never took the long-context form (scores / PV chains spread over the chip) past 512 positions.  The stage now counts
+    the position on the host (last pass + steps) and keeps a graph per (form, row count).  Two stages of one Mistral-shaped layer each, one sequence:
+    a short generation first (captures the fused form), then a 500-token prompt decoded across position 512 — ids equal a single session's, whose
+    decode loop switches forms itself; both forms are bit-identical, so equality does not depend on which one ran: the plan at the positions the loop
+    crosses is asserted from the launcher's own answer."""
+    hp = gpu.MISTRAL_7B()
+    hp.n_layer = 2
+    model = gpu.LlmModel(hp).fill_synthetic(4)
+    hp = model.hparams
+    CTX = 560
+    assert gpu.attention_plan(1, hp.n_head, hp.n_kv_head, hp.head_dim, CTX, True, top_position=500)[0] != 3
+    assert gpu.attention_plan(1, hp.n_head, hp.n_kv_head, hp.head_dim, CTX, True, top_position=520)[0] == 3
+    sess = [gpu.LlmSession(model, 1, CTX) for _ in range(2)]
+    pipes = [gpu.LlmPipe(sess[s], s, 2, s, s + 1) for s in range(2)]
+    for s in range(2):
+        pipes[s].connect_local(pipes[1 - s], pipes[1 - s])
+    rng = np.random.default_rng(13)
+    ref = gpu.LlmSession(model, 1, CTX)
+    for n_prompt, n_dec in ((6, 4), (500, 30)):
+        prompts = rng.integers(3, hp.vocab, (1, n_prompt)).astype(np.int32)
+        for s in range(2):
+            _drive_stage(pipes[s], prompts, n_dec, rows_per_pass=256)
+        fed = pipes[0].sync(1, n_dec)
+        sampled = pipes[1].sync(1, n_dec)
+        first = ref.prefill(prompts)
+        toks, _ = ref.decode(1, n_dec)
+        want = np.concatenate([first[None, :], toks])
+        assert np.array_equal(sampled, want[1:n_dec + 1]) and np.array_equal(fed, want[:n_dec]), (n_prompt, n_dec)
+    for p in pipes:
+        p.close()
+    for s_ in sess + [ref]:
+        s_.close()
+    model.close()
+
+
 @pytest.mark.timeout(120)
 def test_pipe_wait_is_bounded_fails_fast_and_stays_failed(gpu, monkeypatch):
     """a stage whose producer never publishes must not hang: the first device-side wait gives up after the pipe's timeout
