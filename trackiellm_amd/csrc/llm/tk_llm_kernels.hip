@@ -6,7 +6,7 @@
  * inside a 256-block, float accumulation across blocks in ascending order, canonical
  * reduction trees elsewhere.  Results are bit-identical to the oracle.
  *
- * Roofline: the dominant kernels are k_gemv_w4a8 (passes of <= 32 rows), k_gemm_w4a8 (33..128 rows) and k_gemm32_w4a8 (129..256 rows):
+ * Roofline: the dominant kernels are k_gemv_w4a8 (passes of <= 32 rows), k_gemm_w4a8 (33..192 rows) and k_gemm32_w4a8 (193..256 rows):
  * weights streamed once per pass, 0.5625 / 0.8203 B per weight; MFMA carries the int8 contraction
  * [16 row slots x 64 k] x [64 k x 16 weight rows] (32 x 32 x 32 in the widest kernel), so one weight pass serves up to 256
  * (sequence, position) rows.  Measured fractions and where the time goes: DESIGN.md §7.
@@ -829,7 +829,8 @@ __global__ __launch_bounds__(512) void k_gemv_w4a8(TkGemvArgs a, int groups, int
 
 /* ------------------------------------------------------------------------------------------
  * Batched passes (33..256 rows: prefill chunks, wide decode batches): same work mapping and the same per-row arithmetic as
- * k_gemv_w4a8, but the weight tile is unpacked ONCE and multiplied against MT = 4, 8 or 16 M-tiles, so the dequantisation VALU
+ * k_gemv_w4a8, but the weight tile is unpacked ONCE and multiplied against MT = 4, 6, 8, 10 or 12 M-tiles (the pass's rows / 16 rounded up to the next
+ * instantiation; 14 and 16 exist for the TK_MI355X_G32_FROM=257 A/B against the 32x32x32 kernel), so the dequantisation VALU
  * work and the HBM bytes per row drop by MT.  The K-range's activations no longer fit in LDS, so they stream through a
  * two-slot ring of 256-k blocks (MT x {4 KiB int8 image, 512 B f16 sub-block sums, 64 B scales} each):
  *
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(NT == 2 ? 256 : 512) void k_gemm_w4a8(TkGemvArgs a,
 
 
 /* ------------------------------------------------------------------------------------------
- * Wide passes (129..256 rows): the same arithmetic on v_mfma_i32_32x32x32_i8.
+ * Wide passes (193..256 rows by default, from 129 with TK_MI355X_G32_FROM=129): the same arithmetic on v_mfma_i32_32x32x32_i8.
  *
  * Why: per (16 rows x 16 weight rows x 256 k) the 16x16x64 formulation above issues 8 int8 MFMAs + 1 f16 MFMA (9 x 8 issue cycles) and four
  * ds_read_b128; the 32x32x32 form does the same multiply-adds with HALF the MFMA issue slots and HALF the LDS operand bytes per MAC (one
@@ -1378,7 +1379,7 @@ __device__ __forceinline__ void g32_k_loop(const uint8_t* tile, size_t tile_byte
     }
 }
 
-/* 129..256 rows (and one row half alone).  A workgroup = 4 waves, one per SIMD = four pairs of weight tiles (128 weight rows) x ONE half
+/* 193..256 rows (129..192 as MTW = 3 under TK_MI355X_G32_FROM; and one row half alone).  A workgroup = 4 waves, one per SIMD = four pairs of weight tiles (128 weight rows) x ONE half
  * of the pass's rows (128 rows = four 32-row M-tiles per wave); the two row halves of the same weights are two workgroups that share a CU
  * (73 KiB of ring each) and nothing else.  The SIMD's two resident waves therefore belong to DIFFERENT workgroups: no barrier couples
  * them, so one's weight unpack (190 VALU instructions, no MFMA) drifts under the other's MFMA phases.  With both halves in one 8-wave
@@ -1576,7 +1577,7 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
     /* 129..192 rows: the 16x16x64 kernel at ten / twelve M-tiles (its time grows by ~0.4 ms per 32 rows: 3.3 / 3.7 ms per decode step's launch set
      * against 4.2 of the 32x32x32 kernel at three tiles per half, profiles/r06_width_curve.txt); TK_MI355X_G32_FROM=129 keeps the round-5 split */
     if (a.nrows >= tk_g32_from()) {
-        /* 129..256 rows: the 32x32x32 kernel, one type per wave (a mixed q / k / v launch needs no split): four (weight-tile pair) slots per
+        /* tk_g32_from() .. 256 rows: the 32x32x32 kernel, one type per wave (a mixed q / k / v launch needs no split): four (weight-tile pair) slots per
          * workgroup, one workgroup per row half */
         const int pairs = a.swiglu ? a.seg[0].row_tiles : row_tiles / 2; /* every segment holds a multiple of 4 row tiles: pairs never straddle segments */
         const int g32 = (pairs + 3) / 4;
@@ -1593,7 +1594,7 @@ void tk_launch_gemv(const TkGemvArgs& a, hipStream_t s) {
 #undef TK_G32_LAUNCH_M
         return;
     }
-    if (a.nrows > 2 * TK_ROW_SLOTS) { /* batched passes of 33..128 rows: K-streamed activations, 4 or 8 M-tiles per weight tile */
+    if (a.nrows > 2 * TK_ROW_SLOTS) { /* batched passes of 33 rows and more: K-streamed activations, as many M-tiles per weight tile as the pass's rows fill */
         /* 16-row M-tiles a weight tile is multiplied against: 65..96 rows walk six, not eight */
         const int mtb = a.nrows > 14 * TK_ROW_SLOTS ? 16 : a.nrows > 12 * TK_ROW_SLOTS ? 14 : a.nrows > 10 * TK_ROW_SLOTS ? 12 : a.nrows > 8 * TK_ROW_SLOTS ? 10 : a.nrows > 6 * TK_ROW_SLOTS ? 8 : a.nrows > 4 * TK_ROW_SLOTS ? 6 : 4;
         const size_t ldsb = (size_t)2 * TK_RING_BLOCKS * mtb * TK_RING_TILE_BYTES;
