@@ -32,3 +32,76 @@ for G in a.groups:
     print(f"{a.tag} groups {G} x rows {a.rows} {'llm-only' if a.llm_only else 'fused'}: {cycles * a.steps / r['elapsed']:.2f} cycles/s, decode {r['decode_ms_per_step']:.3f} ms per step and group, "
           f"decode window {window:.4f}, whole run {whole:.4f} of 8 TB/s (prefill {r['prefill_s'] * 1e3:.1f} ms, decode {r['decode_s'] * 1e3:.1f} ms per step)", flush=True)
     cb.close()
+
+
+def free_running(G, rows, steps, fused):
+    """the same work with the groups NOT joined per step: every group thread runs `steps` cycles batches (perception of its rows beside its prefill +
+    decode) on its own clock, group g starting g / G of a step late — prefill passes (compute-bound, 256 rows) of one group then fall beside the decode
+    passes (HBM-bound, 16 rows) of the others instead of all groups prefilling, then all decoding, together"""
+    import threading
+    import time
+    import numpy as np
+    hp = model.hparams
+    sess = [tk.LlmSession(model, rows, P + N + 8) for _ in range(G)]
+    prompts = []
+    for g in range(G):
+        pr = np.stack([bench.splitmix_tokens(3 + 1000 * (g * rows + s), P, 3, hp.vocab) for s in range(rows)])
+        pr[:, 0] = 1
+        prompts.append(pr)
+    det = asr = vad = None
+    if fused:
+        det = [tk.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", width=640, height=640, conf=0.5, iou=0.5, max_batch=rows) for _ in range(G)]
+        asr = [tk.Asr(hp=tk.WHISPER_TINY_EN(), seed=6, max_batch=rows) for _ in range(G)]
+        vad = [tk.Vad() for _ in range(G)]
+        rng = np.random.default_rng(1)
+        frames = [rng.integers(0, 256, (640, 640, 3), dtype=np.uint8) for _ in range(rows)]
+        pcm = np.clip(np.random.default_rng(2).normal(0, 3000, (rows, 16000)), -32768, 32767).astype(np.int16)
+
+    def perception(g):
+        det[g].detect_batch(frames)
+        for b in range(rows):
+            vad[g].reset()
+            vad[g].process_with_events(pcm[b])
+        asr[g].transcribe_tokens(pcm, 16, want_aux=False)
+
+    def cycle_batch(g):
+        th = threading.Thread(target=perception, args=(g,)) if fused else None
+        if th:
+            th.start()
+        sess[g].prefill(prompts[g])
+        sess[g].decode(rows, N)
+        if th:
+            th.join()
+
+    for g in range(G):  # warm-up: captures, engines
+        cycle_batch(g)
+    t_one = time.time()
+    cycle_batch(0)
+    t_one = time.time() - t_one
+    done = [0.0] * G
+
+    def run(g):
+        time.sleep(g * 1.6 * t_one / G)  # a lone batch takes t_one; G concurrent ones ~1.6 x that: spread the starts over one such step
+        for _ in range(steps):
+            cycle_batch(g)
+        done[g] = time.time()
+
+    th = [threading.Thread(target=run, args=(g,)) for g in range(G)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    elapsed = max(done) - t0
+    n_pre = G * (-(-(rows * (P - 1)) // 256) + 1)
+    passes = G * N + n_pre
+    whole = model.weight_bytes * passes * steps / elapsed / 8e12
+    print(f"{a.tag} FREE-RUNNING groups {G} x rows {rows} {'fused' if fused else 'llm-only'}: {G * rows * steps / elapsed:.2f} cycles/s, whole run {whole:.4f} of 8 TB/s "
+          f"({steps} cycle batches per group, staggered starts included in the time)", flush=True)
+    for s in sess:
+        s.close()
+
+
+if os.environ.get("TK_NS_FREE") == "1":
+    for G in a.groups:
+        free_running(G, a.rows, max(a.steps, 4), not a.llm_only)
