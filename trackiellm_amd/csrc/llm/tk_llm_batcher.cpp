@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 
 TkLlmBatcher::~TkLlmBatcher() {
     {
@@ -10,6 +12,14 @@ TkLlmBatcher::~TkLlmBatcher() {
     }
     cv_.notify_all();
     if (worker_.joinable()) worker_.join();
+    if (!trace_path_.empty()) {
+        if (FILE* f = fopen(trace_path_.c_str(), "a")) {
+            fprintf(f, "# batcher %p: woke_ms formed_ms done_ms rows ahead completing queued_after captures capture_ms\n", (void*)this);
+            for (const PassTrace& t : trace_)
+                fprintf(f, "%.3f %.3f %.3f %d %d %d %d %llu %.2f\n", t.woke, t.formed, t.done, t.rows, t.ahead, t.completing, t.queued_after, (unsigned long long)t.captures, t.capture_ms);
+            fclose(f);
+        }
+    }
 }
 
 bool TkLlmBatcher::init(TkLlmModel* model, int slots, int n_ctx, int32_t eos, std::string* err) {
@@ -20,6 +30,8 @@ bool TkLlmBatcher::init(TkLlmModel* model, int slots, int n_ctx, int32_t eos, st
     slot_used_.assign((size_t)slots, 0);
     ahead_.assign((size_t)slots, Ahead());
     eos_ = eos;
+    if (const char* e = getenv("TK_MI355X_BATCHER_DECODE_FIRST")) decode_first_ = e[0] == '1';
+    if (const char* e = getenv("TK_MI355X_BATCHER_TRACE")) { trace_path_ = e; trace_.reserve(4096); }
     worker_ = std::thread([this] { loop(); });
     return true;
 }
@@ -106,19 +118,26 @@ void TkLlmBatcher::loop() {
     std::vector<int32_t> sq, ps, tk, am;
     std::vector<const uint32_t*> masks;
     std::vector<TkSampleRow> samps;
-    std::vector<Request*> in_pass, completing;
-    std::vector<int> ahead_rows; /* slots whose run-ahead row rides this pass, in row order after the queued requests' rows */
+    struct Taken { Request* r; int take, last_row; };   /* `take` rows of a request end at row `last_row` of the pass */
+    struct AheadRow { int slot, row; };                  /* a sequence's run-ahead row and where it sits in the pass */
+    std::vector<Taken> in_pass;
+    std::vector<Request*> completing;
+    std::vector<AheadRow> ahead_rows;
     auto any_planned = [&] {
         for (const Ahead& a : ahead_) if (a.st == Ahead::PLANNED) return true;
         return false;
     };
+    const auto t_origin = std::chrono::steady_clock::now();
+    auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_origin).count(); };
     for (;;) {
+        double t_woke = 0.0;
         in_pass.clear(); completing.clear(); ahead_rows.clear();
         sq.clear(); ps.clear(); tk.clear(); masks.clear(); samps.clear();
         bool any_mask = false, any_samp = false;
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait(lk, [&] { return stop_ || !queue_.empty() || any_planned(); });
+            t_woke = trace_path_.empty() ? 0.0 : now_ms();
             if (stop_) {
                 for (Request* r : queue_) { r->ok = false; r->error = "scheduler stopped"; r->finished = true; r->cv.notify_all(); }
                 queue_.clear();
@@ -134,11 +153,15 @@ void TkLlmBatcher::loop() {
                 const int64_t us = std::min<int64_t>(2500, 200 + 8 * (int64_t)expect_);
                 cv_.wait_for(lk, std::chrono::microseconds(us), [&] { return stop_ || queue_.size() >= expect_; });
             }
-            /* FIFO; a request contributes as many of its remaining rows as the pass still holds.  A grammar-masked request samples
-             * under its own token mask, which the arg max kernel takes per ROW: masked and unmasked requests share passes. */
-            for (Request* r : queue_) {
-                if ((int)sq.size() >= TK_MAX_ROWS) break;
-                const int take = std::min(r->n - r->done_rows, TK_MAX_ROWS - (int)sq.size());
+            /* FIFO: a request contributes as many of its remaining rows as the pass still holds, then the run-ahead rows.  A grammar-masked
+             * request samples under its own token mask, which the arg max kernel takes per ROW: masked and unmasked requests share passes.
+             * A row's result does not depend on its place in a pass or on the pass it rides.
+             * TK_MI355X_BATCHER_DECODE_FIRST=1 (measured, not the default: profiles/r06_batcher_trace.txt) takes the rows that end in a sampled
+             * token first — one-row requests and run-ahead rows — so that a decoding sequence rides the passes that carry other sequences'
+             * prompt rows instead of waiting behind them: K cortices driven in lock step gain little (their prompts and their decode steps
+             * arrive together whatever the order) and a pass that mixes one-row sequences with prompt chunks pays for 16-row attention
+             * tiles that hold one row each (256-row pass: 8.7 -> 9.6 .. 12.3 ms). */
+            auto add_rows = [&](Request* r, int take) {
                 for (int i = 0; i < take; ++i) {
                     sq.push_back(r->slot);
                     ps.push_back(r->pos0 + r->done_rows + i);
@@ -146,7 +169,7 @@ void TkLlmBatcher::loop() {
                     masks.push_back(nullptr);
                     samps.push_back(TkSampleRow{});
                 }
-                in_pass.push_back(r);
+                in_pass.push_back(Taken{r, take, (int)sq.size() - 1});
                 if (r->done_rows + take == r->n) {
                     completing.push_back(r);
                     masks.back() = r->mask; /* the row that is sampled */
@@ -154,23 +177,38 @@ void TkLlmBatcher::loop() {
                     any_mask = any_mask || r->mask != nullptr;
                     any_samp = any_samp || r->samp.temp > 0.0f;
                 }
+            };
+            const bool decode_first = decode_first_;
+            if (decode_first)
+                for (Request* r : queue_) {
+                    if ((int)sq.size() >= TK_MAX_ROWS) break;
+                    if (r->n - r->done_rows == 1) add_rows(r, 1);
+                }
+            auto add_ahead = [&] {
+                for (size_t s = 0; s < ahead_.size() && (int)sq.size() < TK_MAX_ROWS; ++s) {
+                    Ahead& a = ahead_[s];
+                    if (a.st != Ahead::PLANNED) continue;
+                    a.st = Ahead::INFLIGHT;
+                    sq.push_back((int32_t)s);
+                    ps.push_back(a.pos);
+                    tk.push_back(a.tok);
+                    masks.push_back(nullptr);
+                    samps.push_back(TkSampleRow{});
+                    ahead_rows.push_back(AheadRow{(int)s, (int)sq.size() - 1});
+                }
+            };
+            if (decode_first) add_ahead(); /* one per sequence whose owner holds the id they feed */
+            for (Request* r : queue_) {
+                if ((int)sq.size() >= TK_MAX_ROWS) break;
+                if (decode_first && r->n - r->done_rows == 1) continue; /* taken above */
+                add_rows(r, std::min(r->n - r->done_rows, TK_MAX_ROWS - (int)sq.size()));
             }
-            /* then the run-ahead rows, one per sequence whose owner holds the id they feed */
-            for (size_t s = 0; s < ahead_.size() && (int)sq.size() < TK_MAX_ROWS; ++s) {
-                Ahead& a = ahead_[s];
-                if (a.st != Ahead::PLANNED) continue;
-                a.st = Ahead::INFLIGHT;
-                sq.push_back((int32_t)s);
-                ps.push_back(a.pos);
-                tk.push_back(a.tok);
-                masks.push_back(nullptr);
-                samps.push_back(TkSampleRow{});
-                ahead_rows.push_back((int)s);
-            }
+            if (!decode_first) add_ahead();
         }
         const int nrows = (int)sq.size();
         if (nrows == 0) continue;
         am.assign((size_t)nrows, -1);
+        const double t_formed = trace_path_.empty() ? 0.0 : now_ms();
         const bool head = !completing.empty() || !ahead_rows.empty();
         const bool ok = session_.forward(nrows, sq.data(), ps.data(), tk.data(), nullptr, head ? am.data() : nullptr, head, head && any_mask ? masks.data() : nullptr,
                                         head && any_samp ? samps.data() : nullptr);
@@ -179,11 +217,10 @@ void TkLlmBatcher::loop() {
             passes_++;
             if (nrows > max_rows_) max_rows_ = nrows;
             if (!ok) last_error_ = session_.error;
-            int row = 0;
             size_t held = 0; /* completing requests that got no run-ahead row: their owners are waited for */
-            for (Request* r : in_pass) {
-                const int take = std::min(r->n - r->done_rows, TK_MAX_ROWS - row);
-                row += take;
+            for (const Taken& t : in_pass) {
+                Request* r = t.r;
+                const int take = t.take, row = t.last_row + 1;
                 rows_ += (uint64_t)take;
                 r->done_rows += take;
                 if (!ok) { r->ok = false; r->error = session_.error; r->done_rows = r->n; }
@@ -197,10 +234,10 @@ void TkLlmBatcher::loop() {
                     r->cv.notify_all();
                 }
             }
-            for (int s : ahead_rows) {
+            for (const AheadRow& ar : ahead_rows) {
+                const int s = ar.slot;
                 Ahead& a = ahead_[(size_t)s];
-                const int32_t got = ok ? am[(size_t)row] : -1;
-                ++row;
+                const int32_t got = ok ? am[(size_t)ar.row] : -1;
                 if (a.discard) { wasted_++; a = Ahead(); continue; }
                 if (a.waiter) { /* the owner is already waiting for exactly this row */
                     Request* w = a.waiter;
@@ -220,6 +257,8 @@ void TkLlmBatcher::loop() {
                 }
             }
             expect_ = held;
+            if (!trace_path_.empty())
+                trace_.push_back(PassTrace{t_woke, t_formed, now_ms(), nrows, (int)ahead_rows.size(), (int)completing.size(), (int)queue_.size(), session_.n_captures, session_.capture_ms});
         }
     }
 }

@@ -81,9 +81,15 @@ private:
     std::condition_variable cv_;
     std::deque<Request*> queue_;
     bool stop_ = false;
+    bool decode_first_ = false; /* TK_MI355X_BATCHER_DECODE_FIRST=1: sampled rows before prompt rows when a pass is formed (A/B; tk_llm_batcher.cpp) */
     size_t expect_ = 0; /* requests finished by the last pass: their owners are about to submit the next token */
     uint64_t passes_ = 0, rows_ = 0;
     int max_rows_ = 0;
+    /* TK_MI355X_BATCHER_TRACE=<file>: one line per pass (times in ms since the scheduler started: woken, pass formed, pass done; rows, of them
+     * run-ahead rows, requests completed, requests still queued, graph captures so far and their host time), written when the batcher dies */
+    struct PassTrace { double woke, formed, done; int rows, ahead, completing, queued_after; uint64_t captures; double capture_ms; };
+    std::vector<PassTrace> trace_;
+    std::string trace_path_;
     std::thread worker_;
 };
 

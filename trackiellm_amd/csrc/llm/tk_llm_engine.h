@@ -150,6 +150,10 @@ private:
     int32_t* d_tiles = nullptr;                         /* [1 + TK_MAX_ROWS] 16-row tiles of a multi-position pass (k_att_tiles) */
     size_t tab_cap = 0;
     bool capture_pass(hipGraphExec_t* slot, int nrows, bool lm_head, bool fused_attn);
+public:
+    uint64_t n_captures = 0; /* passes recorded into a graph so far, and the host time that took (diagnostics: TK_MI355X_BATCHER_TRACE) */
+    double capture_ms = 0.0;
+private:
 };
 
 #endif

@@ -3,6 +3,8 @@
  * scheduling and hipGraph capture.  See tk_llm_engine.h for the reference call sites replaced.
  */
 #include "tk_llm_engine.h"
+
+#include <chrono>
 #include "tk_lora.h"
 
 #include <math.h>
@@ -514,6 +516,8 @@ void TkLlmSession::choose_attention_top(int top, int nrows) {
 
 bool TkLlmSession::capture_pass(hipGraphExec_t* slot, int nrows, bool lm_head, bool fused_attn) {
     if (*slot) return true;
+    const auto t_cap = std::chrono::steady_clock::now();
+    struct Tally { TkLlmSession* s; std::chrono::steady_clock::time_point t0; ~Tally() { s->n_captures++; s->capture_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } tally{this, t_cap};
     std::lock_guard<std::mutex> lk(g_capture_mu);
     hipGraph_t g = nullptr;
     HIPQ(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
