@@ -548,6 +548,44 @@ def reference_abi_batched_cortex(tk, K, N, progress=False):
             "data_dependent": True}
 
 
+def perception_fast_contraction(tk, device, asr_steps):
+    """VERDICT r05 item 8's second `perception` object: the opt-in fast contraction (convolutions / the ASR's long passes on the f16 matrix pipe with
+    split operands, tk_mi355x_detector_set_fast_contraction / tk_mi355x_asr_set_fast_contraction) beside the exact path, stand-alone, 32 frames and
+    32 one-second clips per call; the headline and every parity claim stay on the exact path."""
+    PB = 32
+    rng = np.random.default_rng(1)
+    frames = [rng.integers(0, 256, (640, 640, 3), dtype=np.uint8) for _ in range(PB)]
+    pcm = np.clip(np.random.default_rng(2).normal(0, 3000, (PB, 16000)), -32768, 32767).astype(np.int16)
+
+    def ms(fn, n=3):
+        fn()
+        t = time.time()
+        for _ in range(n):
+            fn()
+        return round(1000.0 * (time.time() - t) / n, 2)
+
+    det = tk.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", width=640, height=640, conf=0.5, iou=0.5, device=device, max_batch=PB)
+    x = rng.random((1, 640, 640, 3), dtype=np.float32)
+    d_exact, raw_e, dets_e = ms(lambda: det.detect_batch(frames)), det.forward_raw(x), det.detect_batch(frames)
+    det.set_fast_contraction(True)
+    d_fast, raw_f, dets_f = ms(lambda: det.detect_batch(frames)), det.forward_raw(x), det.detect_batch(frames)
+    det.close()
+    asr = tk.Asr(hp=tk.WHISPER_TINY_EN(), seed=6, device=device, max_batch=PB)
+    a_exact = ms(lambda: asr.transcribe_tokens(pcm, asr_steps, want_aux=False))
+    tok_e, _, enc_e, _ = asr.transcribe_tokens(pcm[:2], asr_steps, want_aux=True)
+    asr.set_fast_contraction(True)
+    a_fast = ms(lambda: asr.transcribe_tokens(pcm, asr_steps, want_aux=False))
+    tok_f, _, enc_f, _ = asr.transcribe_tokens(pcm[:2], asr_steps, want_aux=True)
+    asr.close()
+    same_sets = all(sorted((a[0], a[3]) for a in e) == sorted((b[0], b[3]) for b in f) for e, f in zip(dets_e, dets_f))
+    return {"what": "opt-in split-f16 contraction beside the exact fp32 chains, stand-alone, per 32 frames / 32 one-second clips (not the headline's path)",
+            "dtype": "f16 x 2 halves per operand on v_mfma_f32_32x32x16_f16, fp32 accumulation",
+            "detector_ms_per_32": {"exact": d_exact, "fast": d_fast}, "asr_ms_per_32": {"exact": a_exact, "fast": a_fast, "forced_steps": asr_steps},
+            "head_maps_max_err_of_scale": float(np.abs(raw_f - raw_e).max() / np.abs(raw_e).max()),
+            "encoder_max_err_of_scale": float(np.abs(enc_f - enc_e).max() / np.abs(enc_e).max()),
+            "detections_same_set_per_frame": bool(same_sets), "asr_ids_equal": bool(np.array_equal(tok_f, tok_e))}
+
+
 def reference_abi_runners(tk, K, N):
     """K tk_llm_runner_t handles on ONE model handle, each driven by its own host thread through tk_llm_runner_prepare_generation /
     tk_llm_runner_generate_next_token only: what a host gets when it opens K runners instead of one (continuous batching behind the
@@ -806,6 +844,11 @@ def main():
                 out["reference_abi_batched_cortex"].append(reference_abi_batched_cortex(tk, K, N))
             except Exception as e:  # reported, never fatal for the headline
                 out["reference_abi_batched_cortex"].append({"cortices": K, "error": str(e)[:200]})
+    if extras and fused:
+        try:
+            out["perception_fast_contraction"] = perception_fast_contraction(tk, local_rank, args.asr_steps)
+        except Exception as e:  # reported, never fatal for the headline
+            out["perception_fast_contraction"] = {"error": str(e)[:200]}
     if extras and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(tk, model, hp, P, N, args.asr_steps)
     print(json.dumps(out), flush=True)

@@ -100,6 +100,11 @@ TK_API void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_
  * enable = 0 restores the earlier rounds' decode (<|notimestamps|> prompt, bare arg max, exactly decode_steps tokens); vocabularies without
  * whisper's special-token layout (fewer than 51864 tokens) always decode that way. */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_set_reference_decode(tk_asr_whisper_context_t* ctx, int enable);
+/* Opt-in fast contraction (the detector's twin is tk_mi355x_detector_set_fast_contraction): the long passes of a transcription
+ * — log-mel, the encoder's convolutions, linear layers and Q K^T — contract on the f16 matrix pipe with every operand split into two f16 halves
+ * (~22 significant bits, fp32 accumulation): within ~1e-6 of the exact chains' scale, not their bits.  Decoder steps keep the exact path.  Off by
+ * default; the exact path stays the parity path and the checker (tests/test_audio_gpu.py::test_asr_fast_contraction_gate). */
+TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_set_fast_contraction(tk_asr_whisper_context_t* ctx, int on);
 /* one utterance through that decode: tokens [n_steps] (eot behind the row's end), log-probabilities [n_steps] (may be NULL), *result_len = tokens that
  * make up the text, *status = 0 (n_steps reached), 1 (completed), 2 (failed: whisper.cpp would fall back to the next temperature) */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_transcribe_ref(tk_asr_whisper_context_t* ctx, const int16_t* pcm, int n_samples, int n_steps, float temperature,

@@ -613,3 +613,33 @@ def test_asr_reference_parameter_decode(gpu, tmp_path):
     assert (asr.process_audio(utts[0][:15000], True)[0] or "") == ""
     for a in ctx + [asr]:
         a.close()
+
+
+def test_asr_fast_contraction_gate(gpu):
+    """the opt-in fast contraction (tk_mi355x_asr_set_fast_contraction: log-mel and the encoder's long passes on the f16 matrix pipe with split
+    operands) against the exact path and the HF fixture at the tiny.en geometry — VERDICT r05 item 8's gate: log-mel within 1e-4, encoder states and
+    first-step logits within 1e-5 of their scale of the exact path and inside the HF fixture's tolerance, forced-decode ids equal; switched
+    off again the context returns the exact path's bits."""
+    from test_oracle_audio import check_against_hf_full_geometry, full_geometry_pcm
+    asr = gpu.Asr()
+    pcm = full_geometry_pcm()
+    te, me, ee, le = asr.transcribe_tokens(pcm, 8)
+    asr.set_fast_contraction(True)
+    tf, mf, ef, lf = asr.transcribe_tokens(pcm, 8)
+    assert not np.array_equal(ef, ee)                                          # the other kernels did run
+    assert np.abs(mf - me).max() < 1e-4
+    assert np.abs(ef - ee).max() < 1e-5 * np.abs(ee).max() and np.abs(lf - le).max() < 1e-5 * np.abs(le).max()
+    assert np.array_equal(tf, te)
+    check_against_hf_full_geometry(mf, ef, lf, tf[0, 0])
+    rng = np.random.default_rng(12)                                            # a batch: three clips, one shorter
+    clips = np.clip(rng.normal(0, 3000, (3, 16000)), -32768, 32767).astype(np.int16)
+    clips[1, 7000:] = 0
+    batch = gpu.Asr(hp=gpu.WHISPER_TINY_EN(), seed=6, max_batch=4)
+    t0 = batch.transcribe_tokens(clips, 8, want_aux=False)[0]
+    batch.set_fast_contraction(True)
+    assert np.array_equal(batch.transcribe_tokens(clips, 8, want_aux=False)[0], t0)
+    batch.close()
+    asr.set_fast_contraction(False)
+    t2, m2, e2, l2 = asr.transcribe_tokens(pcm, 8)
+    assert np.array_equal(m2, me) and np.array_equal(e2, ee) and np.array_equal(l2, le) and np.array_equal(t2, te)
+    asr.close()

@@ -582,11 +582,14 @@ def test_decode_with_kv_cache_matches_hf_fixture(gpu):
     assert np.abs(got - hf).max() < 0.05 * np.abs(hf).max()
 
 
-def test_runners_on_one_model_share_decode_passes(gpu):
+@pytest.mark.parametrize("order", ["arrival", "sampled_rows_first"])
+def test_runners_on_one_model_share_decode_passes(gpu, monkeypatch, order):
     """continuous batching behind the reference ABI (csrc/llm/tk_llm_batcher.h): K tk_llm_runner_t handles driven from K host threads
     through tk_llm_runner_* only.  Every runner gets exactly the tokens it gets when it runs alone (and the oracle's), while the
-    scheduler's counters show that their rows shared passes."""
+    scheduler's counters show that their rows shared passes.  Both pass orders of the scheduler (arrival order, the default; sampled rows
+    before prompt rows, TK_MI355X_BATCHER_DECODE_FIRST=1, read when the model's scheduler starts) give the same tokens."""
     import threading
+    monkeypatch.setenv("TK_MI355X_BATCHER_DECODE_FIRST", "1" if order == "sampled_rows_first" else "0")
     K, NTOK = 8, 12
     loader = gpu.ModelLoader()
     h = loader.load("synthetic://tiny?seed=4")

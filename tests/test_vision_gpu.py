@@ -339,3 +339,48 @@ def test_detector_runs_a_yolov5u_class_onnx_through_the_graph_executor(gpu, tmp_
     with pytest.raises(gpu.TkError):
         other.detect(frame)
     other.close()
+
+
+def test_detector_fast_contraction_gate(gpu):
+    """the opt-in fast contraction (tk_mi355x_detector_set_fast_contraction: convolutions on the f16 matrix pipe with split operands) against the
+    exact path and the independent torch fixtures — VERDICT r05 item 8's gate: (a) head maps at 640 x 640 within 1e-5 of their scale of the
+    exact path and inside the torch fixture's 2e-4; (b) on yolo_tiny_dets.npz anchor indices and classes identical to the torch post-processor's,
+    boxes within 1e-3 px; (c) on a full-size frame the same (anchor, class) set as the exact path, boxes within 1e-3 px, order equal wherever
+    two scores differ by more than 1e-6; (d) switched off again the handle returns the exact path's bits."""
+    g = np.load(os.path.join(GOLD, "yolo_full_640.npz"))
+    det = gpu.ObjectDetector(width=640, height=640, conf=0.05)
+    x = np.random.default_rng(11).standard_normal((1, 640, 640, 3)).astype(np.float32)
+    exact = det.forward_raw(x)
+    det.set_fast_contraction(True)
+    fast = det.forward_raw(x)
+    scale = float(np.abs(exact).max())
+    assert not np.array_equal(fast, exact)                                    # the other kernels did run
+    assert np.abs(fast - exact).max() < 1e-5 * scale, np.abs(fast - exact).max() / scale
+    assert np.abs(fast[0][g["idx"][:, 0], g["idx"][:, 1]] - g["torch_vals"]).max() < 2e-4 * max(1.0, float(g["scale"]))
+    det.set_fast_contraction(False)
+    assert np.array_equal(det.forward_raw(x), exact)
+    det.close()
+    # (c) the bench's detector (dense detections: ~100 per frame at confidence 0.5)
+    dense = gpu.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", width=640, height=640, conf=0.5, iou=0.5)
+    frame = np.random.default_rng(1).integers(0, 256, (640, 640, 3), dtype=np.uint8)   # the bench's kind of frame, through the whole path
+    dense.detect(frame)
+    eb, ec, ea = dense.last_boxes(0)
+    dense.set_fast_contraction(True)
+    dense.detect(frame)
+    fb, fc, fa = dense.last_boxes(0)
+    assert len(ea) > 20 and sorted(zip(ea.tolist(), ec.tolist())) == sorted(zip(fa.tolist(), fc.tolist()))
+    by_anchor = {(int(a), int(c)): i for i, (a, c) in enumerate(zip(fa, fc))}
+    for i, (a, c) in enumerate(zip(ea, ec)):
+        j = by_anchor[(int(a), int(c))]
+        assert np.abs(eb[i, :4] - fb[j, :4]).max() < 1e-3 and abs(float(eb[i, 4]) - float(fb[j, 4])) < 1e-6
+        if i != j:                                                            # a swap only between detections the exact path scores within 1e-6
+            assert abs(float(eb[i, 4]) - float(eb[j, 4])) < 1e-6
+    dense.close()
+    t = np.load(os.path.join(GOLD, "yolo_tiny_dets.npz"))
+    tiny = gpu.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-1", width=160, height=160, conf=float(t["conf"]), iou=float(t["iou"]))
+    tiny.set_fast_contraction(True)
+    tiny.forward_raw(t["x"])
+    boxes, cls, anc = tiny.last_boxes()
+    assert np.array_equal(anc, t["torch_anchors"]) and np.array_equal(cls, t["torch_cls"])
+    assert np.abs(boxes - t["torch_boxes"]).max() < 1e-3
+    tiny.close()

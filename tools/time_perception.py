@@ -11,7 +11,11 @@ import trackiellm_amd as tk  # noqa: E402
 
 PB = 32
 det = tk.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", width=640, height=640, conf=0.5, iou=0.5, device=0, max_batch=PB)
+if os.environ.get("TK_PERC_FAST") == "1":  # the opt-in split-f16 contraction (tools/time_fast_perception.py compares it with the exact path)
+    det.set_fast_contraction(True)
 asr = tk.Asr(hp=tk.WHISPER_TINY_EN(), seed=6, device=0, max_batch=PB)
+if os.environ.get("TK_PERC_FAST") == "1":
+    asr.set_fast_contraction(True)
 vad = tk.Vad()
 rng = np.random.default_rng(1)
 frames = [rng.integers(0, 256, (640, 640, 3), dtype=np.uint8) for _ in range(PB)]

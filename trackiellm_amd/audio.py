@@ -88,6 +88,10 @@ class Asr:
         """process_audio decodes under the reference's whisper.cpp parameters (logit filters, timestamps) — the default; False = the forced-greedy decode"""
         check(lib().tk_mi355x_asr_set_reference_decode(self.h, int(enable)))
 
+    def set_fast_contraction(self, on=True):
+        """opt-in: the long passes (log-mel, encoder) on the f16 matrix pipe with split operands (~1e-6 of scale off the exact chains)"""
+        check(lib().tk_mi355x_asr_set_fast_contraction(self.h, 1 if on else 0))
+
     def transcribe_ref(self, pcm, n_steps, temperature=0.0, seed=0):
         """one utterance through the reference-parameter decode -> (tokens [n_steps], logprobs [n_steps], result_len, status)"""
         pcm = np.ascontiguousarray(pcm, np.int16).reshape(-1)

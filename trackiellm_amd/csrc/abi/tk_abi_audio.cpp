@@ -59,6 +59,7 @@ struct AsrReq {
     std::vector<int32_t> prompt;
     bool policy = false;         /* a temperature / log-probability decode (one utterance per job: its draws are keyed by the batch row) */
     bool ref = false;            /* the decode under the reference's whisper.cpp parameters (logit filters, timestamps): TkAsr::transcribe_ref */
+    bool fast = false;           /* tk_mi355x_asr_set_fast_contraction: requests of one kind share a job */
     float temperature = 0.0f;
     uint64_t seed = 0;
     int32_t* tokens = nullptr;   /* [n_steps] */
@@ -122,7 +123,7 @@ struct SharedAsr {
             else
                 for (auto it = q.begin(); it != q.end() && (int)job.size() < TK_ASR_SHARED_MAX_BATCH;) {
                     AsrReq* r = *it;
-                    if (!r->policy && r->ref == first->ref && r->n_steps == first->n_steps && r->prompt == first->prompt) { job.push_back(r); it = q.erase(it); }
+                    if (!r->policy && r->ref == first->ref && r->fast == first->fast && r->n_steps == first->n_steps && r->prompt == first->prompt) { job.push_back(r); it = q.erase(it); }
                     else ++it;
                 }
             int cap = 1;
@@ -132,6 +133,7 @@ struct SharedAsr {
             std::unique_lock<std::mutex> el(eng_mu);
             bool ok = ensure_engine(cap, &err); /* a no-op after grow_for_handles(): the engine already takes this many */
             if (ok) {
+                eng->fast = first->fast;
                 const int B = (int)job.size();
                 int n_max = 0;
                 for (AsrReq* r : job) n_max = r->n_samples > n_max ? r->n_samples : n_max;
@@ -203,6 +205,7 @@ struct tk_asr_whisper_context_s {
     /* whisper.cpp's decoding policy as the reference's wrapper arms it (src/audio/tk_asr_whisper.c:126-138); off unless
      * tk_mi355x_asr_set_decode_policy switched it on (the default path is the plain greedy decode the parity tests pin) */
     bool forced_greedy = false; /* tk_mi355x_asr_set_reference_decode(ctx, 0): the round-1..5 decode — <|notimestamps|> prompt, bare arg max, decode_steps tokens */
+    bool fast = false; /* tk_mi355x_asr_set_fast_contraction */
     bool policy_on = false;
     float temperature_inc = 0.2f, entropy_thold = 2.4f, logprob_thold = -1.0f;
     uint64_t policy_seed = 0;
@@ -369,7 +372,7 @@ static tk_error_code_t asr_run_ref(tk_asr_whisper_context_s* c, const int16_t* p
     if (prompt.empty() || (int)prompt.size() + n_steps > h.n_text_ctx) return afail(TK_ERROR_INFERENCE_FAILED, "prompt + steps exceed the text context");
     if (sh->scheduled) {
         AsrReq r;
-        r.pcm = pcm; r.n_samples = n_samples; r.n_steps = n_steps; r.prompt = prompt; r.ref = true; r.policy = temperature > 0.0f; r.temperature = temperature; r.seed = seed;
+        r.pcm = pcm; r.n_samples = n_samples; r.n_steps = n_steps; r.prompt = prompt; r.ref = true; r.fast = c->fast; r.policy = temperature > 0.0f; r.temperature = temperature; r.seed = seed;
         r.tokens = tokens_out; r.logprobs = logprobs_out;
         sh->submit(&r);
         if (!r.ok) return afail(TK_ERROR_INFERENCE_FAILED, r.err);
@@ -380,6 +383,7 @@ static tk_error_code_t asr_run_ref(tk_asr_whisper_context_s* c, const int16_t* p
     std::lock_guard<std::mutex> lk(sh->eng_mu);
     const int32_t len = n_samples;
     int32_t rl = 0, stt = 0;
+    sh->eng->fast = c->fast;
     if (!sh->eng->transcribe_ref(1, pcm, n_samples, &len, prompt.data(), (int)prompt.size(), n_steps, temperature, seed, sh->suppress.data(), sh->token_beg, sh->token_eot,
                                  tokens_out, logprobs_out, &rl, &stt))
         return afail(TK_ERROR_INFERENCE_FAILED, sh->eng->error);
@@ -395,7 +399,7 @@ static tk_error_code_t asr_run(tk_asr_whisper_context_s* c, int batch, const int
     SharedAsr* sh = c->sh.get();
     if (sh->scheduled && batch == 1 && !mel && !enc && !lg) {
         AsrReq r;
-        r.pcm = pcm; r.n_samples = n_samples; r.n_steps = n_steps; r.prompt = prompt; r.policy = policy; r.temperature = temperature; r.seed = seed;
+        r.pcm = pcm; r.n_samples = n_samples; r.n_steps = n_steps; r.prompt = prompt; r.fast = c->fast; r.policy = policy; r.temperature = temperature; r.seed = seed;
         r.tokens = tokens_out; r.logprobs = logprobs_out;
         const TkWhisperHP& h = sh->model.hp;
         if (n_samples < 0 || n_samples > h.n_samples()) return afail(TK_ERROR_INFERENCE_FAILED, "audio longer than the model window");
@@ -407,6 +411,7 @@ static tk_error_code_t asr_run(tk_asr_whisper_context_s* c, int batch, const int
     std::lock_guard<std::mutex> lk(sh->eng_mu);
     std::string err;
     if (!sh->ensure_engine(batch, &err)) return afail(TK_ERROR_GPU_MEMORY, err);
+    sh->eng->fast = c->fast;
     const bool ok = policy ? sh->eng->transcribe_policy(batch, pcm, n_samples, prompt.data(), (int)prompt.size(), n_steps, temperature, seed, tokens_out, logprobs_out)
                            : sh->eng->transcribe(batch, pcm, n_samples, prompt.data(), (int)prompt.size(), n_steps, tokens_out, mel, enc, lg);
     return ok ? TK_SUCCESS : afail(TK_ERROR_INFERENCE_FAILED, sh->eng->error);
@@ -477,6 +482,12 @@ void tk_mi355x_asr_share_stats(const tk_asr_whisper_context_t* c, uint64_t* hand
     if (batches) *batches = c->sh->n_batches;
     if (utterances) *utterances = c->sh->n_utts;
     if (widest) *widest = c->sh->widest;
+}
+
+tk_error_code_t tk_mi355x_asr_set_fast_contraction(tk_asr_whisper_context_t* c, int on) {
+    if (!c) return TK_ERROR_INVALID_ARGUMENT;
+    c->fast = on != 0;
+    return TK_SUCCESS;
 }
 
 tk_error_code_t tk_mi355x_asr_set_reference_decode(tk_asr_whisper_context_t* c, int enable) {

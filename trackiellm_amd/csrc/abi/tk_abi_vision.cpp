@@ -46,6 +46,7 @@ struct DetReq {
     const uint8_t* frame = nullptr;
     uint32_t w = 0, h = 0, stride = 0, bpp = 3;
     float conf = 0.5f, iou = 0.5f;
+    bool fast = false;           /* tk_mi355x_detector_set_fast_contraction: requests of one kind share a job */
     bool want_attr = false;      /* classify the first `max_objects` boxes (0 = all) while the frame is resident */
     uint32_t max_objects = 0;
     std::vector<TkDetection> dets;
@@ -109,7 +110,7 @@ struct SharedDetector {
             DetReq* first = q.front();
             for (auto it = q.begin(); it != q.end() && (int)job.size() < TK_DET_SHARED_MAX_BATCH;) {
                 DetReq* r = *it;
-                if (r->w == first->w && r->h == first->h && r->stride == first->stride && r->bpp == first->bpp && r->conf == first->conf && r->iou == first->iou) {
+                if (r->w == first->w && r->h == first->h && r->stride == first->stride && r->bpp == first->bpp && r->conf == first->conf && r->iou == first->iou && r->fast == first->fast) {
                     job.push_back(r);
                     it = q.erase(it);
                 } else ++it;
@@ -126,6 +127,7 @@ struct SharedDetector {
                 for (size_t i = 0; i < job.size(); ++i) ptrs[i] = job[i]->frame;
                 eng->conf = first->conf;
                 eng->iou = first->iou;
+                eng->fast = first->fast;
                 ok = eng->detect((int)job.size(), ptrs.data(), first->w, first->h, first->stride, first->bpp, &out);
                 if (!ok) err = eng->error;
             }
@@ -176,6 +178,7 @@ struct tk_object_detector_s {
     size_t class_count = 0;
     int in_w = 640, in_h = 640;
     float conf = 0.5f, iou = 0.5f;
+    bool fast = false; /* tk_mi355x_detector_set_fast_contraction */
     std::vector<std::vector<TkDetection>> last;
     ~tk_object_detector_s() {
         own.reset(); /* before the weights it reads */
@@ -335,7 +338,7 @@ tk_error_code_t tk_mi355x_detector_detect_batch(tk_object_detector_t* d, int n, 
     if (n == 1 && !d->own) {
         /* the reference's one-frame call: through the shared engine, coalesced with the other handles' frames */
         DetReq r;
-        r.frame = frames[0].data; r.w = frames[0].width; r.h = frames[0].height; r.stride = pitch(frames[0]); r.bpp = bpp; r.conf = d->conf; r.iou = d->iou;
+        r.frame = frames[0].data; r.w = frames[0].width; r.h = frames[0].height; r.stride = pitch(frames[0]); r.bpp = bpp; r.conf = d->conf; r.iou = d->iou; r.fast = d->fast;
         if (r.w < 2 || r.h < 2 || r.stride < r.w * bpp) return vfail(TK_ERROR_INFERENCE_FAILED, "frame geometry invalid (need w,h >= 2 and stride >= w*bpp)");
         d->sh->submit(&r);
         if (!r.ok) return vfail(TK_ERROR_INFERENCE_FAILED, r.err);
@@ -347,6 +350,7 @@ tk_error_code_t tk_mi355x_detector_detect_batch(tk_object_detector_t* d, int n, 
         if (!e) return vfail(TK_ERROR_GPU_MEMORY, err);
         e->conf = d->conf;
         e->iou = d->iou;
+        e->fast = d->fast;
         if (!e->detect(n, ptrs.data(), frames[0].width, frames[0].height, pitch(frames[0]), bpp, &d->last)) return vfail(TK_ERROR_INFERENCE_FAILED, e->error);
     }
     for (int i = 0; i < n; ++i) {
@@ -374,6 +378,12 @@ void tk_object_detector_update_thresholds(tk_object_detector_t* detector, float 
     detector->iou = iou_threshold;
 }
 
+tk_error_code_t tk_mi355x_detector_set_fast_contraction(tk_object_detector_t* detector, int on) {
+    if (!detector) return TK_ERROR_INVALID_ARGUMENT;
+    detector->fast = on != 0;
+    return TK_SUCCESS;
+}
+
 tk_error_code_t tk_mi355x_detector_forward_raw(tk_object_detector_t* d, int batch, const float* nhwc, float* raw_out, size_t raw_floats) {
     if (!d || !nhwc || !raw_out) return TK_ERROR_INVALID_ARGUMENT;
     std::vector<float> raw;
@@ -382,6 +392,7 @@ tk_error_code_t tk_mi355x_detector_forward_raw(tk_object_detector_t* d, int batc
     if (!e) return vfail(TK_ERROR_GPU_MEMORY, err);
     e->conf = d->conf;
     e->iou = d->iou;
+    e->fast = d->fast;
     if (!e->forward_tensor(batch, nhwc, &raw)) return vfail(TK_ERROR_INFERENCE_FAILED, e->error);
     if (raw.size() > raw_floats) return vfail(TK_ERROR_BUFFER_TOO_SMALL, "raw_out too small");
     memcpy(raw_out, raw.data(), raw.size() * 4);
@@ -397,6 +408,7 @@ tk_error_code_t tk_mi355x_detector_forward_graph(tk_object_detector_t* d, int ba
     if (!e) return vfail(TK_ERROR_GPU_MEMORY, err);
     e->conf = d->conf;
     e->iou = d->iou;
+    e->fast = d->fast;
     if (!e->forward_graph(batch, nchw, &o)) return vfail(TK_ERROR_INFERENCE_FAILED, e->error);
     if (o.size() > out_floats) return vfail(TK_ERROR_BUFFER_TOO_SMALL, "out too small");
     memcpy(out, o.data(), o.size() * 4);
@@ -610,7 +622,7 @@ tk_error_code_t tk_vision_pipeline_process_frame(tk_vision_pipeline_t* pipeline,
             DetReq r;
             const uint32_t bpp = (uint32_t)bytes_per_pixel(video_frame);
             r.frame = video_frame->data; r.w = video_frame->width; r.h = video_frame->height; r.stride = video_frame->stride ? video_frame->stride : video_frame->width * bpp;
-            r.bpp = bpp; r.conf = d->conf; r.iou = d->iou; r.want_attr = bpp == 3 && r.stride == r.w * 3; r.max_objects = pipeline->max_objects;
+            r.bpp = bpp; r.conf = d->conf; r.iou = d->iou; r.fast = d->fast; r.want_attr = bpp == 3 && r.stride == r.w * 3; r.max_objects = pipeline->max_objects;
             ok = r.w >= 2 && r.h >= 2 && r.stride >= r.w * bpp;
             if (ok) {
                 d->sh->submit(&r);

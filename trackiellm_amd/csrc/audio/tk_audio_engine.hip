@@ -243,6 +243,13 @@ struct TkAudioGpuOps {
     /* a linear layer whose weights have tiles runs on the tiled GEMM (same k-ascending fp32 chain, bit-identical, ~3x the rate of the
      * LDS-staged kernel on these shapes and one short launch instead of a latency chain for the decoder's few rows) */
     void gemm(const TkGemm& g) {
+        if (a->fast && g.M >= 256) { /* opt-in fast contraction of the long passes (TkAsr::fast): row-major operands, split-f16 MFMA where the shape allows */
+            drop_image();
+            TkGemm f = g;
+            f.fast = 1;
+            tk_launch_gemm(f, s);
+            return;
+        }
         const int idx = tk_tiled_gemm_applies(g) ? a->model->tensor_of(g.B) : -1;
         if (idx < 0 || !a->model->wt[(size_t)idx]) { drop_image(); tk_launch_gemm(g, s); return; }
         if (!(pk.live && pk.A == g.A && pk.M == g.M && pk.K == g.K && pk.lda == g.lda)) {
@@ -299,7 +306,7 @@ struct TkAudioGpuOps {
     void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) { drop_image(); tk_launch_im2col1d(x, B, T, C, ldx, kw, stride, pad, col, s); }
     void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) {
         drop_image();
-        float* img = D % 128 == 0 ? image_for(y, rows, D, D) : nullptr; /* a norm feeds linear layers: packed on the way out */
+        float* img = D % 128 == 0 && !(a->fast && rows >= 256) ? image_for(y, rows, D, D) : nullptr; /* a norm feeds linear layers: packed on the way out */
         tk_launch_layernorm(x, rows, D, w, b, TK_WH_LN_EPS, y, s, img);
     }
     void softmax_rows(float* x, int rows, int cols, int ld) { drop_image(); tk_launch_softmax_rows(x, rows, cols, ld, s); }

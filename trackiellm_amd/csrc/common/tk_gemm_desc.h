@@ -30,6 +30,10 @@ struct TkGemm {
      * im_Ho x im_Wo outputs and column k = (ky im_kw + kx) im_C + c address it directly (zero outside the image), K = kh kw im_C.
      * Same values in the same order as the explicit column matrix; lda, batch and b_kn are unused */
     int im_C, im_H, im_W, im_ldx, im_kw, im_stride, im_pad, im_Ho, im_Wo;
+    /* opt-in (0 = the exact chain above, always what the oracle evaluates): the HIP backend may contract on the f16 matrix pipe with every
+     * operand split into two f16 halves (x = hi + lo / 2048 to ~22 bits; hi.hi + (hi.lo + lo.hi) / 2048 with fp32 accumulation): NOT the
+     * chain's bits — within ~1e-6 of its scale — for callers that asked for speed under a tolerance (csrc/nn/tk_nn_kernels.hip: k_gemm_h3_*) */
+    int fast;
 };
 
 

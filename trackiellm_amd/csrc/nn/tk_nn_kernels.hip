@@ -130,6 +130,16 @@ __device__ __forceinline__ void load_b4_kn(const TkGemm& g, const float* B, bool
 
 /* epilogue of one 32x32 accumulator tile: v = act(alpha acc + bias[n]) + residual, rows m_base + (r % 4) + 8 (r / 4) + 4 (lane / 32),
  * column n.  The activation is chosen once per tile, not per element. */
+/* activations of the opt-in fast contraction: the hardware's exp2 / reciprocal (~1 ulp each) instead of the exact-math sequences, whose
+ * ~70 instructions per element outweigh a split-f16 launch's matrix work on short K */
+__device__ __forceinline__ float fast_sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+__device__ __forceinline__ float fast_geluf(float x) {
+    const float inner = 0.797884560802865356f * (x + 0.044715f * ((x * x) * x));
+    const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(inner * 2.8853900817779268f) + 1.0f);
+    return (0.5f * x) * (1.0f + th);
+}
+
+template <bool FASTACT = false>
 __device__ __forceinline__ void store_tile(const TkGemm& g, const v16f& acc, float* C, const float* R, int m_base, int n, int lane) {
     if (n >= g.N) return;
     const float bias = g.bias ? g.bias[n] : 0.0f;
@@ -145,13 +155,13 @@ __device__ __forceinline__ void store_tile(const TkGemm& g, const v16f& acc, flo
     for (int r = 0; r < 16; ++r) v[r] = v[r] + bias;
     if (g.act == TK_ACT_SILU) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = tk_siluf(v[r]);
+        for (int r = 0; r < 16; ++r) v[r] = FASTACT ? v[r] * fast_sigmoidf(v[r]) : tk_siluf(v[r]);
     } else if (g.act == TK_ACT_GELU) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = tk_geluf(v[r]);
+        for (int r = 0; r < 16; ++r) v[r] = FASTACT ? fast_geluf(v[r]) : tk_geluf(v[r]);
     } else if (g.act == TK_ACT_SIGMOID) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = tk_sigmoidf(v[r]);
+        for (int r = 0; r < 16; ++r) v[r] = FASTACT ? fast_sigmoidf(v[r]) : tk_sigmoidf(v[r]);
     }
     const int mb = m_base + 4 * (lane >> 5);
     float* cp = C + (int64_t)mb * g.ldc + n;
@@ -436,6 +446,198 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(TkGemm g) {
         for (int i = 0; i < 2; ++i) store_tile(g, acc[i][j], C, R, m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32 + (lane & 31), lane);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Opt-in fast contraction (TkGemm::fast): the same tiles, loaders and epilogue on the f16 matrix pipe.
+ * v_mfma_f32_32x32x16_f16 retires 16 k per 8 passes where v_mfma_f32_32x32x2_f32 retires 2 per 16: 16 x the rate, with operands of 11
+ * significant bits.  To stay near fp32 every operand is split on its way into LDS: hi = f16(x), lo = f16((x - hi) * 2048) (the scale keeps
+ * lo a normal f16 number), so x = hi + lo / 2048 to ~22 bits, and a product is hi.hi + (hi.lo + lo.hi) / 2048 (lo.lo, 2^-22 of it, is
+ * dropped): three MFMAs per 16 k into two fp32 accumulators, joined once in the epilogue.  Products of f16 values are exact in fp32; what
+ * differs from the exact chain is the ~2^-22 truncation and the order in which the pipe adds 16 products — results agree with the chain to
+ * ~1e-6 of their scale, NOT bit for bit, which is why this is never the default and never what a parity test of the exact path runs.
+ * Values beyond the f16 range (|x| > 65504) are not representable in hi: the networks of this path stay far below it.
+ * LDS rows hold 32 k as halves + 8 of padding (80 B): 16-byte aligned, and the 16 lanes of a ds_read_b128 phase hit 64 distinct banks.
+ * ------------------------------------------------------------------------------------------ */
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+#define HLD 40
+#define H3_SCALE 2048.0f
+__device__ __forceinline__ void h3_split4(const float x[4], _Float16* hi, _Float16* lo) {
+    v4h h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 t = (_Float16)x[i];
+        h[i] = t;
+        l[i] = (_Float16)((x[i] - (float)t) * H3_SCALE);
+    }
+    *(v4h*)hi = h;
+    *(v4h*)lo = l;
+}
+__device__ __forceinline__ v16f h3_join(const v16f& hh, const v16f& hx) {
+    v16f o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = hh[r] + hx[r] * (1.0f / H3_SCALE);
+    return o;
+}
+#define H3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+
+/* k_gemm_f32_tall's tiling (128 rows x all columns, N < 96) */
+template <bool IM, int NT>
+__global__ __launch_bounds__(256) void k_gemm_h3_tall(TkGemm g) {
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[NBM * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[NBM * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bh[NT * 32 * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bl[NT * 32 * HLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * NBM;
+    const float* A = g.A;
+    const float* B = g.B;
+    v16f acc[NT], acx[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; acx[t][i] = 0.0f; }
+    float ra[4][4], rb[NT][4];
+    ImRow ir[4]; ImCol ic;
+    if (IM) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ir[h] = im_row(g, m0 + ((tid + 256 * h) >> 3));
+        ic = im_col(g, (tid & 7) * 4);
+    }
+    auto gload = [&](int k0) {
+        const int k = k0 + (tid & 7) * 4;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
+            else load_a4<1>(g, A, true, m0 + ((tid + 256 * h) >> 3), k, ra[h]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) load_b4_nk<1>(g, B, true, (tid >> 3) + 32 * t, k, rb[t]);
+        if (IM) im_advance(g, ic, BK);
+    };
+    auto lstore = [&]() {
+        const int kc = (tid & 7) * 4;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int o = ((tid + 256 * h) >> 3) * HLD + kc;
+            h3_split4(ra[h], Ah + o, Al + o);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = ((tid >> 3) + 32 * t) * HLD + kc;
+            h3_split4(rb[t], Bh + o, Bl + o);
+        }
+    };
+    gload(0);
+    const int ao = (wave * 32 + (lane & 31)) * HLD + (lane >> 5) * 8, bo = (lane & 31) * HLD + (lane >> 5) * 8;
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < g.K) gload(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 16) {
+            const v8h ah = *(const v8h*)(Ah + ao + ks), al = *(const v8h*)(Al + ao + ks);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const v8h bh = *(const v8h*)(Bh + bo + t * 32 * HLD + ks), bl = *(const v8h*)(Bl + bo + t * 32 * HLD + ks);
+                acc[t] = H3_MFMA(ah, bh, acc[t]);
+                acx[t] = H3_MFMA(ah, bl, acx[t]);
+                acx[t] = H3_MFMA(al, bh, acx[t]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) store_tile<true>(g, h3_join(acc[t], acx[t]), g.C, g.residual, m0 + wave * 32, 32 * t + (lane & 31), lane);
+}
+
+/* k_gemm_f32_big's tiling (128 x 128 per workgroup, 2 x 2 MFMA tiles per wave, double-buffered slabs) */
+template <bool IM>
+__global__ __launch_bounds__(256, 2) void k_gemm_h3_big(TkGemm g) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 hsm[]; /* [2 buffers][Ah, Al, Bh, Bl][128 rows][HLD] */
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    int64_t oA, oB, oC, oR;
+    batch_offsets(g, blockIdx.z, oA, oB, oC, oR);
+    const float* A = g.A + oA;
+    const float* B = g.B + oB;
+    float* C = g.C + oC;
+    v16f acc[2][2], acx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acx[i][j][r] = 0.0f; }
+    float ra[4][4], rb[4][4];
+    ImRow ir[4]; ImCol ic;
+    if (IM) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ir[h] = im_row(g, m0 + ((tid + 256 * h) >> 3));
+        ic = im_col(g, (tid & 7) * 4);
+    }
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int e = tid + 256 * h, row = e >> 3, k = k0 + (e & 7) * 4;
+            if (IM) im_load4(g, A, ir[h], ic, k, ra[h]);
+            else load_a4<1>(g, A, true, m0 + row, k, ra[h]);
+            load_b4_nk<1>(g, B, true, n0 + row, k, rb[h]);
+        }
+        if (IM) im_advance(g, ic, BK);
+    };
+    constexpr int PLANE = LBM * HLD; /* LBM == LBN */
+    auto lstore = [&](int buf) {
+        _Float16* base = hsm + buf * 4 * PLANE;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int e = tid + 256 * h, o = (e >> 3) * HLD + (e & 7) * 4;
+            h3_split4(ra[h], base + o, base + PLANE + o);
+            h3_split4(rb[h], base + 2 * PLANE + o, base + 3 * PLANE + o);
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    const int ao = (wm * 64 + (lane & 31)) * HLD + (lane >> 5) * 8, bo = (wn * 64 + (lane & 31)) * HLD + (lane >> 5) * 8;
+    /* (a second slab in flight — requested two iterations before it is split into LDS — measured no faster: 18.7 against 17.8 ms per 32
+     * clips; the loop is not waiting on its loads.  profiles/r06_fast_perception.txt) */
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        const bool more = k0 + BK < g.K;
+        if (more) gload(k0 + BK);
+        const _Float16* base = hsm + buf * 4 * PLANE;
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 16) {
+            v8h ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *(const v8h*)(base + ao + i * 32 * HLD + ks);
+                al[i] = *(const v8h*)(base + PLANE + ao + i * 32 * HLD + ks);
+                bh[i] = *(const v8h*)(base + 2 * PLANE + bo + i * 32 * HLD + ks);
+                bl[i] = *(const v8h*)(base + 3 * PLANE + bo + i * 32 * HLD + ks);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = H3_MFMA(ah[i], bh[j], acc[i][j]);
+                    acx[i][j] = H3_MFMA(ah[i], bl[j], acx[i][j]);
+                    acx[i][j] = H3_MFMA(al[i], bh[j], acx[i][j]);
+                }
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const float* R = g.residual ? g.residual + oR : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) store_tile<true>(g, h3_join(acc[i][j], acx[i][j]), C, R, m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32 + (lane & 31), lane);
+}
+#define H3_BIG_LDS ((size_t)2 * 4 * LBM * HLD * sizeof(_Float16))
+
 /* > 64 KiB of dynamic LDS is an opt-in HIP keeps per (function, device): one flag per device, set once under a lock (several host
  * threads drive the detector / ASR / VAD streams, possibly on different GPUs).  Callers that capture launches into a hipGraph (the LLM's
  * f16-weight passes) call tk_nn_prepare_device() first so that no attribute is ever set inside a capture. */
@@ -451,6 +653,9 @@ bool tk_nn_prepare_device() {
                           (const void*)k_gemm_f32_big<true, 1>};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    const void* h3[2] = {(const void*)k_gemm_h3_big<false>, (const void*)k_gemm_h3_big<true>};
+    for (const void* f : h3)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H3_BIG_LDS) != hipSuccess) return false;
     g_big_opted[dev].store(true, std::memory_order_release);
     return true;
 }
@@ -478,10 +683,18 @@ void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
         else if (path == 2) hipLaunchKernelGGL((KERNEL<false, 2>), GRID, dim3(256), LDS, s, g);               \
         else hipLaunchKernelGGL((KERNEL<false, 0>), GRID, dim3(256), LDS, s, g);                              \
     } while (0)
+    /* TkGemm::fast: the split-f16 kernels where the operands meet the one-load-per-group conditions ([N][K] f32 weights); every other
+     * shape keeps the exact chain */
+    const bool fast = g.fast != 0 && !g.b_kn && (im || path == 1);
     if (g.M >= 256 && g.N >= 96) {
         const size_t lds = (size_t)2 * (LBM + LBN) * LDS_LD * sizeof(float);
         (void)tk_nn_prepare_device();
         const dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
+        if (fast) {
+            if (im) hipLaunchKernelGGL((k_gemm_h3_big<true>), grid, dim3(256), H3_BIG_LDS, s, g);
+            else hipLaunchKernelGGL((k_gemm_h3_big<false>), grid, dim3(256), H3_BIG_LDS, s, g);
+            return;
+        }
         TK_GEMM_PATHS(k_gemm_f32_big, grid, lds);
         return;
     }
@@ -494,6 +707,13 @@ void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
         else if (path == 1) hipLaunchKernelGGL((k_gemm_f32_tall<false, 1, NTV>), grid, dim3(256), 0, s, g);   \
         else hipLaunchKernelGGL((k_gemm_f32_tall<false, 0, NTV>), grid, dim3(256), 0, s, g);                  \
     } while (0)
+#define TK_TALL_H3(NTV)                                                                                       \
+    do {                                                                                                      \
+        if (im) hipLaunchKernelGGL((k_gemm_h3_tall<true, NTV>), grid, dim3(256), 0, s, g);                    \
+        else hipLaunchKernelGGL((k_gemm_h3_tall<false, NTV>), grid, dim3(256), 0, s, g);                      \
+    } while (0)
+        if (fast) { if (nt == 1) TK_TALL_H3(1); else if (nt == 2) TK_TALL_H3(2); else TK_TALL_H3(3); return; }
+#undef TK_TALL_H3
         if (nt == 1) TK_TALL(1); else if (nt == 2) TK_TALL(2); else TK_TALL(3);
 #undef TK_TALL
         return;

@@ -61,6 +61,8 @@ public:
     TkYoloModel* model = nullptr;
     int in_w = 640, in_h = 640, max_batch = 1;
     float conf = 0.5f, iou = 0.5f;
+    /* opt-in: the convolutions contract on the f16 matrix pipe with split operands (TkGemm::fast) — ~1e-6 of scale off the exact chain */
+    bool fast = false;
     float mean[3] = {0.485f, 0.456f, 0.406f}, std_dev[3] = {0.229f, 0.224f, 0.225f};
     std::string error;
     hipStream_t stream = nullptr;

@@ -232,6 +232,7 @@ struct TkGpuOps {
         g.residual = res ? res->p : nullptr; g.ldr = res ? res->ld : 0;
         g.act = sp.act ? TK_ACT_SILU : TK_ACT_NONE;
         g.alpha = 1.0f; g.batch = 1;
+        g.fast = d->fast ? 1 : 0;
         tk_launch_gemm(g, s);
     }
     void maxpool5(const TkT& x, const TkT& y) { tk_launch_maxpool5(x.p, x.B, x.H, x.W, x.C, x.ld, y.p, y.ld, s); }

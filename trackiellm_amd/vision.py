@@ -101,6 +101,10 @@ class ObjectDetector:
         check(lib().tk_mi355x_detector_forward_raw(self.h, B, x.ctypes.data_as(C.c_void_p), raw.ctypes.data_as(C.c_void_p), C.c_size_t(raw.size)))
         return raw
 
+    def set_fast_contraction(self, on=True):
+        """opt-in: convolutions on the f16 matrix pipe with split operands (~1e-6 of scale off the exact chain, not its bits)"""
+        check(lib().tk_mi355x_detector_set_fast_contraction(self.h, 1 if on else 0))
+
     def is_graph(self):
         """True when the model file is not the YOLOv8n topology and runs its own graph on the ONNX executor"""
         return bool(lib().tk_mi355x_detector_is_graph(self.h))
