@@ -503,13 +503,15 @@ def swin_spec():
     return out
 
 
-def spec_model(spec, floats, ints, in_dims, out_dims, extra_op=None):
-    """any node-dict list as an ONNX file: float initialisers `floats`, int64 initialisers `ints` (name -> (values, dims or None))"""
+def spec_nodes(spec):
+    """node dicts -> NodeProto payloads; an attribute given as bytes is an already encoded sub-graph (the body of a Loop / Scan)"""
     nodes = []
     for nd in spec:
         attrs = []
         for k, v in nd["attrs"].items():
-            if isinstance(v, str):
+            if isinstance(v, bytes):
+                attrs.append(attr_graph(k, v))
+            elif isinstance(v, str):
                 attrs.append(attr_str(k, v))
             elif isinstance(v, float):
                 attrs.append(attr_float(k, v))
@@ -517,12 +519,102 @@ def spec_model(spec, floats, ints, in_dims, out_dims, extra_op=None):
                 attrs.append(attr_int(k, v))
             else:
                 attrs.append(attr_ints(k, v))
-        nodes.append(node(nd["op"], nd["in"], nd["out"], attrs, name=nd["out"][0] + "_node"))
+        nodes.append(node(nd["op"], nd["in"], nd["out"], attrs, name=next(o for o in nd["out"] if o) + "_node"))
+    return nodes
+
+
+def spec_model(spec, floats, ints, in_dims, out_dims, extra_op=None):
+    """any node-dict list as an ONNX file: float initialisers `floats`, int64 initialisers `ints` (name -> (values, dims or None))"""
+    nodes = spec_nodes(spec)
     if extra_op:
         nodes.append(node(extra_op, ["output"], ["unused"], name="extra"))
-    # the Where mask goes out as ONNX bool (what masked_fill exports), everything else as int64
-    inits = [tensor(k, v) for k, v in floats.items()] + [(bool_tensor if k == "mask" else int_tensor)(k, np.asarray(v[0]).reshape(-1), v[1]) for k, v in ints.items()]
+    # the Where mask and names that start with "bool_" go out as ONNX bool (what masked_fill / loop conditions export), everything else as int64
+    inits = [tensor(k, v) for k, v in floats.items()] + [(bool_tensor if k == "mask" or k.startswith("bool_") else int_tensor)(k, np.asarray(v[0]).reshape(-1), v[1]) for k, v in ints.items()]
     return model(nodes, inits, [value_info("input", 1, in_dims)], [value_info("output", 1, out_dims)])
+
+
+# ---- a small image graph with a Loop (a residual block applied T times, a per-iteration scan output) and a Scan (a first-order recurrence down the
+# rows), and its hand-unrolled twin: the control-flow ops against the same nodes written out (tests/test_depth_gpu.py) ----
+LOOPNET = {"H": 16, "C": 4, "T": 3}
+
+
+def loopnet_weights(seed):
+    rng = np.random.default_rng(seed)
+    f = lambda *sh: (rng.standard_normal(sh) * 0.3).astype(np.float32)  # noqa: E731
+    H, Cc = LOOPNET["H"], LOOPNET["C"]
+    return {"c0.w": f(Cc, 3, 3, 3), "c0.b": f(Cc), "cb.w": f(Cc, Cc, 3, 3), "cb.b": f(Cc), "c1.w": f(1, Cc, 3, 3), "c1.b": f(1),
+            "decay": np.array([0.5], np.float32), "acc0": np.zeros((1, Cc, H), np.float32)}
+
+
+def loopnet_ints():
+    H, Cc, T = LOOPNET["H"], LOOPNET["C"], LOOPNET["T"]
+    ints = {"shape_z": ([1, H, H], None), "shape_q": ([1, 1, H], None), "trip": ([T], []), "one": ([1], []), "limit": ([T], []), "bool_go": ([1], []),
+            "shape_s": ([1, 1, H, H], None), "shape_a": ([1, 1, Cc, H], None), "shape_x": ([1, Cc, H], None), "ax0": ([0], None)}
+    for t in range(H):
+        ints["st%d" % t] = ([t], None)
+        ints["en%d" % t] = ([t + 1], None)
+    return ints
+
+
+def _n(op, i, o, **a):
+    return {"op": op, "in": i, "out": o, "attrs": a}
+
+
+def _loop_body(y, sfx):
+    """the block one iteration applies to `y` -> (nodes, new y, scan value)"""
+    return [_n("Conv", [y, "cb.w", "cb.b"], ["t" + sfx], pads=[1, 1, 1, 1], kernel_shape=[3, 3]), _n("Relu", ["t" + sfx], ["r" + sfx]),
+            _n("Add", ["r" + sfx, y], ["y" + sfx]), _n("ReduceSum", ["y" + sfx], ["s" + sfx], axes=[1], keepdims=0)], "y" + sfx, "s" + sfx
+
+
+def _loopnet_tail(y_final, S, Y):
+    return [_n("Conv", [y_final, "c1.w", "c1.b"], ["z"], pads=[1, 1, 1, 1], kernel_shape=[3, 3]), _n("Reshape", ["z", "shape_z"], ["zr"]),
+            _n("ReduceSum", [S], ["m"], axes=[0], keepdims=0), _n("ReduceSum", [Y], ["q0"], axes=[0], keepdims=0),
+            _n("ReduceSum", ["q0"], ["q1"], axes=[1], keepdims=0), _n("Reshape", ["q1", "shape_q"], ["qr"]),
+            _n("Add", ["zr", "m"], ["zm"]), _n("Add", ["zm", "qr"], ["output"])]
+
+
+def loopnet_unrolled_spec():
+    H, T = LOOPNET["H"], LOOPNET["T"]
+    spec = [_n("Conv", ["input", "c0.w", "c0.b"], ["y_0"], pads=[1, 1, 1, 1], kernel_shape=[3, 3])]
+    y = "y_0"
+    for t in range(T):
+        nodes, y, s_ = _loop_body(y, "_%d" % (t + 1))
+        spec += nodes + [_n("Reshape", [s_, "shape_s"], ["S%d" % t])]
+    spec.append(_n("Concat", ["S%d" % t for t in range(T)], ["S"], axis=0))
+    spec.append(_n("Transpose", [y, ], ["X"], perm=[2, 0, 1, 3]))
+    acc = "acc0"
+    for t in range(H):
+        spec += [_n("Slice", ["X", "st%d" % t, "en%d" % t, "ax0"], ["xs%d" % t]), _n("Reshape", ["xs%d" % t, "shape_x"], ["x%d" % t]),
+                 _n("Mul", [acc, "decay"], ["a%d" % t]), _n("Add", ["a%d" % t, "x%d" % t], ["acc%d" % (t + 1)]),
+                 _n("Reshape", ["acc%d" % (t + 1), "shape_a"], ["Y%d" % t])]
+        acc = "acc%d" % (t + 1)
+    spec.append(_n("Concat", ["Y%d" % t for t in range(H)], ["Y"], axis=0))
+    return spec + _loopnet_tail(y, "S", "Y")
+
+
+def loopnet_spec(mode="count"):
+    """mode "count": trip count input, the body hands the condition through; "cond": no trip count, the body computes the condition from the
+    iteration number (integer Add + Less on the host)"""
+    H, Cc = LOOPNET["H"], LOOPNET["C"]
+    body_nodes, y_out, s_out = _loop_body("y_in", "_b")
+    if mode == "count":
+        body_nodes.append(_n("Identity", ["go_in"], ["go_out"]))
+    else:
+        body_nodes += [_n("Add", ["it", "one"], ["it1"]), _n("Less", ["it1", "limit"], ["go_out"])]
+    body = graph_proto(spec_nodes(body_nodes), [], [value_info("it", 7, []), value_info("go_in", 9, []), value_info("y_in", 1, [1, Cc, H, H])],
+                       [value_info("go_out", 9, []), value_info(y_out, 1, [1, Cc, H, H]), value_info(s_out, 1, [1, H, H])], name=b"loop_body")
+    scan_nodes = [_n("Mul", ["acc_in", "decay"], ["a_b"]), _n("Add", ["a_b", "x_in"], ["acc_out"]), _n("Identity", ["acc_out"], ["y_row"])]
+    scan_body = graph_proto(spec_nodes(scan_nodes), [], [value_info("acc_in", 1, [1, Cc, H]), value_info("x_in", 1, [1, Cc, H])],
+                            [value_info("acc_out", 1, [1, Cc, H]), value_info("y_row", 1, [1, Cc, H])], name=b"scan_body")
+    return [_n("Conv", ["input", "c0.w", "c0.b"], ["y_0"], pads=[1, 1, 1, 1], kernel_shape=[3, 3]),
+            _n("Loop", ["trip" if mode == "count" else "", "bool_go", "y_0"], ["y_fin", "S"], body=body),
+            _n("Transpose", ["y_fin"], ["X"], perm=[2, 0, 1, 3]),
+            _n("Scan", ["acc0", "X"], ["acc_fin", "Y"], body=scan_body, num_scan_inputs=1)] + _loopnet_tail("y_fin", "S", "Y")
+
+
+def loopnet_model(W, spec):
+    H = LOOPNET["H"]
+    return spec_model(spec, W, loopnet_ints(), [1, 3, H, H], [1, H, H])
 
 
 def swin_model(W, extra_op=None):

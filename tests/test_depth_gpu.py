@@ -185,3 +185,42 @@ def test_graph_executor_rejects_bad_attributes_at_load(gpu, tmp_path):
         p.write_bytes(data)
         with pytest.raises(gpu.TkError):
             gpu.DepthEstimator(str(p), 16, 16)
+
+
+def test_loop_and_scan_equal_the_unrolled_graph(gpu, tmp_path):
+    """ONNX control flow beyond If (VERDICT r05 "missing" 3): a graph with a Loop (a residual block applied three times with a per-iteration scan
+    output; trip count as an input, or none and a condition the body computes from the iteration number) and a Scan (a first-order recurrence
+    down the rows) gives, bit for bit, what the same nodes written out by hand give — and that unrolled graph agrees with the numpy graph oracle.
+    Refusals say what is not covered: a scan axis other than 0, a body whose inputs do not match the node."""
+    W = OX.loopnet_weights(3)
+    H = OX.LOOPNET["H"]
+    x = np.random.default_rng(4).standard_normal((3, H, H)).astype(np.float32)
+    consts = dict(W)
+    consts.update({k: np.asarray(v[0], np.int64).reshape(v[1] if v[1] is not None else -1) for k, v in OX.loopnet_ints().items()})
+    want = DO.run_graph(OX.loopnet_unrolled_spec(), consts, {"input": x[None]})["output"][0]
+    pu = tmp_path / "unrolled.onnx"
+    pu.write_bytes(OX.loopnet_model(W, OX.loopnet_unrolled_spec()))
+    eu = gpu.DepthEstimator(str(pu), H, H)
+    got_u = eu.forward_raw(x)
+    eu.close()
+    assert np.abs(got_u - want).max() <= TOL * float(np.abs(want).max())
+    for mode in ("count", "cond"):
+        p = tmp_path / ("loop_%s.onnx" % mode)
+        p.write_bytes(OX.loopnet_model(W, OX.loopnet_spec(mode)))
+        e = gpu.DepthEstimator(str(p), H, H)
+        got = e.forward_raw(x)
+        assert np.array_equal(got.view(np.uint32), got_u.view(np.uint32)), (mode, np.abs(got - got_u).max())
+        assert np.array_equal(e.forward_raw(x).view(np.uint32), got.view(np.uint32))     # a second run on the same handle
+        e.close()
+    bad = OX.loopnet_spec("count")
+    bad[3]["attrs"]["scan_input_axes"] = [1]
+    pb = tmp_path / "scan_axis.onnx"
+    pb.write_bytes(OX.loopnet_model(W, bad))
+    with pytest.raises(gpu.TkError):
+        gpu.DepthEstimator(str(pb), H, H)
+    bad = OX.loopnet_spec("count")
+    bad[1]["in"] = ["trip", "bool_go", "y_0", "y_0"]                                     # one carried value more than the body takes
+    pb = tmp_path / "loop_arity.onnx"
+    pb.write_bytes(OX.loopnet_model(W, bad))
+    with pytest.raises(gpu.TkError):
+        gpu.DepthEstimator(str(pb), H, H)

@@ -59,10 +59,13 @@ def test_vad_graph_probe_accepts_the_silero_class_and_names_unsupported_ops(tmp_
     n, ni, ns = C.c_int32(), C.c_int32(), C.c_int32()
     assert tk.lib().tk_mi355x_vad_onnx_probe(str(ok).encode(), C.byref(n), C.byref(ni), C.byref(ns)) == 0
     assert n.value == 24 and ni.value == len(W) + 5 and ns.value == 2          # h and c are recurrent inputs
-    bad = tmp_path / "vad_loop.onnx"
-    bad.write_bytes(X.vad_model(W, extra_op="Loop"))
+    bad = tmp_path / "vad_einsum.onnx"
+    bad.write_bytes(X.vad_model(W, extra_op="Einsum"))
     assert tk.lib().tk_mi355x_vad_onnx_probe(str(bad).encode(), None, None, None) == 4001   # TK_ERROR_MODEL_VERIFICATION_FAILED
-    assert b"'Loop'" in tk.lib().tk_error_get_detail()
+    assert b"'Einsum'" in tk.lib().tk_error_get_detail()
+    nobody = tmp_path / "vad_loop.onnx"
+    nobody.write_bytes(X.vad_model(W, extra_op="Loop"))                          # a Loop without its body graph
+    assert tk.lib().tk_mi355x_vad_onnx_probe(str(nobody).encode(), None, None, None) == 4001 and b"body" in tk.lib().tk_error_get_detail()
     # If with its two branch graphs (what per-sample-rate exports use) is read, its branches' ops are checked too
     sw = tmp_path / "vad_if.onnx"
     sw.write_bytes(X.vad_model(W, with_if=True))
@@ -75,3 +78,22 @@ def test_vad_graph_probe_accepts_the_silero_class_and_names_unsupported_ops(tmp_
     junk = tmp_path / "junk.onnx"
     junk.write_bytes(b"\x3a\xff\xff\xff\xff\x0f" + b"\0" * 16)                   # a graph field longer than the file
     assert tk.lib().tk_mi355x_vad_onnx_probe(str(junk).encode(), None, None, None) == 3004
+
+
+def test_loop_and_scan_graphs_pass_the_op_check_and_malformed_ones_do_not(tmp_path):
+    """Loop / Scan bodies are read as sub-graphs, their nodes checked like the outer ones, their arity against the node's (no GPU)"""
+    W = X.loopnet_weights(3)
+    n = C.c_int32()
+    for mode in ("count", "cond"):
+        p = tmp_path / ("loop_%s.onnx" % mode)
+        p.write_bytes(X.loopnet_model(W, X.loopnet_spec(mode)))
+        assert tk.lib().tk_mi355x_depth_onnx_probe(str(p).encode(), C.byref(n)) == 0, tk.lib().tk_error_get_detail()
+    bad = X.loopnet_spec("count")
+    bad[1]["in"] = ["trip", "bool_go", "y_0", "y_0"]
+    p = tmp_path / "arity.onnx"
+    p.write_bytes(X.loopnet_model(W, bad))
+    assert tk.lib().tk_mi355x_depth_onnx_probe(str(p).encode(), C.byref(n)) != 0 and b"body" in tk.lib().tk_error_get_detail()
+    bad = X.loopnet_spec("count")
+    bad[3]["attrs"].pop("num_scan_inputs")
+    p.write_bytes(X.loopnet_model(W, bad))
+    assert tk.lib().tk_mi355x_depth_onnx_probe(str(p).encode(), C.byref(n)) != 0

@@ -15,7 +15,10 @@
  *   Max / Min / Where, ConvTranspose, strided Slice, Shape and integer shape arithmetic, rank-6 Transpose / Reshape (tk_onnx_exec_seq.hip).
  *   control flow: If whose condition is host data (Equal / Less / Greater / Not / And / Or on integer or bool tensors — the per-sample-rate
  *   switch of Silero-class VAD exports): the chosen branch's nodes run in the same value map, its initialisers and Constant nodes are
- *   resident like the outer graph's.  Loop / Scan are refused.
+ *   resident like the outer graph's.  Loop (trip count and / or condition as host data: a constant, or integer arithmetic on the iteration
+ *   number inside the body; loop-carried values, scan outputs stacked along a new leading axis) and Scan (state values + scan inputs sliced
+ *   along axis 0, forward or reversed; scan outputs along axis 0) run their body graph in the same value map, one fresh set of arena tensors
+ *   per iteration — what exporters emit for recurrences written as Python loops.
  * Anything else fails at load time with the op's name.
  * Arithmetic: fp32; every contraction is one k-ascending fma chain per output element (input channel outer, kernel row, kernel column
  * inner; the bias enters last), the exact-math exp / tanh / sigmoid / sqrt of common/tk_exact_math.h.

@@ -373,7 +373,7 @@ static const char* kSupported[] = {"Conv", "Relu", "Sigmoid", "Tanh", "Sqrt", "A
                                    "BatchNormalization", "MatMul", "Gemm", "Softmax", "Dropout", "Split",
                                    /* tk_onnx_exec_seq.hip */
                                    "LayerNormalization", "Erf", "Gelu", "Gather", "ReduceSum", "ReduceL2", "ReduceMax", "ReduceMin", "Expand", "Max", "Min", "Where",
-                                   "ConvTranspose", "Shape", "If", "Equal", "Less", "Greater", "Not", "And", "Or"};
+                                   "ConvTranspose", "Shape", "If", "Loop", "Scan", "Equal", "Less", "Greater", "Not", "And", "Or"};
 
 bool TkOnnxExec::ops_supported(const TkOnnxGraph& g, std::string* err) {
     std::vector<const TkOnnxNode*> all;
@@ -387,6 +387,15 @@ bool TkOnnxExec::ops_supported(const TkOnnxGraph& g, std::string* err) {
             auto tb = nd.attr.find("then_branch"), eb = nd.attr.find("else_branch");
             if (tb == nd.attr.end() || eb == nd.attr.end() || !tb->second.g || !eb->second.g) { *err = "If node '" + nd.name + "' lacks a then_branch / else_branch graph"; return false; }
             if (tb->second.g->outputs.size() != nd.out.size() || eb->second.g->outputs.size() != nd.out.size()) { *err = "If node '" + nd.name + "': its branches declare another number of outputs than the node"; return false; }
+        }
+        if (nd.op == "Loop" || nd.op == "Scan") {
+            auto bd = nd.attr.find("body");
+            if (bd == nd.attr.end() || !bd->second.g) { *err = nd.op + " node '" + nd.name + "' lacks a body graph"; return false; }
+            const TkOnnxGraph& b = *bd->second.g;
+            const size_t carried = nd.op == "Loop" ? (nd.in.size() >= 2 ? nd.in.size() - 2 : 0) : nd.in.size() - (size_t)std::min<int64_t>(std::max<int64_t>(nd.ai("num_scan_inputs", 0), 0), (int64_t)nd.in.size());
+            const bool shape_ok = nd.op == "Loop" ? (nd.in.size() >= 2 && b.inputs.size() == nd.in.size() && b.outputs.size() >= carried + 1 && nd.out.size() == b.outputs.size() - 1)
+                                                  : (nd.ai("num_scan_inputs", 0) >= 1 && b.inputs.size() == nd.in.size() && b.outputs.size() >= carried && nd.out.size() == b.outputs.size());
+            if (!shape_ok) { *err = nd.op + " node '" + nd.name + "': the body's inputs / outputs do not match the node's"; return false; }
         }
     }
     if (g.outputs.empty()) { *err = "the graph declares no outputs"; return false; }

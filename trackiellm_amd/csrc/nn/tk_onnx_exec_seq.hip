@@ -232,6 +232,152 @@ bool TkOnnxExec::exec_seq_op(const TkOnnxNode& nd, std::map<std::string, Val>& v
         }
         return true;
     }
+    if (op == "Loop" || op == "Scan") {
+        /* Loop (a counted / conditional repetition of a body graph with loop-carried values and per-iteration "scan" outputs) and Scan (a body
+         * graph mapped over the slices of its scan inputs along axis 0, with state values): what exporters emit for recurrences written as
+         * Python loops.  Trip count and condition are host data, like If's condition (an integer / bool tensor, possibly computed by the body
+         * from the iteration number).  The body's nodes run in this value map (ONNX name scoping: a sub-graph sees the outer scope), every
+         * iteration's outputs are fresh arena tensors, carried values are rebound by name.  Scan outputs are stacked along a new (Loop) or the
+         * first (Scan) axis.  Not covered: scan axes other than 0, reversed scan OUTPUTS, sequence-typed carried values. */
+        auto bd = nd.attr.find("body");
+        if (bd == nd.attr.end() || !bd->second.g) { error = "body graph missing"; return false; }
+        const TkOnnxGraph& body = *bd->second.g;
+        const bool is_loop = op == "Loop";
+        auto host_flag = [&](const Val& c, bool* flag) {
+            if (c.is_int && c.ints.size() == 1) { *flag = c.ints[0] != 0; return true; }
+            if (!c.is_int && c.host.size() == 1) { *flag = c.host[0] != 0.0f; return true; }
+            return false;
+        };
+        auto run_body = [&]() {
+            for (const auto& sn : body.nodes) {
+                if (sn.op == "Constant") continue;
+                if (!exec(sn, v)) { if (error.find(sn.op) == std::string::npos) error = sn.op + " (node '" + sn.name + "' of a loop body): " + error; return false; }
+            }
+            return true;
+        };
+        auto fetch = [&](const std::string& name, Val* dst) {
+            auto it = v.find(name);
+            if (it == v.end()) { error = "body output '" + name + "' was not produced"; return false; }
+            *dst = it->second;
+            return true;
+        };
+        /* stack per-iteration values along a new leading axis (Loop) or concatenate their leading axes (Scan: every slice result gets axis 0 = 1) */
+        auto stack = [&](const std::vector<Val>& parts, const std::string& name) {
+            if (name.empty()) return true;
+            Val o;
+            if (parts.empty()) { o.shape = {0}; o.is_int = true; v[name] = o; return true; }
+            o.shape = parts[0].shape;
+            o.shape.insert(o.shape.begin(), (int64_t)parts.size());
+            o.is_int = parts[0].is_int;
+            const int64_t each = parts[0].count();
+            for (const Val& p : parts)
+                if (p.shape != parts[0].shape || p.is_int != o.is_int) { error = "a scan output changes its shape between iterations"; return false; }
+            if (o.is_int) {
+                for (const Val& p : parts) o.ints.insert(o.ints.end(), p.ints.begin(), p.ints.end());
+            } else {
+                o.d = alloc(each * (int64_t)parts.size());
+                if (!o.d) { error = "activation arena exhausted"; return false; }
+                for (size_t i = 0; i < parts.size(); ++i)
+                    if (each > 0) SQ(hipMemcpyAsync(o.d + (int64_t)i * each, parts[i].d, (size_t)each * 4, hipMemcpyDeviceToDevice, stream_));
+            }
+            v[name] = o;
+            return true;
+        };
+        const int64_t kMaxIter = 1 << 16; /* a run's activations live in one arena: a loop that long has exhausted it long before */
+        if (is_loop) {
+            if (nd.in.size() < 2) { error = "Loop needs the trip-count and condition inputs (either may be empty)"; return false; }
+            const size_t N = nd.in.size() - 2;
+            if (body.inputs.size() != N + 2 || body.outputs.size() < N + 1) { error = "the body's inputs / outputs do not match the node's loop-carried values"; return false; }
+            const size_t K = body.outputs.size() - 1 - N;
+            if (nd.out.size() != N + K) { error = "the node declares another number of outputs than carried values + scan outputs"; return false; }
+            int64_t trip = kMaxIter + 1;
+            bool keep = true;
+            if (Val* m = in(0)) {
+                if (!m->is_int || m->ints.size() != 1) { error = "the trip count must be an integer scalar known on the host"; return false; }
+                trip = m->ints[0];
+            }
+            if (Val* c = in(1)) {
+                if (!host_flag(*c, &keep)) { error = "the condition must be a scalar known on the host"; return false; }
+            }
+            std::vector<Val> carried(N);
+            for (size_t i = 0; i < N; ++i) {
+                Val* x = in(2 + i);
+                if (!x) { error = "loop-carried input " + std::to_string(i) + " is missing"; return false; }
+                carried[i] = *x;
+            }
+            std::vector<std::vector<Val>> scans(K);
+            for (int64_t it = 0; it < trip && keep; ++it) {
+                if (it >= kMaxIter) { error = "more than 65536 iterations"; return false; }
+                Val iv; iv.is_int = true; iv.ints = {it};
+                Val cv; cv.is_int = true; cv.ints = {1};
+                v[body.inputs[0].name] = iv;
+                v[body.inputs[1].name] = cv;
+                for (size_t i = 0; i < N; ++i) v[body.inputs[2 + i].name] = carried[i];
+                if (!run_body()) return false;
+                Val co;
+                if (!fetch(body.outputs[0].name, &co)) return false;
+                if (!host_flag(co, &keep)) { error = "the body's condition output must be a scalar known on the host (integer / bool arithmetic on the iteration number)"; return false; }
+                std::vector<Val> next(N);
+                for (size_t i = 0; i < N; ++i) if (!fetch(body.outputs[1 + i].name, &next[i])) return false;
+                carried.swap(next);
+                for (size_t k = 0; k < K; ++k) { Val s; if (!fetch(body.outputs[1 + N + k].name, &s)) return false; scans[k].push_back(s); }
+            }
+            for (size_t i = 0; i < N; ++i) if (!nd.out[i].empty()) v[nd.out[i]] = carried[i];
+            for (size_t k = 0; k < K; ++k) if (!stack(scans[k], nd.out[N + k])) return false;
+            return true;
+        }
+        /* Scan (opset >= 9: no sequence_lens input) */
+        const int64_t M = nd.ai("num_scan_inputs", 0);
+        if (M < 1 || (size_t)M > nd.in.size()) { error = "num_scan_inputs is missing or larger than the input count"; return false; }
+        const size_t N = nd.in.size() - (size_t)M;
+        if (body.inputs.size() != nd.in.size() || body.outputs.size() < N) { error = "the body's inputs / outputs do not match the node's state and scan inputs"; return false; }
+        const size_t K = body.outputs.size() - N;
+        if (nd.out.size() != N + K) { error = "the node declares another number of outputs than state values + scan outputs"; return false; }
+        for (const char* a : {"scan_input_axes", "scan_output_axes"})
+            if (const std::vector<int64_t>* ax = nd.aints(a))
+                for (int64_t x : *ax) if (x != 0) { error = std::string(a) + " other than 0"; return false; }
+        if (const std::vector<int64_t>* od = nd.aints("scan_output_directions"))
+            for (int64_t x : *od) if (x != 0) { error = "reversed scan outputs"; return false; }
+        const std::vector<int64_t>* idir = nd.aints("scan_input_directions");
+        std::vector<Val> state(N), xs((size_t)M);
+        for (size_t i = 0; i < N; ++i) {
+            Val* x = in(i);
+            if (!x) { error = "state input " + std::to_string(i) + " is missing"; return false; }
+            state[i] = *x;
+        }
+        int64_t T = -1;
+        for (size_t j = 0; j < (size_t)M; ++j) {
+            Val* x = in(N + j);
+            if (!x || x->shape.empty()) { error = "scan input " + std::to_string(j) + " is missing or a scalar"; return false; }
+            if (T >= 0 && x->shape[0] != T) { error = "the scan inputs disagree in their length"; return false; }
+            T = x->shape[0];
+            xs[j] = *x;
+        }
+        if (T > kMaxIter) { error = "more than 65536 iterations"; return false; }
+        std::vector<std::vector<Val>> scans(K);
+        for (int64_t t = 0; t < T; ++t) {
+            for (size_t i = 0; i < N; ++i) v[body.inputs[i].name] = state[i];
+            for (size_t j = 0; j < (size_t)M; ++j) { /* slice t (or T - 1 - t) of scan input j: a view, the tensors are row-major */
+                const bool rev = idir && j < idir->size() && (*idir)[j] == 1;
+                const int64_t at = rev ? T - 1 - t : t;
+                Val sl;
+                sl.shape.assign(xs[j].shape.begin() + 1, xs[j].shape.end());
+                const int64_t each = sl.count();
+                sl.is_int = xs[j].is_int;
+                if (sl.is_int) sl.ints.assign(xs[j].ints.begin() + at * each, xs[j].ints.begin() + (at + 1) * each);
+                else sl.d = xs[j].d + at * each;
+                v[body.inputs[N + j].name] = sl;
+            }
+            if (!run_body()) return false;
+            std::vector<Val> next(N);
+            for (size_t i = 0; i < N; ++i) if (!fetch(body.outputs[i].name, &next[i])) return false;
+            state.swap(next);
+            for (size_t k = 0; k < K; ++k) { Val s; if (!fetch(body.outputs[N + k].name, &s)) return false; scans[k].push_back(s); }
+        }
+        for (size_t i = 0; i < N; ++i) if (!nd.out[i].empty()) v[nd.out[i]] = state[i];
+        for (size_t k = 0; k < K; ++k) if (!stack(scans[k], nd.out[N + k])) return false;
+        return true;
+    }
     if (op == "Equal" || op == "Less" || op == "Greater" || op == "And" || op == "Or" || op == "Not") {
         Val* a = in(0);
         if (!a || !a->is_int) { error = "comparisons and logic run on host integer / bool tensors only"; return false; }

@@ -39,7 +39,7 @@ struct TkOnnxAttr {
     std::vector<float> floats;
     TkOnnxTensor t;
     bool has_t = false;
-    std::shared_ptr<TkOnnxGraph> g; /* then_branch / else_branch of an If node (nesting depth limited by the reader) */
+    std::shared_ptr<TkOnnxGraph> g; /* a sub-graph: then_branch / else_branch of an If node, the body of a Loop / Scan (nesting depth limited by the reader) */
 };
 
 struct TkOnnxNode {
