@@ -224,3 +224,68 @@ def test_loop_and_scan_equal_the_unrolled_graph(gpu, tmp_path):
     pb.write_bytes(OX.loopnet_model(W, bad))
     with pytest.raises(gpu.TkError):
         gpu.DepthEstimator(str(pb), H, H)
+
+
+def test_control_flow_decided_by_device_data(gpu, tmp_path):
+    """an If whose condition and a Loop whose continuation are computed from activations (ReduceMax -> Greater / Less against a threshold: the
+    comparison's operands are brought to the host): the If graph equals, bit for bit, the graph that holds only the branch taken, for an input
+    on either side of the threshold; the Loop doubles its input until the maximum passes a limit — the trip count is the data's."""
+    H = 16
+    rng = np.random.default_rng(9)
+    w = (rng.standard_normal((4, 3, 3, 3)) * 0.3).astype(np.float32)
+    b = (rng.standard_normal(4) * 0.3).astype(np.float32)
+    conv = [OX.attr_ints("pads", [1, 1, 1, 1]), OX.attr_ints("kernel_shape", [3, 3])]
+    allax = [OX.attr_ints("axes", [0, 1, 2, 3]), OX.attr_int("keepdims", 0)]
+    fin = [OX.attr_ints("axes", [1]), OX.attr_int("keepdims", 0)]
+
+    def file(nodes, floats):
+        return OX.model(nodes, [OX.tensor(k, v) for k, v in floats.items()], [OX.value_info("input", 1, [1, 3, H, H])], [OX.value_info("output", 1, [1, H, H])])
+    then_nodes = [OX.node("Conv", ["input", "w", "b"], ["t0"], conv, name="tc"), OX.node("Relu", ["t0"], ["branch"], name="tr")]
+    else_nodes = [OX.node("Conv", ["input", "w", "b"], ["e0"], conv, name="ec"), OX.node("Neg", ["e0"], ["branch"], name="en")]
+    tail = [OX.node("ReduceSum", ["y"], ["output"], fin, name="fin")]
+    W = {"w": w, "b": b, "thr": np.array(3.0, np.float32)}
+    g_then = OX.graph_proto(then_nodes, [], [], [OX.value_info("branch", 1, [1, 4, H, H])], name=b"then")
+    g_else = OX.graph_proto(else_nodes, [], [], [OX.value_info("branch", 1, [1, 4, H, H])], name=b"else")
+    cond = [OX.node("ReduceMax", ["input"], ["mx"], allax, name="mx"), OX.node("Greater", ["mx", "thr"], ["hot"], name="gt")]
+    files = {"if": file(cond + [OX.node("If", ["hot"], ["y"], [OX.attr_graph("then_branch", g_then), OX.attr_graph("else_branch", g_else)], name="sw")] + tail, W),
+             "then": file(then_nodes[:1] + [OX.node("Relu", ["t0"], ["y"], name="tr")] + tail, W),
+             "else": file(else_nodes[:1] + [OX.node("Neg", ["e0"], ["y"], name="en")] + tail, W)}
+    est = {}
+    for k, data in files.items():
+        p = tmp_path / (k + ".onnx")
+        p.write_bytes(data)
+        est[k] = gpu.DepthEstimator(str(p), H, H)
+    x = rng.standard_normal((3, H, H)).astype(np.float32)
+    x_lo = np.clip(x, -2.5, 2.5)
+    x_hi = x_lo.copy()
+    x_hi[1, 5, 7] = 3.5
+    assert np.array_equal(est["if"].forward_raw(x_hi).view(np.uint32), est["then"].forward_raw(x_hi).view(np.uint32))
+    assert np.array_equal(est["if"].forward_raw(x_lo).view(np.uint32), est["else"].forward_raw(x_lo).view(np.uint32))
+    assert not np.array_equal(est["if"].forward_raw(x_lo), est["then"].forward_raw(x_lo))
+    for e in est.values():
+        e.close()
+    # a Loop that runs while the doubled activations stay under a limit
+    body = OX.graph_proto([OX.node("Mul", ["y_in", "two"], ["y_out"], name="dbl"), OX.node("ReduceMax", ["y_out"], ["m_b"], allax, name="mb"),
+                           OX.node("Less", ["m_b", "limit"], ["go_out"], name="lt")], [],
+                          [OX.value_info("it", 7, []), OX.value_info("go_in", 9, []), OX.value_info("y_in", 1, [1, 3, H, H])],
+                          [OX.value_info("go_out", 9, []), OX.value_info("y_out", 1, [1, 3, H, H])], name=b"body")
+    # (a trip count of 12 beside the condition: the all-zero frame of the create-time trial run never reaches the limit)
+    loop = OX.model([OX.node("Loop", ["most", "bool_go", "input"], ["y"], [OX.attr_graph("body", body)], name="lp")] + tail,
+                    [OX.tensor("two", np.array([2.0], np.float32)), OX.tensor("limit", np.array(40.0, np.float32)), OX.bool_tensor("bool_go", [1], []),
+                     OX.int_tensor("most", [12], [])],
+                    [OX.value_info("input", 1, [1, 3, H, H])], [OX.value_info("output", 1, [1, H, H])])
+    p = tmp_path / "loop_data.onnx"
+    p.write_bytes(loop)
+    e = gpu.DepthEstimator(str(p), H, H)
+    for xin in (x_lo, x_hi, x_lo * np.float32(0.01), x_lo * np.float32(1e-6)):
+        y = xin.copy()
+        trips = 0
+        while True:                                                             # the body runs, then its condition decides about the next trip
+            y = y * np.float32(2)
+            trips += 1
+            if not y.max() < 40.0 or trips == 12:
+                break
+        want = y.sum(axis=0, dtype=np.float32)
+        got = e.forward_raw(xin)
+        assert np.abs(got - want).max() <= TOL * float(np.abs(want).max()), trips
+    e.close()

@@ -18,7 +18,8 @@
  *   resident like the outer graph's.  Loop (trip count and / or condition as host data: a constant, or integer arithmetic on the iteration
  *   number inside the body; loop-carried values, scan outputs stacked along a new leading axis) and Scan (state values + scan inputs sliced
  *   along axis 0, forward or reversed; scan outputs along axis 0) run their body graph in the same value map, one fresh set of arena tensors
- *   per iteration — what exporters emit for recurrences written as Python loops.
+ *   per iteration — what exporters emit for recurrences written as Python loops.  A condition computed from activations (Equal / Less / Greater
+ *   on float tensors of up to 64 elements) is evaluated on the host after a stream synchronisation.
  * Anything else fails at load time with the op's name.
  * Arithmetic: fp32; every contraction is one k-ascending fma chain per output element (input channel outer, kernel row, kernel column
  * inner; the bias enters last), the exact-math exp / tanh / sigmoid / sqrt of common/tk_exact_math.h.

@@ -261,7 +261,7 @@ bool TkOnnxExec::exec_seq_op(const TkOnnxNode& nd, std::map<std::string, Val>& v
             *dst = it->second;
             return true;
         };
-        /* stack per-iteration values along a new leading axis (Loop) or concatenate their leading axes (Scan: every slice result gets axis 0 = 1) */
+        /* stack the per-iteration values along a new leading axis (Loop and Scan alike) */
         auto stack = [&](const std::vector<Val>& parts, const std::string& name) {
             if (name.empty()) return true;
             Val o;
@@ -378,9 +378,36 @@ bool TkOnnxExec::exec_seq_op(const TkOnnxNode& nd, std::map<std::string, Val>& v
         for (size_t k = 0; k < K; ++k) if (!stack(scans[k], nd.out[N + k])) return false;
         return true;
     }
+    if ((op == "Equal" || op == "Less" || op == "Greater") && in(0) && in(1) && (!in(0)->is_int || !in(1)->is_int)) {
+        /* a comparison of small FLOAT tensors — the data-dependent condition of an If / Loop ("is the largest activation above a threshold?"): both
+         * sides are brought to the host (a stream synchronisation: the price of control flow decided by device data) and the result is host
+         * data like every other condition.  Up to 64 elements; larger float comparisons are masks, not conditions, and are not covered. */
+        auto fetch_small = [&](Val* x, std::vector<float>* dst) {
+            const int64_t n = x->is_int ? (int64_t)x->ints.size() : x->count();
+            if (n < 1 || n > 64) { error = "float comparisons are evaluated on the host for up to 64 elements (conditions, not masks)"; return false; }
+            dst->resize((size_t)n);
+            if (x->is_int) { for (int64_t i = 0; i < n; ++i) (*dst)[(size_t)i] = (float)x->ints[(size_t)i]; return true; }
+            if ((int64_t)x->host.size() == n) { *dst = x->host; return true; }
+            SQ(hipMemcpyAsync(dst->data(), x->d, (size_t)n * 4, hipMemcpyDeviceToHost, stream_));
+            SQ(hipStreamSynchronize(stream_));
+            return true;
+        };
+        std::vector<float> fa, fb;
+        Val ac = *in(0), bc = *in(1);
+        if (!fetch_small(&ac, &fa) || !fetch_small(&bc, &fb)) return false;
+        const size_t na = fa.size(), nb = fb.size();
+        if (na != nb && na != 1 && nb != 1) { error = "operands do not broadcast"; return false; }
+        std::vector<int64_t> o(std::max(na, nb));
+        for (size_t i = 0; i < o.size(); ++i) {
+            const float x = fa[na == 1 ? 0 : i], y = fb[nb == 1 ? 0 : i];
+            o[i] = op == "Equal" ? x == y : op == "Less" ? x < y : x > y;
+        }
+        out_i(na >= nb ? ac.shape : bc.shape, std::move(o));
+        return true;
+    }
     if (op == "Equal" || op == "Less" || op == "Greater" || op == "And" || op == "Or" || op == "Not") {
         Val* a = in(0);
-        if (!a || !a->is_int) { error = "comparisons and logic run on host integer / bool tensors only"; return false; }
+        if (!a || !a->is_int) { error = "logic runs on host integer / bool tensors only"; return false; }
         const Val ac = *a;
         std::vector<int64_t> o(ac.ints.size());
         if (op == "Not") {
