@@ -176,6 +176,7 @@ struct CpuAudioOps {
         }
     }
     bool attend1(const float*, const float*, const float*, float*, int, int, int64_t, int64_t, int, int) { return false; }
+    bool attend_fused(const float*, const float*, const float*, float*, int, int, int, int64_t, int64_t, int, int) { return false; }
     void softmax_rows(float* x, int rows, int cols, int ld) {
         for (int r = 0; r < rows; ++r) {
             float* xr = x + (int64_t)r * ld;

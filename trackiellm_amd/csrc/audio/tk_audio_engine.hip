@@ -319,6 +319,12 @@ struct TkAudioGpuOps {
         hipLaunchKernelGGL(k_attend1, dim3(nh, B), dim3(256), ldsb, s, q, k, v, out, Tk, q_bstride, kv_bstride, d, hd, tk_divf(1.0f, tk_sqrtf((float)hd)), img);
         return true;
     }
+    /* the opt-in fast contraction's attention (TkAsr::fast): Q K^T, softmax and P V of a long pass in one kernel, no score matrix in HBM */
+    bool attend_fused(const float* q, const float* k, const float* v, float* out, int B, int Tq, int Tk, int64_t q_bstride, int64_t kv_bstride, int d, int nh) {
+        if (!a->fast || Tq < 256 || nh < 1 || d != nh * 64) return false;
+        drop_image();
+        return tk_launch_attention_h3(q, k, v, out, B, nh, Tq, Tk, q_bstride, kv_bstride, d, tk_divf(1.0f, tk_sqrtf(64.0f)), s);
+    }
     void add_rows(float* x, const float* add, int rows, int D, int add_rows) { drop_image(); tk_launch_add_rows(x, add, rows, D, add_rows, s); }
     void embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out) {
         drop_image();
@@ -374,6 +380,7 @@ struct TkAudioSizeOps {
     void layernorm(const float*, int rows, int D, const float*, const float*, float*) { image(rows, D); }
     void softmax_rows(float*, int, int, int) {}
     bool attend1(const float*, const float*, const float*, float*, int B, int, int64_t, int64_t, int d, int) { image(B, d); return true; }
+    bool attend_fused(const float*, const float*, const float*, float*, int, int, int, int64_t, int64_t, int, int) { return false; } /* sized for the exact form */
     void add_rows(float*, const float*, int, int, int) {}
     void embed_rows(const float*, const float*, const int32_t*, const int32_t*, int, int, float*) {}
     void argmax_rows(const float*, int, int, int, int32_t*) {}

@@ -14,6 +14,8 @@
  *   void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y);
  *   void softmax_rows(float* x, int rows, int cols, int ld);
  *   bool attend1(...): optional fused form of attention() for one query row per sequence (same arithmetic); false = not provided
+ *   bool attend_fused(...): optional one-kernel form of attention() for many query rows (the GPU's opt-in fast contraction: NOT the same
+ *     arithmetic, ~1e-6 of scale off; the oracle and the exact path return false)
  *   void add_rows(float* x, const float* add, int rows, int D, int add_rows);
  *   void embed_rows(const float* table, const float* pos, const int32_t* idx, const int32_t* pos_idx, int rows, int D, float* out);
  *   void argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out);
@@ -207,6 +209,7 @@ struct TkWhisperGraph {
                    int d, int nh, float* scores) const {
         const int hd = d / nh;
         if (Tq == 1 && o.attend1(q, k, v, out, B, Tk, q_bstride, kv_bstride, d, nh)) return; /* decoder steps: one kernel, same arithmetic */
+        if (Tq > 1 && o.attend_fused(q, k, v, out, B, Tq, Tk, q_bstride, kv_bstride, d, nh)) return; /* opt-in fast path only */
         const int Tp = score_pitch(Tk);
         TkGemm s{};
         s.A = q; s.B = k; s.C = scores; s.M = Tq; s.N = Tk; s.K = hd; s.lda = d; s.ldb = d; s.ldc = Tp; s.b_kn = 0; s.act = 0;

@@ -30,6 +30,11 @@ bool tk_launch_conv_stem(const float* x, int B, int H, int W, int C, int ldx, co
 /* opts the large-tile GEMM into its dynamic LDS on the calling thread's current device; idempotent, thread-safe.  tk_launch_gemm does
  * it on first use; callers that capture launches into a hipGraph call it beforehand. */
 bool tk_nn_prepare_device();
+/* opt-in (the fast contraction's companion, TkGemm::fast): attention over Tk keys for Tq queries per (sequence, head) in ONE kernel — Q K^T, online
+ * softmax, P V on the f16 matrix pipe with split operands, no score matrix in HBM; head_dim 64, q / k / v / out rows of pitch d = nh * 64,
+ * 16-byte aligned.  false (nothing launched): another geometry.  ~1e-6 of scale off the exact three-launch form, not its bits. */
+bool tk_launch_attention_h3(const float* q, const float* k, const float* v, float* out, int B, int nh, int Tq, int Tk, int64_t q_bstride, int64_t kv_bstride, int d,
+                            float scale, hipStream_t s);
 
 /* NHWC im2col: col[b*Ho*Wo + oy*Wo + ox][(ky*kw + kx)*C + c]; input row stride ldx floats per pixel */
 void tk_launch_im2col(const float* x, int B, int H, int W, int C, int ldx, int kh, int kw, int stride, int pad, float* col, hipStream_t s);

@@ -638,6 +638,168 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3_big(TkGemm g) {
 }
 #define H3_BIG_LDS ((size_t)2 * 4 * LBM * HLD * sizeof(_Float16))
 
+/* ------------------------------------------------------------------------------------------
+ * Opt-in fused attention for the fast contraction (head_dim 64, many queries per sequence: the Whisper encoder): Q K^T, softmax and P V in
+ * one kernel, nothing of the [Tq][Tk] score matrix ever in HBM (the exact path writes it, normalises it in place and reads it back: 8 of the
+ * fast ASR's 15.6 ms per 32 clips, profiles/r06_fast_perception.txt).  Online softmax (running maximum and sum per query, the output rescaled
+ * when the maximum moves) — a different association than the exact path's two passes, inside the fast path's ~1e-6.
+ * A workgroup takes 128 queries of one (sequence, head) — 32 per wave — and walks the keys 32 at a time:
+ *   S^T = K Q^T   (keys x queries; A = the key block from LDS, B = the wave's queries, split once, in registers): the accumulator layout then
+ *                 gives every lane ONE query (column lane % 32) and 16 of the block's 32 keys — the row maximum / sum are 16 registers and
+ *                 one exchange with lane ^ 32, and the rescale factor is a per-lane scalar;
+ *   O^T += V^T P^T (dims x queries; B = the lane's 16 probabilities, split in registers — the MFMA's k slots are filled in the order the
+ *                 accumulator holds the keys; A = V^T from LDS, staged transposed with its key columns in that same order).
+ * Every operand is split into two f16 halves as in k_gemm_h3_*: three MFMAs per 16 k.
+ * ------------------------------------------------------------------------------------------ */
+#define FA_KLD 72 /* halves per K row in LDS: 64 dims + 8 */
+#define FA_VLD 40 /* halves per V^T row: 32 keys + 8 */
+__global__ __launch_bounds__(256, 2) void k_attention_h3(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
+                                                      int Tq, int Tk, int64_t q_bstride, int64_t kv_bstride, int d, float scale) {
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[32 * FA_KLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Kl[32 * FA_KLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[64 * FA_VLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[64 * FA_VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, n = lane & 31;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int qrow = blockIdx.x * 128 + wave * 32 + n;
+    const float* qp = q + (int64_t)b * q_bstride + (int64_t)head * 64;
+    const float* kp = k + (int64_t)b * kv_bstride + (int64_t)head * 64;
+    const float* vp = v + (int64_t)b * kv_bstride + (int64_t)head * 64;
+    /* the lane's query row as the B operand of S^T: dims 16 ks + 8 g + [0, 8), scaled, split once */
+    v8h qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float x[8];
+        ld4_if(qrow < Tq, qp + (int64_t)qrow * d + ks * 16 + g * 8, x);
+        ld4_if(qrow < Tq, qp + (int64_t)qrow * d + ks * 16 + g * 8 + 4, x + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float t = x[i] * scale;
+            const _Float16 hi = (_Float16)t;
+            qh[ks][i] = hi;
+            ql[ks][i] = (_Float16)((t - (float)hi) * H3_SCALE);
+        }
+    }
+    v16f o_hh[2], o_hx[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o_hh[t][r] = 0.0f; o_hx[t][r] = 0.0f; }
+    float m_run = -INFINITY, l_run = 0.0f;
+    /* staging.  K: 32 keys x 64 dims = 512 groups of four floats, thread -> (key = e / 16, dims 4 (e % 16) ..) for e = tid, tid + 256.
+     * V goes into LDS TRANSPOSED ([dim][key], what the A operand of O^T = V^T P^T reads) with its key columns in the order the S^T accumulator
+     * holds the keys: column c = 16 s + 8 g + j  <->  key 16 s + 4 g + (j % 4) + 8 (j / 4).  Thread -> (dim = tid % 64, column group tid / 64):
+     * its eight keys are eight loads that a wave coalesces over the dims, and ONE 16-byte LDS store per half-plane (2-byte transposing
+     * stores from a key-major thread mapping measured the same: the staging is not what a block waits for) */
+    float rk[2][4], rv[8];
+    const int vd = tid & 63, vc = tid >> 6; /* column group vc = 2 s + g */
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i, key = k0 + (e >> 4), dg = (e & 15) * 4;
+            ld4_if(key < Tk, kp + (int64_t)key * d + dg, rk[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = k0 + 16 * (vc >> 1) + 4 * (vc & 1) + (j & 3) + 8 * (j >> 2);
+            rv[j] = key < Tk ? vp[(int64_t)key * d + vd] : 0.0f;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i, key = e >> 4, dg = (e & 15) * 4;
+            h3_split4(rk[i], Kh + key * FA_KLD + dg, Kl + key * FA_KLD + dg);
+        }
+        v8h hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 t = (_Float16)rv[j];
+            hi[j] = t;
+            lo[j] = (_Float16)((rv[j] - (float)t) * H3_SCALE);
+        }
+        *(v8h*)(Vh + vd * FA_VLD + vc * 8) = hi;
+        *(v8h*)(Vl + vd * FA_VLD + vc * 8) = lo;
+    };
+    const float L2E = 1.4426950408889634f;
+    gload(0);
+    for (int k0 = 0; k0 < Tk; k0 += 32) {
+        __syncthreads(); /* everybody is done with the previous block's K / V */
+        lstore();
+        __syncthreads();
+        if (k0 + 32 < Tk) gload(k0 + 32);
+        v16f s_hh, s_hx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s_hh[r] = 0.0f; s_hx[r] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const v8h ah = *(const v8h*)(Kh + n * FA_KLD + ks * 16 + g * 8), al = *(const v8h*)(Kl + n * FA_KLD + ks * 16 + g * 8);
+            s_hh = H3_MFMA(ah, qh[ks], s_hh);
+            s_hx = H3_MFMA(ah, ql[ks], s_hx);
+            s_hx = H3_MFMA(al, qh[ks], s_hx);
+        }
+        float st[16], mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + 4 * g + (r & 3) + 8 * (r >> 2);
+            st[r] = key < Tk ? s_hh[r] + s_hx[r] * (1.0f / H3_SCALE) : -INFINITY;
+            mloc = fmaxf(mloc, st[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc); /* finite: every block holds at least one key */
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
+        m_run = m_new;
+        float psum = 0.0f;
+        v8h ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pr = __builtin_amdgcn_exp2f((st[r] - m_new) * L2E);
+            psum += pr;
+            const _Float16 hi = (_Float16)pr;
+            ph[r >> 3][r & 7] = hi;
+            pl[r >> 3][r & 7] = (_Float16)((pr - (float)hi) * H3_SCALE);
+        }
+        l_run = l_run * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) { /* wave-uniform: after the first blocks a query's maximum seldom moves, and the 64 accumulator values stay put */
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o_hh[t][r] *= alpha; o_hx[t][r] *= alpha; }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const v8h vh = *(const v8h*)(Vh + (t * 32 + n) * FA_VLD + sp * 16 + g * 8), vl = *(const v8h*)(Vl + (t * 32 + n) * FA_VLD + sp * 16 + g * 8);
+                o_hh[t] = H3_MFMA(vh, ph[sp], o_hh[t]);
+                o_hx[t] = H3_MFMA(vh, pl[sp], o_hx[t]);
+                o_hx[t] = H3_MFMA(vl, ph[sp], o_hx[t]);
+            }
+    }
+    const float l = l_run + __shfl_xor(l_run, 32);
+    if (qrow >= Tq) return;
+    const float inv = __builtin_amdgcn_rcpf(l);
+    float* op = out + (int64_t)b * q_bstride + (int64_t)qrow * d + (int64_t)head * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { /* rows (dims) t 32 + 4 g + 8 rr + [0, 4): one 16-byte store */
+            float4 w;
+            w.x = (o_hh[t][4 * rr + 0] + o_hx[t][4 * rr + 0] * (1.0f / H3_SCALE)) * inv;
+            w.y = (o_hh[t][4 * rr + 1] + o_hx[t][4 * rr + 1] * (1.0f / H3_SCALE)) * inv;
+            w.z = (o_hh[t][4 * rr + 2] + o_hx[t][4 * rr + 2] * (1.0f / H3_SCALE)) * inv;
+            w.w = (o_hh[t][4 * rr + 3] + o_hx[t][4 * rr + 3] * (1.0f / H3_SCALE)) * inv;
+            *(float4*)(op + t * 32 + 4 * g + 8 * rr) = w;
+        }
+}
+
+bool tk_launch_attention_h3(const float* q, const float* k, const float* v, float* out, int B, int nh, int Tq, int Tk, int64_t q_bstride, int64_t kv_bstride, int d,
+                            float scale, hipStream_t s) {
+    if (d != nh * 64 || (d & 3) || Tq < 1 || Tk < 1 || ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) || (q_bstride & 3) || (kv_bstride & 3)) return false;
+    hipLaunchKernelGGL(k_attention_h3, dim3((Tq + 127) / 128, nh, B), dim3(256), 0, s, q, k, v, out, Tq, Tk, q_bstride, kv_bstride, d, scale);
+    return true;
+}
+
 /* > 64 KiB of dynamic LDS is an opt-in HIP keeps per (function, device): one flag per device, set once under a lock (several host
  * threads drive the detector / ASR / VAD streams, possibly on different GPUs).  Callers that capture launches into a hipGraph (the LLM's
  * f16-weight passes) call tk_nn_prepare_device() first so that no attribute is ever set inside a capture. */
