@@ -101,7 +101,7 @@ TK_API void tk_mi355x_asr_set_decode_steps(tk_asr_whisper_context_t* ctx, int n_
  * whisper's special-token layout (fewer than 51864 tokens) always decode that way. */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_set_reference_decode(tk_asr_whisper_context_t* ctx, int enable);
 /* Opt-in fast contraction (the detector's twin is tk_mi355x_detector_set_fast_contraction): the long passes of a transcription
- * — log-mel, the encoder's convolutions, linear layers and Q K^T — contract on the f16 matrix pipe with every operand split into two f16 halves
+ * — log-mel, the encoder's convolutions and linear layers, and its attention as one fused kernel (no score matrix in memory) — contract on the f16 matrix pipe with every operand split into two f16 halves
  * (~22 significant bits, fp32 accumulation): within ~1e-6 of the exact chains' scale, not their bits.  Decoder steps keep the exact path.  Off by
  * default; the exact path stays the parity path and the checker (tests/test_audio_gpu.py::test_asr_fast_contraction_gate). */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_asr_set_fast_contraction(tk_asr_whisper_context_t* ctx, int on);

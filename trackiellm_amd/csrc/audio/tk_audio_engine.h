@@ -39,8 +39,8 @@ class TkAsr {
 public:
     TkWhisperModel* model = nullptr;
     int max_batch = 1;
-    /* opt-in: the contractions of long passes (encoder: convolutions, linear layers, Q K^T; log-mel) on the f16 matrix pipe with split operands
-     * (TkGemm::fast) — ~1e-6 of scale off the exact chains; decoder steps (a few rows) keep the exact tiled path */
+    /* opt-in: the contractions of long passes (log-mel; encoder: convolutions, linear layers, attention as ONE kernel: k_attention_h3) on the f16
+     * matrix pipe with split operands (TkGemm::fast) — ~1e-6 of scale off the exact chains; decoder steps (a few rows) keep the exact tiled path */
     bool fast = false;
     std::string error;
     hipStream_t stream = nullptr;
