@@ -90,6 +90,9 @@ class CycleBench:
             self.det = tk.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-0.45", width=640, height=640, conf=0.5, iou=0.5,
                                          device=device if vision_device is None else vision_device, max_batch=PB)
             self.asr = tk.Asr(hp=tk.WHISPER_TINY_EN(), seed=6, device=device if audio_device is None else audio_device, max_batch=PB)
+            if os.environ.get("TK_BENCH_FAST_PERCEPTION") == "1":  # --fast-perception: the opt-in split-f16 contraction (never the default: parity is claimed on the exact path)
+                self.det.set_fast_contraction(True)
+                self.asr.set_fast_contraction(True)
             self.vad = tk.Vad()
             frng = np.random.default_rng(1 + rank)
             self.frames = [frng.integers(0, 256, (640, 640, 3), dtype=np.uint8) for _ in range(G * B)]
@@ -678,6 +681,7 @@ def main():
                     help="only the isolated per-shape timing of the dominant kernel (the roofline objects); profile THIS command with "
                          "rocprofv3 --kernel-trace to compare its kernel durations with the HIP-event numbers (tools/roofline_check.py)")
     ap.add_argument("--perception-batch", type=int, default=64, help="frames / utterances per detector / ASR call")
+    ap.add_argument("--fast-perception", action="store_true", help="A/B only: detector and ASR on the opt-in fast contraction (split-f16 operands, ~1e-6 of scale off the exact chains); the line is marked and is not the headline")
     ap.add_argument("--asr-steps", type=int, default=16, help="forced greedy decoder steps per utterance (SURVEY.md 8d)")
     ap.add_argument("--ns-steps", type=int, default=4, help="timed steps of the north_star_point run")
     ap.add_argument("--cortices", type=lambda v: [int(x) for x in v.split(",") if x], default=[16, 64],
@@ -688,6 +692,8 @@ def main():
                     help="f16: BASELINE configs[4]'s fp16 checkpoint (14.2 GB of weights per decode step) on the exact fp32 MFMA GEMM; LLM stream only, "
                          "no W4A8 roofline object (other kernels)")
     args = ap.parse_args()
+    if args.fast_perception:
+        os.environ["TK_BENCH_FAST_PERCEPTION"] = "1"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -798,7 +804,10 @@ def main():
     }
     if fused:
         out["perception"] = {"vision_ms_per_batch": round(float(np.mean(cb.perc_ms["vision"])), 2), "audio_ms_per_batch": round(float(np.mean(cb.perc_ms["audio"])), 2),
-                             "detections_last_batch": cb.n_dets, "overlapped_with_llm": True, "dtype": "f32 (exact fp32 MFMA chain)"}
+                             "detections_last_batch": cb.n_dets, "overlapped_with_llm": True,
+                             "dtype": "split-f16 operands on the f16 MFMA (--fast-perception: opt-in, ~1e-6 of scale off the exact chains)" if args.fast_perception else "f32 (exact fp32 MFMA chain)"}
+        if args.fast_perception:
+            out["not_the_headline"] = "--fast-perception: the perception streams ran the opt-in fast contraction; parity is claimed on the exact path only"
     if args.layers != 32:
         out["invalid"] = "debug run with fewer layers"
     if not COLL_CUDA:
