@@ -573,7 +573,7 @@ def _loopnet_tail(y_final, S, Y):
             _n("Add", ["zr", "m"], ["zm"]), _n("Add", ["zm", "qr"], ["output"])]
 
 
-def loopnet_unrolled_spec():
+def loopnet_unrolled_spec(reverse=False):
     H, T = LOOPNET["H"], LOOPNET["T"]
     spec = [_n("Conv", ["input", "c0.w", "c0.b"], ["y_0"], pads=[1, 1, 1, 1], kernel_shape=[3, 3])]
     y = "y_0"
@@ -584,7 +584,8 @@ def loopnet_unrolled_spec():
     spec.append(_n("Transpose", [y, ], ["X"], perm=[2, 0, 1, 3]))
     acc = "acc0"
     for t in range(H):
-        spec += [_n("Slice", ["X", "st%d" % t, "en%d" % t, "ax0"], ["xs%d" % t]), _n("Reshape", ["xs%d" % t, "shape_x"], ["x%d" % t]),
+        row = H - 1 - t if reverse else t                                   # a reversed Scan reads its slices last to first; its outputs stay in iteration order
+        spec += [_n("Slice", ["X", "st%d" % row, "en%d" % row, "ax0"], ["xs%d" % t]), _n("Reshape", ["xs%d" % t, "shape_x"], ["x%d" % t]),
                  _n("Mul", [acc, "decay"], ["a%d" % t]), _n("Add", ["a%d" % t, "x%d" % t], ["acc%d" % (t + 1)]),
                  _n("Reshape", ["acc%d" % (t + 1), "shape_a"], ["Y%d" % t])]
         acc = "acc%d" % (t + 1)
@@ -592,7 +593,7 @@ def loopnet_unrolled_spec():
     return spec + _loopnet_tail(y, "S", "Y")
 
 
-def loopnet_spec(mode="count"):
+def loopnet_spec(mode="count", reverse=False):
     """mode "count": trip count input, the body hands the condition through; "cond": no trip count, the body computes the condition from the
     iteration number (integer Add + Less on the host)"""
     H, Cc = LOOPNET["H"], LOOPNET["C"]
@@ -609,7 +610,7 @@ def loopnet_spec(mode="count"):
     return [_n("Conv", ["input", "c0.w", "c0.b"], ["y_0"], pads=[1, 1, 1, 1], kernel_shape=[3, 3]),
             _n("Loop", ["trip" if mode == "count" else "", "bool_go", "y_0"], ["y_fin", "S"], body=body),
             _n("Transpose", ["y_fin"], ["X"], perm=[2, 0, 1, 3]),
-            _n("Scan", ["acc0", "X"], ["acc_fin", "Y"], body=scan_body, num_scan_inputs=1)] + _loopnet_tail("y_fin", "S", "Y")
+            _n("Scan", ["acc0", "X"], ["acc_fin", "Y"], body=scan_body, num_scan_inputs=1, **({"scan_input_directions": [1]} if reverse else {}))] + _loopnet_tail("y_fin", "S", "Y")
 
 
 def loopnet_model(W, spec):

@@ -212,6 +212,17 @@ def test_loop_and_scan_equal_the_unrolled_graph(gpu, tmp_path):
         assert np.array_equal(got.view(np.uint32), got_u.view(np.uint32)), (mode, np.abs(got - got_u).max())
         assert np.array_equal(e.forward_raw(x).view(np.uint32), got.view(np.uint32))     # a second run on the same handle
         e.close()
+    # a reversed Scan (scan_input_directions = 1) against the twin that slices the rows last to first
+    pr, pru = tmp_path / "scan_rev.onnx", tmp_path / "scan_rev_unrolled.onnx"
+    pr.write_bytes(OX.loopnet_model(W, OX.loopnet_spec("count", reverse=True)))
+    pru.write_bytes(OX.loopnet_model(W, OX.loopnet_unrolled_spec(reverse=True)))
+    er, eru = gpu.DepthEstimator(str(pr), H, H), gpu.DepthEstimator(str(pru), H, H)
+    got_r = er.forward_raw(x)
+    assert np.array_equal(got_r.view(np.uint32), eru.forward_raw(x).view(np.uint32)) and not np.array_equal(got_r, got_u)
+    want_r = DO.run_graph(OX.loopnet_unrolled_spec(reverse=True), consts, {"input": x[None]})["output"][0]
+    assert np.abs(got_r - want_r).max() <= TOL * float(np.abs(want_r).max())
+    er.close()
+    eru.close()
     bad = OX.loopnet_spec("count")
     bad[3]["attrs"]["scan_input_axes"] = [1]
     pb = tmp_path / "scan_axis.onnx"
