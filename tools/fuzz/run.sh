@@ -20,9 +20,10 @@ gguf_util.write_lora_gguf(W + "/b.gguf", 8.0, fs, f16=True)
 gguf_util.write_llama_gguf(W + "/model.gguf", O.OracleLlm(cfg, seed=4), cfg)
 convs = [{"name": "c%d" % i, "w": rng.normal(0, .1, s).astype(np.float32), "b": rng.normal(0, .1, s[0]).astype(np.float32)} for i, s in enumerate([(8, 3, 3, 3), (8, 8, 1, 1)])]
 open(W + "/y.onnx", "wb").write(X.yolo_model(convs, with_dfl=False))
+open(W + "/loop.onnx", "wb").write(X.loopnet_model(X.loopnet_weights(3), X.loopnet_spec("cond")))  # nested graphs: the bodies of a Loop and a Scan
 open(W + "/g.gbnf", "w").write('root ::= "{" ws item ("," ws item)* "}"\nitem ::= [a-z]+ ":" [0-9]+\nws ::= [ \\t\\n]*\n')
 PY
 cd $ROOT/trackiellm_amd/csrc
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I. -I$ROOT/include \
     $ROOT/tools/fuzz/fuzz_readers.cpp llm/tk_lora.cpp llm/tk_gguf.cpp llm/tk_grammar.cpp llm/tk_tokenizer.cpp audio/tk_whisper_ggml.cpp nn/tk_onnx_graph.cpp vision/tk_onnx_weights.cpp -o $W/fuzz_readers
-$W/fuzz_readers $W/scratch.bin ${1:-1500} $(ls $W/a.ggla $W/b.gguf $W/model.gguf $W/g.gbnf $W/y.onnx 2>/dev/null)
+$W/fuzz_readers $W/scratch.bin ${1:-1500} $(ls $W/a.ggla $W/b.gguf $W/model.gguf $W/g.gbnf $W/y.onnx $W/loop.onnx 2>/dev/null)

@@ -58,7 +58,7 @@ bool parse_tensor(Span s, std::string* name, Tensor* t, std::string* err) {
         } else if (num == 2 && wt == 0) t->dtype = (int)v;
         else if (num == 4) { /* float_data */
             if (wt == 5) { float f; uint32_t u = (uint32_t)v; memcpy(&f, &u, 4); fdata.push_back(f); }
-            else if (wt == 2) { const size_t n = (size_t)(sub.e - sub.p) / 4; const size_t o = fdata.size(); fdata.resize(o + n); memcpy(fdata.data() + o, sub.p, n * 4); }
+            else if (wt == 2) { const size_t n = (size_t)(sub.e - sub.p) / 4; const size_t o = fdata.size(); fdata.resize(o + n); if (n) memcpy(fdata.data() + o, sub.p, n * 4); }
         } else if (num == 8 && wt == 2) name->assign((const char*)sub.p, (size_t)(sub.e - sub.p));
         else if (num == 9 && wt == 2) raw = sub;
     }
