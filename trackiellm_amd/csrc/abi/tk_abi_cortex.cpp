@@ -96,7 +96,8 @@ static void run_llm(tk_cortex_s* c) {
     int n = 0;
     for (; n < c->max_tokens && !c->stop.load(); ++n) {
         const char* p = tk_llm_runner_generate_next_token(c->runner);
-        if (!p && debug) fprintf(stderr, "tk_cortex: generate_next_token returned NULL after %d tokens: %s\n", n, tk_error_get_detail());
+        if (!p && debug) /* NULL is also the normal end (EOS, context full): the thread's last error detail is printed for what it is worth, it may predate this response */
+            fprintf(stderr, "tk_cortex: generate_next_token returned NULL after %d tokens (EOS / end of context, or a failure; last error detail of this thread: %s)\n", n, tk_error_get_detail());
         if (!p || p == TK_TOOL_CALL_TOKEN) break;
         resp += p;
     }
