@@ -132,7 +132,8 @@ TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_set_max_batch(tk_object_d
 /* Opt-in fast contraction: the detector's convolutions run on the f16 matrix pipe with every operand split into two f16
  * halves (~22 significant bits, fp32 accumulation) instead of the exact fp32 chain — results within ~1e-6 of the chain's scale, not its bits.
  * Off by default; the exact path stays the parity path and the checker (tests/test_vision_gpu.py::test_detector_fast_contraction_gate).
- * Handles of one model file with different settings still share the engine; their frames ride separate jobs. */
+ * Handles of one model file with different settings still share the engine; their frames ride separate jobs.  A fast handle's result for a
+ * frame does not depend on the frames that share its job (the kernel that evaluates a layer is chosen by the layer, never by the batch). */
 TK_API TK_NODISCARD tk_error_code_t tk_mi355x_detector_set_fast_contraction(tk_object_detector_t* detector, int on);
 TK_API void tk_mi355x_detector_share_stats(const tk_object_detector_t* detector, uint64_t* handles, uint64_t* batches, uint64_t* frames, uint64_t* widest);
 /* ONNX detector file (tk_object_detector_config_t.model_path, src/vision/tk_object_detector.c:93-152): parse the Conv initialisers

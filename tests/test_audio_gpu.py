@@ -643,3 +643,43 @@ def test_asr_fast_contraction_gate(gpu):
     t2, m2, e2, l2 = asr.transcribe_tokens(pcm, 8)
     assert np.array_equal(m2, me) and np.array_equal(e2, ee) and np.array_equal(l2, le) and np.array_equal(t2, te)
     asr.close()
+
+
+def test_asr_contexts_with_and_without_fast_contraction_share_an_engine(gpu):
+    """contexts of one checkpoint may differ in the opt-in fast contraction: their utterances ride separate jobs of the shared engine, and every context
+    returns what it returns alone — four contexts, two of them fast, fed from four threads at once"""
+    import threading
+    rng = np.random.default_rng(79)
+    K = 4
+    utts = [np.clip(rng.normal(0, 3000, 16000 + 1200 * i), -32768, 32767).astype(np.int16) for i in range(K)]
+
+    def make(i):
+        a = gpu.Asr()
+        a.set_reference_decode(False)
+        a.set_decode_steps(6)
+        a.set_fast_contraction(i % 2 == 1)
+        return a
+    solo = []
+    for i in range(K):
+        a = make(i)
+        solo.append(a.process_audio(utts[i], True)[0])
+        a.close()
+    ctx = [make(i) for i in range(K)]
+    got = [None] * K
+    bar = threading.Barrier(K)
+
+    def run(i):
+        bar.wait()
+        for _ in range(2):
+            got[i] = ctx[i].process_audio(utts[i], True)[0]
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == solo
+    handles, batches, n, widest = ctx[0].share_stats()
+    assert handles == K and n == 2 * K and batches >= 2                          # at least one job per setting
+    for a in ctx:
+        a.close()

@@ -384,3 +384,41 @@ def test_detector_fast_contraction_gate(gpu):
     assert np.array_equal(anc, t["torch_anchors"]) and np.array_equal(cls, t["torch_cls"])
     assert np.abs(boxes - t["torch_boxes"]).max() < 1e-3
     tiny.close()
+
+
+def test_handles_with_and_without_fast_contraction_share_an_engine(gpu):
+    """handles of one model file may differ in the opt-in fast contraction: their one-frame calls ride separate jobs of the shared engine — the exact
+    handles keep returning the exact path's bits, the fast ones what a fast handle returns alone — driven from four threads at once"""
+    import threading
+    rng = np.random.default_rng(21)
+    K = 4
+    fr = [rng.integers(0, 256, (160, 160, 3), dtype=np.uint8) for _ in range(K)]
+    mk = lambda: gpu.ObjectDetector(model="synthetic://yolov8n?seed=5&cls_bias=-1", width=160, height=160, conf=0.3, iou=0.5)  # noqa: E731
+    solo = []
+    for i in range(K):
+        d = mk()
+        d.set_fast_contraction(i % 2 == 1)
+        solo.append(d.detect(fr[i]))
+        d.close()
+    assert any(len(s) > 0 for s in solo)
+    dets = [mk() for _ in range(K)]
+    for i, d in enumerate(dets):
+        d.set_fast_contraction(i % 2 == 1)
+    got = [None] * K
+    bar = threading.Barrier(K)
+
+    def run(i):
+        bar.wait()
+        for _ in range(3):
+            got[i] = dets[i].detect(fr[i])
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == solo
+    handles, batches, frames, widest = dets[0].share_stats()
+    assert handles == K and frames == 3 * K and batches >= 2
+    for d in dets:
+        d.close()

@@ -198,6 +198,9 @@ static inline size_t tk_tiled_gemm_scratch(const TkGemm& g) {
 struct TkAudioGpuOps {
     TkAsr* a;
     hipStream_t s;
+    /* set by the engine around the per-utterance long passes (log-mel, encoder, cross keys / values): there the opt-in fast contraction applies.
+     * The decode steps never take it — a choice by the row count of a launch would make an utterance's result depend on its batch */
+    bool long_ok = false;
     /* the operand image of the last packed activation matrix: consecutive linear layers on the same input (q / k / v, cross k / v) pack it
      * once.  It sits on top of the arena and is dropped — its space handed back — by every other op, by any allocation of the graph and
      * by a GEMM that writes into the matrix it was made from. */
@@ -243,7 +246,7 @@ struct TkAudioGpuOps {
     /* a linear layer whose weights have tiles runs on the tiled GEMM (same k-ascending fp32 chain, bit-identical, ~3x the rate of the
      * LDS-staged kernel on these shapes and one short launch instead of a latency chain for the decoder's few rows) */
     void gemm(const TkGemm& g) {
-        if (a->fast && g.M >= 256) { /* opt-in fast contraction of the long passes (TkAsr::fast): row-major operands, split-f16 MFMA where the shape allows */
+        if (a->fast && long_ok) { /* opt-in fast contraction of the long passes (TkAsr::fast): row-major operands, split-f16 MFMA where the shape allows */
             drop_image();
             TkGemm f = g;
             f.fast = 1;
@@ -306,7 +309,7 @@ struct TkAudioGpuOps {
     void im2col1d(const float* x, int B, int T, int C, int ldx, int kw, int stride, int pad, float* col) { drop_image(); tk_launch_im2col1d(x, B, T, C, ldx, kw, stride, pad, col, s); }
     void layernorm(const float* x, int rows, int D, const float* w, const float* b, float* y) {
         drop_image();
-        float* img = D % 128 == 0 && !(a->fast && rows >= 256) ? image_for(y, rows, D, D) : nullptr; /* a norm feeds linear layers: packed on the way out */
+        float* img = D % 128 == 0 && !(a->fast && long_ok) ? image_for(y, rows, D, D) : nullptr; /* a norm feeds linear layers: packed on the way out */
         tk_launch_layernorm(x, rows, D, w, b, TK_WH_LN_EPS, y, s, img);
     }
     void softmax_rows(float* x, int rows, int cols, int ld) { drop_image(); tk_launch_softmax_rows(x, rows, cols, ld, s); }
@@ -321,7 +324,7 @@ struct TkAudioGpuOps {
     }
     /* the opt-in fast contraction's attention (TkAsr::fast): Q K^T, softmax and P V of a long pass in one kernel, no score matrix in HBM */
     bool attend_fused(const float* q, const float* k, const float* v, float* out, int B, int Tq, int Tk, int64_t q_bstride, int64_t kv_bstride, int d, int nh) {
-        if (!a->fast || Tq < 256 || nh < 1 || d != nh * 64) return false;
+        if (!a->fast || !long_ok || Tq < 2 || nh < 1 || d != nh * 64) return false;
         drop_image();
         return tk_launch_attention_h3(q, k, v, out, B, nh, Tq, Tk, q_bstride, kv_bstride, d, tk_divf(1.0f, tk_sqrtf(64.0f)), s);
     }
@@ -624,9 +627,11 @@ bool TkAsr::transcribe(int B, const int16_t* pcm, int n_samples, const int32_t* 
     launch_error.clear();
     TkAudioGpuOps ops{this, stream};
     TkWhisperGraph<TkAudioGpuOps> g{h, model->man, model->w.data()};
+    ops.long_ok = true;
     float* ml = g.mel(ops, pcm_dev, B, n_samples, n_samples);
     float* enc = g.encode(ops, ml, B);
     auto st = g.begin_decode(ops, enc, B);
+    ops.long_ok = false;
     HIPQ(hipGetLastError());
     if (mel_out) { mel_out->resize((size_t)B * h.n_frames() * h.n_mels); HIPQ(hipMemcpyAsync(mel_out->data(), ml, mel_out->size() * 4, hipMemcpyDeviceToHost, stream)); }
     if (enc_out) { enc_out->resize((size_t)B * h.n_audio_ctx * h.n_audio_state); HIPQ(hipMemcpyAsync(enc_out->data(), enc, enc_out->size() * 4, hipMemcpyDeviceToHost, stream)); }

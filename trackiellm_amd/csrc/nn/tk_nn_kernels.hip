@@ -846,17 +846,33 @@ void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
         else hipLaunchKernelGGL((KERNEL<false, 0>), GRID, dim3(256), LDS, s, g);                              \
     } while (0)
     /* TkGemm::fast: the split-f16 kernels where the operands meet the one-load-per-group conditions ([N][K] f32 weights); every other
-     * shape keeps the exact chain */
+     * shape keeps the exact chain.  Which kernel runs depends on N and the batch layout only, NEVER on M: a row's result must not depend
+     * on how many other rows (frames, utterances) share its launch — the two split kernels evaluate an element identically (the same 16-k
+     * MFMA steps from k = 0), the exact ones differ from them, so a choice by M would make a fast handle's result depend on its batch. */
     const bool fast = g.fast != 0 && !g.b_kn && (im || path == 1);
+    if (fast && g.N >= 96) {
+        (void)tk_nn_prepare_device();
+        const dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
+        if (im) hipLaunchKernelGGL((k_gemm_h3_big<true>), grid, dim3(256), H3_BIG_LDS, s, g);
+        else hipLaunchKernelGGL((k_gemm_h3_big<false>), grid, dim3(256), H3_BIG_LDS, s, g);
+        return;
+    }
+    if (fast && nz == 1 && g.batch_inner == 0) { /* N < 96 */
+        const dim3 grid(1, (g.M + NBM - 1) / NBM, 1);
+        const int nt = (g.N + 31) / 32;
+#define TK_TALL_H3(NTV)                                                                                       \
+    do {                                                                                                      \
+        if (im) hipLaunchKernelGGL((k_gemm_h3_tall<true, NTV>), grid, dim3(256), 0, s, g);                    \
+        else hipLaunchKernelGGL((k_gemm_h3_tall<false, NTV>), grid, dim3(256), 0, s, g);                      \
+    } while (0)
+        if (nt == 1) TK_TALL_H3(1); else if (nt == 2) TK_TALL_H3(2); else TK_TALL_H3(3);
+#undef TK_TALL_H3
+        return;
+    }
     if (g.M >= 256 && g.N >= 96) {
         const size_t lds = (size_t)2 * (LBM + LBN) * LDS_LD * sizeof(float);
         (void)tk_nn_prepare_device();
         const dim3 grid((g.N + LBN - 1) / LBN, (g.M + LBM - 1) / LBM, nz);
-        if (fast) {
-            if (im) hipLaunchKernelGGL((k_gemm_h3_big<true>), grid, dim3(256), H3_BIG_LDS, s, g);
-            else hipLaunchKernelGGL((k_gemm_h3_big<false>), grid, dim3(256), H3_BIG_LDS, s, g);
-            return;
-        }
         TK_GEMM_PATHS(k_gemm_f32_big, grid, lds);
         return;
     }
@@ -869,13 +885,6 @@ void tk_launch_gemm(const TkGemm& g, hipStream_t s) {
         else if (path == 1) hipLaunchKernelGGL((k_gemm_f32_tall<false, 1, NTV>), grid, dim3(256), 0, s, g);   \
         else hipLaunchKernelGGL((k_gemm_f32_tall<false, 0, NTV>), grid, dim3(256), 0, s, g);                  \
     } while (0)
-#define TK_TALL_H3(NTV)                                                                                       \
-    do {                                                                                                      \
-        if (im) hipLaunchKernelGGL((k_gemm_h3_tall<true, NTV>), grid, dim3(256), 0, s, g);                    \
-        else hipLaunchKernelGGL((k_gemm_h3_tall<false, NTV>), grid, dim3(256), 0, s, g);                      \
-    } while (0)
-        if (fast) { if (nt == 1) TK_TALL_H3(1); else if (nt == 2) TK_TALL_H3(2); else TK_TALL_H3(3); return; }
-#undef TK_TALL_H3
         if (nt == 1) TK_TALL(1); else if (nt == 2) TK_TALL(2); else TK_TALL(3);
 #undef TK_TALL
         return;
